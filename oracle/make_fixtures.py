@@ -1,0 +1,298 @@
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE ITSELF.
+
+Run in the build container only (needs /root/reference, which never travels to the GPU box):
+
+    python oracle/make_fixtures.py
+
+What runs: the reference's own `src/model.py` (`FiDT5`, `EncoderWrapper`, `CheckpointWrapper`,
+`get_crossattention_scores`) and `src/util.py` (`set_optim`, `WarmupLinearScheduler`) imported from
+/root/reference, on top of the installed transformers 5.15.0 `modeling_t5.py`.  The reference was
+written against transformers 3.0.2 (README.md:21), which cannot be installed offline, so three
+harness-side monkeypatches (no edits to the reference) adapt call signatures:
+  (i)   CheckpointWrapper.forward accepts the extra positional args HF5 passes to a block,
+  (ii)  EncoderWrapper.forward re-wraps its tuple in BaseModelOutput,
+  (iii) EncoderWrapper.main_input_name = "input_ids" (for generate()).
+`transformers.AdamW` (removed in HF 5) is provided by a harness stub with HF<=4 semantics so that the
+reference's own `set_optim` can construct it (`correct_bias=False`, src/util.py:225).
+
+Only DATA is written (inputs and expected outputs); no reference source is copied.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+import transformers  # noqa: E402
+from transformers.modeling_outputs import BaseModelOutput  # noqa: E402
+
+from oracle import fid_t5_oracle as O  # noqa: E402
+
+
+class _HFAdamW(torch.optim.Optimizer):
+    """Harness stub for the removed `transformers.AdamW` (HF <= 4 semantics)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
+                                      correct_bias=correct_bias))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = torch.zeros_like(p)
+                b1, b2 = group["betas"]
+                st["step"] += 1
+                st["exp_avg"].mul_(b1).add_(p.grad, alpha=1.0 - b1)
+                st["exp_avg_sq"].mul_(b2).addcmul_(p.grad, p.grad, value=1.0 - b2)
+                denom = st["exp_avg_sq"].sqrt().add_(group["eps"])
+                step_size = group["lr"]
+                if group["correct_bias"]:
+                    step_size = step_size * (1.0 - b2 ** st["step"]) ** 0.5 / (1.0 - b1 ** st["step"])
+                p.addcdiv_(st["exp_avg"], denom, value=-step_size)
+                if group["weight_decay"] > 0.0:
+                    p.add_(p, alpha=-group["lr"] * group["weight_decay"])
+
+
+import src.model as rm  # noqa: E402  (reference)
+
+sys.modules["transformers"].AdamW = _HFAdamW   # after src.model: importing it swaps the lazy module object
+import src.util as ru  # noqa: E402  (reference)
+
+
+def _cw_forward(self, hidden_states, attention_mask=None, position_bias=None, *args, **kwargs):
+    return self.module(hidden_states, attention_mask, position_bias, *args, **kwargs)
+
+
+_ew_orig = rm.EncoderWrapper.forward
+
+
+def _ew_forward(self, input_ids=None, attention_mask=None, **kwargs):
+    out = _ew_orig(self, input_ids=input_ids, attention_mask=attention_mask, **kwargs)
+    return BaseModelOutput(last_hidden_state=out[0])
+
+
+rm.CheckpointWrapper.forward = _cw_forward
+rm.EncoderWrapper.forward = _ew_forward
+rm.EncoderWrapper.main_input_name = "input_ids"
+
+
+def build_reference(dims: O.T5Dims, weights: dict[str, torch.Tensor], dropout: float = 0.0):
+    cfg = transformers.T5Config(
+        vocab_size=dims.vocab_size, d_model=dims.d_model, d_kv=dims.d_kv, d_ff=dims.d_ff,
+        num_layers=dims.num_layers, num_decoder_layers=dims.num_decoder_layers, num_heads=dims.num_heads,
+        relative_attention_num_buckets=dims.num_buckets, relative_attention_max_distance=dims.max_distance,
+        dropout_rate=dropout, layer_norm_epsilon=dims.eps, feed_forward_proj="relu",
+        decoder_start_token_id=0, pad_token_id=0, eos_token_id=1)
+    cfg._attn_implementation = "eager"
+    model = rm.FiDT5(cfg)
+    sd = {k: v.clone() for k, v in weights.items()}
+    sd["encoder.embed_tokens.weight"] = sd["shared.weight"]
+    sd["decoder.embed_tokens.weight"] = sd["shared.weight"]
+    sd["lm_head.weight"] = sd["shared.weight"]
+    model.load_t5(sd)                                   # src/model.py:79-82
+    assert model.lm_head.weight.data_ptr() == model.shared.weight.data_ptr()
+    return model
+
+
+def plain_name(wrapped: str) -> str | None:
+    """Wrapped FiD key (encoder.encoder.block.i.module.layer…) → plain T5 key."""
+    if wrapped in ("lm_head.weight", "encoder.encoder.embed_tokens.weight", "decoder.embed_tokens.weight"):
+        return None
+    if wrapped.startswith("encoder.encoder."):
+        wrapped = "encoder." + wrapped[len("encoder.encoder."):]
+    return wrapped.replace(".module.layer.", ".layer.")
+
+
+def ref_grads(model) -> dict[str, np.ndarray]:
+    out = {}
+    for k, p in model.named_parameters():
+        pk = plain_name(k)
+        if pk is not None and p.grad is not None:
+            out[pk] = p.grad.detach().numpy().copy()
+    return out
+
+
+def ref_weights(model) -> dict[str, np.ndarray]:
+    out = {}
+    for k, p in model.named_parameters():
+        pk = plain_name(k)
+        if pk is not None:
+            out[pk] = p.detach().numpy().copy()
+    return out
+
+
+def make_case(name: str, dims: O.T5Dims, B, N, L, T, seed, full_pad=None, fact_case=False, pretrain=0):
+    torch.manual_seed(seed)
+    weights = O.init_weights(dims, seed=seed)
+    ids, mask, labels = O.synthetic_batch(B, N, L, T, dims.vocab_size, seed=seed + 100)
+    if full_pad is not None:                             # a fully padded passage
+        b, n = full_pad
+        mask[b, n] = False
+        ids[b, n] = 0
+    if fact_case:                                        # stream-2 layout: passage 1 = "fact : s1 . s2 . …"
+        g = torch.Generator().manual_seed(seed + 7)
+        for b in range(B):
+            row = torch.randint(11, dims.vocab_size, (L,), generator=g)
+            row[0], row[1] = 7, 10
+            seps = sorted(torch.randperm(L - 4, generator=g)[: 3 + b].add(3).tolist())
+            for s in seps:
+                row[s] = 5
+            valid = int(mask[b, 1].sum())
+            if b == 0:
+                valid = L                                # unterminated final span, no padding
+                row[L - 1] = 9
+            ids[b, 1] = row
+            mask[b, 1] = torch.arange(L) < valid
+            ids[b, 1] = ids[b, 1].masked_fill(~mask[b, 1], 0)
+
+    if pretrain:
+        # Overfit the (data-only) weights to ragged targets with the oracle's trainer so that greedy decode
+        # reproduces them: rows then hit EOS at different steps, which pins the EOS/pad bookkeeping.  The
+        # expected outputs below still come from the reference run on these weights.
+        for b in range(B):
+            tl = 2 + (b * 3) % (T - 1)
+            labels[b] = torch.randint(2, dims.vocab_size, (T,), generator=torch.Generator().manual_seed(seed + b))
+            labels[b, tl - 1] = 1
+            labels[b, tl:] = -100
+        st = {}
+        for k in range(pretrain):
+            O.train_step(weights, dims, st, ids, mask, labels, k, 3e-3, 0.0, 1.0, 5, pretrain + 50, training=False)
+
+    out: dict[str, np.ndarray] = {}
+    out.update({"w/" + k: v.numpy() for k, v in weights.items()})
+    out.update(input_ids=ids.numpy(), attention_mask=mask.numpy(), labels=labels.numpy(),
+               dims=np.array([dims.vocab_size, dims.d_model, dims.d_kv, dims.d_ff, dims.num_layers,
+                              dims.num_decoder_layers, dims.num_heads, dims.num_buckets, dims.max_distance]))
+
+    # ---- forward / backward through the reference -------------------------------------------
+    model = build_reference(dims, weights)
+    model.train()                                        # dropout_rate = 0 → deterministic
+    acts = {}
+    blk0 = model.encoder.encoder.block[0].module
+    hooks = [
+        blk0.layer[0].layer_norm.register_forward_hook(lambda m, i, o: acts.__setitem__("enc0_xn", o.detach())),
+        blk0.layer[0].SelfAttention.q.register_forward_hook(lambda m, i, o: acts.__setitem__("enc0_q", o.detach())),
+        blk0.layer[0].SelfAttention.k.register_forward_hook(lambda m, i, o: acts.__setitem__("enc0_k", o.detach())),
+        blk0.layer[0].SelfAttention.v.register_forward_hook(lambda m, i, o: acts.__setitem__("enc0_v", o.detach())),
+        blk0.layer[0].SelfAttention.o.register_forward_hook(
+            lambda m, i, o: acts.__setitem__("enc0_ctx", i[0].detach())),
+        blk0.layer[1].DenseReluDense.register_forward_hook(
+            lambda m, i, o: acts.__setitem__("enc0_ffn_out", o.detach())),
+        blk0.register_forward_hook(lambda m, i, o: acts.__setitem__("enc0_out", o[0].detach())),
+    ]
+    res = model(input_ids=ids, attention_mask=mask, labels=labels)
+    for h in hooks:
+        h.remove()
+    loss = res[0]
+    loss.backward()
+    out.update(loss=np.array(loss.item(), dtype=np.float64), logits=res.logits.detach().numpy(),
+               enc_out=res.encoder_last_hidden_state.detach().numpy())
+    out.update({"act/" + k: v.numpy() for k, v in acts.items()})
+    grads = ref_grads(model)
+    out.update({"g/" + k: v for k, v in grads.items()})
+    gn = float(np.sqrt(sum(float((g.astype(np.float64) ** 2).sum()) for g in grads.values())))
+    out["grad_norm"] = np.array(gn)
+    bias = blk0.layer[0].SelfAttention.compute_bias(L, L).detach()
+    out["act/enc0_bias"] = bias.numpy()
+    model.zero_grad()
+
+    # ---- 3 optimizer steps through the reference's own set_optim / scheduler ---------------
+    opt = types.SimpleNamespace(optim="adamw", lr=1e-2, weight_decay=1e-2, scheduler="linear", scheduler_steps=None,
+                                total_steps=10, warmup_steps=2, fixed_lr=False)
+    optimizer, scheduler = ru.set_optim(opt, model)      # src/util.py:230-245
+    losses, norms = [], []
+    for k in range(3):
+        bi, bm, bl = O.synthetic_batch(B, N, L, T, dims.vocab_size, seed=seed + 200 + k)
+        tl = model(input_ids=bi, attention_mask=bm, labels=bl)[0]
+        tl.backward()
+        norms.append(float(torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)))   # train_reader.py:76
+        optimizer.step()
+        scheduler.step()
+        model.zero_grad()
+        losses.append(tl.item())
+        if k in (0, 2):
+            out.update({f"w_step{k + 1}/" + n: v for n, v in ref_weights(model).items()})
+    out["train_losses"] = np.array(losses)
+    out["train_gnorms"] = np.array(norms)
+    out["train_hparams"] = np.array([opt.lr, opt.weight_decay, 1.0, opt.warmup_steps, opt.total_steps])
+
+    # ---- greedy generate + step-0 cross-attention scores -----------------------------------
+    model = build_reference(dims, weights)
+    model.eval()
+    qk = {}
+    hooks = []
+    for li, blk in enumerate(model.decoder.block):
+        att = blk.layer[1].EncDecAttention
+        def _keep(kind, li):
+            def hook(m, i, o):                           # first call = decode step 0; must return None
+                qk.setdefault((kind, li), o.detach())
+            return hook
+        hooks.append(att.q.register_forward_hook(_keep("q", li)))
+        hooks.append(att.k.register_forward_hook(_keep("k", li)))
+    with torch.no_grad():
+        for ml in (4, 12):
+            toks = model.generate(input_ids=ids, attention_mask=mask, max_length=ml)
+            out[f"gen_{ml}"] = toks.numpy()
+    for h in hooks:
+        h.remove()
+    H, dk = dims.num_heads, dims.d_kv
+    flat_mask = mask.view(B, -1)
+    per_layer = []
+    for li in range(dims.num_decoder_layers):
+        q = qk[("q", li)].view(B, -1, H, dk).transpose(1, 2)
+        k = qk[("k", li)].view(B, -1, H, dk).transpose(1, 2)
+        s = torch.einsum("bnqd,bnkd->bnqk", q, k)        # the quantity src/model.py:316-329 stores (step 0)
+        s = s + torch.zeros(B, 1, 1, N * L).masked_fill(~flat_mask[:, None, None, :], torch.finfo(torch.float32).min)
+        per_layer.append(s)
+        blk = model.decoder.block[li]
+        blk.layer[1].EncDecAttention.score_storage = s
+    out["cross_scores"] = torch.cat(per_layer, dim=2).numpy()       # [B,H,n_layers,N*L]
+    if N == 2:
+        for style in ("mean", "max", "21mean"):
+            for half in ("no", "yes"):
+                o2 = types.SimpleNamespace(stream=2, n_context=5, use_last_half_layer_attention=half,
+                                           attention_score_style=style)
+                fs = model.get_crossattention_scores(o2, ids, None, mask)         # src/model.py:143-204
+                out[f"fact_scores_{style}_{half}"] = fs.numpy()
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", name + ".npz"), **out)
+    print(name, "loss", loss.item(), "gnorm", gn, "gen", out["gen_12"].tolist())
+
+
+def make_tables():
+    from transformers.models.t5.modeling_t5 import T5Attention
+    rel = torch.arange(-260, 261)
+    enc = T5Attention._relative_position_bucket(rel, bidirectional=True, num_buckets=32, max_distance=128)
+    dec = T5Attention._relative_position_bucket(rel, bidirectional=False, num_buckets=32, max_distance=128)
+    sched = ru.WarmupLinearScheduler(torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1.0),
+                                     warmup_steps=6, scheduler_steps=100, min_ratio=0.0, fixed_lr=False)
+    lam = np.array([sched.lr_lambda(s) for s in range(0, 111)])
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "tables.npz"), rel=rel.numpy(), enc_bucket=enc.numpy(),
+                        dec_bucket=dec.numpy(), lr_lambda_w6_t100=lam)
+    print("tables ok")
+
+
+if __name__ == "__main__":
+    tiny = O.T5Dims.named("tiny")
+    make_tables()
+    make_case("tiny_a", tiny, B=3, N=3, L=12, T=5, seed=1, full_pad=(1, 2))
+    make_case("tiny_fact", tiny, B=3, N=2, L=24, T=4, seed=2, fact_case=True)
+    make_case("tiny_eos", tiny, B=4, N=3, L=12, T=6, seed=5, pretrain=150)
+    # a slightly wider case: odd L, more heads/layers, exercises the log-spaced buckets (L > 16)
+    mid = O.T5Dims(vocab_size=96, d_model=64, d_kv=16, d_ff=128, num_layers=3, num_decoder_layers=2, num_heads=4)
+    make_case("mid_a", mid, B=2, N=4, L=37, T=7, seed=3)

@@ -1,0 +1,95 @@
+"""Pin the oracle (oracle/fid_t5_oracle.py) to golden vectors produced by the reference itself."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fid_t5_oracle as O
+from tests.util_golden import group, load_case
+
+CASES = ["tiny_a", "tiny_fact", "mid_a", "tiny_eos"]
+
+
+def test_bucket_tables(golden_dir):
+    z = np.load(golden_dir + "/tables.npz")
+    rel = torch.from_numpy(z["rel"])
+    assert torch.equal(O.relative_position_bucket(rel, True), torch.from_numpy(z["enc_bucket"]))
+    assert torch.equal(O.relative_position_bucket(rel, False), torch.from_numpy(z["dec_bucket"]))
+    # spot values from SURVEY.md A.1
+    enc = dict(zip(z["rel"].tolist(), z["enc_bucket"].tolist()))
+    assert enc[-91] == 15 and enc[-90] == 14 and enc[0] == 0 and enc[1] == 17 and enc[91] == 31 and enc[8] == 24
+    dec = dict(zip(z["rel"].tolist(), z["dec_bucket"].tolist()))
+    assert dec[5] == 0 and dec[-15] == 15 and dec[-16] == 16 and dec[-113] == 31
+
+
+def test_lr_lambda(golden_dir):
+    z = np.load(golden_dir + "/tables.npz")
+    mine = np.array([O.lr_lambda(s, 6, 100) for s in range(111)])
+    np.testing.assert_allclose(mine, z["lr_lambda_w6_t100"], rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_forward_backward(name):
+    z, dims, w = load_case(name)
+    ids, mask, labels = (torch.from_numpy(z[k]) for k in ("input_ids", "attention_mask", "labels"))
+    leaves = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+    cap = {}
+    loss, logits = O.fid_forward(leaves, dims, ids, mask, labels, training=False, capture=cap)
+    assert abs(loss.item() - float(z["loss"])) < 1e-5
+    torch.testing.assert_close(logits, torch.from_numpy(z["logits"]), atol=2e-5, rtol=1e-5)
+    torch.testing.assert_close(cap["enc_out"], torch.from_numpy(z["enc_out"]), atol=2e-5, rtol=1e-5)
+    acts = group(z, "act/")
+    B, N, L = ids.shape
+    H, dk = dims.num_heads, dims.d_kv
+    torch.testing.assert_close(cap["enc0_xn"], acts["enc0_xn"], atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(cap["enc0_bias"], acts["enc0_bias"], atol=0, rtol=0)
+    for n in "qkv":
+        ref = acts["enc0_" + n].view(B * N, L, H, dk).transpose(1, 2)
+        torch.testing.assert_close(cap["enc0_" + n], ref, atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(cap["enc0_ctx"], acts["enc0_ctx"], atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(cap["enc0_ffn_out"], acts["enc0_ffn_out"], atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(cap["enc0_out"], acts["enc0_out"], atol=2e-5, rtol=1e-5)
+    loss.backward()
+    g = group(z, "g/")
+    assert set(g) == set(leaves)
+    for k, v in leaves.items():
+        torch.testing.assert_close(v.grad, g[k], atol=3e-5, rtol=1e-4, msg=lambda m, k=k: f"{k}: {m}")
+    gn = torch.sqrt(sum((v.grad.double() ** 2).sum() for v in leaves.values())).item()
+    assert abs(gn - float(z["grad_norm"])) < 1e-4
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_train_steps(name):
+    z, dims, w = load_case(name)
+    B, N, L = z["input_ids"].shape
+    T = z["labels"].shape[1]
+    lr, wd, clip, warm, total = z["train_hparams"].tolist()
+    seed = {"tiny_a": 1, "tiny_fact": 2, "mid_a": 3, "tiny_eos": 5}[name]
+    state = {}
+    for k in range(3):
+        bi, bm, bl = O.synthetic_batch(B, N, L, T, dims.vocab_size, seed=seed + 200 + k)
+        loss, gn = O.train_step(w, dims, state, bi, bm, bl, k, lr, wd, clip, int(warm), int(total), training=False)
+        assert abs(loss - z["train_losses"][k]) < 2e-5
+        assert abs(gn - z["train_gnorms"][k]) < 1e-4
+        if k in (0, 2):
+            ref = group(z, f"w_step{k + 1}/")
+            for n, v in w.items():
+                torch.testing.assert_close(v, ref[n], atol=2e-5, rtol=1e-4, msg=lambda m, n=n: f"{n}: {m}")
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_generate_and_scores(name):
+    z, dims, w = load_case(name)
+    ids, mask = torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"])
+    for ml in (4, 12):
+        cap = {}
+        toks = O.fid_generate(w, dims, ids, mask, ml, capture=cap)
+        assert toks.tolist() == z[f"gen_{ml}"].tolist()
+    scores = torch.cat([cap[f"cross_scores_{i}"] for i in range(dims.num_decoder_layers)], dim=2)
+    ref = torch.from_numpy(z["cross_scores"])
+    keep = mask.view(mask.shape[0], 1, 1, -1).expand_as(ref)
+    torch.testing.assert_close(scores[keep], ref[keep], atol=2e-5, rtol=1e-5)
+    if ids.shape[1] == 2:
+        for style in ("mean", "max", "21mean"):
+            for half in ("no", "yes"):
+                mine = O.crossattention_fact_scores(ref, ids, mask, 5, style, half == "yes")
+                np.testing.assert_allclose(mine.numpy(), z[f"fact_scores_{style}_{half}"], rtol=1e-12, atol=1e-12)
