@@ -1,0 +1,176 @@
+/* lako_hip.h — C-ABI of liblako_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the LaKo
+ * Fusion-in-Decoder reader hot path.
+ *
+ * The reference (hackerchenzhuo/LaKo) has NO native code and no FFI: its hot path is
+ * `FiDT5.forward/generate` (src/model.py:39-60,227-234) dispatching stock torch ops from HuggingFace
+ * `modeling_t5.py` ("HF5:line" below = transformers 5.15.0, the readable stand-in for the 3.0.2 the
+ * reference names).  Each entry point here replaces one torch-op sequence of that path; the comment
+ * on each function cites the reference/HF lines whose arithmetic it reproduces.  The Python host side
+ * (lako_amd/ops.py) binds these with ctypes — see INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is a DEVICE pointer unless said otherwise
+ *  - row-major contiguous tensors; activations [rows, features]; weights in HF layout [out, in]
+ *  - dtype: LAKO_F32 or LAKO_BF16 storage; accumulation is always fp32
+ *  - all work is enqueued on `stream` (a hipStream_t); no function allocates, frees or synchronises
+ *  - return 0 on success, negative LAKO_E_* otherwise; lako_last_error() gives the message
+ *  - pointers must be 16-byte aligned; feature dimensions multiples of 8
+ */
+#ifndef LAKO_HIP_H
+#define LAKO_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LAKO_ABI_VERSION 1
+
+enum { LAKO_F32 = 0, LAKO_BF16 = 1 };
+enum { LAKO_OK = 0, LAKO_E_BADARG = -1, LAKO_E_ALIGN = -2, LAKO_E_LAUNCH = -3, LAKO_E_UNSUPPORTED = -4 };
+
+typedef void* lako_stream_t; /* hipStream_t */
+
+int lako_version(void);
+/* copies the calling thread's last error message (NUL-terminated) into buf; returns its length */
+int lako_last_error(char* buf, size_t n);
+
+/* stateless dropout: element idx of site `site` is kept iff hash(seed, site, idx) >= p*2^32; kept
+ * elements are scaled by 1/(1-p) (torch.nn.Dropout semantics, HF5:725,745,83-94,400).  Forward and
+ * backward kernels regenerate the mask from (seed, site); p == 0 disables. */
+typedef struct {
+  float p;
+  uint32_t seed;
+  uint32_t site;
+} lako_dropout_t;
+
+/* ---- GEMM  (K3/K6/K7/K10/K12 of SURVEY.md §2.3: every nn.Linear(bias=False) on the path,
+ *      HF5:304,325-326,367 (q,k,v,o), HF5:83-94 (wi,wo), HF5:1047 (lm_head)) --------------------- */
+enum {
+  LAKO_EPI_RELU = 1,    /* v = max(v, 0)                                  (HF5:85 ReLU)             */
+  LAKO_EPI_RESID = 2,   /* v = resid + dropout(v)                         (HF5:400,141 residual)    */
+  LAKO_EPI_AUXMASK = 4, /* v = aux > 0 ? v * aux_scale : 0                (ReLU+dropout backward)   */
+  LAKO_EPI_ATOMIC = 8   /* C (fp32) += v with float atomics instead of a store                     */
+};
+typedef struct {
+  const void* A; /* [M, K] row-major, lda */
+  const void* B; /* [N, K] row-major, ldb  — C = A · Bᵀ ("NT": both operands K-contiguous)        */
+  void* C;       /* [M, N] row-major, ldc */
+  int64_t M, N, K, lda, ldb, ldc;
+  int in_dtype, out_dtype;
+  float alpha; /* v = alpha * acc first */
+  int flags;   /* LAKO_EPI_* */
+  const void* resid; /* [M, N] in out_dtype, ldr   (LAKO_EPI_RESID) */
+  int64_t ldr;
+  const void* aux; /* [M, N] in in_dtype, ldaux      (LAKO_EPI_AUXMASK) */
+  int64_t ldaux;
+  float aux_scale;
+  lako_dropout_t drop; /* applied after relu / before the residual add; idx = m*N + n */
+} lako_gemm_nt_t;
+int lako_gemm_nt(const lako_gemm_nt_t* p, lako_stream_t stream);
+
+/* C[M,N] (fp32) += alpha * Aᵀ·B with A [K, M], B [K, N] row-major (weight gradients dW = dYᵀ·X —
+ * the autograd of every nn.Linear above).  Split-K over `split_k` workgroups, fp32 atomics. */
+int lako_gemm_tn(const void* A, const void* B, float* C, int64_t M, int64_t N, int64_t K, int64_t lda,
+                 int64_t ldb, int64_t ldc, int in_dtype, float alpha, int split_k, lako_stream_t stream);
+
+/* ---- T5LayerNorm (RMSNorm, HF5:59-72): y = dropout(x * rsqrt(mean(x²) + eps) * w) ----------------
+ * rstd [rows] fp32 is written for the backward.  w is fp32 [d]. */
+int lako_rmsnorm_fwd(const void* x, const float* w, void* y, float* rstd, int64_t rows, int d, float eps,
+                     int dtype, lako_dropout_t drop, lako_stream_t stream);
+/* dx = (dres ? dres : 0) + rmsnorm_bwd(dropout_bwd(dy)); dw (fp32 [d]) += Σ_rows dy·x·rstd (atomics) */
+int lako_rmsnorm_bwd(const void* dy, const void* x, const float* w, const float* rstd, const void* dres,
+                     void* dx, float* dw, int64_t rows, int d, int dtype, lako_dropout_t drop,
+                     lako_stream_t stream);
+
+/* ---- embedding (HF5:678 embed_tokens + HF5:725 dropout) --------------------------------------------
+ * out[t] = dropout(table[ids[t]]);  bwd: dtable (fp32 [vocab, d]) += scatter of dropout_bwd(dout) */
+int lako_embed_fwd(const int64_t* ids, const void* table, void* out, int64_t n_tok, int d, int64_t vocab,
+                   int dtype, lako_dropout_t drop, lako_stream_t stream);
+int lako_embed_bwd(const int64_t* ids, const void* dout, float* dtable, int64_t n_tok, int d, int64_t vocab,
+                   int dtype, lako_dropout_t drop, lako_stream_t stream);
+
+/* ---- relative position bias (HF5:217-279): the bias depends only on (key_pos - query_pos), so the
+ * [nb, H] embedding is expanded once per stack into rel[H, R] with rel[h][r] = table[lut[r]][h];
+ * the attention kernels index it as r = j - i + rel_off.  lut (int32 [R]) holds
+ * _relative_position_bucket(r - (R-1)/2 …) computed on the host in float32 exactly as HF5:217-262. */
+int lako_relpos_expand(const float* table, const int32_t* lut, float* rel, int H, int R, int nb,
+                       lako_stream_t stream);
+/* dtable[lut[r]][h] += drel[h][r] */
+int lako_relpos_reduce(const float* drel, const int32_t* lut, float* dtable, int H, int R, int nb,
+                       lako_stream_t stream);
+
+/* ---- attention (HF5:144-173,281-369; the same math as the reference's own
+ * cross_attention_forward, src/model.py:286-349): P = softmax_fp32(Q·Kᵀ + bias + mask) — scores are
+ * NOT scaled by 1/sqrt(dk) — then dropout(P)·V.  One call covers every (batch row, head).
+ * Used for encoder self-attention (bidirectional bias + key padding mask), decoder self-attention
+ * (causal + unidirectional bias) and cross-attention over the concatenated n_passages·L encoder
+ * states (key padding mask only). */
+typedef struct {
+  const void *q, *k, *v; /* element (b, t, h, c) at ptr + b*stride_b + t*stride_t + h*d_head + c */
+  void* out;             /* same addressing with o_stride_* */
+  float* lse;            /* [Bn, H, Lq] fp32: log-sum-exp of each score row (saved for backward) */
+  int64_t q_stride_b, q_stride_t, k_stride_b, k_stride_t, v_stride_b, v_stride_t, o_stride_b, o_stride_t;
+  const float* rel_bias; /* [H, R] fp32 or NULL */
+  int R, rel_off;        /* bias index = j - i + rel_off */
+  const uint8_t* key_mask; /* [Bn, Lk] 1 = attend, 0 = padding; or NULL */
+  int causal, causal_off;  /* causal: key j visible iff j <= i + causal_off */
+  int Bn, H, Lq, Lk, d_head;
+  int dtype;
+  lako_dropout_t drop; /* on the probabilities; idx = ((b*H + h)*Lq + i)*Lk + j */
+  float* scores_out;   /* optional [Bn, H, Lq, Lk] fp32 raw pre-softmax scores (+bias, masked keys = 0):
+                          the quantity src/model.py:316-329 stores for get_crossattention_scores */
+} lako_attn_fwd_t;
+int lako_attn_fwd(const lako_attn_fwd_t* p, lako_stream_t stream);
+
+typedef struct {
+  const void *q, *k, *v, *out, *dout;
+  const float* lse;
+  void *dq_out, *dk_out, *dv_out; /* same addressing as q / k / v (dK, dV use the k / v strides) */
+  int64_t q_stride_b, q_stride_t, k_stride_b, k_stride_t, v_stride_b, v_stride_t, o_stride_b, o_stride_t;
+  const float* rel_bias;
+  float* drel; /* [H, R] fp32, += (atomics); or NULL */
+  int R, rel_off;
+  const uint8_t* key_mask;
+  int causal, causal_off;
+  int Bn, H, Lq, Lk, d_head;
+  int dtype;
+  lako_dropout_t drop;
+} lako_attn_bwd_t;
+int lako_attn_bwd(const lako_attn_bwd_t* p, lako_stream_t stream);
+
+/* ---- LM-head loss (HF5:1051-1054): CrossEntropyLoss(ignore_index=-100), mean over valid labels ----
+ * logits fp32 [M, V]; loss_out[0] = mean loss, loss_out[1] = number of valid labels;
+ * dlogits (dtype, [M, V], optional) = (softmax - onehot) / n_valid, 0 on ignored rows. */
+int lako_ce_fwd_bwd(const float* logits, const int64_t* labels, float* loss_out, void* dlogits, int64_t M,
+                    int64_t V, int dtype, lako_stream_t stream);
+
+/* ---- optimizer (train_reader.py:76-79; src/util.py:185-227): global-norm clip + HF AdamW with
+ * correct_bias=False + decoupled weight decay, one fused pass over the flat parameter buffer ------ */
+/* out[0] += Σ g²  (caller zeroes out[0]) */
+int lako_sumsq(const float* g, int64_t n, float* out, lako_stream_t stream);
+/* coef = min(1, max_norm / (sqrt(gnorm_sq[0]) * grad_scale + 1e-6)) as torch clip_grad_norm_;
+ * g' = g * grad_scale * coef;  m,v,p updated as A.6 of SURVEY.md;  shadow (dtype) = p if not NULL. */
+int lako_adamw_step(float* p, const float* g, float* m, float* v, void* shadow, int64_t n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, const float* gnorm_sq, float max_norm,
+                    float grad_scale, int shadow_dtype, lako_stream_t stream);
+/* dst[c][r] = (dtype) src[r][c]  — transposed low-precision weight copies used by the dX GEMMs */
+int lako_transpose_cast(const float* src, void* dst, int64_t rows, int64_t cols, int dtype, lako_stream_t stream);
+int lako_cast(const float* src, void* dst, int64_t n, int dtype, lako_stream_t stream);
+
+/* ---- small helpers ------------------------------------------------------------------------------ */
+/* y = dropout_scale_mask(x) (used for the backward of residual-branch dropout, HF5:400,141) */
+int lako_dropout_apply(const void* x, void* y, int64_t n, int dtype, lako_dropout_t drop, lako_stream_t stream);
+/* _shift_right (HF5:618-637): dec[b][0] = 0; dec[b][t] = labels[b][t-1] (−100 → 0) */
+int lako_shift_right(const int64_t* labels, int64_t* dec_ids, int B, int T, lako_stream_t stream);
+/* greedy step (HF generate, num_beams=1, do_sample=False): next = argmax(logits[b]); rows already
+ * done emit pad(0); done |= next == eos.  seq[b*seq_ld + pos] = next; next_ids[b] = next.
+ * n_done[0] = number of finished rows after the step. */
+int lako_greedy_step(const float* logits, int64_t V, int B, int64_t* seq, int64_t seq_ld, int pos, int64_t* next_ids,
+                     uint8_t* done, int32_t* n_done, int64_t eos_id, int64_t pad_id, lako_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LAKO_HIP_H */

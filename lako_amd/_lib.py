@@ -1,0 +1,107 @@
+"""ctypes loader for liblako_hip.so (the C-ABI declared in include/lako_hip.h).
+
+The library is the product: there is NO CPU or PyTorch fallback.  `load()` raises if the shared object
+is missing, and every op raises `LakoError` with the library's own message on a non-zero return.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblako_hip.so")
+
+LAKO_F32, LAKO_BF16 = 0, 1
+EPI_RELU, EPI_RESID, EPI_AUXMASK, EPI_ATOMIC = 1, 2, 4, 8
+
+i64, i32, u32, f32, vp = C.c_int64, C.c_int, C.c_uint32, C.c_float, C.c_void_p
+
+
+class LakoError(RuntimeError):
+    pass
+
+
+class Dropout(C.Structure):
+    _fields_ = [("p", f32), ("seed", u32), ("site", u32)]
+
+
+NO_DROP = Dropout(0.0, 0, 0)
+
+
+class GemmNT(C.Structure):
+    _fields_ = [("A", vp), ("B", vp), ("C", vp), ("M", i64), ("N", i64), ("K", i64), ("lda", i64), ("ldb", i64),
+                ("ldc", i64), ("in_dtype", i32), ("out_dtype", i32), ("alpha", f32), ("flags", i32), ("resid", vp),
+                ("ldr", i64), ("aux", vp), ("ldaux", i64), ("aux_scale", f32), ("drop", Dropout)]
+
+
+class AttnFwd(C.Structure):
+    _fields_ = [("q", vp), ("k", vp), ("v", vp), ("out", vp), ("lse", vp),
+                ("q_stride_b", i64), ("q_stride_t", i64), ("k_stride_b", i64), ("k_stride_t", i64),
+                ("v_stride_b", i64), ("v_stride_t", i64), ("o_stride_b", i64), ("o_stride_t", i64),
+                ("rel_bias", vp), ("R", i32), ("rel_off", i32), ("key_mask", vp), ("causal", i32),
+                ("causal_off", i32), ("Bn", i32), ("H", i32), ("Lq", i32), ("Lk", i32), ("d_head", i32),
+                ("dtype", i32), ("drop", Dropout), ("scores_out", vp)]
+
+
+class AttnBwd(C.Structure):
+    _fields_ = [("q", vp), ("k", vp), ("v", vp), ("out", vp), ("dout", vp), ("lse", vp),
+                ("dq_out", vp), ("dk_out", vp), ("dv_out", vp),
+                ("q_stride_b", i64), ("q_stride_t", i64), ("k_stride_b", i64), ("k_stride_t", i64),
+                ("v_stride_b", i64), ("v_stride_t", i64), ("o_stride_b", i64), ("o_stride_t", i64),
+                ("rel_bias", vp), ("drel", vp), ("R", i32), ("rel_off", i32), ("key_mask", vp), ("causal", i32),
+                ("causal_off", i32), ("Bn", i32), ("H", i32), ("Lq", i32), ("Lk", i32), ("d_head", i32),
+                ("dtype", i32), ("drop", Dropout)]
+
+
+# name -> argtypes (restype is always int).  Must list EVERY function include/lako_hip.h declares:
+# tests/test_abi.py cross-checks this table against the header and the .so's dynamic symbols.
+SIGNATURES = {
+    "lako_version": [],
+    "lako_last_error": [C.c_char_p, C.c_size_t],
+    "lako_gemm_nt": [C.POINTER(GemmNT), vp],
+    "lako_gemm_tn": [vp, vp, vp, i64, i64, i64, i64, i64, i64, i32, f32, i32, vp],
+    "lako_rmsnorm_fwd": [vp, vp, vp, vp, i64, i32, f32, i32, Dropout, vp],
+    "lako_rmsnorm_bwd": [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, Dropout, vp],
+    "lako_embed_fwd": [vp, vp, vp, i64, i32, i64, i32, Dropout, vp],
+    "lako_embed_bwd": [vp, vp, vp, i64, i32, i64, i32, Dropout, vp],
+    "lako_relpos_expand": [vp, vp, vp, i32, i32, i32, vp],
+    "lako_relpos_reduce": [vp, vp, vp, i32, i32, i32, vp],
+    "lako_attn_fwd": [C.POINTER(AttnFwd), vp],
+    "lako_attn_bwd": [C.POINTER(AttnBwd), vp],
+    "lako_ce_fwd_bwd": [vp, vp, vp, vp, i64, i64, i32, vp],
+    "lako_sumsq": [vp, i64, vp, vp],
+    "lako_adamw_step": [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, f32, f32, i32, vp],
+    "lako_transpose_cast": [vp, vp, i64, i64, i32, vp],
+    "lako_cast": [vp, vp, i64, i32, vp],
+    "lako_dropout_apply": [vp, vp, i64, i32, Dropout, vp],
+    "lako_shift_right": [vp, vp, i32, i32, vp],
+    "lako_greedy_step": [vp, i64, i32, vp, i64, i32, vp, vp, vp, i64, i64, vp],
+}
+
+_lib = None
+
+
+def load(path: str | None = None):
+    """dlopen the kernel library.  `import torch` must already have happened in the process so that the
+    library binds to the HIP runtime torch loaded (it is linked without an rpath to /opt/rocm)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise LakoError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        f"(lako_amd/csrc/build.sh).  There is no CPU fallback.")
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        buf = C.create_string_buffer(512)
+        _lib.lako_last_error(buf, 512)
+        raise LakoError(f"{what} failed (rc={rc}): {buf.value.decode(errors='replace')}")

@@ -1,0 +1,657 @@
+// T5 attention for the FiD reader (HF5:144-173,281-369; same math as the reference's own
+// cross_attention_forward, src/model.py:286-349):  P = softmax_fp32(Q·Kᵀ + rel_bias + mask),
+// UNSCALED scores, dropout on P, O = P·V.  Forward + flash-style backward (P recomputed from the
+// saved row max / 1/rowsum, nothing of size Lq×Lk is ever stored).
+//
+// One workgroup (4 waves) per (batch row, head[, row-block group]).  One operand side lives in LDS
+// (16-B padded rows, staged once per workgroup), the other side is held per wave in registers as MFMA
+// fragments loaded straight from HBM; each wave owns 16-row blocks of the register side.
+//   forward, dQ pass : keys (K, V) in LDS, a wave owns 16 queries;   tile = Sᵀ[key][query]
+//   dK/dV pass       : queries (Q, dO) in LDS, a wave owns 16 keys;  tile = S[query][key]
+// In both cases the score tile comes out of the MFMA with the LDS-side index in the accumulator
+// registers and the register-side index on the lane, so (a) softmax row statistics of the forward are
+// 2 cross-lane shuffles, and (b) the tile is directly the B operand of the following product that
+// contracts over the LDS-side index (P·V, dSᵀ·K, Pᵀ·dO, dSᵀ·Q) — its A operand is a transposed read of the
+// LDS image (ds_read_b64_tr_b16 for bf16, plain dwords for fp32).  No P/dS round trip through LDS.
+// bf16: v_mfma_f32_16x16x32_bf16; fp32 (parity mode): v_mfma_f32_16x16x4_f32.
+#include <float.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int CH_MAX = 256;  // LDS-side rows per chunk
+
+template <typename T, int DK> struct AC {
+  static constexpr int ES = sizeof(T);
+  static constexpr int ROWB = DK * ES + 16;   // padded LDS row
+  static constexpr int CPR = DK * ES / 16;    // 16-B chunks per row
+  static constexpr int NF = DK * ES / 64;     // fragment steps along d (4 lane groups × 16 B)
+  static constexpr int NDB = DK / 16;         // 16-wide output blocks along d
+};
+
+struct AttnArgs {
+  // LDS-side / register-side tensors are selected per kernel from these
+  const char *q, *k, *v, *o, *dout;
+  char *out, *dq, *dk, *dv;
+  float* stats;        // [Bn, H, Lq, 2] = (row max, 1 / row sum)
+  const float* rel_bias;
+  float* drel;
+  const uint8_t* key_mask;
+  float* scores_out;
+  int64_t qsb, qst, ksb, kst, vsb, vst, osb, ost;  // strides in elements
+  int R, rel_off, causal, causal_off;
+  int Bn, H, Lq, Lk;
+  int chunk_rows;   // LDS-side rows per chunk (multiple of 32, <= CH_MAX)
+  int blocks_per_wg;  // register-side 16-row blocks per workgroup
+  uint32_t drop_thresh, drop_key;
+  float drop_scale;
+};
+
+template <int N> using FragArr = u32x4[N];
+template <int N> using AccArr = f32x4[N];
+
+template <typename T> struct Mma16;
+template <> struct Mma16<bf16_t> {
+  static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
+                                                   0, 0);
+  }
+};
+template <> struct Mma16<float> {
+  static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+    f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[e], c, 0, 0, 0);
+    return c;
+  }
+};
+
+// Stage rows [r0, r0 + nrows) of a strided [L, ·] tensor (row = `stride` elements, DK used) into a
+// padded LDS image; rows >= L are zero-filled (so padded keys/queries contribute exact zeros).
+template <typename T, int DK>
+__device__ __forceinline__ void stage_image(char* img, const char* base, int64_t stride, int r0, int nrows, int L) {
+  using C = AC<T, DK>;
+  for (int idx = threadIdx.x; idx < nrows * C::CPR; idx += 256) {
+    int row = idx / C::CPR, c = idx % C::CPR;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (r0 + row < L) v = *reinterpret_cast<const u32x4*>(base + (int64_t)(r0 + row) * stride * C::ES + c * 16);
+    *reinterpret_cast<u32x4*>(img + row * C::ROWB + c * 16) = v;
+  }
+}
+
+template <typename T, int DK>
+__device__ __forceinline__ void load_reg_frags(FragArr<AC<T, DK>::NF>& f, const char* base, int64_t stride, int row,
+                                               int L, int lane) {
+  using C = AC<T, DK>;
+  const int g = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < C::NF; ++i) {
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (row < L) v = *reinterpret_cast<const u32x4*>(base + (int64_t)row * stride * C::ES + (i * 4 + g) * 16);
+    f[i] = v;
+  }
+}
+
+// tile[LDS row = row0 + 4g + r][reg-side = lane & 15] = Σ_d X[row0 + ·][d] · Y[·][d]
+template <typename T, int DK>
+__device__ __forceinline__ f32x4 score_tile(const char* img, int row0, const FragArr<AC<T, DK>::NF>& yf, int lane) {
+  using C = AC<T, DK>;
+  const int g = lane >> 4;
+  const char* rp = img + (row0 + (lane & 15)) * C::ROWB + g * 16;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < C::NF; ++i) {
+    u32x4 xf = *reinterpret_cast<const u32x4*>(rp + i * 64);
+    acc = Mma16<T>::run(xf, yf[i], acc);
+  }
+  return acc;
+}
+
+// acc[db][r] (d = db*16 + 4g + r, reg-side = lane & 15) += Σ_{rows of the tile pair} X[row][d] · w[row][lane&15]
+// where w0 / w1 are the two 16-row tiles starting at LDS rows row0 and row0 + 16.
+template <typename T, int DK>
+__device__ __forceinline__ void pv_accumulate(AccArr<AC<T, DK>::NDB>& acc, f32x4 w0, f32x4 w1, const char* img,
+                                              int row0, int lane) {
+  using C = AC<T, DK>;
+  const int g = lane >> 4;
+  if constexpr (sizeof(T) == 2) {
+    bf16x8 bfrag;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      bfrag[e] = (bf16_t)w0[e];
+      bfrag[4 + e] = (bf16_t)w1[e];
+    }
+    const int q = (lane & 15) >> 2, p = lane & 3;
+    const char* a0 = img + (row0 + 4 * g + q) * C::ROWB + p * 8;
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db) {
+      s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + db * 32));
+      s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) s16x4*)(a0 + db * 32 + 16 * C::ROWB));
+      u32x2 u0 = __builtin_bit_cast(u32x2, t0), u1 = __builtin_bit_cast(u32x2, t1);
+      u32x4 afrag = {u0[0], u0[1], u1[0], u1[1]};
+      acc[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, afrag), bfrag, acc[db], 0, 0, 0);
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const f32x4 w = t == 0 ? w0 : w1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const char* ap = img + (row0 + t * 16 + 4 * g + r) * C::ROWB + (lane & 15) * 4;
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db) {
+          float av = *reinterpret_cast<const float*>(ap + db * 64);
+          acc[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w[r], acc[db], 0, 0, 0);
+        }
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ float group_max(float v) {  // across the 4 lane groups (same lane & 15)
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+// LDS carve (all offsets multiples of 16):  img1 | img2 | aux floats
+template <typename T, int DK> __host__ __device__ constexpr int img_bytes(int ch) { return ch * AC<T, DK>::ROWB; }
+
+// =============================================================================================
+// forward
+// =============================================================================================
+template <typename T, int DK>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+  using C = AC<T, DK>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int CH = a.chunk_rows;
+  char* Kimg = smem;
+  char* Vimg = smem + img_bytes<T, DK>(CH);
+  float* kflag = reinterpret_cast<float*>(smem + 2 * img_bytes<T, DK>(CH));  // [CH] 0 ok, 1 masked, 2 beyond Lk
+  float* bias_l = kflag + CH;                                                // [R]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, l15 = lane & 15;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int nqb = (a.Lq + 15) >> 4;
+  const int qb_begin = blockIdx.x * a.blocks_per_wg;
+  const int qb_end = min(nqb, qb_begin + a.blocks_per_wg);
+  const int nchunks = (a.Lk + CH - 1) / CH;
+  const char* qbase = a.q + ((int64_t)b * a.qsb + (int64_t)h * DK) * C::ES;
+  const char* kbase = a.k + ((int64_t)b * a.ksb + (int64_t)h * DK) * C::ES;
+  const char* vbase = a.v + ((int64_t)b * a.vsb + (int64_t)h * DK) * C::ES;
+  char* obase = a.out + ((int64_t)b * a.osb + (int64_t)h * DK) * C::ES;
+  const bool has_bias = a.rel_bias != nullptr;
+  if (has_bias)
+    for (int i = threadIdx.x; i < a.R; i += 256) bias_l[i] = a.rel_bias[(int64_t)h * a.R + i];
+
+  for (int qb0 = qb_begin; qb0 < qb_end; qb0 += 4) {
+    const int qb = qb0 + wave;
+    const bool active = qb < qb_end;
+    const int qi = qb * 16 + l15;  // this lane's query
+    u32x4 qf[C::NF];
+    load_reg_frags<T, DK>(qf, qbase, a.qst, active ? qi : a.Lq, a.Lq, lane);
+    float m = -INFINITY, lsum = 0.f;
+    f32x4 oacc[C::NDB];
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db) oacc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+      const int kc0 = ch * CH;
+      const int nk = min(CH, ((a.Lk - kc0 + 31) >> 5) << 5);  // rows used in this chunk (multiple of 32)
+      if (nchunks > 1 || qb0 == qb_begin) {
+        __syncthreads();
+        stage_image<T, DK>(Kimg, kbase, a.kst, kc0, nk, a.Lk);
+        stage_image<T, DK>(Vimg, vbase, a.vst, kc0, nk, a.Lk);
+        for (int i = threadIdx.x; i < nk; i += 256) {
+          int j = kc0 + i;
+          float f = 0.f;
+          if (j >= a.Lk) f = 2.f;
+          else if (a.key_mask && !a.key_mask[(int64_t)b * a.Lk + j]) f = 1.f;
+          kflag[i] = f;
+        }
+        __syncthreads();
+      }
+      if (!active) continue;
+      const int ntile = nk >> 4;
+      f32x4 s[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t)
+        if (t < ntile) s[t] = score_tile<T, DK>(Kimg, t * 16, qf, lane);
+      float cmax = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        if (t < ntile) {
+          const f32x4 kf = *reinterpret_cast<const f32x4*>(kflag + t * 16 + 4 * g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int j = kc0 + t * 16 + 4 * g + r;
+            float val = s[t][r];
+            if (has_bias) {
+              int bi = j - qi + a.rel_off;
+              if (bi >= 0 && bi < a.R) val += bias_l[bi];
+            }
+            bool masked = kf[r] == 1.f || (a.causal && j > qi + a.causal_off);
+            if (a.scores_out && qi < a.Lq && j < a.Lk)
+              a.scores_out[(((int64_t)b * a.H + h) * a.Lq + qi) * a.Lk + j] = masked ? 0.f : val;
+            if (masked) val = -FLT_MAX;
+            if (kf[r] == 2.f) val = -INFINITY;
+            s[t][r] = val;
+            cmax = fmaxf(cmax, val);
+          }
+        }
+      }
+      cmax = group_max(cmax);
+      const float m_new = fmaxf(m, cmax);
+      const float alpha = __expf(m - m_new);  // m = -inf on the first chunk → 0
+      float psum = 0.f;
+      const uint64_t didx0 = (((uint64_t)b * a.H + h) * a.Lq + (uint64_t)qi) * (uint64_t)a.Lk;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        if (t < ntile) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float p = __expf(s[t][r] - m_new);
+            psum += p;
+            if (a.drop_thresh) {
+              const int j = kc0 + t * 16 + 4 * g + r;
+              p = lako_keep(a.drop_key, didx0 + (uint64_t)j, a.drop_thresh) ? p * a.drop_scale : 0.f;
+            }
+            s[t][r] = p;
+          }
+        }
+      }
+      psum = group_sum(psum);
+      lsum = lsum * alpha + psum;
+      m = m_new;
+#pragma unroll
+      for (int db = 0; db < C::NDB; ++db) oacc[db] *= alpha;
+#pragma unroll
+      for (int tp = 0; tp < 8; ++tp)
+        if (2 * tp < ntile) pv_accumulate<T, DK>(oacc, s[2 * tp], s[2 * tp + 1], Vimg, tp * 32, lane);
+    }
+    if (active && qi < a.Lq) {
+      const float inv = 1.0f / lsum;
+      T* op = reinterpret_cast<T*>(obase + (int64_t)qi * a.ost * C::ES);
+#pragma unroll
+      for (int db = 0; db < C::NDB; ++db) store4(op + db * 16 + 4 * g, oacc[db] * inv);
+      if (g == 0 && a.stats) {
+        float* st = a.stats + (((int64_t)b * a.H + h) * a.Lq + qi) * 2;
+        st[0] = m;
+        st[1] = inv;
+      }
+    }
+  }
+}
+
+// =============================================================================================
+// backward.  MODE 0: dQ pass (keys in LDS, wave owns queries)   MODE 1: dK/dV pass (queries in LDS)
+// =============================================================================================
+template <typename T, int DK, int MODE>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
+  using C = AC<T, DK>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int CH = a.chunk_rows;
+  char* X1 = smem;                               // MODE 0: K   MODE 1: Q
+  char* X2 = smem + img_bytes<T, DK>(CH);        // MODE 0: V   MODE 1: dO
+  float* aux0 = reinterpret_cast<float*>(smem + 2 * img_bytes<T, DK>(CH));  // MODE 0: kflag   MODE 1: row max
+  float* aux1 = aux0 + CH;                       // MODE 1: 1/rowsum
+  float* aux2 = aux1 + CH;                       // MODE 1: delta
+  float* bias_l = aux2 + CH;                     // [R]
+  float* drel_l = bias_l + a.R;                  // [R] (MODE 0)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, l15 = lane & 15;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int LX = MODE == 0 ? a.Lk : a.Lq;  // LDS side length
+  const int LY = MODE == 0 ? a.Lq : a.Lk;  // register side length
+  const int nyb = (LY + 15) >> 4;
+  const int yb_begin = blockIdx.x * a.blocks_per_wg;
+  const int yb_end = min(nyb, yb_begin + a.blocks_per_wg);
+  const int nchunks = (LX + CH - 1) / CH;
+  const int64_t hoff = (int64_t)h * DK;
+  const char* qbase = a.q + ((int64_t)b * a.qsb + hoff) * C::ES;
+  const char* kbase = a.k + ((int64_t)b * a.ksb + hoff) * C::ES;
+  const char* vbase = a.v + ((int64_t)b * a.vsb + hoff) * C::ES;
+  const char* obase = a.o + ((int64_t)b * a.osb + hoff) * C::ES;
+  const char* dobase = a.dout + ((int64_t)b * a.osb + hoff) * C::ES;
+  const float* stats = a.stats + ((int64_t)b * a.H + h) * a.Lq * 2;
+  const bool has_bias = a.rel_bias != nullptr;
+  const bool want_drel = MODE == 0 && a.drel != nullptr;
+  if (has_bias)
+    for (int i = threadIdx.x; i < a.R; i += 256) bias_l[i] = a.rel_bias[(int64_t)h * a.R + i];
+  if (want_drel)
+    for (int i = threadIdx.x; i < a.R; i += 256) drel_l[i] = 0.f;
+
+  for (int yb0 = yb_begin; yb0 < yb_end; yb0 += 4) {
+    const int yb = yb0 + wave;
+    const bool active = yb < yb_end;
+    const int yi = active ? yb * 16 + l15 : LY;  // this lane's register-side row (query in MODE 0, key in MODE 1)
+    u32x4 y1[C::NF], y2[C::NF];
+    float m_q = 0.f, invl_q = 0.f, delta_q = 0.f;
+    bool key_masked = false;
+    if constexpr (MODE == 0) {
+      load_reg_frags<T, DK>(y1, qbase, a.qst, yi, a.Lq, lane);
+      load_reg_frags<T, DK>(y2, dobase, a.ost, yi, a.Lq, lane);
+      u32x4 of[C::NF];
+      load_reg_frags<T, DK>(of, obase, a.ost, yi, a.Lq, lane);
+      float part = 0.f;
+#pragma unroll
+      for (int i = 0; i < C::NF; ++i) {
+        if constexpr (sizeof(T) == 2) {
+          bf16x8 dv = __builtin_bit_cast(bf16x8, y2[i]), ov = __builtin_bit_cast(bf16x8, of[i]);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) part += (float)dv[e] * (float)ov[e];
+        } else {
+          f32x4 dv = __builtin_bit_cast(f32x4, y2[i]), ov = __builtin_bit_cast(f32x4, of[i]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) part += dv[e] * ov[e];
+        }
+      }
+      delta_q = group_sum(part);
+      if (yi < a.Lq) {
+        m_q = stats[yi * 2];
+        invl_q = stats[yi * 2 + 1];
+      }
+    } else {
+      load_reg_frags<T, DK>(y1, kbase, a.kst, yi, a.Lk, lane);
+      load_reg_frags<T, DK>(y2, vbase, a.vst, yi, a.Lk, lane);
+      if (a.key_mask && yi < a.Lk) key_masked = !a.key_mask[(int64_t)b * a.Lk + yi];
+    }
+    f32x4 acc1[C::NDB], acc2[C::NDB];  // MODE 0: dQ (acc1)   MODE 1: dK (acc1), dV (acc2)
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db) {
+      acc1[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc2[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+      const int x0 = ch * CH;
+      const int nx = min(CH, ((LX - x0 + 31) >> 5) << 5);
+      if (nchunks > 1 || yb0 == yb_begin) {
+        __syncthreads();
+        if constexpr (MODE == 0) {
+          stage_image<T, DK>(X1, kbase, a.kst, x0, nx, a.Lk);
+          stage_image<T, DK>(X2, vbase, a.vst, x0, nx, a.Lk);
+          for (int i = threadIdx.x; i < nx; i += 256) {
+            int j = x0 + i;
+            float f = 0.f;
+            if (j >= a.Lk) f = 2.f;
+            else if (a.key_mask && !a.key_mask[(int64_t)b * a.Lk + j]) f = 1.f;
+            aux0[i] = f;
+          }
+        } else {
+          stage_image<T, DK>(X1, qbase, a.qst, x0, nx, a.Lq);
+          stage_image<T, DK>(X2, dobase, a.ost, x0, nx, a.Lq);
+          for (int i = threadIdx.x; i < nx; i += 256) {
+            int qi = x0 + i;
+            float mm = 0.f, il = 0.f, dl = 0.f;
+            if (qi < a.Lq) {
+              mm = stats[qi * 2];
+              il = stats[qi * 2 + 1];
+              const T* dop = reinterpret_cast<const T*>(dobase + (int64_t)qi * a.ost * C::ES);
+              const T* op = reinterpret_cast<const T*>(obase + (int64_t)qi * a.ost * C::ES);
+#pragma unroll 4
+              for (int c = 0; c < DK; c += 4) {
+                f32x4 dv = load4(dop + c), ov = load4(op + c);
+                dl += dv[0] * ov[0] + dv[1] * ov[1] + dv[2] * ov[2] + dv[3] * ov[3];
+              }
+            }
+            aux0[i] = mm;
+            aux1[i] = il;
+            aux2[i] = dl;
+          }
+        }
+        __syncthreads();
+      }
+      if (!active) continue;
+      const int npair = nx >> 5;
+      for (int tp = 0; tp < npair; ++tp) {
+        f32x4 pt[2], ds[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int row0 = tp * 32 + t * 16;
+          f32x4 sv = score_tile<T, DK>(X1, row0, y1, lane);
+          f32x4 dp = score_tile<T, DK>(X2, row0, y2, lane);
+          f32x4 fl = {0.f, 0.f, 0.f, 0.f}, mq = {0.f, 0.f, 0.f, 0.f}, il = mq, dl = mq;
+          if constexpr (MODE == 0) fl = *reinterpret_cast<const f32x4*>(aux0 + row0 + 4 * g);
+          else {
+            mq = *reinterpret_cast<const f32x4*>(aux0 + row0 + 4 * g);
+            il = *reinterpret_cast<const f32x4*>(aux1 + row0 + 4 * g);
+            dl = *reinterpret_cast<const f32x4*>(aux2 + row0 + 4 * g);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int xi = x0 + row0 + 4 * g + r;
+            const int key = MODE == 0 ? xi : yi;
+            const int qi = MODE == 0 ? yi : xi;
+            const bool valid = key < a.Lk && qi < a.Lq;
+            float val = sv[r];
+            int bi = key - qi + a.rel_off;
+            const bool bi_ok = bi >= 0 && bi < a.R;
+            if (has_bias && bi_ok) val += bias_l[bi];
+            bool masked = (MODE == 0 ? fl[r] == 1.f : key_masked) || (a.causal && key > qi + a.causal_off);
+            if (masked) val = -FLT_MAX;
+            const float mm = MODE == 0 ? m_q : mq[r];
+            const float inv = MODE == 0 ? invl_q : il[r];
+            const float dlt = MODE == 0 ? delta_q : dl[r];
+            float p = valid ? __expf(val - mm) * inv : 0.f;
+            float dpd = dp[r];
+            float pd = p;
+            if (a.drop_thresh) {
+              uint64_t idx = (((uint64_t)b * a.H + h) * a.Lq + (uint64_t)qi) * (uint64_t)a.Lk + (uint64_t)key;
+              bool keep = lako_keep(a.drop_key, idx, a.drop_thresh);
+              dpd = keep ? dpd * a.drop_scale : 0.f;
+              pd = keep ? p * a.drop_scale : 0.f;
+            }
+            float d = p * (dpd - dlt);
+            pt[t][r] = pd;
+            ds[t][r] = d;
+            if (want_drel && valid && bi_ok && d != 0.f) atomicAdd(&drel_l[bi], d);
+          }
+        }
+        if constexpr (MODE == 0) {
+          pv_accumulate<T, DK>(acc1, ds[0], ds[1], X1, tp * 32, lane);  // dQᵀ += Kᵀ·dSᵀ
+        } else {
+          pv_accumulate<T, DK>(acc1, ds[0], ds[1], X1, tp * 32, lane);  // dKᵀ += Qᵀ·dS
+          pv_accumulate<T, DK>(acc2, pt[0], pt[1], X2, tp * 32, lane);  // dVᵀ += dOᵀ·P̃
+        }
+      }
+    }
+    if (active && yi < LY) {
+      if constexpr (MODE == 0) {
+        T* op = reinterpret_cast<T*>(a.dq + ((int64_t)b * a.qsb + (int64_t)yi * a.qst + hoff) * C::ES);
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db) store4(op + db * 16 + 4 * g, acc1[db]);
+      } else {
+        T* kp = reinterpret_cast<T*>(a.dk + ((int64_t)b * a.ksb + (int64_t)yi * a.kst + hoff) * C::ES);
+        T* vp = reinterpret_cast<T*>(a.dv + ((int64_t)b * a.vsb + (int64_t)yi * a.vst + hoff) * C::ES);
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db) {
+          store4(kp + db * 16 + 4 * g, acc1[db]);
+          store4(vp + db * 16 + 4 * g, acc2[db]);
+        }
+      }
+    }
+  }
+  if (want_drel) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.R; i += 256) {
+      float v = drel_l[i];
+      if (v != 0.f) atomicAdd(a.drel + (int64_t)h * a.R + i, v);
+    }
+  }
+}
+
+template <typename T, int DK>
+int lds_bytes_fwd(int ch, int R) { return 2 * img_bytes<T, DK>(ch) + (ch + R + 8) * 4; }
+template <typename T, int DK>
+int lds_bytes_bwd(int ch, int R) { return 2 * img_bytes<T, DK>(ch) + (3 * ch + 2 * R + 8) * 4; }
+
+inline int pick_chunk(int L) {
+  int ch = ((L + 31) / 32) * 32;
+  return ch > CH_MAX ? CH_MAX : ch;
+}
+
+// raise the kernel's dynamic-LDS limit only when a launch needs more than any earlier one (`cur` is
+// a per-instantiation static owned by the caller)
+template <typename K>
+void set_lds_attr(K kern, int bytes, int& cur) {
+  if (bytes <= cur) return;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  cur = bytes;
+}
+
+// choose register-side blocks per workgroup: all of them when there are already plenty of workgroups,
+// otherwise split so the grid reaches ~1024 workgroups (no LDS-side merge needed: blocks are independent)
+inline int pick_blocks_per_wg(int nblocks, int64_t bh) {
+  int64_t want = 1024;
+  if (bh >= want || nblocks <= 4) return ((nblocks + 3) / 4) * 4;
+  int groups = (int)((want + bh - 1) / bh);
+  int per = (nblocks + groups - 1) / groups;
+  per = ((per + 3) / 4) * 4;
+  return per < 4 ? 4 : per;
+}
+
+template <typename T, int DK>
+int run_fwd(AttnArgs& a, hipStream_t s) {
+  a.chunk_rows = pick_chunk(a.Lk);
+  const int nqb = (a.Lq + 15) / 16;
+  a.blocks_per_wg = pick_blocks_per_wg(nqb, (int64_t)a.Bn * a.H);
+  const int lds = lds_bytes_fwd<T, DK>(a.chunk_rows, a.R);
+  static int cur = 0;
+  set_lds_attr(&attn_fwd_kernel<T, DK>, lds, cur);
+  dim3 grid((nqb + a.blocks_per_wg - 1) / a.blocks_per_wg, a.H, a.Bn);
+  hipLaunchKernelGGL((attn_fwd_kernel<T, DK>), grid, dim3(256), lds, s, a);
+  return 0;
+}
+
+template <typename T, int DK>
+int run_bwd(AttnArgs& a, hipStream_t s) {
+  {  // dQ pass
+    AttnArgs q = a;
+    q.chunk_rows = pick_chunk(a.Lk);
+    const int nqb = (a.Lq + 15) / 16;
+    q.blocks_per_wg = pick_blocks_per_wg(nqb, (int64_t)a.Bn * a.H);
+    const int lds = lds_bytes_bwd<T, DK>(q.chunk_rows, a.R);
+    static int cur0 = 0;
+    set_lds_attr(&attn_bwd_kernel<T, DK, 0>, lds, cur0);
+    dim3 grid((nqb + q.blocks_per_wg - 1) / q.blocks_per_wg, a.H, a.Bn);
+    hipLaunchKernelGGL((attn_bwd_kernel<T, DK, 0>), grid, dim3(256), lds, s, q);
+  }
+  {  // dK/dV pass
+    AttnArgs k = a;
+    k.chunk_rows = pick_chunk(a.Lq);
+    const int nkb = (a.Lk + 15) / 16;
+    k.blocks_per_wg = pick_blocks_per_wg(nkb, (int64_t)a.Bn * a.H);
+    const int lds = lds_bytes_bwd<T, DK>(k.chunk_rows, a.R);
+    static int cur1 = 0;
+    set_lds_attr(&attn_bwd_kernel<T, DK, 1>, lds, cur1);
+    dim3 grid((nkb + k.blocks_per_wg - 1) / k.blocks_per_wg, a.H, a.Bn);
+    hipLaunchKernelGGL((attn_bwd_kernel<T, DK, 1>), grid, dim3(256), lds, s, k);
+  }
+  return 0;
+}
+
+int check_common(const char* fn, int Bn, int H, int Lq, int Lk, int d_head, int dtype, int64_t qst, int64_t kst,
+                 int64_t vst, int64_t ost, const void* rel_bias, int R, float p) {
+  if (!(Bn > 0 && H > 0 && Lq > 0 && Lk > 0)) { lako_set_error("%s: bad dims", fn); return LAKO_E_BADARG; }
+  if (!(Bn < 65536 && H < 65536)) { lako_set_error("%s: Bn/H too large for the grid", fn); return LAKO_E_BADARG; }
+  if (!(dtype == LAKO_F32 || dtype == LAKO_BF16)) { lako_set_error("%s: bad dtype", fn); return LAKO_E_BADARG; }
+  if (!(d_head == 32 || d_head == 64)) {
+    lako_set_error("%s: d_head=%d unsupported (32 or 64)", fn, d_head);
+    return LAKO_E_UNSUPPORTED;
+  }
+  const int esz = dtype == LAKO_F32 ? 4 : 2;
+  if ((qst * esz) % 16 || (kst * esz) % 16 || (vst * esz) % 16 || (ost * esz) % 16) {
+    lako_set_error("%s: token strides must be multiples of 16 bytes", fn);
+    return LAKO_E_ALIGN;
+  }
+  if (rel_bias && !(R > 0 && R <= 4096)) { lako_set_error("%s: bad R=%d", fn, R); return LAKO_E_BADARG; }
+  if (!(p >= 0.f && p < 1.f)) { lako_set_error("%s: dropout p out of range", fn); return LAKO_E_BADARG; }
+  return LAKO_OK;
+}
+
+}  // namespace
+
+#define ATTN_DISPATCH(dtype, dhead, FN, args, s)                    \
+  if ((dtype) == LAKO_BF16) {                                       \
+    if ((dhead) == 64) FN<bf16_t, 64>(args, s);                     \
+    else FN<bf16_t, 32>(args, s);                                   \
+  } else {                                                          \
+    if ((dhead) == 64) FN<float, 64>(args, s);                      \
+    else FN<float, 32>(args, s);                                    \
+  }
+
+extern "C" int lako_attn_fwd(const lako_attn_fwd_t* p, lako_stream_t stream) {
+  LAKO_CHECK_ARG(p != nullptr, "lako_attn_fwd: null params");
+  int rc = check_common("lako_attn_fwd", p->Bn, p->H, p->Lq, p->Lk, p->d_head, p->dtype, p->q_stride_t, p->k_stride_t,
+                        p->v_stride_t, p->o_stride_t, p->rel_bias, p->R, p->drop.p);
+  if (rc) return rc;
+  LAKO_CHECK_ALIGN(p->q, 16);
+  LAKO_CHECK_ALIGN(p->k, 16);
+  LAKO_CHECK_ALIGN(p->v, 16);
+  LAKO_CHECK_ALIGN(p->out, 8);
+  AttnArgs a = {};
+  a.q = (const char*)p->q;
+  a.k = (const char*)p->k;
+  a.v = (const char*)p->v;
+  a.out = (char*)p->out;
+  a.stats = p->lse;
+  a.rel_bias = p->rel_bias;
+  a.key_mask = p->key_mask;
+  a.scores_out = p->scores_out;
+  a.qsb = p->q_stride_b; a.qst = p->q_stride_t; a.ksb = p->k_stride_b; a.kst = p->k_stride_t;
+  a.vsb = p->v_stride_b; a.vst = p->v_stride_t; a.osb = p->o_stride_b; a.ost = p->o_stride_t;
+  a.R = p->rel_bias ? p->R : 0;
+  a.rel_off = p->rel_off;
+  a.causal = p->causal;
+  a.causal_off = p->causal_off;
+  a.Bn = p->Bn; a.H = p->H; a.Lq = p->Lq; a.Lk = p->Lk;
+  a.drop_thresh = p->drop.p > 0.f ? lako_drop_thresh(p->drop.p) : 0u;
+  a.drop_scale = p->drop.p > 0.f ? 1.0f / (1.0f - p->drop.p) : 1.0f;
+  a.drop_key = lako_drop_key(p->drop.seed, p->drop.site);
+  ATTN_DISPATCH(p->dtype, p->d_head, run_fwd, a, (hipStream_t)stream);
+  LAKO_LAUNCH_CHECK();
+  return LAKO_OK;
+}
+
+extern "C" int lako_attn_bwd(const lako_attn_bwd_t* p, lako_stream_t stream) {
+  LAKO_CHECK_ARG(p != nullptr, "lako_attn_bwd: null params");
+  int rc = check_common("lako_attn_bwd", p->Bn, p->H, p->Lq, p->Lk, p->d_head, p->dtype, p->q_stride_t, p->k_stride_t,
+                        p->v_stride_t, p->o_stride_t, p->rel_bias, p->R, p->drop.p);
+  if (rc) return rc;
+  LAKO_CHECK_ARG(p->lse && p->out && p->dout && p->dq_out && p->dk_out && p->dv_out, "lako_attn_bwd: null tensor");
+  LAKO_CHECK_ARG(!p->drel || p->rel_bias, "lako_attn_bwd: drel without rel_bias");
+  AttnArgs a = {};
+  a.q = (const char*)p->q;
+  a.k = (const char*)p->k;
+  a.v = (const char*)p->v;
+  a.o = (const char*)p->out;
+  a.dout = (const char*)p->dout;
+  a.dq = (char*)p->dq_out;
+  a.dk = (char*)p->dk_out;
+  a.dv = (char*)p->dv_out;
+  a.stats = const_cast<float*>(p->lse);
+  a.rel_bias = p->rel_bias;
+  a.drel = p->drel;
+  a.key_mask = p->key_mask;
+  a.qsb = p->q_stride_b; a.qst = p->q_stride_t; a.ksb = p->k_stride_b; a.kst = p->k_stride_t;
+  a.vsb = p->v_stride_b; a.vst = p->v_stride_t; a.osb = p->o_stride_b; a.ost = p->o_stride_t;
+  a.R = p->rel_bias ? p->R : 0;
+  a.rel_off = p->rel_off;
+  a.causal = p->causal;
+  a.causal_off = p->causal_off;
+  a.Bn = p->Bn; a.H = p->H; a.Lq = p->Lq; a.Lk = p->Lk;
+  a.drop_thresh = p->drop.p > 0.f ? lako_drop_thresh(p->drop.p) : 0u;
+  a.drop_scale = p->drop.p > 0.f ? 1.0f / (1.0f - p->drop.p) : 1.0f;
+  a.drop_key = lako_drop_key(p->drop.seed, p->drop.site);
+  ATTN_DISPATCH(p->dtype, p->d_head, run_bwd, a, (hipStream_t)stream);
+  LAKO_LAUNCH_CHECK();
+  return LAKO_OK;
+}

@@ -1,0 +1,475 @@
+// MFMA GEMMs for the FiD-T5 reader: every nn.Linear(bias=False) of HF5:304,325-326,367 (q,k,v,o),
+// HF5:83-94 (wi,wo) and HF5:1047 (lm_head), forward and backward.
+//
+//   gemm_nt : C[M,N] = epilogue(alpha * A[M,K] · B[N,K]ᵀ)        activations × weights ([out,in] layout)
+//   gemm_tn : C[M,N] += alpha * A[K,M]ᵀ · B[K,N]   (fp32, split-K) weight gradients dW = dYᵀ·X
+//
+// Design (gfx950): 128×128 output tile per 256-thread workgroup (4 waves as 2×2, 64×64 per wave =
+// 4×4 MFMA 16×16 tiles), K stepped in 128-BYTE slices so the bf16 (K=64) and fp32 (K=32) variants
+// share one LDS image and one staging routine.  Global→LDS goes through `buffer_load … lds`
+// (16 B/lane, no VGPR round trip; out-of-range rows / K-tail chunks are zero-filled by the buffer
+// range check), double-buffered.  The LDS image is lane-linear (a DMA constraint), so the
+// bank-conflict swizzle is applied to the per-lane SOURCE address and again on the fragment read.
+// bf16 uses v_mfma_f32_16x16x32_bf16, fp32 uses the exact-f32 v_mfma_f32_16x16x4_f32 (parity mode).
+// Workgroup ids are remapped so that the tiles sharing an A row-panel run on one XCD (one L2).
+#include "common.h"
+
+namespace {
+
+constexpr int TM = 128, TN_ = 128, TKB = 128;  // tile rows, tile cols, K bytes per step
+constexpr int TILE_BYTES = TM * TKB;            // 16 KiB per operand per buffer
+constexpr int GEMM_LDS = 4 * TILE_BYTES;        // A,B × 2 buffers
+
+struct NtArgs {
+  const char* A;
+  const char* B;
+  char* C;
+  const char* resid;
+  const char* aux;
+  int M, N, K;
+  int64_t lda, ldb, ldc, ldr, ldaux;  // in elements
+  float alpha, aux_scale, drop_scale;
+  int flags;
+  uint32_t drop_thresh, drop_key;
+  int tiles_m, tiles_n;
+};
+
+// bijective XCD-aware remap (blocks b and b+8 share an XCD): give each XCD a contiguous id range
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+  int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + (bid >> 3);
+}
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
+                                                   0, 0);
+  }
+};
+template <> struct Mma<float> {
+  static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
+    f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[e], c, 0, 0, 0);
+    return c;
+  }
+};
+
+// Stage one [128 rows][128 B] operand slice: LDS chunk (row, cp) holds logical 16-B chunk
+// c = cp ^ ((row >> 1) & 7) of that row.  `base` points at (row0, kbyte0) of the operand.
+__device__ __forceinline__ void stage_rows(char* lds_tile, const char* base, int rows_valid, int64_t ld_bytes,
+                                           int kbytes_left, int wave, int lane) {
+  uint32_t nrec = (rows_valid > 0 && kbytes_left > 0)
+                      ? (uint32_t)((int64_t)(rows_valid - 1) * ld_bytes + (kbytes_left < TKB ? kbytes_left : TKB))
+                      : 0u;
+  auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)nrec, 0x00020000);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int inst = wave * 4 + i;
+    int row = inst * 8 + (lane >> 3);
+    int cp = lane & 7;
+    int c = cp ^ ((row >> 1) & 7);
+    bool ok = (row < rows_valid) && (c * 16 < kbytes_left);
+    uint32_t voff = ok ? (uint32_t)(row * ld_bytes + c * 16) : 0xFFFFFFF0u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + inst * 1024), 16, (int)voff, 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ u32x4 read_frag_rows(const char* lds_tile, int row, int chunk) {
+  int cp = chunk ^ ((row >> 1) & 7);
+  return *reinterpret_cast<const u32x4*>(lds_tile + row * TKB + cp * 16);
+}
+
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(NtArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int nwg = a.tiles_m * a.tiles_n;
+  const int tid = xcd_remap(blockIdx.x, nwg);
+  const int tile_m = tid / a.tiles_n, tile_n = tid % a.tiles_n;
+  const int m0 = tile_m * TM, n0 = tile_n * TN_;
+  const int rows_a = min(TM, a.M - m0), rows_b = min(TN_, a.N - n0);
+  const int64_t lda_b = a.lda * sizeof(T), ldb_b = a.ldb * sizeof(T);
+  const int kbytes = a.K * (int)sizeof(T);
+  const char* Abase = a.A + (int64_t)m0 * lda_b;
+  const char* Bbase = a.B + (int64_t)n0 * ldb_b;
+  const int nk = (kbytes + TKB - 1) / TKB;
+
+  f32x4 acc[4][4];  // [nt][mt]; element r of lane (l&15, g): C[m = mt*16 + (l&15)][n = nt*16 + 4g + r]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  char* As0 = smem;
+  char* Bs0 = smem + TILE_BYTES;
+  stage_rows(As0, Abase, rows_a, lda_b, kbytes, wave, lane);
+  stage_rows(Bs0, Bbase, rows_b, ldb_b, kbytes, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int r16 = lane & 15, g = lane >> 4;
+  for (int t = 0; t < nk; ++t) {
+    const int cur = t & 1;
+    char* As = smem + cur * 2 * TILE_BYTES;
+    char* Bs = As + TILE_BYTES;
+    if (t + 1 < nk) {
+      char* An = smem + (cur ^ 1) * 2 * TILE_BYTES;
+      int koff = (t + 1) * TKB;
+      stage_rows(An, Abase + koff, rows_a, lda_b, kbytes - koff, wave, lane);
+      stage_rows(An + TILE_BYTES, Bbase + koff, rows_b, ldb_b, kbytes - koff, wave, lane);
+    }
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      u32x4 af[4], bf[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) af[mt] = read_frag_rows(As, wr * 64 + mt * 16 + r16, kh * 4 + g);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) bf[nt] = read_frag_rows(Bs, wc * 64 + nt * 16 + r16, kh * 4 + g);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = Mma<T>::run(bf[nt], af[mt], acc[nt][mt]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue -------------------------------------------------------------------------------
+  TO* C = reinterpret_cast<TO*>(a.C);
+  const TO* R = reinterpret_cast<const TO*>(a.resid);
+  const T* X = reinterpret_cast<const T*>(a.aux);
+  const bool relu = a.flags & LAKO_EPI_RELU, has_res = a.flags & LAKO_EPI_RESID,
+             auxm = a.flags & LAKO_EPI_AUXMASK, atomic = a.flags & LAKO_EPI_ATOMIC;
+  const bool drop = a.drop_thresh != 0;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int m = m0 + wr * 64 + mt * 16 + r16;
+    if (m >= a.M) continue;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int n = n0 + wc * 64 + nt * 16 + 4 * g;
+      if (n >= a.N) continue;  // N % 4 == 0: a group of 4 is all in or all out
+      f32x4 v = acc[nt][mt] * a.alpha;
+      if (relu) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      if (auxm) {
+        f32x4 x = load4(X + (int64_t)m * a.ldaux + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = x[r] > 0.f ? v[r] * a.aux_scale : 0.f;
+      }
+      if (drop) {
+        uint64_t idx = (uint64_t)m * (uint64_t)a.N + (uint64_t)n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = lako_keep(a.drop_key, idx + r, a.drop_thresh) ? v[r] * a.drop_scale : 0.f;
+      }
+      if (has_res) {
+        f32x4 x = load4(R + (int64_t)m * a.ldr + n);
+        v += x;
+      }
+      TO* cp = C + (int64_t)m * a.ldc + n;
+      if constexpr (sizeof(TO) == 4) {
+        if (atomic) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) atomicAdd(reinterpret_cast<float*>(cp) + r, v[r]);
+          continue;
+        }
+      }
+      store4(cp, v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// TN: C[M,N] += alpha * Aᵀ·B, A [K,M], B [K,N]: the reduction index is the ROW of both operands.
+// LDS image per operand: [KR k-rows][128 cols] (bf16: 64 rows × 256 B, fp32: 32 rows × 512 B).
+// bf16 fragments come from ds_read_b64_tr_b16 (hardware 4×16 transpose read); fp32 fragments are
+// single dwords.  bf16 image swizzle: 32-B slot s of row r sits at slot s ^ key(r),
+// key(r) = (r & 3) | (((r >> 3) & 1) << 2): the 8 rows one half-wave touches land in 8 slots.
+// ---------------------------------------------------------------------------------------------
+struct TnArgs {
+  const char* A;
+  const char* B;
+  float* C;
+  int M, N, K;
+  int64_t lda, ldb, ldc;
+  float alpha;
+  int tiles_m, tiles_n, split_k, k_chunk;  // k_chunk: rows of K per split (multiple of 64)
+};
+
+template <typename T> struct TnGeom;
+template <> struct TnGeom<bf16_t> { static constexpr int KR = 64, ROWB = 256, ROWS_PER_INST = 4; };
+template <> struct TnGeom<float> { static constexpr int KR = 32, ROWB = 512, ROWS_PER_INST = 2; };
+
+__device__ __forceinline__ int tn_key(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
+template <typename T>
+__device__ __forceinline__ void stage_cols(char* lds_tile, const char* base, int krows_valid, int64_t ld_bytes,
+                                           int colbytes_valid, int wave, int lane) {
+  using G = TnGeom<T>;
+  uint32_t nrec = (krows_valid > 0 && colbytes_valid > 0)
+                      ? (uint32_t)((int64_t)(krows_valid - 1) * ld_bytes + min(colbytes_valid, G::ROWB))
+                      : 0u;
+  auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)nrec, 0x00020000);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int inst = wave * 4 + i;
+    int row, cb;
+    if constexpr (sizeof(T) == 2) {
+      row = inst * 4 + (lane >> 4);
+      int cp = lane & 15;
+      int c = cp ^ (tn_key(row) << 1);
+      cb = c * 16;
+    } else {
+      row = inst * 2 + (lane >> 5);
+      cb = (lane & 31) * 16;
+    }
+    bool ok = (row < krows_valid) && (cb < colbytes_valid);
+    uint32_t voff = ok ? (uint32_t)(row * ld_bytes + cb) : 0xFFFFFFF0u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + inst * 1024), 16, (int)voff, 0, 0, 0);
+  }
+}
+
+// bf16: 8 k-values (k = kk*32 + 8g + e) of column c0 + (lane & 15)
+__device__ __forceinline__ u32x4 read_frag_tr(const char* lds_tile, int kk, int c0, int lane) {
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const int s = c0 >> 4;
+  u32x4 out;
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk) {
+    int row = kk * 32 + 8 * g + 4 * blk + q;
+    const char* addr = lds_tile + row * 256 + ((s ^ tn_key(row)) * 32) + p * 8;
+    s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(addr));
+    u32x2 u = __builtin_bit_cast(u32x2, t);
+    out[2 * blk] = u[0];
+    out[2 * blk + 1] = u[1];
+  }
+  return out;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs a) {
+  using G = TnGeom<T>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int ntile = a.tiles_m * a.tiles_n;
+  const int split = blockIdx.x / ntile;
+  const int tid = blockIdx.x % ntile;
+  const int tile_m = tid / a.tiles_n, tile_n = tid % a.tiles_n;
+  const int m0 = tile_m * TM, n0 = tile_n * TN_;
+  const int k_begin = split * a.k_chunk;
+  const int k_end = min(a.K, k_begin + a.k_chunk);
+  if (k_begin >= k_end) return;
+  const int64_t lda_b = a.lda * sizeof(T), ldb_b = a.ldb * sizeof(T);
+  const int acols_b = (a.M - m0) * (int)sizeof(T), bcols_b = (a.N - n0) * (int)sizeof(T);
+  const char* Abase = a.A + (int64_t)k_begin * lda_b + (int64_t)m0 * sizeof(T);
+  const char* Bbase = a.B + (int64_t)k_begin * ldb_b + (int64_t)n0 * sizeof(T);
+  const int nk = (k_end - k_begin + G::KR - 1) / G::KR;
+
+  f32x4 acc[4][4];  // [mt][nt]; element r of lane (l&15, g): C[m = mt*16 + 4g + r][n = nt*16 + (l&15)]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  stage_cols<T>(smem, Abase, k_end - k_begin, lda_b, acols_b, wave, lane);
+  stage_cols<T>(smem + TILE_BYTES, Bbase, k_end - k_begin, ldb_b, bcols_b, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int r16 = lane & 15, g = lane >> 4;
+  for (int t = 0; t < nk; ++t) {
+    const int cur = t & 1;
+    const char* As = smem + cur * 2 * TILE_BYTES;
+    const char* Bs = As + TILE_BYTES;
+    if (t + 1 < nk) {
+      char* An = smem + (cur ^ 1) * 2 * TILE_BYTES;
+      int kr = (t + 1) * G::KR;
+      stage_cols<T>(An, Abase + (int64_t)kr * lda_b, k_end - k_begin - kr, lda_b, acols_b, wave, lane);
+      stage_cols<T>(An + TILE_BYTES, Bbase + (int64_t)kr * ldb_b, k_end - k_begin - kr, ldb_b, bcols_b, wave, lane);
+    }
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        u32x4 af[4], bf[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) af[mt] = read_frag_tr(As, kk, wr * 64 + mt * 16, lane);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) bf[nt] = read_frag_tr(Bs, kk, wc * 64 + nt * 16, lane);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = Mma<bf16_t>::run(af[mt], bf[nt], acc[mt][nt]);
+      }
+    } else {
+#pragma unroll
+      for (int kq = 0; kq < 8; ++kq) {  // 8 × (k = 4) per 32-row slice
+        float af[4], bf[4];
+        const int row = kq * 4 + g;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+          af[mt] = *reinterpret_cast<const float*>(As + row * 512 + (wr * 64 + mt * 16 + r16) * 4);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          bf[nt] = *reinterpret_cast<const float*>(Bs + row * 512 + (wc * 64 + nt * 16 + r16) * 4);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wr * 64 + mt * 16 + 4 * g + r;
+      if (m >= a.M) continue;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + wc * 64 + nt * 16 + r16;
+        if (n < a.N) atomicAdd(a.C + (int64_t)m * a.ldc + n, acc[mt][nt][r] * a.alpha);
+      }
+    }
+}
+
+template <typename T, typename TO>
+int launch_nt(const NtArgs& a, hipStream_t s) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, TO>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((gemm_nt_kernel<T, TO>), dim3(a.tiles_m * a.tiles_n), dim3(256), GEMM_LDS, s, a);
+  return 0;
+}
+
+template <typename T>
+int launch_tn(const TnArgs& a, hipStream_t s) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<T>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((gemm_tn_kernel<T>), dim3(a.tiles_m * a.tiles_n * a.split_k), dim3(256), GEMM_LDS, s, a);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int lako_gemm_nt(const lako_gemm_nt_t* p, lako_stream_t stream) {
+  LAKO_CHECK_ARG(p != nullptr, "lako_gemm_nt: null params");
+  LAKO_CHECK_ARG(p->M > 0 && p->N > 0 && p->K > 0, "lako_gemm_nt: bad dims M=%lld N=%lld K=%lld", (long long)p->M,
+                 (long long)p->N, (long long)p->K);
+  LAKO_CHECK_ARG(p->in_dtype == LAKO_F32 || p->in_dtype == LAKO_BF16, "lako_gemm_nt: bad in_dtype");
+  LAKO_CHECK_ARG(p->out_dtype == LAKO_F32 || p->out_dtype == LAKO_BF16, "lako_gemm_nt: bad out_dtype");
+  const int esz = p->in_dtype == LAKO_F32 ? 4 : 2;
+  LAKO_CHECK_ARG((p->K * esz) % 16 == 0 && (p->lda * esz) % 16 == 0 && (p->ldb * esz) % 16 == 0,
+                 "lako_gemm_nt: K/lda/ldb must make 16-byte rows (K=%lld lda=%lld ldb=%lld)", (long long)p->K,
+                 (long long)p->lda, (long long)p->ldb);
+  LAKO_CHECK_ARG(p->N % 4 == 0 && p->ldc % 4 == 0, "lako_gemm_nt: N and ldc must be multiples of 4");
+  LAKO_CHECK_ARG(p->M < (1 << 30) && p->N < (1 << 30) && p->K < (1 << 28), "lako_gemm_nt: dims too large");
+  LAKO_CHECK_ALIGN(p->A, 16);
+  LAKO_CHECK_ALIGN(p->B, 16);
+  LAKO_CHECK_ALIGN(p->C, 8);
+  if (p->flags & LAKO_EPI_RESID) {
+    LAKO_CHECK_ARG(p->resid != nullptr && p->ldr % 4 == 0, "lako_gemm_nt: RESID needs resid, ldr %% 4 == 0");
+  }
+  if (p->flags & LAKO_EPI_AUXMASK) {
+    LAKO_CHECK_ARG(p->aux != nullptr && p->ldaux % 4 == 0, "lako_gemm_nt: AUXMASK needs aux, ldaux %% 4 == 0");
+  }
+  if (p->flags & LAKO_EPI_ATOMIC) LAKO_CHECK_ARG(p->out_dtype == LAKO_F32, "lako_gemm_nt: ATOMIC needs fp32 C");
+  LAKO_CHECK_ARG(p->drop.p >= 0.f && p->drop.p < 1.f, "lako_gemm_nt: dropout p out of range");
+  NtArgs a;
+  a.A = (const char*)p->A;
+  a.B = (const char*)p->B;
+  a.C = (char*)p->C;
+  a.resid = (const char*)p->resid;
+  a.aux = (const char*)p->aux;
+  a.M = (int)p->M;
+  a.N = (int)p->N;
+  a.K = (int)p->K;
+  a.lda = p->lda;
+  a.ldb = p->ldb;
+  a.ldc = p->ldc;
+  a.ldr = p->ldr;
+  a.ldaux = p->ldaux;
+  a.alpha = p->alpha;
+  a.aux_scale = p->aux_scale;
+  a.flags = p->flags;
+  a.drop_thresh = p->drop.p > 0.f ? lako_drop_thresh(p->drop.p) : 0u;
+  a.drop_scale = p->drop.p > 0.f ? 1.0f / (1.0f - p->drop.p) : 1.0f;
+  a.drop_key = lako_drop_key(p->drop.seed, p->drop.site);
+  a.tiles_m = cdiv(p->M, TM);
+  a.tiles_n = cdiv(p->N, TN_);
+  hipStream_t s = (hipStream_t)stream;
+  if (p->in_dtype == LAKO_BF16) {
+    if (p->out_dtype == LAKO_BF16) launch_nt<bf16_t, bf16_t>(a, s);
+    else launch_nt<bf16_t, float>(a, s);
+  } else {
+    if (p->out_dtype == LAKO_BF16) launch_nt<float, bf16_t>(a, s);
+    else launch_nt<float, float>(a, s);
+  }
+  LAKO_LAUNCH_CHECK();
+  return LAKO_OK;
+}
+
+extern "C" int lako_gemm_tn(const void* A, const void* B, float* C, int64_t M, int64_t N, int64_t K, int64_t lda,
+                            int64_t ldb, int64_t ldc, int in_dtype, float alpha, int split_k, lako_stream_t stream) {
+  LAKO_CHECK_ARG(M > 0 && N > 0 && K > 0, "lako_gemm_tn: bad dims");
+  LAKO_CHECK_ARG(in_dtype == LAKO_F32 || in_dtype == LAKO_BF16, "lako_gemm_tn: bad in_dtype");
+  const int esz = in_dtype == LAKO_F32 ? 4 : 2;
+  LAKO_CHECK_ARG((M * esz) % 16 == 0 && (N * esz) % 16 == 0 && (lda * esz) % 16 == 0 && (ldb * esz) % 16 == 0,
+                 "lako_gemm_tn: M/N/lda/ldb must make 16-byte rows");
+  LAKO_CHECK_ARG(M < (1 << 30) && N < (1 << 30) && K < (1 << 30), "lako_gemm_tn: dims too large");
+  LAKO_CHECK_ALIGN(A, 16);
+  LAKO_CHECK_ALIGN(B, 16);
+  LAKO_CHECK_ALIGN(C, 4);
+  TnArgs a;
+  a.A = (const char*)A;
+  a.B = (const char*)B;
+  a.C = C;
+  a.M = (int)M;
+  a.N = (int)N;
+  a.K = (int)K;
+  a.lda = lda;
+  a.ldb = ldb;
+  a.ldc = ldc;
+  a.alpha = alpha;
+  a.tiles_m = cdiv(M, TM);
+  a.tiles_n = cdiv(N, TN_);
+  const int kr = in_dtype == LAKO_BF16 ? 64 : 32;
+  if (split_k <= 0) {  // auto: aim at >= 2 workgroups per CU, at least 4 K-steps per split
+    int tiles = a.tiles_m * a.tiles_n;
+    split_k = cdiv(512, tiles);
+    int max_split = cdiv(K, (int64_t)kr * 4);
+    if (split_k > max_split) split_k = max_split;
+    if (split_k < 1) split_k = 1;
+  }
+  int chunk = cdiv(K, split_k);
+  chunk = cdiv(chunk, kr) * kr;
+  a.split_k = cdiv(K, chunk);
+  a.k_chunk = chunk;
+  // voffset (row * ld_bytes) must stay below 2^32 within one K-step: rows < 64
+  LAKO_CHECK_ARG((int64_t)64 * lda * esz < (1ll << 31) && (int64_t)64 * ldb * esz < (1ll << 31),
+                 "lako_gemm_tn: leading dimension too large");
+  hipStream_t s = (hipStream_t)stream;
+  if (in_dtype == LAKO_BF16) launch_tn<bf16_t>(a, s);
+  else launch_tn<float>(a, s);
+  LAKO_LAUNCH_CHECK();
+  return LAKO_OK;
+}

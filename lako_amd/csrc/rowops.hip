@@ -1,0 +1,631 @@
+// Row-wise and element-wise kernels of the FiD-T5 reader path (all HBM-bound): T5LayerNorm
+// (HF5:59-72), embedding gather/scatter (HF5:678), dropout (HF5:725,745,400,141), LM-head
+// cross-entropy (HF5:1051-1054), global-norm clip + HF AdamW(correct_bias=False) (train_reader.py:76-79,
+// src/util.py:185-227), _shift_right (HF5:618-637), greedy token selection (HF generate, greedy).
+// 16-byte vector accesses per lane everywhere; wave-level (64-lane) shuffle reductions.
+#include <stdarg.h>
+
+#include "common.h"
+
+// ---- error string (thread local) ------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void lako_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" int lako_last_error(char* buf, size_t n) {
+  size_t len = strlen(g_err);
+  if (buf && n) {
+    size_t c = len < n - 1 ? len : n - 1;
+    memcpy(buf, g_err, c);
+    buf[c] = 0;
+  }
+  return (int)len;
+}
+extern "C" int lako_version(void) { return LAKO_ABI_VERSION; }
+
+namespace {
+
+struct DropDev {
+  uint32_t thresh, key;
+  float scale;
+};
+inline DropDev make_drop(const lako_dropout_t& d) {
+  DropDev r;
+  r.thresh = d.p > 0.f ? lako_drop_thresh(d.p) : 0u;
+  r.key = lako_drop_key(d.seed, d.site);
+  r.scale = d.p > 0.f ? 1.0f / (1.0f - d.p) : 1.0f;
+  return r;
+}
+
+// 8 consecutive elements as floats
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+  f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+}
+__device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
+  bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+}
+__device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
+  *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+  *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
+  bf16x8 o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = (bf16_t)v[i];
+  *reinterpret_cast<bf16x8*>(p) = o;
+}
+
+// ---- RMSNorm ----------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                          T* __restrict__ y, float* __restrict__ rstd, int64_t rows,
+                                                          int d, float eps, DropDev dr) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  for (int64_t row = wid; row < rows; row += nw) {
+    const T* xr = x + row * d;
+    float ss = 0.f;
+    for (int c = lane * 8; c < d; c += 512) {
+      float v[8];
+      load8(xr + c, v);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ss += v[i] * v[i];
+    }
+    ss = wave_sum(ss);
+    const float rs = rsqrtf(ss / (float)d + eps);
+    if (lane == 0) rstd[row] = rs;
+    T* yr = y + row * d;
+    for (int c = lane * 8; c < d; c += 512) {
+      float v[8], wv[8];
+      load8(xr + c, v);
+      load8(w + c, wv);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float o = wv[i] * (v[i] * rs);
+        if (dr.thresh) o = lako_keep(dr.key, (uint64_t)row * d + c + i, dr.thresh) ? o * dr.scale : 0.f;
+        v[i] = o;
+      }
+      store8(yr + c, v);
+    }
+  }
+}
+
+// dx = dres + rstd*(w∘dy − x·rstd²·mean(w∘dy∘x));  dw += Σ_rows dy∘x·rstd.   d <= 1024.
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                          const float* __restrict__ w,
+                                                          const float* __restrict__ rstd, const T* __restrict__ dres,
+                                                          T* __restrict__ dx, float* __restrict__ dw, int64_t rows,
+                                                          int d, DropDev dr) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  float dwacc[2][8];
+  float wv[2][8];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    int c = it * 512 + lane * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { dwacc[it][i] = 0.f; wv[it][i] = 0.f; }
+    if (c < d) load8(w + c, wv[it]);
+  }
+  for (int64_t row = wid; row < rows; row += nw) {
+    const float rs = rstd[row];
+    float g[2][8], xv[2][8];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      int c = it * 512 + lane * 8;
+      if (c < d) {
+        load8(dy + row * d + c, g[it]);
+        load8(x + row * d + c, xv[it]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          if (dr.thresh) g[it][i] = lako_keep(dr.key, (uint64_t)row * d + c + i, dr.thresh) ? g[it][i] * dr.scale : 0.f;
+          s += wv[it][i] * g[it][i] * xv[it][i];
+          dwacc[it][i] += g[it][i] * xv[it][i] * rs;
+        }
+      }
+    }
+    s = wave_sum(s);
+    const float k = rs * rs * rs * s / (float)d;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      int c = it * 512 + lane * 8;
+      if (c < d) {
+        float o[8];
+        if (dres) load8(dres + row * d + c, o);
+        else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] += rs * wv[it][i] * g[it][i] - xv[it][i] * k;
+        store8(dx + row * d + c, o);
+      }
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    int c = it * 512 + lane * 8;
+    if (c < d) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) atomicAdd(dw + c + i, dwacc[it][i]);
+    }
+  }
+}
+
+// ---- embedding ----------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ ids, const T* __restrict__ table,
+                                                        T* __restrict__ out, int64_t n_tok, int d, int64_t vocab,
+                                                        DropDev dr) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  for (int64_t t = wid; t < n_tok; t += nw) {
+    int64_t id = ids[t];
+    if (id < 0 || id >= vocab) id = 0;
+    for (int c = lane * 8; c < d; c += 512) {
+      float v[8];
+      load8(table + id * d + c, v);
+      if (dr.thresh) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = lako_keep(dr.key, (uint64_t)t * d + c + i, dr.thresh) ? v[i] * dr.scale : 0.f;
+      }
+      store8(out + t * d + c, v);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, const T* __restrict__ dout,
+                                                        float* __restrict__ dtable, int64_t n_tok, int d,
+                                                        int64_t vocab, DropDev dr) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  for (int64_t t = wid; t < n_tok; t += nw) {
+    int64_t id = ids[t];
+    if (id < 0 || id >= vocab) id = 0;
+    // one dword per lane per instruction: 256 contiguous bytes per wave atomic (full-rate shape)
+    for (int c = lane; c < d; c += 64) {
+      float v = (float)dout[t * d + c];
+      if (dr.thresh) v = lako_keep(dr.key, (uint64_t)t * d + c, dr.thresh) ? v * dr.scale : 0.f;
+      atomicAdd(dtable + id * d + c, v);
+    }
+  }
+}
+
+// ---- dropout apply / cast ---------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_apply_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n,
+                                                            DropDev dr) {
+  int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+  const int64_t stride = (int64_t)gridDim.x * 256 * 8;
+  for (; i < n; i += stride) {
+    float v[8];
+    load8(x + i, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = lako_keep(dr.key, (uint64_t)i + j, dr.thresh) ? v[j] * dr.scale : 0.f;
+    store8(y + i, v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t n) {
+  int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+  const int64_t stride = (int64_t)gridDim.x * 256 * 8;
+  for (; i + 8 <= n; i += stride) {
+    float v[8];
+    load8(src + i, v);
+    store8(dst + i, v);
+  }
+  if (i < n && i + 8 > n)
+    for (int64_t j = i; j < n; ++j) dst[j] = (T)src[j];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __restrict__ src, T* __restrict__ dst,
+                                                             int64_t rows, int64_t cols) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 × 8
+  const int64_t c0 = (int64_t)blockIdx.x * 32, r0 = (int64_t)blockIdx.y * 32;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int64_t r = r0 + ty + 8 * j, c = c0 + tx;
+    tile[ty + 8 * j][tx] = (r < rows && c < cols) ? src[r * cols + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int64_t c = c0 + ty + 8 * j, r = r0 + tx;
+    if (r < rows && c < cols) dst[c * rows + r] = (T)tile[tx][ty + 8 * j];
+  }
+}
+
+// ---- cross-entropy --------------------------------------------------------------------------
+__global__ void ce_init_kernel(float* loss_out, const int64_t* labels, int64_t M) {
+  // single block: count valid labels
+  __shared__ int cnt;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  int c = 0;
+  for (int64_t i = threadIdx.x; i < M; i += blockDim.x) c += labels[i] != -100;
+  atomicAdd(&cnt, c);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    loss_out[0] = 0.f;
+    loss_out[1] = (float)cnt;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                 float* __restrict__ loss_out, T* __restrict__ dlogits, int64_t V) {
+  __shared__ float red[4];
+  __shared__ float bc;
+  const int64_t row = blockIdx.x;
+  const float* lr = logits + row * V;
+  const int64_t label = labels[row];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const float n_valid = loss_out[1];
+  const bool valid = label != -100;
+  float mx = -INFINITY;
+  for (int64_t c = threadIdx.x * 4; c < V; c += 1024) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(lr + c);
+    mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[wv] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) bc = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  mx = bc;
+  float se = 0.f;
+  for (int64_t c = threadIdx.x * 4; c < V; c += 1024) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(lr + c);
+    se += __expf(v[0] - mx) + __expf(v[1] - mx) + __expf(v[2] - mx) + __expf(v[3] - mx);
+  }
+  se = wave_sum(se);
+  __syncthreads();
+  if (lane == 0) red[wv] = se;
+  __syncthreads();
+  if (threadIdx.x == 0) bc = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  se = bc;
+  const float lse = mx + __logf(se);
+  if (threadIdx.x == 0 && valid) atomicAdd(loss_out, (lse - lr[label]) / n_valid);
+  if (dlogits) {
+    T* dr = dlogits + row * V;
+    const float inv = valid ? 1.0f / n_valid : 0.f;
+    for (int64_t c = threadIdx.x * 4; c < V; c += 1024) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(lr + c);
+      f32x4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float p = __expf(v[i] - lse);
+        o[i] = (p - ((c + i) == label ? 1.f : 0.f)) * inv;
+      }
+      store4(dr + c, o);
+    }
+  }
+}
+
+// ---- optimizer ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+  for (; i + 4 <= n; i += stride) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(g + i);
+    s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  if (i < n)
+    for (int64_t j = i; j < n && j < i + 4; ++j) s += g[j] * g[j];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v,
+                                                    T* __restrict__ shadow, int64_t n, float lr, float b1, float b2,
+                                                    float eps, float wd, const float* __restrict__ gnorm_sq,
+                                                    float max_norm, float grad_scale) {
+  float coef = grad_scale;
+  if (gnorm_sq) {
+    float total = sqrtf(gnorm_sq[0]) * grad_scale;
+    float c = max_norm / (total + 1e-6f);
+    coef *= fminf(c, 1.0f);
+  }
+  int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+  for (; i < n; i += stride) {  // n % 4 == 0 (checked on host)
+    f32x4 pv = *reinterpret_cast<f32x4*>(p + i), gv = *reinterpret_cast<const f32x4*>(g + i);
+    f32x4 mv = *reinterpret_cast<f32x4*>(m + i), vv = *reinterpret_cast<f32x4*>(v + i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float gj = gv[j] * coef;
+      mv[j] = mv[j] * b1 + gj * (1.f - b1);
+      vv[j] = vv[j] * b2 + gj * gj * (1.f - b2);
+      float q = pv[j] - lr * (mv[j] / (sqrtf(vv[j]) + eps));
+      if (wd > 0.f) q = q - lr * wd * q;
+      pv[j] = q;
+    }
+    *reinterpret_cast<f32x4*>(p + i) = pv;
+    *reinterpret_cast<f32x4*>(m + i) = mv;
+    *reinterpret_cast<f32x4*>(v + i) = vv;
+    if (shadow) store4(shadow + i, pv);
+  }
+}
+
+// ---- relative position bias table -------------------------------------------------------------
+__global__ void relpos_expand_kernel(const float* table, const int32_t* lut, float* rel, int H, int R, int nb) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= H * R) return;
+  int h = i / R, r = i % R;
+  int b = lut[r];
+  rel[i] = (b >= 0 && b < nb) ? table[b * H + h] : 0.f;
+}
+__global__ void relpos_reduce_kernel(const float* drel, const int32_t* lut, float* dtable, int H, int R, int nb) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= H * R) return;
+  int h = i / R, r = i % R;
+  int b = lut[r];
+  if (b >= 0 && b < nb) atomicAdd(dtable + b * H + h, drel[i]);
+}
+
+// ---- int helpers ------------------------------------------------------------------------------
+__global__ void shift_right_kernel(const int64_t* labels, int64_t* dec, int B, int T) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * T) return;
+  int t = i % T;
+  int64_t v = t == 0 ? 0 : labels[i - 1];
+  dec[i] = v == -100 ? 0 : v;
+}
+
+__global__ __launch_bounds__(256) void greedy_step_kernel(const float* __restrict__ logits, int64_t V,
+                                                          int64_t* seq, int64_t seq_ld, int pos, int64_t* next_ids,
+                                                          uint8_t* done, int64_t eos, int64_t pad) {
+  __shared__ float bv[4];
+  __shared__ int64_t bi[4];
+  const int b = blockIdx.x;
+  const float* lr = logits + (int64_t)b * V;
+  float best = -INFINITY;
+  int64_t besti = V;
+  for (int64_t c = threadIdx.x; c < V; c += 256) {
+    float v = lr[c];
+    if (v > best) { best = v; besti = c; }  // strided scan keeps the lowest index per thread on ties
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ov = __shfl_xor(best, o, 64);
+    int64_t oi = __shfl_xor(besti, o, 64);
+    if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = besti; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (bv[w] > best || (bv[w] == best && bi[w] < besti)) { best = bv[w]; besti = bi[w]; }
+    int64_t nxt = done[b] ? pad : besti;
+    seq[(int64_t)b * seq_ld + pos] = nxt;
+    next_ids[b] = nxt;
+    if (nxt == eos) done[b] = 1;
+  }
+}
+__global__ void count_done_kernel(const uint8_t* done, int B, int32_t* n_done) {
+  __shared__ int cnt;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  int c = 0;
+  for (int i = threadIdx.x; i < B; i += blockDim.x) c += done[i] != 0;
+  atomicAdd(&cnt, c);
+  __syncthreads();
+  if (threadIdx.x == 0) n_done[0] = cnt;
+}
+
+inline int rows_grid(int64_t rows) {
+  int64_t g = (rows + 3) / 4;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+inline int elems_grid(int64_t n, int per_thread) {
+  int64_t g = (n + 256 * per_thread - 1) / (256 * per_thread);
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, ...)                 \
+  if ((dtype) == LAKO_BF16) {                  \
+    using T = bf16_t;                          \
+    __VA_ARGS__;                               \
+  } else {                                     \
+    using T = float;                           \
+    __VA_ARGS__;                               \
+  }
+#define CHECK_DTYPE(fn, dtype) LAKO_CHECK_ARG((dtype) == LAKO_F32 || (dtype) == LAKO_BF16, fn ": bad dtype %d", (int)(dtype))
+
+extern "C" int lako_rmsnorm_fwd(const void* x, const float* w, void* y, float* rstd, int64_t rows, int d, float eps,
+                                int dtype, lako_dropout_t drop, lako_stream_t stream) {
+  CHECK_DTYPE("lako_rmsnorm_fwd", dtype);
+  LAKO_CHECK_ARG(rows > 0 && d > 0 && d % 8 == 0, "lako_rmsnorm_fwd: rows=%lld d=%d (d %% 8 == 0)", (long long)rows, d);
+  LAKO_CHECK_ALIGN(x, 16);
+  LAKO_CHECK_ALIGN(y, 16);
+  LAKO_CHECK_ALIGN(w, 16);
+  DropDev dr = make_drop(drop);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((rmsnorm_fwd_kernel<T>), dim3(rows_grid(rows)), dim3(256), 0,
+                                       (hipStream_t)stream, (const T*)x, w, (T*)y, rstd, rows, d, eps, dr));
+  LAKO_LAUNCH_CHECK();
+  return LAKO_OK;
+}
+
+extern "C" int lako_rmsnorm_bwd(const void* dy, const void* x, const float* w, const float* rstd, const void* dres,
+                                void* dx, float* dw, int64_t rows, int d, int dtype, lako_dropout_t drop,
+                                lako_stream_t stream) {
+  CHECK_DTYPE("lako_rmsnorm_bwd", dtype);
+  LAKO_CHECK_ARG(rows > 0 && d > 0 && d % 8 == 0 && d <= 1024, "lako_rmsnorm_bwd: rows=%lld d=%d (d %% 8 == 0, d <= 1024)",
+                 (long long)rows, d);
+  LAKO_CHECK_ALIGN(dy, 16);
+  LAKO_CHECK_ALIGN(x, 16);
+  LAKO_CHECK_ALIGN(dx, 16);
+  LAKO_CHECK_ALIGN(w, 16);
+  DropDev dr = make_drop(drop);
+  int grid = rows_grid(rows);
+  if (grid > 1024) grid = 1024;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((rmsnorm_bwd_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                       (const T*)dy, (const T*)x, w, rstd, (const T*)dres, (T*)dx, dw, rows, d, dr));
+  LAKO_LAUNCH_CHECK();
+  return LAKO_OK;
+}
+
+extern "C" int lako_embed_fwd(const int64_t* ids, const void* table, void* out, int64_t n_tok, int d, int64_t vocab,
+                              int dtype, lako_dropout_t drop, lako_stream_t stream) {
+  CHECK_DTYPE("lako_embed_fwd", dtype);
+  LAKO_CHECK_ARG(n_tok > 0 && d > 0 && d % 8 == 0 && vocab > 0, "lako_embed_fwd: bad dims");
+  LAKO_CHECK_ALIGN(table, 16);
+  LAKO_CHECK_ALIGN(out, 16);
+  DropDev dr = make_drop(drop);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((embed_fwd_kernel<T>), dim3(rows_grid(n_tok)), dim3(256), 0, (hipStream_t)stream,
+                                       ids, (const T*)table, (T*)out, n_tok, d, vocab, dr));
+  LAKO_LAUNCH_CHECK();
+  return LAKO_OK;
+}
+
+extern "C" int lako_embed_bwd(const int64_t* ids, const void* dout, float* dtable, int64_t n_tok, int d, int64_t vocab,
+                              int dtype, lako_dropout_t drop, lako_stream_t stream) {
+  CHECK_DTYPE("lako_embed_bwd", dtype);
+  LAKO_CHECK_ARG(n_tok > 0 && d > 0 && vocab > 0, "lako_embed_bwd: bad dims");
+  DropDev dr = make_drop(drop);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((embed_bwd_kernel<T>), dim3(rows_grid(n_tok)), dim3(256), 0, (hipStream_t)stream,
+                                       ids, (const T*)dout, dtable, n_tok, d, vocab, dr));
+  LAKO_LAUNCH_CHECK();
+  return LAKO_OK;
+}
+
+extern "C" int lako_dropout_apply(const void* x, void* y, int64_t n, int dtype, lako_dropout_t drop,
+                                  lako_stream_t stream) {
+  CHECK_DTYPE("lako_dropout_apply", dtype);
+  LAKO_CHECK_ARG(n > 0 && n % 8 == 0, "lako_dropout_apply: n must be a positive multiple of 8");
+  LAKO_CHECK_ALIGN(x, 16);
+  LAKO_CHECK_ALIGN(y, 16);
+  DropDev dr = make_drop(drop);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((dropout_apply_kernel<T>), dim3(elems_grid(n, 8)), dim3(256), 0,
+                                       (hipStream_t)stream, (const T*)x, (T*)y, n, dr));
+  LAKO_LAUNCH_CHECK();
+  return LAKO_OK;
+}
+
+extern "C" int lako_cast(const float* src, void* dst, int64_t n, int dtype, lako_stream_t stream) {
+  CHECK_DTYPE("lako_cast", dtype);
+  LAKO_CHECK_ARG(n > 0, "lako_cast: n <= 0");
+  LAKO_CHECK_ALIGN(src, 16);
+  LAKO_CHECK_ALIGN(dst, 16);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((cast_kernel<T>), dim3(elems_grid(n, 8)), dim3(256), 0, (hipStream_t)stream, src,
+                                       (T*)dst, n));
+  LAKO_LAUNCH_CHECK();
+  return LAKO_OK;
+}
+
+extern "C" int lako_transpose_cast(const float* src, void* dst, int64_t rows, int64_t cols, int dtype,
+                                   lako_stream_t stream) {
+  CHECK_DTYPE("lako_transpose_cast", dtype);
+  LAKO_CHECK_ARG(rows > 0 && cols > 0, "lako_transpose_cast: bad dims");
+  dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
+  LAKO_CHECK_ARG(grid.y < 65536, "lako_transpose_cast: too many rows");
+  DISPATCH_T(dtype, hipLaunchKernelGGL((transpose_cast_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, src, (T*)dst,
+                                       rows, cols));
+  LAKO_LAUNCH_CHECK();
+  return LAKO_OK;
+}
+
+extern "C" int lako_ce_fwd_bwd(const float* logits, const int64_t* labels, float* loss_out, void* dlogits, int64_t M,
+                               int64_t V, int dtype, lako_stream_t stream) {
+  CHECK_DTYPE("lako_ce_fwd_bwd", dtype);
+  LAKO_CHECK_ARG(M > 0 && V > 0 && V % 4 == 0, "lako_ce_fwd_bwd: M=%lld V=%lld (V %% 4 == 0)", (long long)M, (long long)V);
+  LAKO_CHECK_ALIGN(logits, 16);
+  hipLaunchKernelGGL(ce_init_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_out, labels, M);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((ce_kernel<T>), dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream, logits,
+                                       labels, loss_out, (T*)dlogits, V));
+  LAKO_LAUNCH_CHECK();
+  return LAKO_OK;
+}
+
+extern "C" int lako_sumsq(const float* g, int64_t n, float* out, lako_stream_t stream) {
+  LAKO_CHECK_ARG(n > 0, "lako_sumsq: n <= 0");
+  LAKO_CHECK_ALIGN(g, 16);
+  int grid = elems_grid(n, 4);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, n, out);
+  LAKO_LAUNCH_CHECK();
+  return LAKO_OK;
+}
+
+extern "C" int lako_adamw_step(float* p, const float* g, float* m, float* v, void* shadow, int64_t n, float lr,
+                               float beta1, float beta2, float eps, float weight_decay, const float* gnorm_sq,
+                               float max_norm, float grad_scale, int shadow_dtype, lako_stream_t stream) {
+  CHECK_DTYPE("lako_adamw_step", shadow_dtype);
+  LAKO_CHECK_ARG(n > 0 && n % 4 == 0, "lako_adamw_step: n must be a positive multiple of 4");
+  LAKO_CHECK_ALIGN(p, 16);
+  LAKO_CHECK_ALIGN(g, 16);
+  LAKO_CHECK_ALIGN(m, 16);
+  LAKO_CHECK_ALIGN(v, 16);
+  if (shadow) LAKO_CHECK_ALIGN(shadow, 8);
+  DISPATCH_T(shadow_dtype,
+             hipLaunchKernelGGL((adamw_kernel<T>), dim3(elems_grid(n, 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                                (T*)shadow, n, lr, beta1, beta2, eps, weight_decay, gnorm_sq, max_norm, grad_scale));
+  LAKO_LAUNCH_CHECK();
+  return LAKO_OK;
+}
+
+extern "C" int lako_relpos_expand(const float* table, const int32_t* lut, float* rel, int H, int R, int nb,
+                                  lako_stream_t stream) {
+  LAKO_CHECK_ARG(H > 0 && R > 0 && nb > 0, "lako_relpos_expand: bad dims");
+  hipLaunchKernelGGL(relpos_expand_kernel, dim3((H * R + 255) / 256), dim3(256), 0, (hipStream_t)stream, table, lut, rel,
+                     H, R, nb);
+  LAKO_LAUNCH_CHECK();
+  return LAKO_OK;
+}
+extern "C" int lako_relpos_reduce(const float* drel, const int32_t* lut, float* dtable, int H, int R, int nb,
+                                  lako_stream_t stream) {
+  LAKO_CHECK_ARG(H > 0 && R > 0 && nb > 0, "lako_relpos_reduce: bad dims");
+  hipLaunchKernelGGL(relpos_reduce_kernel, dim3((H * R + 255) / 256), dim3(256), 0, (hipStream_t)stream, drel, lut,
+                     dtable, H, R, nb);
+  LAKO_LAUNCH_CHECK();
+  return LAKO_OK;
+}
+
+extern "C" int lako_shift_right(const int64_t* labels, int64_t* dec_ids, int B, int T, lako_stream_t stream) {
+  LAKO_CHECK_ARG(B > 0 && T > 0, "lako_shift_right: bad dims");
+  hipLaunchKernelGGL(shift_right_kernel, dim3((B * T + 255) / 256), dim3(256), 0, (hipStream_t)stream, labels, dec_ids,
+                     B, T);
+  LAKO_LAUNCH_CHECK();
+  return LAKO_OK;
+}
+
+extern "C" int lako_greedy_step(const float* logits, int64_t V, int B, int64_t* seq, int64_t seq_ld, int pos,
+                                int64_t* next_ids, uint8_t* done, int32_t* n_done, int64_t eos_id, int64_t pad_id,
+                                lako_stream_t stream) {
+  LAKO_CHECK_ARG(B > 0 && V > 0 && pos >= 0 && pos < seq_ld, "lako_greedy_step: bad dims");
+  hipLaunchKernelGGL(greedy_step_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, V, seq, seq_ld, pos,
+                     next_ids, done, eos_id, pad_id);
+  hipLaunchKernelGGL(count_done_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, done, B, n_done);
+  LAKO_LAUNCH_CHECK();
+  return LAKO_OK;
+}

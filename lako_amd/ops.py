@@ -1,0 +1,229 @@
+"""Tensor-level bindings of the C-ABI (include/lako_hip.h) for torch device tensors.
+
+`HipOps` is the only implementation the product uses.  Every method enqueues one (or two) HIP kernels
+on torch's current stream and returns nothing; outputs are caller-allocated tensors.  PyTorch is used
+here for device memory and streams only — no torch math runs on this path.
+
+The method set is the engine's whole vocabulary (`lako_amd/engine.py`); `tests/ref_ops.py` implements
+the same methods in plain fp32 torch on CPU as a *test double*, used (a) to check each HIP kernel on
+the GPU and (b) to check the engine's orchestration against the oracle without a GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (EPI_ATOMIC, EPI_AUXMASK, EPI_RELU, EPI_RESID, LAKO_BF16, LAKO_F32, AttnBwd, AttnFwd, Dropout,
+                   GemmNT, LakoError, NO_DROP, check)
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return LAKO_F32
+    if t.dtype == torch.bfloat16:
+        return LAKO_BF16
+    raise LakoError(f"unsupported dtype {t.dtype}")
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _drop(d) -> Dropout:
+    if d is None or d[0] <= 0.0:
+        return NO_DROP
+    return Dropout(float(d[0]), int(d[1]) & 0xFFFFFFFF, int(d[2]) & 0xFFFFFFFF)
+
+
+def _rowmajor2d(t: torch.Tensor, name: str):
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise LakoError(f"{name}: expected a 2-D tensor with unit inner stride, got shape {tuple(t.shape)} "
+                        f"strides {t.stride()}")
+    return t.shape[0], t.shape[1], t.stride(0)
+
+
+def _bthd(t: torch.Tensor, name: str):
+    """[B, T, H, dk] view with strides (sb, st, dk, 1)."""
+    if t.dim() != 4 or t.stride(3) != 1 or t.stride(2) != t.shape[3]:
+        raise LakoError(f"{name}: expected [B,T,H,dk] with head-contiguous layout, got {tuple(t.shape)} {t.stride()}")
+    return t.stride(0), t.stride(1)
+
+
+class HipOps:
+    """The product's op set: hand-written gfx950 kernels behind the C-ABI."""
+
+    name = "hip"
+
+    def __init__(self):
+        if not torch.cuda.is_available():
+            raise LakoError("HipOps needs a ROCm device (torch.cuda.is_available() is False); no CPU fallback exists")
+        self.lib = _lib.load()
+        assert self.lib.lako_version() == 1
+
+    @staticmethod
+    def _stream():
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    # ---- plumbing ---------------------------------------------------------------------------
+    def zero_(self, t: torch.Tensor):
+        t.zero_()
+
+    # ---- GEMMs -----------------------------------------------------------------------------
+    def gemm_nt(self, A, B, Cm, *, alpha=1.0, relu=False, resid=None, aux=None, aux_scale=1.0, drop=None,
+                atomic=False):
+        M, K, lda = _rowmajor2d(A, "gemm_nt A")
+        N, K2, ldb = _rowmajor2d(B, "gemm_nt B")
+        M2, N2, ldc = _rowmajor2d(Cm, "gemm_nt C")
+        if K != K2 or M != M2 or N != N2 or A.dtype != B.dtype:
+            raise LakoError(f"gemm_nt: shape/dtype mismatch A{tuple(A.shape)} B{tuple(B.shape)} C{tuple(Cm.shape)}")
+        flags = (EPI_RELU if relu else 0) | (EPI_RESID if resid is not None else 0) | \
+                (EPI_AUXMASK if aux is not None else 0) | (EPI_ATOMIC if atomic else 0)
+        p = GemmNT()
+        p.A, p.B, p.C = A.data_ptr(), B.data_ptr(), Cm.data_ptr()
+        p.M, p.N, p.K, p.lda, p.ldb, p.ldc = M, N, K, lda, ldb, ldc
+        p.in_dtype, p.out_dtype = _dt(A), _dt(Cm)
+        p.alpha, p.flags = float(alpha), flags
+        if resid is not None:
+            if resid.dtype != Cm.dtype or resid.shape != Cm.shape:
+                raise LakoError("gemm_nt: resid must match C")
+            p.resid, p.ldr = resid.data_ptr(), resid.stride(0)
+        if aux is not None:
+            if aux.dtype != A.dtype or aux.shape != Cm.shape:
+                raise LakoError("gemm_nt: aux must be [M,N] in the input dtype")
+            p.aux, p.ldaux = aux.data_ptr(), aux.stride(0)
+        p.aux_scale = float(aux_scale)
+        p.drop = _drop(drop)
+        check(self.lib.lako_gemm_nt(C.byref(p), self._stream()), "lako_gemm_nt")
+
+    def gemm_tn(self, A, B, Cm, *, alpha=1.0, split_k=0):
+        K, M, lda = _rowmajor2d(A, "gemm_tn A")
+        K2, N, ldb = _rowmajor2d(B, "gemm_tn B")
+        M2, N2, ldc = _rowmajor2d(Cm, "gemm_tn C")
+        if K != K2 or M != M2 or N != N2 or A.dtype != B.dtype or Cm.dtype != torch.float32:
+            raise LakoError(f"gemm_tn: shape/dtype mismatch A{tuple(A.shape)} B{tuple(B.shape)} C{tuple(Cm.shape)}")
+        check(self.lib.lako_gemm_tn(_p(A), _p(B), _p(Cm), M, N, K, lda, ldb, ldc, _dt(A), float(alpha), int(split_k),
+                                    self._stream()), "lako_gemm_tn")
+
+    # ---- norm / embedding / dropout ---------------------------------------------------------------
+    def rmsnorm_fwd(self, x, w, y, rstd, eps, drop=None):
+        rows, d = x.shape
+        check(self.lib.lako_rmsnorm_fwd(_p(x), _p(w), _p(y), _p(rstd), rows, d, float(eps), _dt(x), _drop(drop),
+                                        self._stream()), "lako_rmsnorm_fwd")
+
+    def rmsnorm_bwd(self, dy, x, w, rstd, dres, dx, dw, drop=None):
+        rows, d = x.shape
+        check(self.lib.lako_rmsnorm_bwd(_p(dy), _p(x), _p(w), _p(rstd), _p(dres), _p(dx), _p(dw), rows, d, _dt(x),
+                                        _drop(drop), self._stream()), "lako_rmsnorm_bwd")
+
+    def embed_fwd(self, ids, table, out, drop=None):
+        check(self.lib.lako_embed_fwd(_p(ids), _p(table), _p(out), ids.numel(), table.shape[1], table.shape[0],
+                                      _dt(table), _drop(drop), self._stream()), "lako_embed_fwd")
+
+    def embed_bwd(self, ids, dout, dtable, drop=None):
+        check(self.lib.lako_embed_bwd(_p(ids), _p(dout), _p(dtable), ids.numel(), dtable.shape[1], dtable.shape[0],
+                                      _dt(dout), _drop(drop), self._stream()), "lako_embed_bwd")
+
+    def dropout_apply(self, x, y, drop):
+        check(self.lib.lako_dropout_apply(_p(x), _p(y), x.numel(), _dt(x), _drop(drop), self._stream()),
+              "lako_dropout_apply")
+
+    # ---- relative position bias ---------------------------------------------------------------
+    def relpos_expand(self, table, lut, rel):
+        nb, H = table.shape
+        check(self.lib.lako_relpos_expand(_p(table), _p(lut), _p(rel), H, rel.shape[1], nb, self._stream()),
+              "lako_relpos_expand")
+
+    def relpos_reduce(self, drel, lut, dtable):
+        nb, H = dtable.shape
+        check(self.lib.lako_relpos_reduce(_p(drel), _p(lut), _p(dtable), H, drel.shape[1], nb, self._stream()),
+              "lako_relpos_reduce")
+
+    # ---- attention ------------------------------------------------------------------------------
+    def attn_fwd(self, q, k, v, out, stats, *, rel_bias=None, rel_off=0, key_mask=None, causal=False, causal_off=0,
+                 drop=None, scores_out=None):
+        p = AttnFwd()
+        Bn, Lq, H, dk = q.shape
+        Lk = k.shape[1]
+        p.q, p.k, p.v, p.out, p.lse = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), stats.data_ptr()
+        p.q_stride_b, p.q_stride_t = _bthd(q, "attn q")
+        p.k_stride_b, p.k_stride_t = _bthd(k, "attn k")
+        p.v_stride_b, p.v_stride_t = _bthd(v, "attn v")
+        p.o_stride_b, p.o_stride_t = _bthd(out, "attn out")
+        if rel_bias is not None:
+            p.rel_bias, p.R = rel_bias.data_ptr(), rel_bias.shape[1]
+        p.rel_off = int(rel_off)
+        if key_mask is not None:
+            if key_mask.dtype not in (torch.uint8, torch.bool) or tuple(key_mask.shape) != (Bn, Lk):
+                raise LakoError("attn_fwd: key_mask must be uint8/bool [Bn, Lk]")
+            p.key_mask = key_mask.data_ptr()
+        p.causal, p.causal_off = int(causal), int(causal_off)
+        p.Bn, p.H, p.Lq, p.Lk, p.d_head = Bn, H, Lq, Lk, dk
+        p.dtype = _dt(q)
+        p.drop = _drop(drop)
+        if scores_out is not None:
+            p.scores_out = scores_out.data_ptr()
+        check(self.lib.lako_attn_fwd(C.byref(p), self._stream()), "lako_attn_fwd")
+
+    def attn_bwd(self, q, k, v, out, dout, stats, dq, dk_, dv, *, rel_bias=None, drel=None, rel_off=0, key_mask=None,
+                 causal=False, causal_off=0, drop=None):
+        p = AttnBwd()
+        Bn, Lq, H, dk = q.shape
+        Lk = k.shape[1]
+        p.q, p.k, p.v, p.out, p.dout, p.lse = (q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
+                                               dout.data_ptr(), stats.data_ptr())
+        p.dq_out, p.dk_out, p.dv_out = dq.data_ptr(), dk_.data_ptr(), dv.data_ptr()
+        p.q_stride_b, p.q_stride_t = _bthd(q, "attn q")
+        p.k_stride_b, p.k_stride_t = _bthd(k, "attn k")
+        p.v_stride_b, p.v_stride_t = _bthd(v, "attn v")
+        p.o_stride_b, p.o_stride_t = _bthd(out, "attn out")
+        for a, b_, n in ((dq, q, "dq"), (dk_, k, "dk"), (dv, v, "dv"), (dout, out, "dout")):
+            if a.stride() != b_.stride() or a.shape != b_.shape:
+                raise LakoError(f"attn_bwd: {n} must share the layout of its forward tensor")
+        if rel_bias is not None:
+            p.rel_bias, p.R = rel_bias.data_ptr(), rel_bias.shape[1]
+        if drel is not None:
+            p.drel = drel.data_ptr()
+        p.rel_off = int(rel_off)
+        if key_mask is not None:
+            p.key_mask = key_mask.data_ptr()
+        p.causal, p.causal_off = int(causal), int(causal_off)
+        p.Bn, p.H, p.Lq, p.Lk, p.d_head = Bn, H, Lq, Lk, dk
+        p.dtype = _dt(q)
+        p.drop = _drop(drop)
+        check(self.lib.lako_attn_bwd(C.byref(p), self._stream()), "lako_attn_bwd")
+
+    # ---- loss / optimizer -----------------------------------------------------------------------
+    def ce_fwd_bwd(self, logits, labels, loss_out, dlogits):
+        M, V = logits.shape
+        check(self.lib.lako_ce_fwd_bwd(_p(logits), _p(labels), _p(loss_out), _p(dlogits), M, V,
+                                       _dt(dlogits) if dlogits is not None else LAKO_F32, self._stream()),
+              "lako_ce_fwd_bwd")
+
+    def sumsq(self, g, out):
+        check(self.lib.lako_sumsq(_p(g), g.numel(), _p(out), self._stream()), "lako_sumsq")
+
+    def adamw_step(self, p, g, m, v, shadow, *, lr, beta1, beta2, eps, weight_decay, gnorm_sq, max_norm, grad_scale):
+        check(self.lib.lako_adamw_step(_p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), float(lr), float(beta1),
+                                       float(beta2), float(eps), float(weight_decay), _p(gnorm_sq), float(max_norm),
+                                       float(grad_scale), _dt(shadow) if shadow is not None else LAKO_F32,
+                                       self._stream()), "lako_adamw_step")
+
+    def transpose_cast(self, src, dst):
+        rows, cols = src.shape
+        check(self.lib.lako_transpose_cast(_p(src), _p(dst), rows, cols, _dt(dst), self._stream()),
+              "lako_transpose_cast")
+
+    def cast(self, src, dst):
+        check(self.lib.lako_cast(_p(src), _p(dst), src.numel(), _dt(dst), self._stream()), "lako_cast")
+
+    # ---- integer helpers ------------------------------------------------------------------------
+    def shift_right(self, labels, dec_ids):
+        B, T = labels.shape
+        check(self.lib.lako_shift_right(_p(labels), _p(dec_ids), B, T, self._stream()), "lako_shift_right")
+
+    def greedy_step(self, logits, seq, pos, next_ids, done, n_done, eos_id=1, pad_id=0):
+        B, V = logits.shape
+        check(self.lib.lako_greedy_step(_p(logits), V, B, _p(seq), seq.stride(0), int(pos), _p(next_ids), _p(done),
+                                        _p(n_done), int(eos_id), int(pad_id), self._stream()), "lako_greedy_step")

@@ -1,0 +1,240 @@
+"""TEST DOUBLE of lako_amd.ops.HipOps — plain fp32 torch restatement of every C-ABI op's contract.
+
+Lives under tests/ on purpose: it is never imported by the product.  Two uses:
+  * `-m gpu` tests run each HIP kernel and this reference on the same inputs and compare;
+  * `-m "not gpu"` tests inject it into lako_amd.engine to check the host-side orchestration
+    (manual forward/backward, parameter layout, optimizer plumbing) against the oracle on CPU.
+Works on any device; low-precision tensors are upcast to fp32, computed, and rounded on store.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+M32 = 0xFFFFFFFF
+FLT_MAX = float(np.finfo(np.float32).max)
+
+
+def _mul32(x: torch.Tensor, c: int) -> torch.Tensor:
+    """(x * c) mod 2^32 for int64 tensors holding uint32 values (no int64 overflow)."""
+    lo, hi = x & 0xFFFF, x >> 16
+    return (lo * c + (((hi * c) & M32) << 16)) & M32
+
+
+def hash32(x: torch.Tensor) -> torch.Tensor:
+    x = x ^ (x >> 16)
+    x = _mul32(x, 0x7FEB352D)
+    x = x ^ (x >> 15)
+    x = _mul32(x, 0x846CA68B)
+    return x ^ (x >> 16)
+
+
+def _hash32_int(x: int) -> int:
+    x &= M32
+    x ^= x >> 16
+    x = (x * 0x7FEB352D) & M32
+    x ^= x >> 15
+    x = (x * 0x846CA68B) & M32
+    return x ^ (x >> 16)
+
+
+def drop_key(seed: int, site: int) -> int:
+    return _hash32_int((seed * 0x9E3779B9 + site * 0x85EBCA6B + 0x1234567) & M32)
+
+
+def keep_mask(drop, idx: torch.Tensor):
+    """(keep bool tensor, scale) for element indices `idx` (int64) — the integer recipe of csrc/common.h."""
+    p, seed, site = drop
+    p32 = float(np.float32(p))
+    thresh = min(int(p32 * 4294967296.0), M32)
+    key = drop_key(int(seed) & M32, int(site) & M32)
+    lo, hi = idx & M32, idx >> 32
+    h = hash32(lo ^ key ^ ((hi * 0x27D4EB2F) & M32))
+    scale = float(np.float32(1.0) / (np.float32(1.0) - np.float32(p)))
+    return h >= thresh, scale
+
+
+def _on(d):
+    return d is not None and d[0] > 0.0
+
+
+def _apply_drop(x: torch.Tensor, drop, idx=None):
+    if not _on(drop):
+        return x
+    if idx is None:
+        idx = torch.arange(x.numel(), device=x.device, dtype=torch.int64).view(x.shape)
+    keep, scale = keep_mask(drop, idx)
+    return torch.where(keep, x * scale, torch.zeros_like(x))
+
+
+def f(t):
+    return t.float()
+
+
+class RefOps:
+    name = "ref"
+
+    def zero_(self, t):
+        t.zero_()
+
+    # ---- GEMMs -----------------------------------------------------------------------------
+    def gemm_nt(self, A, B, Cm, *, alpha=1.0, relu=False, resid=None, aux=None, aux_scale=1.0, drop=None,
+                atomic=False):
+        v = (f(A) @ f(B).t()) * alpha
+        if relu:
+            v = torch.relu(v)
+        if aux is not None:
+            v = torch.where(f(aux) > 0, v * aux_scale, torch.zeros_like(v))
+        v = _apply_drop(v, drop)
+        if resid is not None:
+            v = v + f(resid)
+        if atomic:
+            Cm += v
+        else:
+            Cm.copy_(v)
+
+    def gemm_tn(self, A, B, Cm, *, alpha=1.0, split_k=0):
+        Cm += (f(A).t() @ f(B)) * alpha
+
+    # ---- norm / embedding / dropout ------------------------------------------------------------
+    def rmsnorm_fwd(self, x, w, y, rstd, eps, drop=None):
+        xf = f(x)
+        rs = torch.rsqrt(xf.pow(2).mean(-1) + eps)
+        rstd.copy_(rs)
+        y.copy_(_apply_drop(w * (xf * rs[:, None]), drop))
+
+    def rmsnorm_bwd(self, dy, x, w, rstd, dres, dx, dw, drop=None):
+        g = _apply_drop(f(dy), drop)
+        xf, rs = f(x), rstd[:, None]
+        d = xf.shape[1]
+        s = (w * g * xf).sum(-1, keepdim=True)
+        out = rs * w * g - xf * (rs ** 3) * s / d
+        if dres is not None:
+            out = out + f(dres)
+        dx.copy_(out)
+        dw += (g * xf * rs).sum(0)
+
+    def embed_fwd(self, ids, table, out, drop=None):
+        out.copy_(_apply_drop(f(table)[ids.reshape(-1)], drop).view(out.shape))
+
+    def embed_bwd(self, ids, dout, dtable, drop=None):
+        g = _apply_drop(f(dout).reshape(-1, dtable.shape[1]), drop)
+        dtable.index_add_(0, ids.reshape(-1), g)
+
+    def dropout_apply(self, x, y, drop):
+        y.copy_(_apply_drop(f(x).reshape(-1), drop).view(y.shape))
+
+    # ---- relative position bias --------------------------------------------------------------
+    def relpos_expand(self, table, lut, rel):
+        rel.copy_(table[lut.long()].t())
+
+    def relpos_reduce(self, drel, lut, dtable):
+        dtable.index_add_(0, lut.long(), drel.t().contiguous())
+
+    # ---- attention ------------------------------------------------------------------------------
+    @staticmethod
+    def _attn_core(q, k, v, rel_bias, rel_off, key_mask, causal, causal_off, drop):
+        """q,k,v fp32 [B,L,H,dk] → (out [B,Lq,H,dk], m, inv_l, raw scores, masked bool)."""
+        B, Lq, H, dk = q.shape
+        Lk = k.shape[1]
+        dev = q.device
+        s = torch.einsum("bqhd,bkhd->bhqk", q, k)
+        i = torch.arange(Lq, device=dev)[:, None]
+        j = torch.arange(Lk, device=dev)[None, :]
+        if rel_bias is not None:
+            bi = j - i + rel_off
+            ok = (bi >= 0) & (bi < rel_bias.shape[1])
+            bias = rel_bias[:, bi.clamp(0, rel_bias.shape[1] - 1)] * ok
+            s = s + bias[None]
+        masked = torch.zeros(B, 1, Lq, Lk, dtype=torch.bool, device=dev)
+        if key_mask is not None:
+            masked = masked | ~key_mask.bool()[:, None, None, :]
+        if causal:
+            masked = masked | (j > i + causal_off)[None, None]
+        masked = masked.expand(B, H, Lq, Lk)
+        raw = torch.where(masked, torch.zeros_like(s), s)
+        # HF ADDS finfo.min (HF5:163-164): s + min rounds to min, so a fully masked row becomes uniform AND
+        # the gradient still flows to the scores of masked keys (torch.where would block it)
+        sm = s + masked.float() * (-FLT_MAX)
+        m = sm.max(-1).values
+        p = torch.exp(sm - m[..., None])
+        l = p.sum(-1)
+        pn = p / l[..., None]
+        if _on(drop):
+            idx = torch.arange(B * H * Lq * Lk, device=dev, dtype=torch.int64).view(B, H, Lq, Lk)
+            keep, scale = keep_mask(drop, idx)
+            pn = torch.where(keep, pn * scale, torch.zeros_like(pn))
+        out = torch.einsum("bhqk,bkhd->bqhd", pn, v)
+        return out, m, 1.0 / l, raw
+
+    def attn_fwd(self, q, k, v, out, stats, *, rel_bias=None, rel_off=0, key_mask=None, causal=False, causal_off=0,
+                 drop=None, scores_out=None):
+        o, m, il, raw = self._attn_core(f(q), f(k), f(v), rel_bias, rel_off, key_mask, causal, causal_off, drop)
+        out.copy_(o)
+        stats.copy_(torch.stack([m, il], -1))
+        if scores_out is not None:
+            scores_out.copy_(raw)
+
+    def attn_bwd(self, q, k, v, out, dout, stats, dq, dk_, dv, *, rel_bias=None, drel=None, rel_off=0, key_mask=None,
+                 causal=False, causal_off=0, drop=None):
+        with torch.enable_grad():
+            qf, kf, vf = (f(t).detach().clone().requires_grad_(True) for t in (q, k, v))
+            rb = rel_bias.detach().clone().requires_grad_(True) if rel_bias is not None else None
+            o, _, _, _ = self._attn_core(qf, kf, vf, rb, rel_off, key_mask, causal, causal_off, drop)
+            ins = [qf, kf, vf] + ([rb] if rb is not None else [])
+            gs = torch.autograd.grad(o, ins, f(dout))
+        dq.copy_(gs[0])
+        dk_.copy_(gs[1])
+        dv.copy_(gs[2])
+        if drel is not None:
+            drel += gs[3]
+
+    # ---- loss / optimizer -----------------------------------------------------------------------
+    def ce_fwd_bwd(self, logits, labels, loss_out, dlogits):
+        valid = labels != -100
+        n = valid.sum().float()
+        lse = torch.logsumexp(logits, -1)
+        tgt = logits.gather(1, labels.clamp(min=0)[:, None])[:, 0]
+        loss_out[0] = ((lse - tgt) * valid).sum() / n
+        loss_out[1] = n
+        if dlogits is not None:
+            p = torch.softmax(logits, -1)
+            p[torch.arange(len(labels), device=labels.device), labels.clamp(min=0)] -= 1.0
+            dlogits.copy_(p * (valid[:, None] / n))
+
+    def sumsq(self, g, out):
+        out += (g.double() ** 2).sum().float()
+
+    def adamw_step(self, p, g, m, v, shadow, *, lr, beta1, beta2, eps, weight_decay, gnorm_sq, max_norm, grad_scale):
+        coef = grad_scale
+        if gnorm_sq is not None:
+            total = torch.sqrt(gnorm_sq[0]) * grad_scale
+            coef = coef * torch.clamp(max_norm / (total + 1e-6), max=1.0)
+        gg = g * coef
+        m.mul_(beta1).add_(gg, alpha=1 - beta1)
+        v.mul_(beta2).addcmul_(gg, gg, value=1 - beta2)
+        p.sub_(lr * (m / (v.sqrt() + eps)))
+        if weight_decay > 0:
+            p.sub_(lr * weight_decay * p)
+        if shadow is not None:
+            shadow.copy_(p)
+
+    def transpose_cast(self, src, dst):
+        dst.copy_(src.t())
+
+    def cast(self, src, dst):
+        dst.copy_(src.view(dst.shape))
+
+    # ---- integer helpers ------------------------------------------------------------------------
+    def shift_right(self, labels, dec_ids):
+        dec_ids[:, 0] = 0
+        dec_ids[:, 1:] = labels[:, :-1]
+        dec_ids.masked_fill_(dec_ids == -100, 0)
+
+    def greedy_step(self, logits, seq, pos, next_ids, done, n_done, eos_id=1, pad_id=0):
+        nxt = logits.argmax(-1)
+        nxt = torch.where(done.bool(), torch.full_like(nxt, pad_id), nxt)
+        seq[:, pos] = nxt
+        next_ids.copy_(nxt)
+        done |= (nxt == eos_id).to(done.dtype)
+        n_done[0] = int(done.sum())

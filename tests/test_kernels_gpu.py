@@ -1,0 +1,331 @@
+"""-m gpu: every HIP kernel behind the C-ABI against the fp32 torch restatement of its contract
+(tests/ref_ops.py), on the same seeded inputs.  fp32 kernels (exact-f32 MFMA) must agree to ~1e-4;
+bf16 kernels are compared against the reference evaluated on the same bf16-rounded inputs with a
+tolerance of a few bf16 ulps of the output scale (stated per test)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.ref_ops import RefOps, keep_mask
+
+pytestmark = pytest.mark.gpu
+
+DT = {"f32": torch.float32, "bf16": torch.bfloat16}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from lako_amd.ops import HipOps
+    return HipOps()
+
+
+@pytest.fixture(scope="module")
+def ref():
+    return RefOps()
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, dtype=torch.float32, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed + int(np.prod(shape)) % 9973)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(dev())
+
+
+def close(got, want, dtype, what, k=1.0):
+    got, want = got.float(), want.float()
+    scale = max(want.abs().max().item(), 1e-6)
+    if dtype == torch.float32:
+        atol, rtol = 2e-5 * scale * k + 1e-6, 2e-4 * k
+    else:
+        atol, rtol = 1.5e-2 * scale * k, 2e-2 * k
+    err = (got - want).abs()
+    bad = err > atol + rtol * want.abs()
+    assert not bool(bad.any()), (f"{what}: {int(bad.sum())}/{bad.numel()} off, max err {err.max().item():.3e} "
+                                 f"(scale {scale:.3e}) first bad idx {bad.nonzero()[0].tolist()}")
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (300, 264, 200), (108, 64, 32), (1024, 768, 768), (77, 2304, 64),
+                                   (256, 128, 3072)])
+def test_gemm_nt_plain(ops, ref, dt, M, N, K):
+    T = DT[dt]
+    A, B = rnd(M, K, dtype=T, seed=1), rnd(N, K, dtype=T, seed=2)
+    for out_t in (T, torch.float32):
+        C = torch.full((M, N), 7.0, dtype=out_t, device=dev())
+        Cr = torch.zeros(M, N, device=dev())
+        ops.gemm_nt(A, B, C, alpha=0.5)
+        ref.gemm_nt(A, B, Cr, alpha=0.5)
+        close(C, Cr, T, f"gemm_nt {dt}->{out_t} {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_gemm_nt_epilogues(ops, ref, dt):
+    T = DT[dt]
+    M, N, K = 200, 136, 96
+    A, B = rnd(M, K, dtype=T, seed=3), rnd(N, K, dtype=T, seed=4)
+    R = rnd(M, N, dtype=T, seed=5)
+    aux = rnd(M, N, dtype=T, seed=6)
+    drop = (0.1, 1234, 77)
+    cases = [dict(relu=True, drop=drop), dict(resid=R, drop=drop), dict(aux=aux, aux_scale=1.0 / 0.9),
+             dict(relu=True), dict(resid=R)]
+    for kw in cases:
+        C = torch.empty(M, N, dtype=T, device=dev())
+        Cr = torch.zeros(M, N, device=dev())
+        ops.gemm_nt(A, B, C, **kw)
+        ref.gemm_nt(A, B, Cr, **kw)
+        close(C, Cr, T, f"gemm_nt epi {list(kw)} {dt}")
+    # strided views: A = middle slice of a wider matrix, C = slice of a wider output, atomic accumulate
+    wide = rnd(M, 3 * K, dtype=T, seed=7)
+    Cw = torch.ones(M, 2 * N, dtype=torch.float32, device=dev())
+    Cwr = Cw.clone()
+    ops.gemm_nt(wide[:, K:2 * K], B, Cw[:, N:], atomic=True)
+    ref.gemm_nt(wide[:, K:2 * K], B, Cwr[:, N:], atomic=True)
+    close(Cw, Cwr, T, f"gemm_nt strided/atomic {dt}")
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("K,M,N,split", [(500, 264, 136, 0), (108, 64, 32, 1), (4096, 768, 768, 0), (130, 128, 128, 3),
+                                         (64, 96, 2304, 0)])
+def test_gemm_tn(ops, ref, dt, K, M, N, split):
+    T = DT[dt]
+    A, B = rnd(K, M, dtype=T, seed=8), rnd(K, N, dtype=T, seed=9)
+    C = torch.ones(M, N, device=dev())
+    Cr = C.clone()
+    ops.gemm_tn(A, B, C, alpha=0.25, split_k=split)
+    ref.gemm_tn(A, B, Cr, alpha=0.25)
+    close(C, Cr, T, f"gemm_tn {dt} K{K} {M}x{N}")
+    # strided operands (column slices of wider activations)
+    Aw, Bw = rnd(K, 2 * M, dtype=T, seed=10), rnd(K, 3 * N, dtype=T, seed=11)
+    C.fill_(0)
+    Cr.fill_(0)
+    ops.gemm_tn(Aw[:, M:], Bw[:, N:2 * N], C)
+    ref.gemm_tn(Aw[:, M:], Bw[:, N:2 * N], Cr)
+    close(C, Cr, T, f"gemm_tn strided {dt}")
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("rows,d", [(37, 32), (1000, 768), (513, 1024), (64, 512)])
+def test_rmsnorm(ops, ref, dt, rows, d):
+    T = DT[dt]
+    x = rnd(rows, d, dtype=T, seed=12)
+    w = 1.0 + 0.1 * rnd(d, seed=13)
+    for drop in (None, (0.1, 5, 9)):
+        y, yr = torch.empty_like(x), torch.empty(rows, d, device=dev())
+        rs, rsr = torch.empty(rows, device=dev()), torch.empty(rows, device=dev())
+        ops.rmsnorm_fwd(x, w, y, rs, 1e-6, drop)
+        ref.rmsnorm_fwd(x, w, yr, rsr, 1e-6, drop)
+        close(rs, rsr, torch.float32, "rstd")
+        close(y, yr, T, f"rmsnorm_fwd {dt} drop={drop}")
+        dy, dres = rnd(rows, d, dtype=T, seed=14), rnd(rows, d, dtype=T, seed=15)
+        for dr in (None, dres):
+            dx, dxr = torch.empty_like(x), torch.empty(rows, d, device=dev())
+            dw, dwr = torch.ones(d, device=dev()), torch.ones(d, device=dev())
+            ops.rmsnorm_bwd(dy, x, w, rsr, dr, dx, dw, drop)
+            ref.rmsnorm_bwd(dy, x, w, rsr, dr, dxr, dwr, drop)
+            close(dx, dxr, T, f"rmsnorm_bwd dx {dt}")
+            close(dw, dwr, torch.float32, f"rmsnorm_bwd dw {dt}", k=20)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_embed_dropout(ops, ref, dt):
+    T = DT[dt]
+    V, d, n = 96, 64, 300
+    table = rnd(V, d, dtype=T, seed=16)
+    ids = torch.randint(0, V, (n,), generator=torch.Generator().manual_seed(1)).to(dev())
+    for drop in (None, (0.25, 3, 4)):
+        out, outr = torch.empty(n, d, dtype=T, device=dev()), torch.empty(n, d, device=dev())
+        ops.embed_fwd(ids, table, out, drop)
+        ref.embed_fwd(ids, table, outr, drop)
+        assert torch.equal(out.float(), outr.to(T).float()), "embed_fwd must be exact"
+        dout = rnd(n, d, dtype=T, seed=17)
+        dt_, dtr = torch.zeros(V, d, device=dev()), torch.zeros(V, d, device=dev())
+        ops.embed_bwd(ids, dout, dt_, drop)
+        ref.embed_bwd(ids, dout, dtr, drop)
+        close(dt_, dtr, torch.float32, "embed_bwd", k=5)
+    x = rnd(4096 * 8, dtype=T, seed=18)
+    y, yr = torch.empty_like(x), torch.empty(x.numel(), device=dev())
+    ops.dropout_apply(x, y, (0.1, 42, 7))
+    ref.dropout_apply(x, yr, (0.1, 42, 7))
+    assert torch.equal(y == 0, yr == 0), "dropout keep pattern must be bit-identical to the integer recipe"
+    frac = (y == 0).float().mean().item()
+    assert abs(frac - 0.1) < 0.01, frac
+    close(y, yr, T, "dropout_apply")
+
+
+def test_relpos(ops, ref):
+    H, nb, R = 12, 32, 399
+    table = rnd(nb, H, seed=19)
+    lut = torch.randint(0, nb, (R,), generator=torch.Generator().manual_seed(2)).int().to(dev())
+    rel, relr = torch.empty(H, R, device=dev()), torch.empty(H, R, device=dev())
+    ops.relpos_expand(table, lut, rel)
+    ref.relpos_expand(table, lut, relr)
+    assert torch.equal(rel, relr)
+    drel = rnd(H, R, seed=20)
+    dtab, dtabr = torch.zeros(nb, H, device=dev()), torch.zeros(nb, H, device=dev())
+    ops.relpos_reduce(drel, lut, dtab)
+    ref.relpos_reduce(drel, lut, dtabr)
+    close(dtab, dtabr, torch.float32, "relpos_reduce", k=5)
+
+
+# ------------------------------------------------------------------------------------------------
+ATTN_CASES = [
+    # name, Bn, H, Lq, Lk, dk, bias, mask, causal, drop, packed
+    ("enc_tiny", 3, 2, 12, 12, 32, True, True, False, None, True),
+    ("enc_odd", 2, 4, 37, 37, 32, True, True, False, None, True),
+    ("enc_base", 2, 12, 200, 200, 64, True, True, False, None, True),
+    ("enc_base_drop", 2, 3, 200, 200, 64, True, True, False, (0.1, 11, 3), True),
+    ("dec_self", 4, 12, 7, 7, 64, True, False, True, None, True),
+    ("dec_self_drop", 4, 2, 9, 9, 32, True, False, True, (0.1, 12, 4), False),
+    ("cross", 3, 4, 5, 600, 64, False, True, False, None, False),
+    ("cross_drop", 2, 2, 20, 300, 32, False, True, False, (0.1, 13, 5), False),
+    ("decode_step", 4, 8, 1, 23, 64, True, False, False, None, False),
+]
+
+
+def make_attn(case, T):
+    name, Bn, H, Lq, Lk, dk, bias, mask, causal, drop, packed = case
+    inner = H * dk
+    if packed and Lq == Lk:
+        qkv = rnd(Bn, Lq, 3 * inner, dtype=T, seed=21, scale=0.5)
+        q = qkv[:, :, 0:inner].view(Bn, Lq, H, dk)
+        k = qkv[:, :, inner:2 * inner].view(Bn, Lk, H, dk)
+        v = qkv[:, :, 2 * inner:].view(Bn, Lk, H, dk)
+    else:
+        q = rnd(Bn, Lq, H, dk, dtype=T, seed=22, scale=0.5)
+        kv = rnd(Bn, Lk, 2 * inner, dtype=T, seed=23, scale=0.5)
+        k = kv[:, :, :inner].view(Bn, Lk, H, dk)
+        v = kv[:, :, inner:].view(Bn, Lk, H, dk)
+    rel, rel_off = None, 0
+    if bias:
+        R = Lq + Lk - 1 if name != "decode_step" else 2 * 50 - 1
+        rel = rnd(H, R, seed=24)
+        rel_off = Lq - 1 if name != "decode_step" else 49 - (Lk - 1)   # query sits at position Lk-1
+    km = None
+    if mask:
+        g = torch.Generator().manual_seed(3)
+        lens = torch.randint(max(1, Lk // 2), Lk + 1, (Bn,), generator=g)
+        km = (torch.arange(Lk)[None, :] < lens[:, None])
+        km[Bn - 1] = False                      # one fully padded row
+        km = km.to(torch.uint8).to(dev())
+    return q, k, v, rel, rel_off, km, causal, drop
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("case", ATTN_CASES, ids=[c[0] for c in ATTN_CASES])
+def test_attention(ops, ref, dt, case):
+    T = DT[dt]
+    q, k, v, rel, rel_off, km, causal, drop = make_attn(case, T)
+    Bn, Lq, H, dk = q.shape
+    Lk = k.shape[1]
+    kw = dict(rel_bias=rel, rel_off=rel_off, key_mask=km, causal=causal, causal_off=0, drop=drop)
+    out = torch.zeros(Bn, Lq, H, dk, dtype=T, device=dev())
+    outr = torch.zeros(Bn, Lq, H, dk, device=dev())
+    st, stg = torch.zeros(Bn, H, Lq, 2, device=dev()), torch.zeros(Bn, H, Lq, 2, device=dev())
+    sc, scr = torch.zeros(Bn, H, Lq, Lk, device=dev()), torch.zeros(Bn, H, Lq, Lk, device=dev())
+    ops.attn_fwd(q, k, v, out, stg, scores_out=sc, **kw)
+    ref.attn_fwd(q, k, v, outr, st, scores_out=scr, **kw)
+    close(sc, scr, T, f"attn scores {case[0]} {dt}")
+    close(stg[..., 0], st[..., 0], T, f"attn rowmax {case[0]} {dt}")
+    close(stg[..., 1], st[..., 1], T, f"attn 1/rowsum {case[0]} {dt}", k=2)
+    close(out, outr, T, f"attn_fwd out {case[0]} {dt}")
+    # backward (feed the reference's forward products so the comparison isolates the backward kernels)
+    dout = rnd(Bn, Lq, H, dk, dtype=T, seed=25)
+    o_in = outr.to(T)
+    dq, dk_, dv = (torch.zeros_like(t) for t in (q, k, v))
+    dq = torch.zeros(q.shape, dtype=T, device=dev()) if not q.is_contiguous() else dq
+    # gradient tensors must share the layout of their forward tensors: rebuild the packed layout
+    if not q.is_contiguous():
+        inner = H * dk
+        dqkv = torch.zeros(Bn, Lq, 3 * inner, dtype=T, device=dev())
+        dq = dqkv[:, :, :inner].view(Bn, Lq, H, dk)
+        dk_ = dqkv[:, :, inner:2 * inner].view(Bn, Lk, H, dk)
+        dv = dqkv[:, :, 2 * inner:].view(Bn, Lk, H, dk)
+    elif not k.is_contiguous():
+        inner = H * dk
+        dkv = torch.zeros(Bn, Lk, 2 * inner, dtype=T, device=dev())
+        dk_ = dkv[:, :, :inner].view(Bn, Lk, H, dk)
+        dv = dkv[:, :, inner:].view(Bn, Lk, H, dk)
+    dqr, dkr, dvr = (torch.zeros(t.shape, device=dev()) for t in (q, k, v))
+    drel = torch.zeros_like(rel) if rel is not None else None
+    drelr = torch.zeros_like(rel) if rel is not None else None
+    bkw = dict(rel_bias=rel, rel_off=rel_off, key_mask=km, causal=causal, causal_off=0, drop=drop)
+    ops.attn_bwd(q, k, v, o_in, dout, st, dq, dk_, dv, drel=drel, **bkw)
+    ref.attn_bwd(q, k, v, o_in, dout, st, dqr, dkr, dvr, drel=drelr, **bkw)
+    close(dq, dqr, T, f"attn_bwd dq {case[0]} {dt}", k=2)
+    close(dk_, dkr, T, f"attn_bwd dk {case[0]} {dt}", k=2)
+    close(dv, dvr, T, f"attn_bwd dv {case[0]} {dt}", k=2)
+    if rel is not None:
+        close(drel, drelr, T, f"attn_bwd drel {case[0]} {dt}", k=4)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("M,V", [(12, 64), (128, 32128)])
+def test_cross_entropy(ops, ref, dt, M, V):
+    T = DT[dt]
+    logits = rnd(M, V, seed=26, scale=2.0)
+    labels = torch.randint(0, V, (M,), generator=torch.Generator().manual_seed(4))
+    labels[::3] = -100
+    labels = labels.to(dev())
+    lo, lor = torch.zeros(2, device=dev()), torch.zeros(2, device=dev())
+    dl, dlr = torch.empty(M, V, dtype=T, device=dev()), torch.empty(M, V, device=dev())
+    ops.ce_fwd_bwd(logits, labels, lo, dl)
+    ref.ce_fwd_bwd(logits, labels, lor, dlr)
+    assert abs(lo[0].item() - lor[0].item()) < 1e-4 * max(1.0, abs(lor[0].item())), (lo, lor)
+    assert lo[1].item() == lor[1].item()
+    close(dl, dlr, T, f"ce dlogits {dt}")
+
+
+def test_optimizer(ops, ref):
+    n = 1000 * 4
+    p, g = rnd(n, seed=27), rnd(n, seed=28, scale=3.0)
+    m, v = rnd(n, seed=29, scale=0.1), rnd(n, seed=30).abs() * 0.01
+    for T in (torch.float32, torch.bfloat16):
+        for use_norm in (True, False):
+            a = [t.clone() for t in (p, g, m, v)]
+            b = [t.clone() for t in (p, g, m, v)]
+            sh, shr = torch.empty(n, dtype=T, device=dev()), torch.empty(n, device=dev())
+            ns, nsr = torch.zeros(1, device=dev()), torch.zeros(1, device=dev())
+            ops.sumsq(a[1], ns)
+            ref.sumsq(b[1], nsr)
+            close(ns, nsr, torch.float32, "sumsq")
+            kw = dict(lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-6, weight_decay=1e-2, max_norm=1.0, grad_scale=0.5)
+            ops.adamw_step(a[0], a[1], a[2], a[3], sh, gnorm_sq=ns if use_norm else None, **kw)
+            ref.adamw_step(b[0], b[1], b[2], b[3], shr, gnorm_sq=nsr if use_norm else None, **kw)
+            for x, y, nm in zip(a, b, "pgmv"):
+                close(x, y, torch.float32, f"adamw {nm}")
+            close(sh, shr, T, "adamw shadow")
+    src = rnd(70, 200, seed=31)
+    for T in (torch.float32, torch.bfloat16):
+        dst = torch.empty(200, 70, dtype=T, device=dev())
+        ops.transpose_cast(src, dst)
+        assert torch.equal(dst, src.t().to(T))
+        d2 = torch.empty(70 * 200, dtype=T, device=dev())
+        ops.cast(src.view(-1), d2)
+        assert torch.equal(d2, src.view(-1).to(T))
+
+
+def test_int_helpers(ops, ref):
+    labels = torch.tensor([[5, 9, 1, -100], [7, 1, -100, -100]], device=dev())
+    dec = torch.full_like(labels, 99)
+    ops.shift_right(labels, dec)
+    assert dec.tolist() == [[0, 5, 9, 1], [0, 7, 1, 0]]
+    B, V = 5, 32128
+    logits = rnd(B, V, seed=32)
+    logits[2, 100] = logits[2, 7000] = 50.0           # tie → lowest index (torch.argmax semantics)
+    logits[3, 1] = 60.0                                # EOS
+    seq = torch.zeros(B, 6, dtype=torch.long, device=dev())
+    nxt = torch.zeros(B, dtype=torch.long, device=dev())
+    done = torch.zeros(B, dtype=torch.uint8, device=dev())
+    done[4] = 1
+    nd = torch.zeros(1, dtype=torch.int32, device=dev())
+    ops.greedy_step(logits, seq, 2, nxt, done, nd)
+    exp = logits.argmax(-1)
+    exp[4] = 0
+    assert nxt.tolist() == exp.tolist() and nxt[2].item() == 100 and nxt[3].item() == 1
+    assert seq[:, 2].tolist() == exp.tolist() and done.tolist() == [0, 0, 0, 1, 1] and nd.item() == 2
