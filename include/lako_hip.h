@@ -142,9 +142,10 @@ int lako_attn_bwd(const lako_attn_bwd_t* p, lako_stream_t stream);
 
 /* ---- LM-head loss (HF5:1051-1054): CrossEntropyLoss(ignore_index=-100), mean over valid labels ----
  * logits fp32 [M, V]; loss_out[0] = mean loss, loss_out[1] = number of valid labels;
- * dlogits (dtype, [M, V], optional) = (softmax - onehot) / n_valid, 0 on ignored rows. */
-int lako_ce_fwd_bwd(const float* logits, const int64_t* labels, float* loss_out, void* dlogits, int64_t M,
-                    int64_t V, int dtype, lako_stream_t stream);
+ * dlogits (dtype, [M, V], optional) = upstream * (softmax - onehot) / n_valid, 0 on ignored rows;
+ * upstream = device pointer to the scalar d(objective)/d(loss) (NULL = 1). */
+int lako_ce_fwd_bwd(const float* logits, const int64_t* labels, float* loss_out, void* dlogits,
+                    const float* upstream, int64_t M, int64_t V, int dtype, lako_stream_t stream);
 
 /* ---- optimizer (train_reader.py:76-79; src/util.py:185-227): global-norm clip + HF AdamW with
  * correct_bias=False + decoupled weight decay, one fused pass over the flat parameter buffer ------ */

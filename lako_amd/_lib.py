@@ -68,7 +68,7 @@ SIGNATURES = {
     "lako_relpos_reduce": [vp, vp, vp, i32, i32, i32, vp],
     "lako_attn_fwd": [C.POINTER(AttnFwd), vp],
     "lako_attn_bwd": [C.POINTER(AttnBwd), vp],
-    "lako_ce_fwd_bwd": [vp, vp, vp, vp, i64, i64, i32, vp],
+    "lako_ce_fwd_bwd": [vp, vp, vp, vp, vp, i64, i64, i32, vp],
     "lako_sumsq": [vp, i64, vp, vp],
     "lako_adamw_step": [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, f32, f32, i32, vp],
     "lako_transpose_cast": [vp, vp, i64, i64, i32, vp],

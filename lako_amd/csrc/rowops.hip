@@ -270,7 +270,8 @@ __global__ void ce_init_kernel(float* loss_out, const int64_t* labels, int64_t M
 
 template <typename T>
 __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
-                                                 float* __restrict__ loss_out, T* __restrict__ dlogits, int64_t V) {
+                                                 float* __restrict__ loss_out, T* __restrict__ dlogits,
+                                                 const float* __restrict__ upstream, int64_t V) {
   __shared__ float red[4];
   __shared__ float bc;
   const int64_t row = blockIdx.x;
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
   if (threadIdx.x == 0 && valid) atomicAdd(loss_out, (lse - lr[label]) / n_valid);
   if (dlogits) {
     T* dr = dlogits + row * V;
-    const float inv = valid ? 1.0f / n_valid : 0.f;
+    const float inv = valid ? (upstream ? upstream[0] : 1.0f) / n_valid : 0.f;
     for (int64_t c = threadIdx.x * 4; c < V; c += 1024) {
       f32x4 v = *reinterpret_cast<const f32x4*>(lr + c);
       f32x4 o;
@@ -555,14 +556,14 @@ extern "C" int lako_transpose_cast(const float* src, void* dst, int64_t rows, in
   return LAKO_OK;
 }
 
-extern "C" int lako_ce_fwd_bwd(const float* logits, const int64_t* labels, float* loss_out, void* dlogits, int64_t M,
-                               int64_t V, int dtype, lako_stream_t stream) {
+extern "C" int lako_ce_fwd_bwd(const float* logits, const int64_t* labels, float* loss_out, void* dlogits,
+                               const float* upstream, int64_t M, int64_t V, int dtype, lako_stream_t stream) {
   CHECK_DTYPE("lako_ce_fwd_bwd", dtype);
   LAKO_CHECK_ARG(M > 0 && V > 0 && V % 4 == 0, "lako_ce_fwd_bwd: M=%lld V=%lld (V %% 4 == 0)", (long long)M, (long long)V);
   LAKO_CHECK_ALIGN(logits, 16);
   hipLaunchKernelGGL(ce_init_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_out, labels, M);
   DISPATCH_T(dtype, hipLaunchKernelGGL((ce_kernel<T>), dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream, logits,
-                                       labels, loss_out, (T*)dlogits, V));
+                                       labels, loss_out, (T*)dlogits, upstream, V));
   LAKO_LAUNCH_CHECK();
   return LAKO_OK;
 }

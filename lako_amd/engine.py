@@ -1,0 +1,549 @@
+"""Host-side engine of the FiD reader: parameter layout in HBM, workspaces, and the hand-orchestrated
+forward / backward / greedy-decode schedules over the op vocabulary of `lako_amd.ops.HipOps`.
+
+What it reproduces (reference file:line; HF5 = transformers 5.15.0 modeling_t5.py):
+  * FiDT5.forward + EncoderWrapper.forward reshapes            src/model.py:39-51, 227-234
+  * T5Stack / T5Block / attention / FFN / final norm            HF5:663-750, 448-509, 281-369, 83-94, 59-72
+  * shift_right, tied LM head × d_model^-0.5, CE(ignore=-100)   HF5:618-637, 1044-1054
+  * autograd of all of the above (train_reader.py:73)          written out by hand below
+  * greedy generate with KV cache                              src/model.py:54-60, train_reader.py:142-146
+
+Memory plan (sized for 288 GB HBM3E — nothing is recomputed unless `use_checkpoint`):
+  P   fp32 master parameters, one flat buffer               G   fp32 gradients, same layout
+  W   compute-dtype shadow of P (aliases P in fp32 mode)      WT  per-matrix transposed shadows ([in,out])
+so that every GEMM of the step is either NT (X·Wᵀ forward, dY·(Wᵀ)ᵀ for dX) or TN (dYᵀ·X for dW).
+q,k,v weights of a layer are adjacent rows of one [3·inner, d] block (one fused QKV GEMM), and the
+cross-attention k,v weights of ALL decoder layers form one [L_dec·2·inner, d] block, so the encoder
+output [B·N·L, d] is read once for all layers' K/V projections.
+Gradient buffer order = the order gradients complete in backward (decoder, cross-K/V, encoder layers
+last→first, embedding), so data-parallel buckets can be all-reduced while backward is still running.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from .config import FiDConfig
+from .relpos import bucket_lut
+
+ALIGN = 64  # elements; keeps every block 256-B aligned in fp32 and 128-B aligned in bf16
+
+# dropout site ids (unique per place a torch.nn.Dropout sits in the reference graph)
+S_ENC_EMBED, S_ENC_FINAL, S_DEC_EMBED, S_DEC_FINAL = 1, 2, 3, 4
+
+
+def _enc_site(i, k):   # k: 0 attn probs, 1 attn out, 2 ffn act, 3 ffn out
+    return 100 + i * 8 + k
+
+
+def _dec_site(i, k):   # k: 0 self probs, 1 self out, 2 cross probs, 3 cross out, 4 ffn act, 5 ffn out
+    return 4000 + i * 8 + k
+
+
+@dataclass
+class Block:
+    name: str
+    shape: tuple
+    members: list            # [(plain HF name, row0, nrows)]
+    transpose: bool = False  # keep a transposed low-precision copy (GEMM weights)
+    off: int = 0
+    toff: int = -1
+
+    @property
+    def numel(self):
+        return int(np.prod(self.shape))
+
+
+class Mat:
+    """One GEMM weight block: p fp32 master [N,K], g fp32 grad, w compute-dtype [N,K], wt compute-dtype [K,N]."""
+    __slots__ = ("p", "g", "w", "wt")
+
+
+class Vec:
+    __slots__ = ("p", "g")
+
+
+def build_layout(cfg: FiDConfig) -> list[Block]:
+    d, f, inner, H, nb = cfg.d_model, cfg.d_ff, cfg.inner_dim, cfg.num_heads, cfg.relative_attention_num_buckets
+    blocks: list[Block] = []
+
+    def add(name, shape, members, transpose=False):
+        blocks.append(Block(name, tuple(shape), members, transpose))
+
+    Ld, Le = cfg.num_decoder_layers, cfg.num_layers
+    add("dec.final_ln", (d,), [("decoder.final_layer_norm.weight", 0, d)])
+    for i in range(Ld):
+        p = f"decoder.block.{i}.layer."
+        add(f"dec.{i}.qkv", (3 * inner, d), [(p + f"0.SelfAttention.{n}.weight", j * inner, inner)
+                                             for j, n in enumerate("qkv")], True)
+        add(f"dec.{i}.o", (d, inner), [(p + "0.SelfAttention.o.weight", 0, d)], True)
+        add(f"dec.{i}.ln1", (d,), [(p + "0.layer_norm.weight", 0, d)])
+        add(f"dec.{i}.cq", (inner, d), [(p + "1.EncDecAttention.q.weight", 0, inner)], True)
+        add(f"dec.{i}.co", (d, inner), [(p + "1.EncDecAttention.o.weight", 0, d)], True)
+        add(f"dec.{i}.ln2", (d,), [(p + "1.layer_norm.weight", 0, d)])
+        add(f"dec.{i}.wi", (f, d), [(p + "2.DenseReluDense.wi.weight", 0, f)], True)
+        add(f"dec.{i}.wo", (d, f), [(p + "2.DenseReluDense.wo.weight", 0, d)], True)
+        add(f"dec.{i}.ln3", (d,), [(p + "2.layer_norm.weight", 0, d)])
+    add("dec.rel", (nb, H), [("decoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight", 0, nb)])
+    kv = []
+    for i in range(Ld):
+        p = f"decoder.block.{i}.layer.1.EncDecAttention."
+        kv += [(p + "k.weight", 2 * i * inner, inner), (p + "v.weight", (2 * i + 1) * inner, inner)]
+    add("dec.kv_all", (Ld * 2 * inner, d), kv, True)
+    add("enc.final_ln", (d,), [("encoder.final_layer_norm.weight", 0, d)])
+    for i in reversed(range(Le)):
+        p = f"encoder.block.{i}.layer."
+        add(f"enc.{i}.qkv", (3 * inner, d), [(p + f"0.SelfAttention.{n}.weight", j * inner, inner)
+                                             for j, n in enumerate("qkv")], True)
+        add(f"enc.{i}.o", (d, inner), [(p + "0.SelfAttention.o.weight", 0, d)], True)
+        add(f"enc.{i}.ln1", (d,), [(p + "0.layer_norm.weight", 0, d)])
+        add(f"enc.{i}.wi", (f, d), [(p + "1.DenseReluDense.wi.weight", 0, f)], True)
+        add(f"enc.{i}.wo", (d, f), [(p + "1.DenseReluDense.wo.weight", 0, d)], True)
+        add(f"enc.{i}.ln2", (d,), [(p + "1.layer_norm.weight", 0, d)])
+    add("enc.rel", (nb, H), [("encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight", 0, nb)])
+    add("shared", (cfg.vocab_size, d), [("shared.weight", 0, cfg.vocab_size)], True)
+    off = toff = 0
+    for b in blocks:
+        b.off = off
+        off += -(-b.numel // ALIGN) * ALIGN
+        if b.transpose:
+            b.toff = toff
+            toff += -(-b.numel // ALIGN) * ALIGN
+    return blocks
+
+
+def layout_sizes(blocks):
+    last = blocks[-1]
+    n = last.off + -(-last.numel // ALIGN) * ALIGN
+    tb = [b for b in blocks if b.transpose]
+    nt = tb[-1].toff + -(-tb[-1].numel // ALIGN) * ALIGN
+    return n, nt
+
+
+@dataclass
+class _Ctx:
+    """What forward leaves behind for backward."""
+    B: int = 0
+    N: int = 0
+    L: int = 0
+    T: int = 0
+    p: float = 0.0
+    seed: int = 0
+    ids: torch.Tensor = None
+    mask_u8: torch.Tensor = None
+    labels: torch.Tensor = None
+    dec_ids: torch.Tensor = None
+    ws: dict = field(default_factory=dict)
+
+
+class Engine:
+    def __init__(self, cfg: FiDConfig, ops, device, dtype=torch.bfloat16, seed: int = 0):
+        if cfg.d_kv not in (32, 64):
+            raise ValueError(f"d_kv={cfg.d_kv} unsupported by the attention kernels (32 or 64)")
+        if cfg.d_model % 8 or cfg.d_ff % 8 or cfg.vocab_size % 8:
+            raise ValueError("d_model, d_ff and vocab_size must be multiples of 8")
+        self.cfg, self.ops, self.device, self.dtype = cfg, ops, torch.device(device), dtype
+        self.blocks = build_layout(cfg)
+        self.n_param, self.n_trans = layout_sizes(self.blocks)
+        dev = self.device
+        self.P = torch.zeros(self.n_param, dtype=torch.float32, device=dev)
+        self.G = torch.zeros(self.n_param, dtype=torch.float32, device=dev)
+        self.W = self.P if dtype == torch.float32 else torch.zeros(self.n_param, dtype=dtype, device=dev)
+        self.WT = torch.zeros(self.n_trans, dtype=dtype, device=dev)
+        self.opt_m = None   # AdamW moments, allocated by the optimizer on first use
+        self.opt_v = None
+        self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.by_name = {b.name: b for b in self.blocks}
+        self._bind()
+        self.seed_base = int(seed)
+        self.step_count = 0
+        self.use_checkpoint = False
+        self._ws_cache: dict = {}
+        self._lut_cache: dict = {}
+        self.ctx: _Ctx | None = None
+        self.grad_hook = None    # callable(lo, hi): gradients G[lo:hi] are final (data-parallel overlap)
+        self.shadows_stale = True
+
+    # ------------------------------------------------------------------------------------------
+    # parameter views
+    # ------------------------------------------------------------------------------------------
+    def _view(self, flat, b: Block, transposed=False):
+        if transposed:
+            return flat[b.toff:b.toff + b.numel].view(b.shape[1], b.shape[0])
+        return flat[b.off:b.off + b.numel].view(b.shape)
+
+    def _mat(self, name) -> Mat:
+        b = self.by_name[name]
+        m = Mat()
+        m.p, m.g, m.w = self._view(self.P, b), self._view(self.G, b), self._view(self.W, b)
+        m.wt = self._view(self.WT, b, True)
+        return m
+
+    def _vec(self, name) -> Vec:
+        b = self.by_name[name]
+        v = Vec()
+        v.p, v.g = self._view(self.P, b), self._view(self.G, b)
+        return v
+
+    def _bind(self):
+        cfg = self.cfg
+        self.shared = self._mat("shared")
+        self.kv_all = self._mat("dec.kv_all")
+        self.enc_final, self.dec_final = self._vec("enc.final_ln"), self._vec("dec.final_ln")
+        self.enc_rel, self.dec_rel = self._vec("enc.rel"), self._vec("dec.rel")
+        self.enc, self.dec = [], []
+        for i in range(cfg.num_layers):
+            self.enc.append(dict(qkv=self._mat(f"enc.{i}.qkv"), o=self._mat(f"enc.{i}.o"), ln1=self._vec(f"enc.{i}.ln1"),
+                                 wi=self._mat(f"enc.{i}.wi"), wo=self._mat(f"enc.{i}.wo"), ln2=self._vec(f"enc.{i}.ln2")))
+        for i in range(cfg.num_decoder_layers):
+            self.dec.append(dict(qkv=self._mat(f"dec.{i}.qkv"), o=self._mat(f"dec.{i}.o"), ln1=self._vec(f"dec.{i}.ln1"),
+                                 cq=self._mat(f"dec.{i}.cq"), co=self._mat(f"dec.{i}.co"), ln2=self._vec(f"dec.{i}.ln2"),
+                                 wi=self._mat(f"dec.{i}.wi"), wo=self._mat(f"dec.{i}.wo"), ln3=self._vec(f"dec.{i}.ln3")))
+
+    def named_param_views(self, flat=None):
+        """plain HF-T5 name → view into `flat` (default: the fp32 master)."""
+        flat = self.P if flat is None else flat
+        out = {}
+        for b in self.blocks:
+            v = self._view(flat, b)
+            for name, r0, nr in b.members:
+                out[name] = v[r0:r0 + nr] if len(b.shape) == 2 else v
+        return out
+
+    def refresh_shadows(self):
+        """Re-derive the compute-dtype copies (W, WT) from the fp32 master after it changed."""
+        if self.W is not self.P:
+            self.ops.cast(self.P, self.W)
+        for b in self.blocks:
+            if b.transpose:
+                self.ops.transpose_cast(self._view(self.P, b), self._view(self.WT, b, True))
+        self.shadows_stale = False
+
+    def zero_grad(self):
+        self.ops.zero_(self.G)
+
+    # ------------------------------------------------------------------------------------------
+    # helpers
+    # ------------------------------------------------------------------------------------------
+    def _lut(self, qlen, klen, bidirectional):
+        key = (qlen, klen, bidirectional)
+        if key not in self._lut_cache:
+            lut = bucket_lut(qlen, klen, bidirectional, self.cfg.relative_attention_num_buckets,
+                             self.cfg.relative_attention_max_distance)
+            self._lut_cache[key] = torch.from_numpy(lut).to(self.device)
+        return self._lut_cache[key]
+
+    def _buf(self, ws, name, shape, dtype=None):
+        t = ws.get(name)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = torch.empty(shape, dtype=dtype or self.dtype, device=self.device)
+            ws[name] = t
+        return t
+
+    def _workspace(self, key):
+        return self._ws_cache.setdefault(key, {})
+
+    def _heads(self, t2d, rows_b, rows_t, col0):
+        """[rows_b*rows_t, ld] buffer → [B, T, H, dk] view of columns [col0, col0 + inner)."""
+        H, dk = self.cfg.num_heads, self.cfg.d_kv
+        ld = t2d.shape[1]
+        return t2d.view(rows_b, rows_t, ld)[:, :, col0:col0 + H * dk].unflatten(2, (H, dk))
+
+    # ------------------------------------------------------------------------------------------
+    # forward
+    # ------------------------------------------------------------------------------------------
+    def _encode(self, ws, ids_flat, mask_u8, BN, L, p, seed, save: bool):
+        cfg, ops = self.cfg, self.ops
+        d, f, inner, H = cfg.d_model, cfg.d_ff, cfg.inner_dim, cfg.num_heads
+        Me, Le, eps = BN * L, cfg.num_layers, cfg.layer_norm_epsilon
+        dr = (lambda site: (p, seed, site)) if p > 0 else (lambda site: None)
+        ix = (lambda i: i) if save else (lambda i: 0)
+        hx = (lambda i: i) if save else (lambda i: i % 2)
+        ops.embed_fwd(ids_flat, self.shared.w, self._buf(ws, f"e.h{hx(0)}", (Me, d)), dr(S_ENC_EMBED))
+        rel = self._buf(ws, "e.rel", (H, 2 * L - 1), torch.float32)
+        ops.relpos_expand(self.enc_rel.p, self._lut(L, L, True), rel)
+        for i in range(Le):
+            lw, j = self.enc[i], ix(i)
+            h = ws[f"e.h{hx(i)}"]
+            xn1 = self._buf(ws, f"e.xn1.{j}", (Me, d))
+            ops.rmsnorm_fwd(h, lw["ln1"].p, xn1, self._buf(ws, f"e.rs1.{j}", (Me,), torch.float32), eps)
+            qkv = self._buf(ws, f"e.qkv.{j}", (Me, 3 * inner))
+            ops.gemm_nt(xn1, lw["qkv"].w, qkv)
+            ctx = self._buf(ws, f"e.ctx.{j}", (Me, inner))
+            ops.attn_fwd(self._heads(qkv, BN, L, 0), self._heads(qkv, BN, L, inner), self._heads(qkv, BN, L, 2 * inner),
+                         self._heads(ctx, BN, L, 0), self._buf(ws, f"e.st.{j}", (BN, H, L, 2), torch.float32),
+                         rel_bias=rel, rel_off=L - 1, key_mask=mask_u8, drop=dr(_enc_site(i, 0)))
+            h1 = self._buf(ws, f"e.h1.{j}", (Me, d))
+            ops.gemm_nt(ctx, lw["o"].w, h1, resid=h, drop=dr(_enc_site(i, 1)))
+            xn2 = self._buf(ws, f"e.xn2.{j}", (Me, d))
+            ops.rmsnorm_fwd(h1, lw["ln2"].p, xn2, self._buf(ws, f"e.rs2.{j}", (Me,), torch.float32), eps)
+            a1 = self._buf(ws, f"e.a1.{j}", (Me, f))
+            ops.gemm_nt(xn2, lw["wi"].w, a1, relu=True, drop=dr(_enc_site(i, 2)))
+            ops.gemm_nt(a1, lw["wo"].w, self._buf(ws, f"e.h{hx(i + 1)}", (Me, d)), resid=h1, drop=dr(_enc_site(i, 3)))
+        enc_out = self._buf(ws, "e.out", (Me, d))
+        ops.rmsnorm_fwd(ws[f"e.h{hx(Le)}"], self.enc_final.p, enc_out, self._buf(ws, "e.rsf", (Me,), torch.float32),
+                        eps, dr(S_ENC_FINAL))
+        # K/V projections of every decoder layer's cross-attention in ONE GEMM (reads enc_out once)
+        kv = self._buf(ws, "e.kv", (Me, self.kv_all.w.shape[0]))
+        ops.gemm_nt(enc_out, self.kv_all.w, kv)
+        return enc_out, kv
+
+    def forward_loss(self, input_ids, attention_mask, labels, training: bool):
+        """input_ids/attention_mask [B,N,L], labels [B,T] (−100 = ignore) → (loss 0-d fp32, logits [B,T,V] fp32)."""
+        if self.shadows_stale:
+            self.refresh_shadows()
+        cfg, ops = self.cfg, self.ops
+        B, N, L = input_ids.shape
+        T = labels.shape[1]
+        d, f, inner, H, V = cfg.d_model, cfg.d_ff, cfg.inner_dim, cfg.num_heads, cfg.vocab_size
+        p = float(cfg.dropout_rate) if training else 0.0
+        seed = (self.seed_base * 1000003 + self.step_count) & 0xFFFFFFFF
+        ws = self._workspace(("train", B, N, L, T))
+        ctx = _Ctx(B=B, N=N, L=L, T=T, p=p, seed=seed, ws=ws)
+        ctx.ids = input_ids.reshape(-1).contiguous()
+        ctx.mask_u8 = attention_mask.reshape(B * N, L).to(torch.uint8).contiguous()
+        ctx.labels = labels.reshape(-1).contiguous()
+        dr = (lambda site: (p, seed, site)) if p > 0 else (lambda site: None)
+        eps = cfg.layer_norm_epsilon
+        enc_out, kv = self._encode(ws, ctx.ids, ctx.mask_u8, B * N, L, p, seed, save=True)
+        # ---- decoder ------------------------------------------------------------------------
+        Md, S, Ld = B * T, N * L, cfg.num_decoder_layers
+        enc_mask = ctx.mask_u8.view(B, S)
+        dec_ids = self._buf(ws, "d.ids", (B, T), torch.int64)
+        ops.shift_right(labels.contiguous(), dec_ids)
+        ctx.dec_ids = dec_ids
+        ops.embed_fwd(dec_ids.view(-1), self.shared.w, self._buf(ws, "d.h0", (Md, d)), dr(S_DEC_EMBED))
+        rel = self._buf(ws, "d.rel", (H, 2 * T - 1), torch.float32)
+        ops.relpos_expand(self.dec_rel.p, self._lut(T, T, False), rel)
+        for i in range(Ld):
+            lw = self.dec[i]
+            h = ws[f"d.h{i}"]
+            xn1 = self._buf(ws, f"d.xn1.{i}", (Md, d))
+            ops.rmsnorm_fwd(h, lw["ln1"].p, xn1, self._buf(ws, f"d.rs1.{i}", (Md,), torch.float32), eps)
+            qkv = self._buf(ws, f"d.qkv.{i}", (Md, 3 * inner))
+            ops.gemm_nt(xn1, lw["qkv"].w, qkv)
+            c1 = self._buf(ws, f"d.ctx.{i}", (Md, inner))
+            ops.attn_fwd(self._heads(qkv, B, T, 0), self._heads(qkv, B, T, inner), self._heads(qkv, B, T, 2 * inner),
+                         self._heads(c1, B, T, 0), self._buf(ws, f"d.st.{i}", (B, H, T, 2), torch.float32),
+                         rel_bias=rel, rel_off=T - 1, causal=True, drop=dr(_dec_site(i, 0)))
+            h1 = self._buf(ws, f"d.h1.{i}", (Md, d))
+            ops.gemm_nt(c1, lw["o"].w, h1, resid=h, drop=dr(_dec_site(i, 1)))
+            xn2 = self._buf(ws, f"d.xn2.{i}", (Md, d))
+            ops.rmsnorm_fwd(h1, lw["ln2"].p, xn2, self._buf(ws, f"d.rs2.{i}", (Md,), torch.float32), eps)
+            qc = self._buf(ws, f"d.qc.{i}", (Md, inner))
+            ops.gemm_nt(xn2, lw["cq"].w, qc)
+            c2 = self._buf(ws, f"d.cctx.{i}", (Md, inner))
+            ops.attn_fwd(self._heads(qc, B, T, 0), self._heads(kv, B, S, 2 * i * inner),
+                         self._heads(kv, B, S, (2 * i + 1) * inner), self._heads(c2, B, T, 0),
+                         self._buf(ws, f"d.cst.{i}", (B, H, T, 2), torch.float32), key_mask=enc_mask,
+                         drop=dr(_dec_site(i, 2)))
+            h2 = self._buf(ws, f"d.h2.{i}", (Md, d))
+            ops.gemm_nt(c2, lw["co"].w, h2, resid=h1, drop=dr(_dec_site(i, 3)))
+            xn3 = self._buf(ws, f"d.xn3.{i}", (Md, d))
+            ops.rmsnorm_fwd(h2, lw["ln3"].p, xn3, self._buf(ws, f"d.rs3.{i}", (Md,), torch.float32), eps)
+            a1 = self._buf(ws, f"d.a1.{i}", (Md, f))
+            ops.gemm_nt(xn3, lw["wi"].w, a1, relu=True, drop=dr(_dec_site(i, 4)))
+            ops.gemm_nt(a1, lw["wo"].w, self._buf(ws, f"d.h{i + 1}", (Md, d)), resid=h2, drop=dr(_dec_site(i, 5)))
+        dec_out = self._buf(ws, "d.out", (Md, d))
+        ops.rmsnorm_fwd(ws[f"d.h{Ld}"], self.dec_final.p, dec_out, self._buf(ws, "d.rsf", (Md,), torch.float32), eps,
+                        dr(S_DEC_FINAL))
+        logits = self._buf(ws, "d.logits", (Md, V), torch.float32)
+        ops.gemm_nt(dec_out, self.shared.w, logits, alpha=d ** -0.5)       # tied LM head × d_model^-0.5
+        loss_buf = self._buf(ws, "d.loss", (2,), torch.float32)
+        ops.ce_fwd_bwd(logits, ctx.labels, loss_buf, None)
+        self.ctx = ctx
+        return loss_buf[0], logits.view(B, T, V)
+
+    # ------------------------------------------------------------------------------------------
+    # backward
+    # ------------------------------------------------------------------------------------------
+    def _ready(self, first_block: str, last_block: str):
+        if self.grad_hook is not None:
+            a, b = self.by_name[first_block], self.by_name[last_block]
+            self.grad_hook(a.off, b.off + -(-b.numel // ALIGN) * ALIGN)
+
+    def _ffn_bwd(self, lw, dh, a1, xn, h_in, rs, ln, p, drop_out, tmp):
+        """residual FFN sublayer backward; dh is updated in place to the gradient wrt the sublayer input."""
+        ops = self.ops
+        M, d = dh.shape
+        f = a1.shape[1]
+        dy = dh
+        if p > 0:
+            dy = self._buf(tmp, f"dy.{M}", (M, d))
+            ops.dropout_apply(dh, dy, drop_out)
+        ops.gemm_tn(dy, a1, lw["wo"].g)
+        dpre = self._buf(tmp, f"dpre.{M}", (M, f))
+        ops.gemm_nt(dy, lw["wo"].wt, dpre, aux=a1, aux_scale=1.0 / (1.0 - p))   # ∘ [relu'>0] ∘ dropout
+        ops.gemm_tn(dpre, xn, lw["wi"].g)
+        dxn = self._buf(tmp, f"dxn.{M}", (M, d))
+        ops.gemm_nt(dpre, lw["wi"].wt, dxn)
+        ops.rmsnorm_bwd(dxn, h_in, ln.p, rs, dh, dh, ln.g)
+
+    def backward(self, upstream=None):
+        """Accumulate d(loss)/d(params) into G.  `upstream`: optional device scalar tensor multiplying the loss."""
+        ctx, cfg, ops = self.ctx, self.cfg, self.ops
+        if ctx is None:
+            raise RuntimeError("backward() without a preceding forward_loss()")
+        ws, p, seed = ctx.ws, ctx.p, ctx.seed
+        B, N, L, T = ctx.B, ctx.N, ctx.L, ctx.T
+        d, f, inner, H, V = cfg.d_model, cfg.d_ff, cfg.inner_dim, cfg.num_heads, cfg.vocab_size
+        Md, Me, S, Ld, Le = B * T, B * N * L, N * L, cfg.num_decoder_layers, cfg.num_layers
+        dr = (lambda site: (p, seed, site)) if p > 0 else (lambda site: None)
+        tmp = self._workspace(("bwd", B, N, L, T))
+        enc_mask = ctx.mask_u8.view(B, S)
+        # ---- loss + LM head ------------------------------------------------------------------
+        dlog = self._buf(tmp, "dlogits", (Md, V))
+        ops.ce_fwd_bwd(ws["d.logits"], ctx.labels, self._buf(tmp, "loss2", (2,), torch.float32), dlog, upstream)
+        alpha = d ** -0.5
+        dh = self._buf(tmp, "d.dh", (Md, d))
+        dout = self._buf(tmp, f"dxn.{Md}", (Md, d))
+        ops.gemm_nt(dlog, self.shared.wt, dout, alpha=alpha)
+        ops.gemm_tn(dlog, ws["d.out"], self.shared.g, alpha=alpha)
+        ops.rmsnorm_bwd(dout, ws[f"d.h{Ld}"], self.dec_final.p, ws["d.rsf"], None, dh, self.dec_final.g, dr(S_DEC_FINAL))
+        dkv = self._buf(tmp, "dkv", (Me, self.kv_all.w.shape[0]))
+        drel = self._buf(tmp, "d.drel", (H, 2 * T - 1), torch.float32)
+        ops.zero_(drel)
+        kv = ws["e.kv"]
+        for i in reversed(range(Ld)):
+            lw = self.dec[i]
+            self._ffn_bwd(lw, dh, ws[f"d.a1.{i}"], ws[f"d.xn3.{i}"], ws[f"d.h2.{i}"], ws[f"d.rs3.{i}"], lw["ln3"], p,
+                          dr(_dec_site(i, 5)), tmp)
+            # cross-attention
+            dy = dh
+            if p > 0:
+                dy = self._buf(tmp, f"dy.{Md}", (Md, d))
+                ops.dropout_apply(dh, dy, dr(_dec_site(i, 3)))
+            ops.gemm_tn(dy, ws[f"d.cctx.{i}"], lw["co"].g)
+            dctx = self._buf(tmp, f"dctx.{Md}", (Md, inner))
+            ops.gemm_nt(dy, lw["co"].wt, dctx)
+            dqc = self._buf(tmp, "d.dqc", (Md, inner))
+            ops.attn_bwd(self._heads(ws[f"d.qc.{i}"], B, T, 0), self._heads(kv, B, S, 2 * i * inner),
+                         self._heads(kv, B, S, (2 * i + 1) * inner), self._heads(ws[f"d.cctx.{i}"], B, T, 0),
+                         self._heads(dctx, B, T, 0), ws[f"d.cst.{i}"], self._heads(dqc, B, T, 0),
+                         self._heads(dkv, B, S, 2 * i * inner), self._heads(dkv, B, S, (2 * i + 1) * inner),
+                         key_mask=enc_mask, drop=dr(_dec_site(i, 2)))
+            ops.gemm_tn(dqc, ws[f"d.xn2.{i}"], lw["cq"].g)
+            dxn = self._buf(tmp, f"dxn.{Md}", (Md, d))
+            ops.gemm_nt(dqc, lw["cq"].wt, dxn)
+            ops.rmsnorm_bwd(dxn, ws[f"d.h1.{i}"], lw["ln2"].p, ws[f"d.rs2.{i}"], dh, dh, lw["ln2"].g)
+            # causal self-attention
+            dy = dh
+            if p > 0:
+                ops.dropout_apply(dh, dy := self._buf(tmp, f"dy.{Md}", (Md, d)), dr(_dec_site(i, 1)))
+            ops.gemm_tn(dy, ws[f"d.ctx.{i}"], lw["o"].g)
+            ops.gemm_nt(dy, lw["o"].wt, dctx)
+            qkv = ws[f"d.qkv.{i}"]
+            dqkv = self._buf(tmp, f"dqkv.{Md}", (Md, 3 * inner))
+            ops.attn_bwd(self._heads(qkv, B, T, 0), self._heads(qkv, B, T, inner), self._heads(qkv, B, T, 2 * inner),
+                         self._heads(ws[f"d.ctx.{i}"], B, T, 0), self._heads(dctx, B, T, 0), ws[f"d.st.{i}"],
+                         self._heads(dqkv, B, T, 0), self._heads(dqkv, B, T, inner), self._heads(dqkv, B, T, 2 * inner),
+                         rel_bias=ws["d.rel"], drel=drel, rel_off=T - 1, causal=True, drop=dr(_dec_site(i, 0)))
+            ops.gemm_tn(dqkv, ws[f"d.xn1.{i}"], lw["qkv"].g)
+            ops.gemm_nt(dqkv, lw["qkv"].wt, dxn)
+            ops.rmsnorm_bwd(dxn, ws[f"d.h{i}"], lw["ln1"].p, ws[f"d.rs1.{i}"], dh, dh, lw["ln1"].g)
+        ops.embed_bwd(ctx.dec_ids.view(-1), dh, self.shared.g, dr(S_DEC_EMBED))
+        ops.relpos_reduce(drel, self._lut(T, T, False), self.dec_rel.g)
+        # ---- cross K/V projection of all decoder layers -----------------------------------------
+        ops.gemm_tn(dkv, ws["e.out"], self.kv_all.g)
+        deh = self._buf(tmp, "e.dh", (Me, d))
+        dxe = self._buf(tmp, f"dxn.{Me}", (Me, d))
+        ops.gemm_nt(dkv, self.kv_all.wt, dxe)
+        ops.rmsnorm_bwd(dxe, ws[f"e.h{Le}"], self.enc_final.p, ws["e.rsf"], None, deh, self.enc_final.g, dr(S_ENC_FINAL))
+        self._ready("dec.final_ln", "enc.final_ln")
+        # ---- encoder ---------------------------------------------------------------------------
+        BN = B * N
+        drel_e = self._buf(tmp, "e.drel", (H, 2 * L - 1), torch.float32)
+        ops.zero_(drel_e)
+        for i in reversed(range(Le)):
+            lw = self.enc[i]
+            self._ffn_bwd(lw, deh, ws[f"e.a1.{i}"], ws[f"e.xn2.{i}"], ws[f"e.h1.{i}"], ws[f"e.rs2.{i}"], lw["ln2"], p,
+                          dr(_enc_site(i, 3)), tmp)
+            dy = deh
+            if p > 0:
+                ops.dropout_apply(deh, dy := self._buf(tmp, f"dy.{Me}", (Me, d)), dr(_enc_site(i, 1)))
+            ops.gemm_tn(dy, ws[f"e.ctx.{i}"], lw["o"].g)
+            dctx = self._buf(tmp, f"dctx.{Me}", (Me, inner))
+            ops.gemm_nt(dy, lw["o"].wt, dctx)
+            qkv = ws[f"e.qkv.{i}"]
+            dqkv = self._buf(tmp, f"dqkv.{Me}", (Me, 3 * inner))
+            ops.attn_bwd(self._heads(qkv, BN, L, 0), self._heads(qkv, BN, L, inner), self._heads(qkv, BN, L, 2 * inner),
+                         self._heads(ws[f"e.ctx.{i}"], BN, L, 0), self._heads(dctx, BN, L, 0), ws[f"e.st.{i}"],
+                         self._heads(dqkv, BN, L, 0), self._heads(dqkv, BN, L, inner),
+                         self._heads(dqkv, BN, L, 2 * inner), rel_bias=ws["e.rel"], drel=drel_e, rel_off=L - 1,
+                         key_mask=ctx.mask_u8, drop=dr(_enc_site(i, 0)))
+            ops.gemm_tn(dqkv, ws[f"e.xn1.{i}"], lw["qkv"].g)
+            ops.gemm_nt(dqkv, lw["qkv"].wt, dxe)
+            ops.rmsnorm_bwd(dxe, ws[f"e.h{i}"], lw["ln1"].p, ws[f"e.rs1.{i}"], deh, deh, lw["ln1"].g)
+            self._ready(f"enc.{i}.qkv", f"enc.{i}.ln2")
+        ops.embed_bwd(ctx.ids, deh, self.shared.g, dr(S_ENC_EMBED))
+        ops.relpos_reduce(drel_e, self._lut(L, L, True), self.enc_rel.g)
+        self._ready("enc.rel", "shared")
+        self.step_count += 1   # next forward draws fresh dropout masks
+        self.ctx = None
+
+    # ------------------------------------------------------------------------------------------
+    # greedy decode  (HF generate: num_beams=1, do_sample=False, use_cache=True)
+    # ------------------------------------------------------------------------------------------
+    def generate(self, input_ids, attention_mask, max_length: int, capture_scores: bool = False):
+        if self.shadows_stale:
+            self.refresh_shadows()
+        cfg, ops = self.cfg, self.ops
+        B, N, L = input_ids.shape
+        d, f, inner, H, V = cfg.d_model, cfg.d_ff, cfg.inner_dim, cfg.num_heads, cfg.vocab_size
+        S, Ld, eps, dk = N * L, cfg.num_decoder_layers, cfg.layer_norm_epsilon, cfg.d_kv
+        ws = self._workspace(("gen", B, N, L, max_length))
+        ids = input_ids.reshape(-1).contiguous()
+        mask_u8 = attention_mask.reshape(B * N, L).to(torch.uint8).contiguous()
+        enc_mask = mask_u8.view(B, S)
+        _, kv = self._encode(ws, ids, mask_u8, B * N, L, 0.0, 0, save=False)
+        ML = max_length
+        seq = self._buf(ws, "g.seq", (B, ML), torch.int64)
+        nxt = self._buf(ws, "g.next", (B,), torch.int64)
+        done = self._buf(ws, "g.done", (B,), torch.uint8)
+        ndone = self._buf(ws, "g.ndone", (1,), torch.int32)
+        for t_ in (seq, nxt, done, ndone):
+            ops.zero_(t_)                                  # decoder_start_token_id = pad = 0
+        rel = self._buf(ws, "g.rel", (H, 2 * ML - 1), torch.float32)
+        ops.relpos_expand(self.dec_rel.p, self._lut(ML, ML, False), rel)
+        cache = [self._buf(ws, f"g.cache.{i}", (B, ML, 2 * inner)) for i in range(Ld)]
+        scores = self._buf(ws, "g.scores", (Ld, B, H, 1, S), torch.float32) if capture_scores else None
+        h, h1, h2, xn = (self._buf(ws, f"g.{n}", (B, d)) for n in ("h", "h1", "h2", "xn"))
+        rs = self._buf(ws, "g.rs", (B,), torch.float32)
+        q, c1, qc, c2 = (self._buf(ws, f"g.{n}", (B, inner)) for n in ("q", "c1", "qc", "c2"))
+        st = self._buf(ws, "g.st", (B, H, 1, 2), torch.float32)
+        a1 = self._buf(ws, "g.a1", (B, f))
+        logits = self._buf(ws, "g.logits", (B, V), torch.float32)
+        n_out = 1
+        for t in range(ML - 1):
+            ops.embed_fwd(nxt, self.shared.w, h)
+            for i in range(Ld):
+                lw = self.dec[i]
+                ops.rmsnorm_fwd(h, lw["ln1"].p, xn, rs, eps)
+                ops.gemm_nt(xn, lw["qkv"].w[:inner], q)
+                ops.gemm_nt(xn, lw["qkv"].w[inner:], cache[i].view(B, ML * 2 * inner)[:, t * 2 * inner:(t + 1) * 2 * inner])
+                kc = cache[i][:, :t + 1, :inner].unflatten(2, (H, dk))
+                vc = cache[i][:, :t + 1, inner:].unflatten(2, (H, dk))
+                ops.attn_fwd(q.view(B, 1, H, dk), kc, vc, c1.view(B, 1, H, dk), st, rel_bias=rel, rel_off=ML - 1 - t)
+                ops.gemm_nt(c1, lw["o"].w, h1, resid=h)
+                ops.rmsnorm_fwd(h1, lw["ln2"].p, xn, rs, eps)
+                ops.gemm_nt(xn, lw["cq"].w, qc)
+                ops.attn_fwd(qc.view(B, 1, H, dk), self._heads(kv, B, S, 2 * i * inner),
+                             self._heads(kv, B, S, (2 * i + 1) * inner), c2.view(B, 1, H, dk), st, key_mask=enc_mask,
+                             scores_out=scores[i] if (capture_scores and t == 0) else None)
+                ops.gemm_nt(c2, lw["co"].w, h2, resid=h1)
+                ops.rmsnorm_fwd(h2, lw["ln3"].p, xn, rs, eps)
+                ops.gemm_nt(xn, lw["wi"].w, a1, relu=True)
+                ops.gemm_nt(a1, lw["wo"].w, h, resid=h2)
+            ops.rmsnorm_fwd(h, self.dec_final.p, xn, rs, eps)
+            ops.gemm_nt(xn, self.shared.w, logits, alpha=d ** -0.5)
+            ops.greedy_step(logits, seq, t + 1, nxt, done, ndone, cfg.eos_token_id, cfg.pad_token_id)
+            n_out = t + 2
+            if int(ndone.item()) == B:       # HF stops right after the step in which the last row emitted EOS
+                break
+        out = seq[:, :n_out].clone()
+        if capture_scores:
+            # [B, H, n_layers, S] — the layout get_crossattention_scores builds with torch.cat(dim=2), src/model.py:152-160
+            return out, scores[:, :, :, 0, :].permute(1, 2, 0, 3).contiguous()
+        return out

@@ -195,9 +195,9 @@ class HipOps:
         check(self.lib.lako_attn_bwd(C.byref(p), self._stream()), "lako_attn_bwd")
 
     # ---- loss / optimizer -----------------------------------------------------------------------
-    def ce_fwd_bwd(self, logits, labels, loss_out, dlogits):
+    def ce_fwd_bwd(self, logits, labels, loss_out, dlogits, upstream=None):
         M, V = logits.shape
-        check(self.lib.lako_ce_fwd_bwd(_p(logits), _p(labels), _p(loss_out), _p(dlogits), M, V,
+        check(self.lib.lako_ce_fwd_bwd(_p(logits), _p(labels), _p(loss_out), _p(dlogits), _p(upstream), M, V,
                                        _dt(dlogits) if dlogits is not None else LAKO_F32, self._stream()),
               "lako_ce_fwd_bwd")
 

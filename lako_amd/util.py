@@ -1,0 +1,173 @@
+"""Optimizer / scheduler / clip helpers mirroring the reference's `src/util.py` names and semantics.
+
+  set_optim(opt, model)            src/util.py:230-245
+  WarmupLinearScheduler            src/util.py:149-168
+  FixedScheduler                   src/util.py:171-176
+  AdamW                            the HF<=4 `transformers.AdamW(correct_bias=False)` src/util.py:225 builds
+  clip_grad_norm_(model, max_norm) train_reader.py:76 (torch.nn.utils.clip_grad_norm_)
+  average_main / weighted_average  src/util.py:248-275 (scalar reduces to rank 0)
+
+The optimizer is fused: one kernel launch updates the whole flat fp32 parameter buffer (clip coefficient,
+Adam moments without bias correction, decoupled weight decay) and writes the low-precision shadow.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def _model_of(params):
+    for p in params:
+        m = getattr(p, "_lako_model", None)
+        if m is not None:
+            return m()
+    raise ValueError("these parameters do not belong to a lako_amd.FiDT5 (use model.parameters())")
+
+
+class AdamW(torch.optim.Optimizer):
+    """HF<=4 AdamW semantics: m ← β1 m + (1−β1) g; v ← β2 v + (1−β2) g²;
+    p ← p − lr·m/(√v+eps); p ← p − lr·wd·p.  `correct_bias=True` is not implemented (the reference passes
+    False, src/util.py:225).  All parameter groups must share lr / weight_decay (they do: src/util.py:189-194)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=False,
+                 model=None):
+        if correct_bias:
+            raise NotImplementedError("correct_bias=True: the reference trains with correct_bias=False")
+        params = list(params)
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, correct_bias=False))
+        if model is None:
+            model = _model_of(p for g in self.param_groups for p in g["params"])
+        self._model = model
+
+    def _find_model(self):
+        return self._model
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        model = self._find_model()
+        g0 = self.param_groups[0]
+        for g in self.param_groups[1:]:
+            if g["lr"] != g0["lr"] or g["weight_decay"] != g0["weight_decay"]:
+                raise ValueError("fused AdamW needs identical lr / weight_decay in all groups")
+        eng = model._get_engine()
+        sync = getattr(model, "_grad_sync", None)
+        scale = 1.0
+        if sync is not None:
+            sync.finish()
+            scale = 1.0 / sync.world_size
+        if eng.opt_m is None:
+            eng.opt_m = torch.zeros_like(eng.P)
+            eng.opt_v = torch.zeros_like(eng.P)
+        clip = getattr(model, "_pending_clip", None)
+        b1, b2 = g0["betas"]
+        eng.ops.adamw_step(eng.P, eng.G, eng.opt_m, eng.opt_v, None if eng.W is eng.P else eng.W,
+                           lr=g0["lr"], beta1=b1, beta2=b2, eps=g0["eps"], weight_decay=g0["weight_decay"],
+                           gnorm_sq=eng.gnorm_sq if clip is not None else None,
+                           max_norm=clip if clip is not None else 0.0, grad_scale=scale)
+        model._pending_clip = None
+        for b in eng.blocks:
+            if b.transpose:
+                eng.ops.transpose_cast(eng._view(eng.P, b), eng._view(eng.WT, b, True))
+        eng.shadows_stale = False
+
+    def state_dict(self):
+        sd = super().state_dict()
+        eng = self._find_model()._engine
+        if eng is not None and eng.opt_m is not None:
+            sd["lako_exp_avg"], sd["lako_exp_avg_sq"] = eng.opt_m.detach().cpu(), eng.opt_v.detach().cpu()
+        return sd
+
+    def load_state_dict(self, sd):
+        sd = dict(sd)
+        m, v = sd.pop("lako_exp_avg", None), sd.pop("lako_exp_avg_sq", None)
+        super().load_state_dict(sd)
+        if m is not None:
+            eng = self._find_model()._get_engine()
+            eng.opt_m, eng.opt_v = m.to(eng.device), v.to(eng.device)
+
+
+def clip_grad_norm_(model, max_norm: float):
+    """Global L2 norm of all gradients (after the data-parallel all-reduce) computed on the device; the
+    clip coefficient min(1, max_norm/(norm+1e-6)) is applied inside the fused optimizer step, so no host
+    sync happens here.  Returns the norm as a 0-d device tensor."""
+    eng = model._get_engine()
+    sync = getattr(model, "_grad_sync", None)
+    scale = 1.0
+    if sync is not None:
+        sync.finish()
+        scale = 1.0 / sync.world_size
+    eng.ops.zero_(eng.gnorm_sq)
+    eng.ops.sumsq(eng.G, eng.gnorm_sq)
+    model._pending_clip = float(max_norm)
+    return eng.gnorm_sq[0].sqrt() * scale
+
+
+class WarmupLinearScheduler(torch.optim.lr_scheduler.LambdaLR):
+    def __init__(self, optimizer, warmup_steps, scheduler_steps, min_ratio, fixed_lr, last_epoch=-1):
+        self.warmup_steps = warmup_steps
+        self.scheduler_steps = scheduler_steps
+        self.min_ratio = min_ratio
+        self.fixed_lr = fixed_lr
+        super().__init__(optimizer, self.lr_lambda, last_epoch=last_epoch)
+
+    def lr_lambda(self, step):
+        if step < self.warmup_steps:
+            return (1 - self.min_ratio) * step / float(max(1, self.warmup_steps)) + self.min_ratio
+        if self.fixed_lr:
+            return 1.0
+        return max(0.0, 1.0 + (self.min_ratio - 1) * (step - self.warmup_steps)
+                   / float(max(1.0, self.scheduler_steps - self.warmup_steps)))
+
+
+class FixedScheduler(torch.optim.lr_scheduler.LambdaLR):
+    def __init__(self, optimizer, last_epoch=-1):
+        super().__init__(optimizer, self.lr_lambda, last_epoch=last_epoch)
+
+    def lr_lambda(self, step):
+        return 1.0
+
+
+def set_optim(opt, model):
+    """src/util.py:230-245 with the fused AdamW in place of HF's."""
+    if opt.optim == "adamw":
+        no_decay = ["bias", "LayerNorm.bias", "LayerNorm.weight"]
+        named = list(model.named_parameters())
+        groups = [
+            {"params": [p for n, p in named if not any(nd in n for nd in no_decay)], "weight_decay": opt.weight_decay},
+            {"params": [p for n, p in named if any(nd in n for nd in no_decay)], "weight_decay": opt.weight_decay},
+        ]
+        optimizer = AdamW(groups, lr=opt.lr, correct_bias=False, model=model)
+    else:
+        raise NotImplementedError(f"--optim {opt.optim}: only adamw is fused (the reference's scripts use adamw)")
+    if opt.scheduler == "fixed":
+        scheduler = FixedScheduler(optimizer)
+    elif opt.scheduler == "linear":
+        steps = opt.total_steps if getattr(opt, "scheduler_steps", None) is None else opt.scheduler_steps
+        scheduler = WarmupLinearScheduler(optimizer, warmup_steps=opt.warmup_steps, scheduler_steps=steps,
+                                          min_ratio=0.0, fixed_lr=opt.fixed_lr)
+    else:
+        raise ValueError(opt.scheduler)
+    return optimizer, scheduler
+
+
+def average_main(x, opt):
+    """src/util.py:248-255: sum-reduce a scalar to rank 0 and divide there."""
+    if not getattr(opt, "is_distributed", False):
+        return x
+    if opt.world_size > 1:
+        dist.reduce(x, 0, op=dist.ReduceOp.SUM)
+        if opt.is_main:
+            x = x / opt.world_size
+    return x
+
+
+def weighted_average(x, count, opt):
+    """src/util.py:266-275."""
+    if not getattr(opt, "is_distributed", False):
+        return x, count
+    dev = opt.device if hasattr(opt, "device") else "cpu"
+    t_loss = torch.tensor([x * count], device=dev)
+    t_total = torch.tensor([count], device=dev)
+    dist.reduce(t_loss, 0, op=dist.ReduceOp.SUM)
+    dist.reduce(t_total, 0, op=dist.ReduceOp.SUM)
+    return (t_loss / t_total).item(), t_total.item()

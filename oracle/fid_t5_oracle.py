@@ -53,7 +53,7 @@ class T5Dims:
         if size == "large":
             return T5Dims(d_model=1024, d_ff=4096, num_layers=24, num_decoder_layers=24, num_heads=16)
         if size == "tiny":  # the fixture config
-            return T5Dims(vocab_size=64, d_model=32, d_kv=16, d_ff=64, num_layers=2, num_decoder_layers=2,
+            return T5Dims(vocab_size=64, d_model=32, d_kv=32, d_ff=64, num_layers=2, num_decoder_layers=2,
                           num_heads=2)
         raise ValueError(size)
 

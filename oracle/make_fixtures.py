@@ -294,5 +294,5 @@ if __name__ == "__main__":
     make_case("tiny_fact", tiny, B=3, N=2, L=24, T=4, seed=2, fact_case=True)
     make_case("tiny_eos", tiny, B=4, N=3, L=12, T=6, seed=5, pretrain=150)
     # a slightly wider case: odd L, more heads/layers, exercises the log-spaced buckets (L > 16)
-    mid = O.T5Dims(vocab_size=96, d_model=64, d_kv=16, d_ff=128, num_layers=3, num_decoder_layers=2, num_heads=4)
+    mid = O.T5Dims(vocab_size=96, d_model=64, d_kv=32, d_ff=128, num_layers=3, num_decoder_layers=2, num_heads=4)
     make_case("mid_a", mid, B=2, N=4, L=37, T=7, seed=3)

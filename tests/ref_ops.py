@@ -190,7 +190,7 @@ class RefOps:
             drel += gs[3]
 
     # ---- loss / optimizer -----------------------------------------------------------------------
-    def ce_fwd_bwd(self, logits, labels, loss_out, dlogits):
+    def ce_fwd_bwd(self, logits, labels, loss_out, dlogits, upstream=None):
         valid = labels != -100
         n = valid.sum().float()
         lse = torch.logsumexp(logits, -1)
@@ -200,7 +200,8 @@ class RefOps:
         if dlogits is not None:
             p = torch.softmax(logits, -1)
             p[torch.arange(len(labels), device=labels.device), labels.clamp(min=0)] -= 1.0
-            dlogits.copy_(p * (valid[:, None] / n))
+            up = upstream[0] if upstream is not None else 1.0
+            dlogits.copy_(p * (valid[:, None] / n) * up)
 
     def sumsq(self, g, out):
         out += (g.double() ** 2).sum().float()

@@ -1,0 +1,177 @@
+"""Host logic on CPU: lako_amd.FiDT5 / engine / optimizer driven through the TEST DOUBLE op set
+(tests/ref_ops.py, fp32 torch) and compared with the golden vectors the reference itself produced.
+
+This checks everything that is not a kernel: parameter layout and key names, the hand-written backward
+schedule, tied-embedding / shared-bias gradient accumulation, clip + AdamW + scheduler plumbing, greedy
+decode bookkeeping, score capture.  (The kernels themselves are checked on the GPU, tests/test_kernels_gpu.py
+and tests/test_parity_gpu.py.)"""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from lako_amd import FiDConfig, FiDT5
+from lako_amd import util as U
+from lako_amd.model import plain_name, wrapped_name
+from tests.ref_ops import RefOps
+from tests.util_golden import group, load_case
+
+CASES = ["tiny_a", "tiny_fact", "mid_a", "tiny_eos"]
+SEEDS = {"tiny_a": 1, "tiny_fact": 2, "mid_a": 3, "tiny_eos": 5}
+
+
+def cfg_of(dims, dropout=0.0):
+    return FiDConfig(vocab_size=dims.vocab_size, d_model=dims.d_model, d_kv=dims.d_kv, d_ff=dims.d_ff,
+                     num_layers=dims.num_layers, num_decoder_layers=dims.num_decoder_layers, num_heads=dims.num_heads,
+                     relative_attention_num_buckets=dims.num_buckets,
+                     relative_attention_max_distance=dims.max_distance, dropout_rate=dropout)
+
+
+def build(name, dropout=0.0):
+    z, dims, w = load_case(name)
+    model = FiDT5(cfg_of(dims, dropout), dtype=torch.float32, _ops=RefOps())
+    model.load_t5(w)
+    return z, dims, w, model
+
+
+def test_key_names_roundtrip():
+    _, _, w, model = build("tiny_a")
+    names = [n for n, _ in model.named_parameters()]
+    assert "encoder.encoder.block.0.module.layer.0.SelfAttention.q.weight" in names
+    assert "decoder.block.1.layer.1.EncDecAttention.k.weight" in names and "shared.weight" in names
+    assert len(names) == len(w)
+    for n in names:
+        assert wrapped_name(plain_name(n)) == n
+    sd = model.state_dict()
+    assert sd["lm_head.weight"].data_ptr() == sd["shared.weight"].data_ptr()
+    for k, v in w.items():
+        assert torch.equal(sd[wrapped_name(k)], v)
+    model.unwrap_encoder()
+    assert "encoder.block.0.layer.0.SelfAttention.q.weight" in dict(model.named_parameters())
+    model.wrap_encoder()
+    # a 3.0.2-era checkpoint carries one extra legacy tensor: load-and-ignore (SURVEY.md §7 version skew)
+    sd = {k: v.clone() for k, v in sd.items()}
+    sd["decoder.block.0.layer.1.EncDecAttention.relative_attention_bias.weight"] = torch.zeros(32, 2)
+    model.load_state_dict(sd)
+
+
+def test_save_load_pretrained(tmp_path):
+    _, _, w, model = build("tiny_a")
+    model.save_pretrained(str(tmp_path / "ckpt"))
+    m2 = FiDT5.from_pretrained(str(tmp_path / "ckpt"), dtype=torch.float32, _ops=RefOps())
+    for (n1, p1), (n2, p2) in zip(model.named_parameters(), m2.named_parameters()):
+        assert n1 == n2 and torch.equal(p1, p2)
+
+
+def test_no_cpu_fallback():
+    z, dims, w = load_case("tiny_a")
+    model = FiDT5(cfg_of(dims), dtype=torch.float32)
+    model.load_t5(w)
+    ids, mask, labels = (torch.from_numpy(z[k]) for k in ("input_ids", "attention_mask", "labels"))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        model(input_ids=ids, attention_mask=mask, labels=labels)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_forward_backward_vs_reference(name):
+    z, dims, w, model = build(name)
+    ids, mask, labels = (torch.from_numpy(z[k]) for k in ("input_ids", "attention_mask", "labels"))
+    model.train()
+    out = model(input_ids=ids, attention_mask=mask, labels=labels)
+    assert abs(out[0].item() - float(z["loss"])) < 2e-5
+    torch.testing.assert_close(out.logits, torch.from_numpy(z["logits"]), atol=5e-5, rtol=1e-4)
+    enc = model._engine.ctx.ws["e.out"].view(ids.shape[0], -1, dims.d_model)
+    torch.testing.assert_close(enc, torch.from_numpy(z["enc_out"]), atol=5e-5, rtol=1e-4)
+    out[0].backward()
+    g = group(z, "g/")
+    params = {plain_name(n): p for n, p in model.named_parameters()}
+    assert set(params) == set(g)
+    for k, p in params.items():
+        torch.testing.assert_close(p.grad, g[k], atol=5e-5, rtol=2e-4, msg=lambda m, k=k: f"{k}: {m}")
+    # 2-D (already flattened) inputs reuse the remembered n_passages (src/model.py:40-46)
+    model.zero_grad()
+    out2 = model(input_ids=ids.view(ids.shape[0], -1), attention_mask=mask.view(ids.shape[0], -1), labels=labels)
+    assert abs(out2[0].item() - out[0].item()) < 1e-6
+    # upstream gradient scaling: (0.5 * loss).backward() halves every gradient
+    (out2[0] * 0.5).backward()
+    for k, p in params.items():
+        torch.testing.assert_close(p.grad, g[k] * 0.5, atol=5e-5, rtol=2e-4)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_train_steps_vs_reference(name):
+    """train_reader.py:67-82 order: fwd → bwd → clip(1.0) → optimizer.step → scheduler.step → zero_grad."""
+    from oracle import fid_t5_oracle as O
+    z, dims, w, model = build(name)
+    B, N, L = z["input_ids"].shape
+    T = z["labels"].shape[1]
+    lr, wd, clip, warm, total = z["train_hparams"].tolist()
+    opt = types.SimpleNamespace(optim="adamw", lr=lr, weight_decay=wd, scheduler="linear", scheduler_steps=None,
+                                total_steps=int(total), warmup_steps=int(warm), fixed_lr=False)
+    optimizer, scheduler = U.set_optim(opt, model)
+    model.train()
+    for k in range(3):
+        bi, bm, bl = O.synthetic_batch(B, N, L, T, dims.vocab_size, seed=SEEDS[name] + 200 + k)
+        loss = model(input_ids=bi, attention_mask=bm, labels=bl)[0]
+        loss.backward()
+        gn = U.clip_grad_norm_(model, clip)
+        optimizer.step()
+        scheduler.step()
+        model.zero_grad()
+        assert abs(loss.item() - z["train_losses"][k]) < 3e-5
+        # later steps of the over-fitted tiny_eos model amplify 1e-6 weight differences: relative 1e-3
+        assert abs(gn.item() - z["train_gnorms"][k]) < (2e-4 if k == 0 else 1e-3) * max(1.0, z["train_gnorms"][k])
+        if k in (0, 2):
+            ref = group(z, f"w_step{k + 1}/")
+            # Adam divides by sqrt(v)+1e-6: on the over-fitted tiny_eos weights (gradients ~1e-7) the update
+            # direction of near-zero-gradient elements is rounding noise, so step 3 there gets a looser bound
+            atol = 5e-4 if (name == "tiny_eos" and k == 2) else 3e-5
+            for n, p in model.named_parameters():
+                torch.testing.assert_close(p.detach(), ref[plain_name(n)], atol=atol, rtol=2e-4,
+                                           msg=lambda m, n=n: f"{n}: {m}")
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_generate_and_scores_vs_reference(name):
+    z, dims, w, model = build(name)
+    ids, mask = torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"])
+    model.eval()
+    for ml in (4, 12):
+        toks = model.generate(input_ids=ids, attention_mask=mask, max_length=ml)
+        assert toks.tolist() == z[f"gen_{ml}"].tolist()
+    model.overwrite_forward_crossattention()
+    model.reset_score_storage()
+    model.generate(input_ids=ids, attention_mask=mask, max_length=4)
+    ref = torch.from_numpy(z["cross_scores"])
+    keep = mask.view(mask.shape[0], 1, 1, -1).expand_as(ref)
+    torch.testing.assert_close(model._score_storage[keep], ref[keep], atol=5e-5, rtol=1e-4)
+    if ids.shape[1] == 2:
+        for style in ("mean", "max", "21mean"):
+            for half in ("no", "yes"):
+                o = types.SimpleNamespace(stream=2, n_context=5, use_last_half_layer_attention=half,
+                                          attention_score_style=style)
+                mine = model.get_crossattention_scores(o, ids, None, mask)
+                assert mine.dtype == torch.float64
+                np.testing.assert_allclose(mine.numpy(), z[f"fact_scores_{style}_{half}"], rtol=2e-5, atol=2e-6)
+
+
+def test_dropout_training_is_deterministic_and_unbiased():
+    """With dropout on, two models with the same seed produce the same loss/grads (stateless hash RNG,
+    regenerated in backward), and a different step draws a different mask."""
+    z, dims, w = load_case("tiny_a")
+    ids, mask, labels = (torch.from_numpy(z[k]) for k in ("input_ids", "attention_mask", "labels"))
+    res = []
+    for _ in range(2):
+        m = FiDT5(cfg_of(dims, 0.1), dtype=torch.float32, seed=7, _ops=RefOps())
+        m.load_t5(w)
+        m.train()
+        loss = m(input_ids=ids, attention_mask=mask, labels=labels)[0]
+        loss.backward()
+        res.append((loss.item(), m._engine.G.clone()))
+        l2 = m(input_ids=ids, attention_mask=mask, labels=labels)[0].item()
+        assert l2 != loss.item()                    # step counter advanced → new masks
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])
+    assert abs(res[0][0] - float(z["loss"])) < 0.5   # same ballpark as the no-dropout loss
+    m.eval()
+    assert abs(m(input_ids=ids, attention_mask=mask, labels=labels)[0].item() - float(z["loss"])) < 2e-5

@@ -274,8 +274,9 @@ def test_cross_entropy(ops, ref, dt, M, V):
     labels = labels.to(dev())
     lo, lor = torch.zeros(2, device=dev()), torch.zeros(2, device=dev())
     dl, dlr = torch.empty(M, V, dtype=T, device=dev()), torch.empty(M, V, device=dev())
-    ops.ce_fwd_bwd(logits, labels, lo, dl)
-    ref.ce_fwd_bwd(logits, labels, lor, dlr)
+    up = torch.tensor([0.5], device=dev())
+    ops.ce_fwd_bwd(logits, labels, lo, dl, up)
+    ref.ce_fwd_bwd(logits, labels, lor, dlr, up)
     assert abs(lo[0].item() - lor[0].item()) < 1e-4 * max(1.0, abs(lor[0].item())), (lo, lor)
     assert lo[1].item() == lor[1].item()
     close(dl, dlr, T, f"ce dlogits {dt}")
