@@ -110,7 +110,8 @@ int lako_relpos_reduce(const float* drel, const int32_t* lut, float* dtable, int
 typedef struct {
   const void *q, *k, *v; /* element (b, t, h, c) at ptr + b*stride_b + t*stride_t + h*d_head + c */
   void* out;             /* same addressing with o_stride_* */
-  float* lse;            /* [Bn, H, Lq] fp32: log-sum-exp of each score row (saved for backward) */
+  float* lse;            /* [Bn, H, Lq, 4] fp32 softmax row statistics saved for backward: (row max, 1/row sum,
+                            scratch for delta = rowsum(dO∘O) written by lako_attn_bwd, unused) */
   int64_t q_stride_b, q_stride_t, k_stride_b, k_stride_t, v_stride_b, v_stride_t, o_stride_b, o_stride_t;
   const float* rel_bias; /* [H, R] fp32 or NULL */
   int R, rel_off;        /* bias index = j - i + rel_off */
@@ -126,7 +127,7 @@ int lako_attn_fwd(const lako_attn_fwd_t* p, lako_stream_t stream);
 
 typedef struct {
   const void *q, *k, *v, *out, *dout;
-  const float* lse;
+  float* lse; /* the forward's [Bn, H, Lq, 4] statistics; slot 2 is overwritten with delta = rowsum(dO∘O) */
   void *dq_out, *dk_out, *dv_out; /* same addressing as q / k / v (dK, dV use the k / v strides) */
   int64_t q_stride_b, q_stride_t, k_stride_b, k_stride_t, v_stride_b, v_stride_t, o_stride_b, o_stride_t;
   const float* rel_bias;

@@ -34,7 +34,7 @@ struct AttnArgs {
   // LDS-side / register-side tensors are selected per kernel from these
   const char *q, *k, *v, *o, *dout;
   char *out, *dq, *dk, *dv;
-  float* stats;        // [Bn, H, Lq, 2] = (row max, 1 / row sum)
+  float* stats;        // [Bn, H, Lq, 4] = (row max, 1 / row sum, delta = rowsum(dO∘O) [written by the dQ pass], -)
   const float* rel_bias;
   float* drel;
   const uint8_t* key_mask;
@@ -72,11 +72,25 @@ template <> struct Mma16<float> {
 template <typename T, int DK>
 __device__ __forceinline__ void stage_image(char* img, const char* base, int64_t stride, int r0, int nrows, int L) {
   using C = AC<T, DK>;
-  for (int idx = threadIdx.x; idx < nrows * C::CPR; idx += 256) {
-    int row = idx / C::CPR, c = idx % C::CPR;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (r0 + row < L) v = *reinterpret_cast<const u32x4*>(base + (int64_t)(r0 + row) * stride * C::ES + c * 16);
-    *reinterpret_cast<u32x4*>(img + row * C::ROWB + c * 16) = v;
+  // 8 independent 16-B loads in flight per thread before the first LDS write (a load→store chain per
+  // element would pay one HBM round trip per 16 bytes)
+  const int total = nrows * C::CPR;
+  for (int idx0 = threadIdx.x; idx0 < total; idx0 += 256 * 8) {
+    u32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = idx0 + u * 256;
+      const int row = idx / C::CPR, c = idx % C::CPR;
+      v[u] = u32x4{0u, 0u, 0u, 0u};
+      if (idx < total && r0 + row < L)
+        v[u] = *reinterpret_cast<const u32x4*>(base + (int64_t)(r0 + row) * stride * C::ES + c * 16);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = idx0 + u * 256;
+      const int row = idx / C::CPR, c = idx % C::CPR;
+      if (idx < total) *reinterpret_cast<u32x4*>(img + row * C::ROWB + c * 16) = v[u];
+    }
   }
 }
 
@@ -190,8 +204,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   if (has_bias)
     for (int i = threadIdx.x; i < a.R; i += 256) bias_l[i] = a.rel_bias[(int64_t)h * a.R + i];
 
+  // Key-split mode: a workgroup that owns a single 16-query block (cross-attention, decode steps) lets its
+  // 4 waves share that block and split every key chunk between them (tile pair tp → wave tp & 3); the
+  // partial (max, sum, O) of the 4 waves are merged through LDS at the end.
+  const bool ksplit = nqb == 1 && a.Lk > 64;   // host reserves the merge scratch only when Lq <= 16
+  float* mrg = bias_l + ((a.R + 3) & ~3);   // [4 waves][16 queries][DK + 2] (ksplit only)
+
   for (int qb0 = qb_begin; qb0 < qb_end; qb0 += 4) {
-    const int qb = qb0 + wave;
+    const int qb = ksplit ? qb0 : qb0 + wave;
     const bool active = qb < qb_end;
     const int qi = qb * 16 + l15;  // this lane's query
     u32x4 qf[C::NF];
@@ -219,14 +239,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
       }
       if (!active) continue;
       const int ntile = nk >> 4;
+#define MINE(t) ((t) < ntile && (!ksplit || (((t) >> 1) & 3) == wave))
       f32x4 s[16];
 #pragma unroll
       for (int t = 0; t < 16; ++t)
-        if (t < ntile) s[t] = score_tile<T, DK>(Kimg, t * 16, qf, lane);
+        if (MINE(t)) s[t] = score_tile<T, DK>(Kimg, t * 16, qf, lane);
       float cmax = -INFINITY;
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
-        if (t < ntile) {
+        if (MINE(t)) {
           const f32x4 kf = *reinterpret_cast<const f32x4*>(kflag + t * 16 + 4 * g);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -247,13 +268,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         }
       }
       cmax = group_max(cmax);
+      if (cmax == -INFINITY) continue;      // ksplit: this wave owns no valid key of this chunk (wave-uniform)
       const float m_new = fmaxf(m, cmax);
       const float alpha = __expf(m - m_new);  // m = -inf on the first chunk → 0
       float psum = 0.f;
       const uint64_t didx0 = (((uint64_t)b * a.H + h) * a.Lq + (uint64_t)qi) * (uint64_t)a.Lk;
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
-        if (t < ntile) {
+        if (MINE(t)) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float p = __expf(s[t][r] - m_new);
@@ -273,15 +295,54 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
       for (int db = 0; db < C::NDB; ++db) oacc[db] *= alpha;
 #pragma unroll
       for (int tp = 0; tp < 8; ++tp)
-        if (2 * tp < ntile) pv_accumulate<T, DK>(oacc, s[2 * tp], s[2 * tp + 1], Vimg, tp * 32, lane);
+        if (MINE(2 * tp)) pv_accumulate<T, DK>(oacc, s[2 * tp], s[2 * tp + 1], Vimg, tp * 32, lane);
+#undef MINE
     }
-    if (active && qi < a.Lq) {
+    if (ksplit) {
+      // merge the 4 waves' partial softmax states (all waves hold the SAME 16 queries)
+      float* mine = mrg + (wave * 16 + l15) * (DK + 2);
+#pragma unroll
+      for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mine[db * 16 + 4 * g + r] = oacc[db][r];
+      if (g == 0) {
+        mine[DK] = m;
+        mine[DK + 1] = lsum;
+      }
+      __syncthreads();
+      if (wave == 0) {
+        float mw[4], M = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          mw[w] = mrg[(w * 16 + l15) * (DK + 2) + DK];
+          M = fmaxf(M, mw[w]);
+        }
+        float sc[4];
+        lsum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          sc[w] = mw[w] == -INFINITY ? 0.f : __expf(mw[w] - M);
+          lsum += sc[w] * mrg[(w * 16 + l15) * (DK + 2) + DK + 1];
+        }
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float acc = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) acc += sc[w] * mrg[(w * 16 + l15) * (DK + 2) + db * 16 + 4 * g + r];
+            oacc[db][r] = acc;
+          }
+        m = M;
+      }
+    }
+    if (active && qi < a.Lq && (!ksplit || wave == 0)) {
       const float inv = 1.0f / lsum;
       T* op = reinterpret_cast<T*>(obase + (int64_t)qi * a.ost * C::ES);
 #pragma unroll
       for (int db = 0; db < C::NDB; ++db) store4(op + db * 16 + 4 * g, oacc[db] * inv);
       if (g == 0 && a.stats) {
-        float* st = a.stats + (((int64_t)b * a.H + h) * a.Lq + qi) * 2;
+        float* st = a.stats + (((int64_t)b * a.H + h) * a.Lq + qi) * 4;
         st[0] = m;
         st[1] = inv;
       }
@@ -320,7 +381,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   const char* vbase = a.v + ((int64_t)b * a.vsb + hoff) * C::ES;
   const char* obase = a.o + ((int64_t)b * a.osb + hoff) * C::ES;
   const char* dobase = a.dout + ((int64_t)b * a.osb + hoff) * C::ES;
-  const float* stats = a.stats + ((int64_t)b * a.H + h) * a.Lq * 2;
+  float* stats = a.stats + ((int64_t)b * a.H + h) * a.Lq * 4;
   const bool has_bias = a.rel_bias != nullptr;
   const bool want_drel = MODE == 0 && a.drel != nullptr;
   if (has_bias)
@@ -328,8 +389,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   if (want_drel)
     for (int i = threadIdx.x; i < a.R; i += 256) drel_l[i] = 0.f;
 
+  // key-split (dQ pass only): a workgroup owning one query block shares it between its 4 waves, which split the
+  // keys (tile pair tp → wave tp & 3); the partial dQ tiles are summed through LDS at the end.
+  const bool ksplit = MODE == 0 && nyb == 1 && a.Lk > 64;   // merge scratch reserved only when Lq <= 16
+  float* mrg = drel_l + ((a.R + 3) & ~3);   // [4][16][DK] (ksplit only)
+
   for (int yb0 = yb_begin; yb0 < yb_end; yb0 += 4) {
-    const int yb = yb0 + wave;
+    const int yb = ksplit ? yb0 : yb0 + wave;
     const bool active = yb < yb_end;
     const int yi = active ? yb * 16 + l15 : LY;  // this lane's register-side row (query in MODE 0, key in MODE 1)
     u32x4 y1[C::NF], y2[C::NF];
@@ -355,8 +421,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
       }
       delta_q = group_sum(part);
       if (yi < a.Lq) {
-        m_q = stats[yi * 2];
-        invl_q = stats[yi * 2 + 1];
+        m_q = stats[yi * 4];
+        invl_q = stats[yi * 4 + 1];
+        if (g == 0) stats[yi * 4 + 2] = delta_q;   // handed to the dK/dV pass (launched after this one)
       }
     } else {
       load_reg_frags<T, DK>(y1, kbase, a.kst, yi, a.Lk, lane);
@@ -392,15 +459,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
             int qi = x0 + i;
             float mm = 0.f, il = 0.f, dl = 0.f;
             if (qi < a.Lq) {
-              mm = stats[qi * 2];
-              il = stats[qi * 2 + 1];
-              const T* dop = reinterpret_cast<const T*>(dobase + (int64_t)qi * a.ost * C::ES);
-              const T* op = reinterpret_cast<const T*>(obase + (int64_t)qi * a.ost * C::ES);
-#pragma unroll 4
-              for (int c = 0; c < DK; c += 4) {
-                f32x4 dv = load4(dop + c), ov = load4(op + c);
-                dl += dv[0] * ov[0] + dv[1] * ov[1] + dv[2] * ov[2] + dv[3] * ov[3];
-              }
+              const f32x4 st4 = *reinterpret_cast<const f32x4*>(stats + qi * 4);
+              mm = st4[0];
+              il = st4[1];
+              dl = st4[2];                     // delta = rowsum(dO∘O), written by the dQ pass
             }
             aux0[i] = mm;
             aux1[i] = il;
@@ -412,6 +474,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
       if (!active) continue;
       const int npair = nx >> 5;
       for (int tp = 0; tp < npair; ++tp) {
+        if (ksplit && (tp & 3) != wave) continue;
         f32x4 pt[2], ds[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -463,7 +526,26 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
         }
       }
     }
-    if (active && yi < LY) {
+    if (ksplit) {
+      float* mine = mrg + (wave * 16 + l15) * DK;
+#pragma unroll
+      for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mine[db * 16 + 4 * g + r] = acc1[db][r];
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float acc = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) acc += mrg[(w * 16 + l15) * DK + db * 16 + 4 * g + r];
+            acc1[db][r] = acc;
+          }
+      }
+    }
+    if (active && yi < LY && (!ksplit || wave == 0)) {
       if constexpr (MODE == 0) {
         T* op = reinterpret_cast<T*>(a.dq + ((int64_t)b * a.qsb + (int64_t)yi * a.qst + hoff) * C::ES);
 #pragma unroll
@@ -489,9 +571,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
 }
 
 template <typename T, int DK>
-int lds_bytes_fwd(int ch, int R) { return 2 * img_bytes<T, DK>(ch) + (ch + R + 8) * 4; }
+int lds_bytes_fwd(int ch, int R, bool merge) {
+  return 2 * img_bytes<T, DK>(ch) + (ch + R + 8 + (merge ? 4 * 16 * (DK + 2) : 0)) * 4;
+}
 template <typename T, int DK>
-int lds_bytes_bwd(int ch, int R) { return 2 * img_bytes<T, DK>(ch) + (3 * ch + 2 * R + 8) * 4; }
+int lds_bytes_bwd(int ch, int R, bool merge) {
+  return 2 * img_bytes<T, DK>(ch) + (3 * ch + 2 * R + 8 + (merge ? 4 * 16 * DK : 0)) * 4;
+}
 
 inline int pick_chunk(int L) {
   int ch = ((L + 31) / 32) * 32;
@@ -523,7 +609,7 @@ int run_fwd(AttnArgs& a, hipStream_t s) {
   a.chunk_rows = pick_chunk(a.Lk);
   const int nqb = (a.Lq + 15) / 16;
   a.blocks_per_wg = pick_blocks_per_wg(nqb, (int64_t)a.Bn * a.H);
-  const int lds = lds_bytes_fwd<T, DK>(a.chunk_rows, a.R);
+  const int lds = lds_bytes_fwd<T, DK>(a.chunk_rows, a.R, nqb == 1);
   static int cur = 0;
   set_lds_attr(&attn_fwd_kernel<T, DK>, lds, cur);
   dim3 grid((nqb + a.blocks_per_wg - 1) / a.blocks_per_wg, a.H, a.Bn);
@@ -538,7 +624,7 @@ int run_bwd(AttnArgs& a, hipStream_t s) {
     q.chunk_rows = pick_chunk(a.Lk);
     const int nqb = (a.Lq + 15) / 16;
     q.blocks_per_wg = pick_blocks_per_wg(nqb, (int64_t)a.Bn * a.H);
-    const int lds = lds_bytes_bwd<T, DK>(q.chunk_rows, a.R);
+    const int lds = lds_bytes_bwd<T, DK>(q.chunk_rows, a.R, nqb == 1);
     static int cur0 = 0;
     set_lds_attr(&attn_bwd_kernel<T, DK, 0>, lds, cur0);
     dim3 grid((nqb + q.blocks_per_wg - 1) / q.blocks_per_wg, a.H, a.Bn);
@@ -549,7 +635,7 @@ int run_bwd(AttnArgs& a, hipStream_t s) {
     k.chunk_rows = pick_chunk(a.Lq);
     const int nkb = (a.Lk + 15) / 16;
     k.blocks_per_wg = pick_blocks_per_wg(nkb, (int64_t)a.Bn * a.H);
-    const int lds = lds_bytes_bwd<T, DK>(k.chunk_rows, a.R);
+    const int lds = lds_bytes_bwd<T, DK>(k.chunk_rows, a.R, false);
     static int cur1 = 0;
     set_lds_attr(&attn_bwd_kernel<T, DK, 1>, lds, cur1);
     dim3 grid((nkb + k.blocks_per_wg - 1) / k.blocks_per_wg, a.H, a.Bn);

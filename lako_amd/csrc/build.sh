@@ -15,7 +15,7 @@ for f in gemm rowops attn; do
   fi
   objs+=($f.o)
 done
-for p in "${pids[@]:-}"; do [ -n "$p" ] && wait $p; done
+for p in "${pids[@]:-}"; do if [ -n "$p" ]; then wait $p || { echo "COMPILE FAILED"; exit 1; }; fi; done
 # link WITHOUT an rpath to /opt/rocm: the library must bind to the HIP runtime torch already loaded
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT "${objs[@]}"
 echo "built $(realpath $OUT)"

@@ -153,14 +153,20 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* __restrict__ 
       }
     }
   }
+  // block-level reduction of the 4 waves' partial dw in LDS, then ONE atomic per column per block (all
+  // blocks add into the same d addresses, so the number of adders per address is what costs)
+  __shared__ float red[4][1024];
+  const int wave_id = threadIdx.x >> 6;
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     int c = it * 512 + lane * 8;
     if (c < d) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) atomicAdd(dw + c + i, dwacc[it][i]);
+      for (int i = 0; i < 8; ++i) red[wave_id][c + i] = dwacc[it][i];
     }
   }
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += 256) atomicAdd(dw + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
 }
 
 // ---- embedding ----------------------------------------------------------------------------------
@@ -489,7 +495,7 @@ extern "C" int lako_rmsnorm_bwd(const void* dy, const void* x, const float* w, c
   LAKO_CHECK_ALIGN(w, 16);
   DropDev dr = make_drop(drop);
   int grid = rows_grid(rows);
-  if (grid > 1024) grid = 1024;
+  if (grid > 512) grid = 512;   // 2 blocks per CU: enough waves to stream, few adders per dw address
   DISPATCH_T(dtype, hipLaunchKernelGGL((rmsnorm_bwd_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
                                        (const T*)dy, (const T*)x, w, rstd, (const T*)dres, (T*)dx, dw, rows, d, dr));
   LAKO_LAUNCH_CHECK();

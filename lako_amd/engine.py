@@ -273,7 +273,7 @@ class Engine:
             ops.gemm_nt(xn1, lw["qkv"].w, qkv)
             ctx = self._buf(ws, f"e.ctx.{j}", (Me, inner))
             ops.attn_fwd(self._heads(qkv, BN, L, 0), self._heads(qkv, BN, L, inner), self._heads(qkv, BN, L, 2 * inner),
-                         self._heads(ctx, BN, L, 0), self._buf(ws, f"e.st.{j}", (BN, H, L, 2), torch.float32),
+                         self._heads(ctx, BN, L, 0), self._buf(ws, f"e.st.{j}", (BN, H, L, 4), torch.float32),
                          rel_bias=rel, rel_off=L - 1, key_mask=mask_u8, drop=dr(_enc_site(i, 0)))
             h1 = self._buf(ws, f"e.h1.{j}", (Me, d))
             ops.gemm_nt(ctx, lw["o"].w, h1, resid=h, drop=dr(_enc_site(i, 1)))
@@ -326,7 +326,7 @@ class Engine:
             ops.gemm_nt(xn1, lw["qkv"].w, qkv)
             c1 = self._buf(ws, f"d.ctx.{i}", (Md, inner))
             ops.attn_fwd(self._heads(qkv, B, T, 0), self._heads(qkv, B, T, inner), self._heads(qkv, B, T, 2 * inner),
-                         self._heads(c1, B, T, 0), self._buf(ws, f"d.st.{i}", (B, H, T, 2), torch.float32),
+                         self._heads(c1, B, T, 0), self._buf(ws, f"d.st.{i}", (B, H, T, 4), torch.float32),
                          rel_bias=rel, rel_off=T - 1, causal=True, drop=dr(_dec_site(i, 0)))
             h1 = self._buf(ws, f"d.h1.{i}", (Md, d))
             ops.gemm_nt(c1, lw["o"].w, h1, resid=h, drop=dr(_dec_site(i, 1)))
@@ -337,7 +337,7 @@ class Engine:
             c2 = self._buf(ws, f"d.cctx.{i}", (Md, inner))
             ops.attn_fwd(self._heads(qc, B, T, 0), self._heads(kv, B, S, 2 * i * inner),
                          self._heads(kv, B, S, (2 * i + 1) * inner), self._heads(c2, B, T, 0),
-                         self._buf(ws, f"d.cst.{i}", (B, H, T, 2), torch.float32), key_mask=enc_mask,
+                         self._buf(ws, f"d.cst.{i}", (B, H, T, 4), torch.float32), key_mask=enc_mask,
                          drop=dr(_dec_site(i, 2)))
             h2 = self._buf(ws, f"d.h2.{i}", (Md, d))
             ops.gemm_nt(c2, lw["co"].w, h2, resid=h1, drop=dr(_dec_site(i, 3)))
@@ -512,7 +512,7 @@ class Engine:
         h, h1, h2, xn = (self._buf(ws, f"g.{n}", (B, d)) for n in ("h", "h1", "h2", "xn"))
         rs = self._buf(ws, "g.rs", (B,), torch.float32)
         q, c1, qc, c2 = (self._buf(ws, f"g.{n}", (B, inner)) for n in ("q", "c1", "qc", "c2"))
-        st = self._buf(ws, "g.st", (B, H, 1, 2), torch.float32)
+        st = self._buf(ws, "g.st", (B, H, 1, 4), torch.float32)
         a1 = self._buf(ws, "g.a1", (B, f))
         logits = self._buf(ws, "g.logits", (B, V), torch.float32)
         n_out = 1

@@ -61,10 +61,30 @@ class HipOps:
             raise LakoError("HipOps needs a ROCm device (torch.cuda.is_available() is False); no CPU fallback exists")
         self.lib = _lib.load()
         assert self.lib.lako_version() == 1
+        self.probe = None   # list → every op records (name, algorithmic flops, start event, end event)
 
     @staticmethod
     def _stream():
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def _timed(self, name, flops, launch):
+        """Launch through `launch()`; when a probe list is installed, bracket it with HIP events recorded on the
+        stream the kernel runs on (torch's current stream — the one `_stream()` hands to the C-ABI)."""
+        if self.probe is None:
+            return launch()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        launch()
+        e1.record()
+        self.probe.append((name, flops, e0, e1))
+
+    def probe_summary(self):
+        """{name: (launches, total ms, total flops)} of the installed probe (call after a device sync)."""
+        out = {}
+        for name, fl, e0, e1 in self.probe or []:
+            n, ms, f = out.get(name, (0, 0.0, 0.0))
+            out[name] = (n + 1, ms + e0.elapsed_time(e1), f + fl)
+        return out
 
     # ---- plumbing ---------------------------------------------------------------------------
     def zero_(self, t: torch.Tensor):
@@ -95,7 +115,7 @@ class HipOps:
             p.aux, p.ldaux = aux.data_ptr(), aux.stride(0)
         p.aux_scale = float(aux_scale)
         p.drop = _drop(drop)
-        check(self.lib.lako_gemm_nt(C.byref(p), self._stream()), "lako_gemm_nt")
+        self._timed(f"gemm_nt.{p.in_dtype}{p.out_dtype}", 2.0 * M * N * K, lambda: check(self.lib.lako_gemm_nt(C.byref(p), self._stream()), "lako_gemm_nt"))
 
     def gemm_tn(self, A, B, Cm, *, alpha=1.0, split_k=0):
         K, M, lda = _rowmajor2d(A, "gemm_tn A")
@@ -103,42 +123,39 @@ class HipOps:
         M2, N2, ldc = _rowmajor2d(Cm, "gemm_tn C")
         if K != K2 or M != M2 or N != N2 or A.dtype != B.dtype or Cm.dtype != torch.float32:
             raise LakoError(f"gemm_tn: shape/dtype mismatch A{tuple(A.shape)} B{tuple(B.shape)} C{tuple(Cm.shape)}")
-        check(self.lib.lako_gemm_tn(_p(A), _p(B), _p(Cm), M, N, K, lda, ldb, ldc, _dt(A), float(alpha), int(split_k),
-                                    self._stream()), "lako_gemm_tn")
+        self._timed("gemm_tn", 2.0 * M * N * K, lambda: check(self.lib.lako_gemm_tn(_p(A), _p(B), _p(Cm), M, N, K, lda, ldb, ldc, _dt(A), float(alpha), int(split_k),
+                                    self._stream()), "lako_gemm_tn"))
 
     # ---- norm / embedding / dropout ---------------------------------------------------------------
     def rmsnorm_fwd(self, x, w, y, rstd, eps, drop=None):
         rows, d = x.shape
-        check(self.lib.lako_rmsnorm_fwd(_p(x), _p(w), _p(y), _p(rstd), rows, d, float(eps), _dt(x), _drop(drop),
-                                        self._stream()), "lako_rmsnorm_fwd")
+        self._timed("rmsnorm_fwd", 0.0, lambda: check(self.lib.lako_rmsnorm_fwd(_p(x), _p(w), _p(y), _p(rstd), rows, d, float(eps), _dt(x), _drop(drop),
+                                        self._stream()), "lako_rmsnorm_fwd"))
 
     def rmsnorm_bwd(self, dy, x, w, rstd, dres, dx, dw, drop=None):
         rows, d = x.shape
-        check(self.lib.lako_rmsnorm_bwd(_p(dy), _p(x), _p(w), _p(rstd), _p(dres), _p(dx), _p(dw), rows, d, _dt(x),
-                                        _drop(drop), self._stream()), "lako_rmsnorm_bwd")
+        self._timed("rmsnorm_bwd", 0.0, lambda: check(self.lib.lako_rmsnorm_bwd(_p(dy), _p(x), _p(w), _p(rstd), _p(dres), _p(dx), _p(dw), rows, d, _dt(x),
+                                        _drop(drop), self._stream()), "lako_rmsnorm_bwd"))
 
     def embed_fwd(self, ids, table, out, drop=None):
-        check(self.lib.lako_embed_fwd(_p(ids), _p(table), _p(out), ids.numel(), table.shape[1], table.shape[0],
-                                      _dt(table), _drop(drop), self._stream()), "lako_embed_fwd")
+        self._timed("embed_fwd", 0.0, lambda: check(self.lib.lako_embed_fwd(_p(ids), _p(table), _p(out), ids.numel(), table.shape[1], table.shape[0],
+                                      _dt(table), _drop(drop), self._stream()), "lako_embed_fwd"))
 
     def embed_bwd(self, ids, dout, dtable, drop=None):
-        check(self.lib.lako_embed_bwd(_p(ids), _p(dout), _p(dtable), ids.numel(), dtable.shape[1], dtable.shape[0],
-                                      _dt(dout), _drop(drop), self._stream()), "lako_embed_bwd")
+        self._timed("embed_bwd", 0.0, lambda: check(self.lib.lako_embed_bwd(_p(ids), _p(dout), _p(dtable), ids.numel(), dtable.shape[1], dtable.shape[0],
+                                      _dt(dout), _drop(drop), self._stream()), "lako_embed_bwd"))
 
     def dropout_apply(self, x, y, drop):
-        check(self.lib.lako_dropout_apply(_p(x), _p(y), x.numel(), _dt(x), _drop(drop), self._stream()),
-              "lako_dropout_apply")
+        self._timed("dropout_apply", 0.0, lambda: check(self.lib.lako_dropout_apply(_p(x), _p(y), x.numel(), _dt(x), _drop(drop), self._stream()), "lako_dropout_apply"))
 
     # ---- relative position bias ---------------------------------------------------------------
     def relpos_expand(self, table, lut, rel):
         nb, H = table.shape
-        check(self.lib.lako_relpos_expand(_p(table), _p(lut), _p(rel), H, rel.shape[1], nb, self._stream()),
-              "lako_relpos_expand")
+        self._timed("relpos_expand", 0.0, lambda: check(self.lib.lako_relpos_expand(_p(table), _p(lut), _p(rel), H, rel.shape[1], nb, self._stream()), "lako_relpos_expand"))
 
     def relpos_reduce(self, drel, lut, dtable):
         nb, H = dtable.shape
-        check(self.lib.lako_relpos_reduce(_p(drel), _p(lut), _p(dtable), H, drel.shape[1], nb, self._stream()),
-              "lako_relpos_reduce")
+        self._timed("relpos_reduce", 0.0, lambda: check(self.lib.lako_relpos_reduce(_p(drel), _p(lut), _p(dtable), H, drel.shape[1], nb, self._stream()), "lako_relpos_reduce"))
 
     # ---- attention ------------------------------------------------------------------------------
     def attn_fwd(self, q, k, v, out, stats, *, rel_bias=None, rel_off=0, key_mask=None, causal=False, causal_off=0,
@@ -164,7 +181,7 @@ class HipOps:
         p.drop = _drop(drop)
         if scores_out is not None:
             p.scores_out = scores_out.data_ptr()
-        check(self.lib.lako_attn_fwd(C.byref(p), self._stream()), "lako_attn_fwd")
+        self._timed("attn_fwd", 4.0 * Bn * H * Lq * Lk * dk, lambda: check(self.lib.lako_attn_fwd(C.byref(p), self._stream()), "lako_attn_fwd"))
 
     def attn_bwd(self, q, k, v, out, dout, stats, dq, dk_, dv, *, rel_bias=None, drel=None, rel_off=0, key_mask=None,
                  causal=False, causal_off=0, drop=None):
@@ -192,38 +209,36 @@ class HipOps:
         p.Bn, p.H, p.Lq, p.Lk, p.d_head = Bn, H, Lq, Lk, dk
         p.dtype = _dt(q)
         p.drop = _drop(drop)
-        check(self.lib.lako_attn_bwd(C.byref(p), self._stream()), "lako_attn_bwd")
+        self._timed("attn_bwd", 8.0 * Bn * H * Lq * Lk * dk, lambda: check(self.lib.lako_attn_bwd(C.byref(p), self._stream()), "lako_attn_bwd"))
 
     # ---- loss / optimizer -----------------------------------------------------------------------
     def ce_fwd_bwd(self, logits, labels, loss_out, dlogits, upstream=None):
         M, V = logits.shape
-        check(self.lib.lako_ce_fwd_bwd(_p(logits), _p(labels), _p(loss_out), _p(dlogits), _p(upstream), M, V,
-                                       _dt(dlogits) if dlogits is not None else LAKO_F32, self._stream()),
-              "lako_ce_fwd_bwd")
+        self._timed("ce_fwd_bwd", 0.0, lambda: check(self.lib.lako_ce_fwd_bwd(_p(logits), _p(labels), _p(loss_out), _p(dlogits), _p(upstream), M, V,
+                                       _dt(dlogits) if dlogits is not None else LAKO_F32, self._stream()), "lako_ce_fwd_bwd"))
 
     def sumsq(self, g, out):
-        check(self.lib.lako_sumsq(_p(g), g.numel(), _p(out), self._stream()), "lako_sumsq")
+        self._timed("sumsq", 0.0, lambda: check(self.lib.lako_sumsq(_p(g), g.numel(), _p(out), self._stream()), "lako_sumsq"))
 
     def adamw_step(self, p, g, m, v, shadow, *, lr, beta1, beta2, eps, weight_decay, gnorm_sq, max_norm, grad_scale):
-        check(self.lib.lako_adamw_step(_p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), float(lr), float(beta1),
+        self._timed("adamw_step", 0.0, lambda: check(self.lib.lako_adamw_step(_p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), float(lr), float(beta1),
                                        float(beta2), float(eps), float(weight_decay), _p(gnorm_sq), float(max_norm),
                                        float(grad_scale), _dt(shadow) if shadow is not None else LAKO_F32,
-                                       self._stream()), "lako_adamw_step")
+                                       self._stream()), "lako_adamw_step"))
 
     def transpose_cast(self, src, dst):
         rows, cols = src.shape
-        check(self.lib.lako_transpose_cast(_p(src), _p(dst), rows, cols, _dt(dst), self._stream()),
-              "lako_transpose_cast")
+        self._timed("transpose_cast", 0.0, lambda: check(self.lib.lako_transpose_cast(_p(src), _p(dst), rows, cols, _dt(dst), self._stream()), "lako_transpose_cast"))
 
     def cast(self, src, dst):
-        check(self.lib.lako_cast(_p(src), _p(dst), src.numel(), _dt(dst), self._stream()), "lako_cast")
+        self._timed("cast", 0.0, lambda: check(self.lib.lako_cast(_p(src), _p(dst), src.numel(), _dt(dst), self._stream()), "lako_cast"))
 
     # ---- integer helpers ------------------------------------------------------------------------
     def shift_right(self, labels, dec_ids):
         B, T = labels.shape
-        check(self.lib.lako_shift_right(_p(labels), _p(dec_ids), B, T, self._stream()), "lako_shift_right")
+        self._timed("shift_right", 0.0, lambda: check(self.lib.lako_shift_right(_p(labels), _p(dec_ids), B, T, self._stream()), "lako_shift_right"))
 
     def greedy_step(self, logits, seq, pos, next_ids, done, n_done, eos_id=1, pad_id=0):
         B, V = logits.shape
-        check(self.lib.lako_greedy_step(_p(logits), V, B, _p(seq), seq.stride(0), int(pos), _p(next_ids), _p(done),
-                                        _p(n_done), int(eos_id), int(pad_id), self._stream()), "lako_greedy_step")
+        self._timed("greedy_step", 0.0, lambda: check(self.lib.lako_greedy_step(_p(logits), V, B, _p(seq), seq.stride(0), int(pos), _p(next_ids), _p(done),
+                                        _p(n_done), int(eos_id), int(pad_id), self._stream()), "lako_greedy_step"))

@@ -171,7 +171,8 @@ class RefOps:
                  drop=None, scores_out=None):
         o, m, il, raw = self._attn_core(f(q), f(k), f(v), rel_bias, rel_off, key_mask, causal, causal_off, drop)
         out.copy_(o)
-        stats.copy_(torch.stack([m, il], -1))
+        stats[..., 0] = m
+        stats[..., 1] = il
         if scores_out is not None:
             scores_out.copy_(raw)
 

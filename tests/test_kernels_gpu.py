@@ -225,7 +225,7 @@ def test_attention(ops, ref, dt, case):
     kw = dict(rel_bias=rel, rel_off=rel_off, key_mask=km, causal=causal, causal_off=0, drop=drop)
     out = torch.zeros(Bn, Lq, H, dk, dtype=T, device=dev())
     outr = torch.zeros(Bn, Lq, H, dk, device=dev())
-    st, stg = torch.zeros(Bn, H, Lq, 2, device=dev()), torch.zeros(Bn, H, Lq, 2, device=dev())
+    st, stg = torch.zeros(Bn, H, Lq, 4, device=dev()), torch.zeros(Bn, H, Lq, 4, device=dev())
     sc, scr = torch.zeros(Bn, H, Lq, Lk, device=dev()), torch.zeros(Bn, H, Lq, Lk, device=dev())
     ops.attn_fwd(q, k, v, out, stg, scores_out=sc, **kw)
     ref.attn_fwd(q, k, v, outr, st, scores_out=scr, **kw)

@@ -1,0 +1,151 @@
+#!/usr/bin/env python
+"""Per-kernel micro-benchmark at the BASELINE config-2 shapes (T5-base, B=16, N=20, L=200, T=8).
+Random (not zero) operands; every op timed with HIP events over `--iters` back-to-back launches after a warm-up.
+    python tools/bench_ops.py [--only gemm,attn,norm] [--iters 20]
+Prints one line per op: avg µs, TFLOP/s (MFMA ops) or GB/s of algorithmic bytes (HBM ops)."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lako_amd.ops import HipOps  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--only", default="gemm,tn,attn,norm,misc")
+ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--dtype", default="bf16")
+args = ap.parse_args()
+only = set(args.only.split(","))
+T = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+ES = 2 if T == torch.bfloat16 else 4
+dev = torch.device("cuda:0")
+ops = HipOps()
+B, N, L, Tt, d, f, H, dk, V, Ld = 16, 20, 200, 8, 768, 3072, 12, 64, 32128, 12
+inner, Me, Md, S = H * dk, B * N * L, B * Tt, N * L
+
+
+def rnd(*shape, dtype=T, scale=1.0):
+    return (torch.randn(*shape, device=dev) * scale).to(dtype)
+
+
+def timeit(name, fn, flops=0.0, bytes_=0.0):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / args.iters
+    extra = f"{flops / us / 1e6:9.1f} TFLOP/s" if flops else (f"{bytes_ / us / 1e3:9.1f} GB/s" if bytes_ else "")
+    print(f"{name:44s} {us:10.1f} us  {extra}", flush=True)
+
+
+drop = (0.1, 1, 2)
+if "gemm" in only:
+    for nm, (M, Nn, K), kw in [
+        ("nt qkv   [Me,768]x[2304,768]", (Me, 3 * inner, d), {}),
+        ("nt o+res [Me,768]x[768,768]", (Me, d, inner), dict(resid=True, drop=drop)),
+        ("nt wi    [Me,768]x[3072,768] relu+drop", (Me, f, d), dict(relu=True, drop=drop)),
+        ("nt wo    [Me,3072]x[768,3072] res+drop", (Me, d, f), dict(resid=True, drop=drop)),
+        ("nt kvall [Me,768]x[18432,768]", (Me, Ld * 2 * inner, d), {}),
+        ("nt dxkv  [Me,18432]x[768,18432]", (Me, d, Ld * 2 * inner), {}),
+        ("nt dpre  [Me,768]x[3072,768] auxmask", (Me, f, d), dict(aux=True)),
+        ("nt lmhead[128,768]x[32128,768] f32 out", (Md, V, d), dict(f32=True)),
+        ("nt square 4096^3", (4096, 4096, 4096), {}),
+        ("nt square 8192^3", (8192, 8192, 8192), {}),
+    ]:
+        A, Bm = rnd(M, K), rnd(Nn, K)
+        C = torch.empty(M, Nn, dtype=torch.float32 if kw.get("f32") else T, device=dev)
+        k2 = {}
+        if kw.get("resid"):
+            k2["resid"] = rnd(M, Nn)
+        if kw.get("aux"):
+            k2["aux"], k2["aux_scale"] = rnd(M, Nn), 1.1
+        if kw.get("relu"):
+            k2["relu"] = True
+        if kw.get("drop"):
+            k2["drop"] = kw["drop"]
+        timeit(nm, lambda: ops.gemm_nt(A, Bm, C, **k2), flops=2.0 * M * Nn * K)
+        del A, Bm, C, k2
+
+if "tn" in only:
+    for nm, (K, M, Nn) in [
+        ("tn dWqkv [Me,2304]^T x [Me,768]", (Me, 3 * inner, d)),
+        ("tn dWo   [Me,768]^T x [Me,768]", (Me, d, inner)),
+        ("tn dWi   [Me,3072]^T x [Me,768]", (Me, f, d)),
+        ("tn dWo2  [Me,768]^T x [Me,3072]", (Me, d, f)),
+        ("tn dWkv  [Me,18432]^T x [Me,768]", (Me, Ld * 2 * inner, d)),
+        ("tn dE    [128,32128]^T x [128,768]", (Md, V, d)),
+    ]:
+        A, Bm = rnd(K, M), rnd(K, Nn)
+        C = torch.zeros(M, Nn, device=dev)
+        timeit(nm, lambda: ops.gemm_tn(A, Bm, C), flops=2.0 * M * Nn * K)
+        del A, Bm, C
+
+if "attn" in only:
+    BN = B * N
+    qkv = rnd(BN * L, 3 * inner, scale=0.5)
+    ctx = torch.empty(BN * L, inner, dtype=T, device=dev)
+
+    def heads(t, rb, rt, c0):
+        return t.view(rb, rt, t.shape[1])[:, :, c0:c0 + inner].unflatten(2, (H, dk))
+    st = torch.empty(BN, H, L, 4, device=dev)
+    rel = rnd(H, 2 * L - 1, dtype=torch.float32)
+    lens = torch.randint(L // 2, L + 1, (BN,), device=dev)
+    km = (torch.arange(L, device=dev)[None] < lens[:, None]).to(torch.uint8)
+    fl = 4.0 * BN * H * L * L * dk
+    for nm, kw in [("attn_fwd enc plain", {}), ("attn_fwd enc bias+mask", dict(rel_bias=rel, rel_off=L - 1, key_mask=km)),
+                   ("attn_fwd enc bias+mask+drop", dict(rel_bias=rel, rel_off=L - 1, key_mask=km, drop=drop))]:
+        timeit(nm, lambda: ops.attn_fwd(heads(qkv, BN, L, 0), heads(qkv, BN, L, inner), heads(qkv, BN, L, 2 * inner),
+                                        heads(ctx, BN, L, 0), st, **kw), flops=fl)
+    ops.attn_fwd(heads(qkv, BN, L, 0), heads(qkv, BN, L, inner), heads(qkv, BN, L, 2 * inner), heads(ctx, BN, L, 0), st,
+                 rel_bias=rel, rel_off=L - 1, key_mask=km, drop=drop)
+    dctx, dqkv = rnd(BN * L, inner), torch.empty(BN * L, 3 * inner, dtype=T, device=dev)
+    drel = torch.zeros_like(rel)
+    for nm, kw in [("attn_bwd enc plain", {}), ("attn_bwd enc bias+mask+drop+drel",
+                                                  dict(rel_bias=rel, rel_off=L - 1, key_mask=km, drop=drop, drel=drel))]:
+        timeit(nm, lambda: ops.attn_bwd(heads(qkv, BN, L, 0), heads(qkv, BN, L, inner), heads(qkv, BN, L, 2 * inner),
+                                        heads(ctx, BN, L, 0), heads(dctx, BN, L, 0), st, heads(dqkv, BN, L, 0),
+                                        heads(dqkv, BN, L, inner), heads(dqkv, BN, L, 2 * inner), **kw), flops=2.5 * fl)
+    # cross attention: T=8 queries over S=4000 keys
+    kv = rnd(B * S, 2 * inner, scale=0.5)
+    q = rnd(Md, inner, scale=0.5)
+    c2 = torch.empty(Md, inner, dtype=T, device=dev)
+    st2 = torch.empty(B, H, Tt, 4, device=dev)
+    em = km.view(B, S)
+    flc = 4.0 * B * H * Tt * S * dk
+    byc = 2.0 * B * S * inner * ES
+    timeit("attn_fwd cross (T=8,S=4000)", lambda: ops.attn_fwd(heads(q, B, Tt, 0), heads(kv, B, S, 0), heads(kv, B, S, inner),
+                                                                heads(c2, B, Tt, 0), st2, key_mask=em, drop=drop), bytes_=byc)
+    dkv, dq, dc2 = torch.empty_like(kv), torch.empty_like(q), rnd(Md, inner)
+    timeit("attn_bwd cross", lambda: ops.attn_bwd(heads(q, B, Tt, 0), heads(kv, B, S, 0), heads(kv, B, S, inner),
+                                                  heads(c2, B, Tt, 0), heads(dc2, B, Tt, 0), st2, heads(dq, B, Tt, 0),
+                                                  heads(dkv, B, S, 0), heads(dkv, B, S, inner), key_mask=em, drop=drop),
+           bytes_=2 * byc)
+
+if "norm" in only:
+    x, w = rnd(Me, d), torch.ones(d, device=dev)
+    y, rs = torch.empty_like(x), torch.empty(Me, device=dev)
+    timeit("rmsnorm_fwd [Me,768]", lambda: ops.rmsnorm_fwd(x, w, y, rs, 1e-6), bytes_=2.0 * Me * d * ES)
+    dy, dx, dw = rnd(Me, d), torch.empty_like(x), torch.zeros(d, device=dev)
+    timeit("rmsnorm_bwd [Me,768] +dres", lambda: ops.rmsnorm_bwd(dy, x, w, rs, dy, dx, dw), bytes_=4.0 * Me * d * ES)
+    timeit("dropout_apply [Me,768]", lambda: ops.dropout_apply(x, y, drop), bytes_=2.0 * Me * d * ES)
+
+if "misc" in only:
+    n = 222_903_552 // 4 * 4
+    p, g, m, v = (torch.randn(n, device=dev) for _ in range(4))
+    v.abs_()
+    sh = torch.empty(n, dtype=T, device=dev)
+    ns = torch.zeros(1, device=dev)
+    timeit("sumsq 223M", lambda: ops.sumsq(g, ns), bytes_=4.0 * n)
+    timeit("adamw 223M (+bf16 shadow)", lambda: ops.adamw_step(p, g, m, v, sh, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-6,
+                                                               weight_decay=1e-4, gnorm_sq=ns, max_norm=1.0, grad_scale=1.0),
+           bytes_=(16 + 12 + ES) * n)
+    timeit("zero grads 223M", lambda: g.zero_(), bytes_=4.0 * n)
+    src, dst = torch.randn(3072, 768, device=dev), torch.empty(768, 3072, dtype=T, device=dev)
+    timeit("transpose_cast 3072x768", lambda: ops.transpose_cast(src, dst), bytes_=3072 * 768 * (4 + ES))
