@@ -172,6 +172,10 @@ int lako_shift_right(const int64_t* labels, int64_t* dec_ids, int B, int T, lako
 int lako_greedy_step(const float* logits, int64_t V, int B, int64_t* seq, int64_t seq_ld, int pos, int64_t* next_ids,
                      uint8_t* done, int32_t* n_done, int64_t eos_id, int64_t pad_id, lako_stream_t stream);
 
+/* Development knob for A/B measurements (tools/bench_ops.py); training never calls it.
+ * "gemm_nt_variant": -1 auto (default), 0 = 128x128 tile / 4 waves, 1 = 256x128 / 8 waves, 2 = 256x256 / 8 waves */
+int lako_set_tuning(const char* key, int value);
+
 #ifdef __cplusplus
 }
 #endif

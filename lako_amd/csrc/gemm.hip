@@ -16,9 +16,9 @@
 
 namespace {
 
-constexpr int TM = 128, TN_ = 128, TKB = 128;  // tile rows, tile cols, K bytes per step
+constexpr int TM = 128, TN_ = 128, TKB = 128;  // TN-kernel tile rows / cols; K bytes per step (both kernels)
 constexpr int TILE_BYTES = TM * TKB;            // 16 KiB per operand per buffer
-constexpr int GEMM_LDS = 4 * TILE_BYTES;        // A,B × 2 buffers
+constexpr int GEMM_LDS = 4 * TILE_BYTES;        // A,B × 2 buffers (TN kernel)
 
 struct NtArgs {
   const char* A;
@@ -57,8 +57,10 @@ template <> struct Mma<float> {
   }
 };
 
-// Stage one [128 rows][128 B] operand slice: LDS chunk (row, cp) holds logical 16-B chunk
-// c = cp ^ ((row >> 1) & 7) of that row.  `base` points at (row0, kbyte0) of the operand.
+// Stage one [ROWS rows][128 B] operand slice: LDS chunk (row, cp) holds logical 16-B chunk
+// c = cp ^ ((row >> 1) & 7) of that row.  `base` points at (row0, kbyte0) of the operand.  Each
+// wave-instruction moves 8 rows (1 KiB); the ROWS/8 instructions are dealt round-robin to the waves.
+template <int ROWS, int NWAVES>
 __device__ __forceinline__ void stage_rows(char* lds_tile, const char* base, int rows_valid, int64_t ld_bytes,
                                            int kbytes_left, int wave, int lane) {
   uint32_t nrec = (rows_valid > 0 && kbytes_left > 0)
@@ -66,8 +68,8 @@ __device__ __forceinline__ void stage_rows(char* lds_tile, const char* base, int
                       : 0u;
   auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)nrec, 0x00020000);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int inst = wave * 4 + i;
+  for (int i = 0; i < ROWS / 8 / NWAVES; ++i) {
+    int inst = wave + i * NWAVES;
     int row = inst * 8 + (lane >> 3);
     int cp = lane & 7;
     int c = cp ^ ((row >> 1) & 7);
@@ -82,62 +84,77 @@ __device__ __forceinline__ u32x4 read_frag_rows(const char* lds_tile, int row, i
   return *reinterpret_cast<const u32x4*>(lds_tile + row * TKB + cp * 16);
 }
 
-template <typename T, typename TO>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(NtArgs a) {
+// Workgroup tile = (WM·MT·16) × (WN·NT·16); WM×WN waves, each owning MT×NT MFMA 16×16 tiles.
+//   <2,2,4,4> 128×128, 4 waves, 64 KiB LDS (2 workgroups / CU)      — small / skinny problems
+//   <2,4,8,4> 256×256, 8 waves, 128 KiB LDS (1 workgroup / CU)      — half the LDS+L2 bytes per FLOP
+template <typename T, typename TO, int WM, int WN, int MT, int NT>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
+  constexpr int NW = WM * WN, BM = WM * MT * 16, BN = WN * NT * 16;
+  constexpr int A_BYTES = BM * TKB, B_BYTES = BN * TKB, BUF = A_BYTES + B_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WN, wc = wave % WN;
   const int nwg = a.tiles_m * a.tiles_n;
-  const int tid = xcd_remap(blockIdx.x, nwg);
-  const int tile_m = tid / a.tiles_n, tile_n = tid % a.tiles_n;
-  const int m0 = tile_m * TM, n0 = tile_n * TN_;
-  const int rows_a = min(TM, a.M - m0), rows_b = min(TN_, a.N - n0);
   const int64_t lda_b = a.lda * sizeof(T), ldb_b = a.ldb * sizeof(T);
   const int kbytes = a.K * (int)sizeof(T);
-  const char* Abase = a.A + (int64_t)m0 * lda_b;
-  const char* Bbase = a.B + (int64_t)n0 * ldb_b;
   const int nk = (kbytes + TKB - 1) / TKB;
+  const int r16 = lane & 15, g = lane >> 4;
 
-  f32x4 acc[4][4];  // [nt][mt]; element r of lane (l&15, g): C[m = mt*16 + (l&15)][n = nt*16 + 4g + r]
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  char* As0 = smem;
-  char* Bs0 = smem + TILE_BYTES;
-  stage_rows(As0, Abase, rows_a, lda_b, kbytes, wave, lane);
-  stage_rows(Bs0, Bbase, rows_b, ldb_b, kbytes, wave, lane);
+  // PERSISTENT: the grid is at most (CUs × resident workgroups); each workgroup walks tiles
+  // v, v + G, v + 2G, …  The first K-slice of the NEXT tile is DMA'd into the free LDS buffer during the
+  // last K-step of the current tile, so neither its HBM latency nor this tile's epilogue stalls the MFMAs.
+  // v = xcd_remap(blockIdx): workgroups of one XCD get consecutive tile ids (they share A row-panels in L2).
+  int tile = xcd_remap(blockIdx.x, gridDim.x);
+  int m0 = (tile / a.tiles_n) * BM, n0 = (tile % a.tiles_n) * BN;
+  int rows_a = min(BM, a.M - m0), rows_b = min(BN, a.N - n0);
+  stage_rows<BM, NW>(smem, a.A + (int64_t)m0 * lda_b, rows_a, lda_b, kbytes, wave, lane);
+  stage_rows<BN, NW>(smem + A_BYTES, a.B + (int64_t)n0 * ldb_b, rows_b, ldb_b, kbytes, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  int cur = 0;
 
-  const int r16 = lane & 15, g = lane >> 4;
-  for (int t = 0; t < nk; ++t) {
-    const int cur = t & 1;
-    char* As = smem + cur * 2 * TILE_BYTES;
-    char* Bs = As + TILE_BYTES;
-    if (t + 1 < nk) {
-      char* An = smem + (cur ^ 1) * 2 * TILE_BYTES;
-      int koff = (t + 1) * TKB;
-      stage_rows(An, Abase + koff, rows_a, lda_b, kbytes - koff, wave, lane);
-      stage_rows(An + TILE_BYTES, Bbase + koff, rows_b, ldb_b, kbytes - koff, wave, lane);
+  while (true) {
+    const int next_tile = tile + gridDim.x;
+    const bool has_next = next_tile < nwg;
+    const int nm0 = has_next ? (next_tile / a.tiles_n) * BM : 0, nn0 = has_next ? (next_tile % a.tiles_n) * BN : 0;
+    const char* Abase = a.A + (int64_t)m0 * lda_b;
+    const char* Bbase = a.B + (int64_t)n0 * ldb_b;
+
+    f32x4 acc[NT][MT];  // element r of lane (l&15, g): C[m = mt*16 + (l&15)][n = nt*16 + 4g + r]
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int t = 0; t < nk; ++t) {
+      const char* As = smem + cur * BUF;
+      const char* Bs = As + A_BYTES;
+      char* An = smem + (cur ^ 1) * BUF;
+      if (t + 1 < nk) {
+        int koff = (t + 1) * TKB;
+        stage_rows<BM, NW>(An, Abase + koff, rows_a, lda_b, kbytes - koff, wave, lane);
+        stage_rows<BN, NW>(An + A_BYTES, Bbase + koff, rows_b, ldb_b, kbytes - koff, wave, lane);
+      } else if (has_next) {
+        stage_rows<BM, NW>(An, a.A + (int64_t)nm0 * lda_b, min(BM, a.M - nm0), lda_b, kbytes, wave, lane);
+        stage_rows<BN, NW>(An + A_BYTES, a.B + (int64_t)nn0 * ldb_b, min(BN, a.N - nn0), ldb_b, kbytes, wave, lane);
+      }
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+        u32x4 af[MT], bf[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bf[nt] = read_frag_rows(Bs, (wc * NT + nt) * 16 + r16, kh * 4 + g);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) af[mt] = read_frag_rows(As, (wr * MT + mt) * 16 + r16, kh * 4 + g);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[nt][mt] = Mma<T>::run(bf[nt], af[mt], acc[nt][mt]);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      cur ^= 1;
     }
-#pragma unroll
-    for (int kh = 0; kh < 2; ++kh) {
-      u32x4 af[4], bf[4];
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) af[mt] = read_frag_rows(As, wr * 64 + mt * 16 + r16, kh * 4 + g);
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) bf[nt] = read_frag_rows(Bs, wc * 64 + nt * 16 + r16, kh * 4 + g);
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = Mma<T>::run(bf[nt], af[mt], acc[nt][mt]);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
 
   // ---- epilogue -------------------------------------------------------------------------------
   TO* C = reinterpret_cast<TO*>(a.C);
@@ -147,12 +164,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtArgs a) {
              auxm = a.flags & LAKO_EPI_AUXMASK, atomic = a.flags & LAKO_EPI_ATOMIC;
   const bool drop = a.drop_thresh != 0;
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    const int m = m0 + wr * 64 + mt * 16 + r16;
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m0 + (wr * MT + mt) * 16 + r16;
     if (m >= a.M) continue;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const int n = n0 + wc * 64 + nt * 16 + 4 * g;
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n0 + (wc * NT + nt) * 16 + 4 * g;
       if (n >= a.N) continue;  // N % 4 == 0: a group of 4 is all in or all out
       f32x4 v = acc[nt][mt] * a.alpha;
       if (relu) {
@@ -183,6 +200,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtArgs a) {
       }
       store4(cp, v);
     }
+  }
+    if (!has_next) break;
+    tile = next_tile;
+    m0 = nm0;
+    n0 = nn0;
+    rows_a = min(BM, a.M - m0);
+    rows_b = min(BN, a.N - n0);
   }
 }
 
@@ -345,15 +369,162 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs a) {
     }
 }
 
-template <typename T, typename TO>
-int launch_nt(const NtArgs& a, hipStream_t s) {
+// ---------------------------------------------------------------------------------------------
+// TN, bf16, 256×256 tile / 8 waves (2 along M × 4 along N, 128×64 per wave): half the operand bytes
+// per FLOP of the 128² kernel — the weight-gradient GEMMs (K = all tokens, tiny M×N) are bound by the
+// global→LDS ingest rate, not by the MFMAs.  Split-K workgroups are placed XCD-locally (xcd_remap over
+// split-major ids) so the tiles that share a K-range share one L2.  The epilogue transposes each
+// 16×64 accumulator slab through LDS so that every atomic wave-instruction adds 256 contiguous bytes
+// of one C row (the full-rate float-atomic shape).
+// ---------------------------------------------------------------------------------------------
+constexpr int TN2_ROWB = 512, TN2_IMG = 64 * TN2_ROWB;  // 64 k-rows × 256 columns of bf16 = 32 KiB
+
+__device__ __forceinline__ void stage_cols256(char* img, const char* base, int krows_valid, int64_t ld_bytes,
+                                              int colbytes_valid, int wave, int lane) {
+  uint32_t nrec = (krows_valid > 0 && colbytes_valid > 0)
+                      ? (uint32_t)((int64_t)(krows_valid - 1) * ld_bytes + min(colbytes_valid, TN2_ROWB))
+                      : 0u;
+  auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)nrec, 0x00020000);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int inst = wave + i * 8;            // 32 wave-instructions of 2 rows each
+    const int row = inst * 2 + (lane >> 5);
+    const int cp = lane & 31;
+    const int cb = (cp ^ (tn_key(row) << 1)) * 16;
+    const bool ok = (row < krows_valid) && (cb < colbytes_valid);
+    const uint32_t voff = ok ? (uint32_t)(row * ld_bytes + cb) : 0xFFFFFFF0u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(img + inst * 1024), 16, (int)voff, 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ u32x4 read_frag_tr256(const char* img, int kk, int c0, int lane) {
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const int s = c0 >> 4;
+  u32x4 out;
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk) {
+    const int row = kk * 32 + 8 * g + 4 * blk + q;
+    const char* addr = img + row * TN2_ROWB + ((s ^ tn_key(row)) * 32) + p * 8;
+    s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(addr));
+    u32x2 u = __builtin_bit_cast(u32x2, t);
+    out[2 * blk] = u[0];
+    out[2 * blk + 1] = u[1];
+  }
+  return out;
+}
+
+__global__ __launch_bounds__(512) void gemm_tn256_kernel(TnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int ntile = a.tiles_m * a.tiles_n;
+  const int flat = xcd_remap(blockIdx.x, gridDim.x);   // one XCD ← consecutive (split, tile) ids
+  const int split = flat / ntile, tid = flat % ntile;
+  const int tile_m = tid / a.tiles_n, tile_n = tid % a.tiles_n;
+  const int m0 = tile_m * 256, n0 = tile_n * 256;
+  const int k_begin = split * a.k_chunk;
+  const int k_end = min(a.K, k_begin + a.k_chunk);
+  if (k_begin >= k_end) return;
+  const int64_t lda_b = a.lda * 2, ldb_b = a.ldb * 2;
+  const int acols_b = (a.M - m0) * 2, bcols_b = (a.N - n0) * 2;
+  const char* Abase = a.A + (int64_t)k_begin * lda_b + (int64_t)m0 * 2;
+  const char* Bbase = a.B + (int64_t)k_begin * ldb_b + (int64_t)n0 * 2;
+  const int krows = k_end - k_begin;
+  const int nk = (krows + 63) / 64;
+
+  f32x4 acc[8][4];  // [mt][nt]; element r of lane (l&15, g): C[m = mt*16 + 4g + r][n = nt*16 + (l&15)]
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  stage_cols256(smem, Abase, krows, lda_b, acols_b, wave, lane);
+  stage_cols256(smem + TN2_IMG, Bbase, krows, ldb_b, bcols_b, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int t = 0; t < nk; ++t) {
+    const int cur = t & 1;
+    const char* As = smem + cur * 2 * TN2_IMG;
+    const char* Bs = As + TN2_IMG;
+    if (t + 1 < nk) {
+      char* An = smem + (cur ^ 1) * 2 * TN2_IMG;
+      const int kr = (t + 1) * 64;
+      stage_cols256(An, Abase + (int64_t)kr * lda_b, krows - kr, lda_b, acols_b, wave, lane);
+      stage_cols256(An + TN2_IMG, Bbase + (int64_t)kr * ldb_b, krows - kr, ldb_b, bcols_b, wave, lane);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      u32x4 af[8], bf[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) bf[nt] = read_frag_tr256(Bs, kk, wc * 64 + nt * 16, lane);
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt) af[mt] = read_frag_tr256(As, kk, wr * 128 + mt * 16, lane);
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = Mma<bf16_t>::run(af[mt], bf[nt], acc[mt][nt]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // epilogue: per wave a private 16×64 fp32 slab in LDS (staging buffers are free after the last barrier)
+  float* slab = reinterpret_cast<float*>(smem) + wave * 1024;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int n = n0 + wc * 64 + lane;
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) slab[(4 * g + r) * 64 + nt * 16 + r16] = acc[mt][nt][r] * a.alpha;
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes have landed
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int row = 0; row < 16; ++row) {
+      const float v = slab[row * 64 + lane];
+      const int m = m0 + wr * 128 + mt * 16 + row;
+      if (m < a.M && n < a.N) atomicAdd(a.C + (int64_t)m * a.ldc + n, v);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+int g_tn_big = 1;
+int g_nt_persistent = 1;
+int g_nt_variant = -1;   // -1 auto; 0: 128x128/4 waves; 1: 256x128/8 waves; 2: 256x256/8 waves (lako_set_tuning)
+
+template <typename T, typename TO, int WM, int WN, int MT, int NT>
+void launch_nt_cfg(NtArgs a, hipStream_t s) {
+  constexpr int BM = WM * MT * 16, BN = WN * NT * 16, LDS = 2 * (BM + BN) * TKB;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, TO>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, TO, WM, WN, MT, NT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_done = true;
   }
-  hipLaunchKernelGGL((gemm_nt_kernel<T, TO>), dim3(a.tiles_m * a.tiles_n), dim3(256), GEMM_LDS, s, a);
+  a.tiles_m = cdiv(a.M, BM);
+  a.tiles_n = cdiv(a.N, BN);
+  // persistent grid: resident workgroups only (LDS-limited: 160 KiB / CU), 256 CUs
+  const int per_cu = (160 * 1024) / LDS > 0 ? (160 * 1024) / LDS : 1;
+  int grid = a.tiles_m * a.tiles_n;
+  if (g_nt_persistent && grid > 256 * per_cu) grid = 256 * per_cu;
+  hipLaunchKernelGGL((gemm_nt_kernel<T, TO, WM, WN, MT, NT>), dim3(grid), dim3(WM * WN * 64), LDS, s, a);
+}
+
+template <typename T, typename TO>
+int launch_nt(const NtArgs& a, hipStream_t s) {
+  int v = g_nt_variant;
+  if (v < 0) {
+    // big tiles once there is enough work to fill the chip with them (>= 1 tile per CU), else 128x128
+    const int64_t t256 = (int64_t)cdiv(a.M, 256) * cdiv(a.N, 256);
+    v = (t256 >= 256 && sizeof(T) == 2) ? 2 : 0;
+  }
+  if (v == 2) launch_nt_cfg<T, TO, 2, 4, 8, 4>(a, s);
+  else if (v == 1) launch_nt_cfg<T, TO, 4, 2, 4, 4>(a, s);
+  else launch_nt_cfg<T, TO, 2, 2, 4, 4>(a, s);
   return 0;
 }
 
@@ -414,8 +585,6 @@ extern "C" int lako_gemm_nt(const lako_gemm_nt_t* p, lako_stream_t stream) {
   a.drop_thresh = p->drop.p > 0.f ? lako_drop_thresh(p->drop.p) : 0u;
   a.drop_scale = p->drop.p > 0.f ? 1.0f / (1.0f - p->drop.p) : 1.0f;
   a.drop_key = lako_drop_key(p->drop.seed, p->drop.site);
-  a.tiles_m = cdiv(p->M, TM);
-  a.tiles_n = cdiv(p->N, TN_);
   hipStream_t s = (hipStream_t)stream;
   if (p->in_dtype == LAKO_BF16) {
     if (p->out_dtype == LAKO_BF16) launch_nt<bf16_t, bf16_t>(a, s);
@@ -452,6 +621,33 @@ extern "C" int lako_gemm_tn(const void* A, const void* B, float* C, int64_t M, i
   a.alpha = alpha;
   a.tiles_m = cdiv(M, TM);
   a.tiles_n = cdiv(N, TN_);
+  hipStream_t s = (hipStream_t)stream;
+  if (in_dtype == LAKO_BF16 && M >= 256 && N >= 256 && g_tn_big) {
+    a.tiles_m = cdiv(M, 256);
+    a.tiles_n = cdiv(N, 256);
+    const int tiles = a.tiles_m * a.tiles_n;
+    int sk = split_k;
+    if (sk <= 0) {   // one workgroup per CU (128 KiB LDS): aim at ~256 workgroups, >= 4 K-steps per split
+      sk = (256 + tiles / 2) / tiles;
+      const int max_split = cdiv(K, 64 * 4);
+      if (sk > max_split) sk = max_split;
+      if (sk < 1) sk = 1;
+    }
+    int chunk = cdiv(cdiv(K, sk), 64) * 64;
+    a.split_k = cdiv(K, chunk);
+    a.k_chunk = chunk;
+    LAKO_CHECK_ARG((int64_t)64 * lda * 2 < (1ll << 31) && (int64_t)64 * ldb * 2 < (1ll << 31),
+                   "lako_gemm_tn: leading dimension too large");
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn256_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TN2_IMG);
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(gemm_tn256_kernel, dim3(tiles * a.split_k), dim3(512), 4 * TN2_IMG, s, a);
+    LAKO_LAUNCH_CHECK();
+    return LAKO_OK;
+  }
   const int kr = in_dtype == LAKO_BF16 ? 64 : 32;
   if (split_k <= 0) {  // auto: aim at >= 2 workgroups per CU, at least 4 K-steps per split
     int tiles = a.tiles_m * a.tiles_n;
@@ -467,9 +663,26 @@ extern "C" int lako_gemm_tn(const void* A, const void* B, float* C, int64_t M, i
   // voffset (row * ld_bytes) must stay below 2^32 within one K-step: rows < 64
   LAKO_CHECK_ARG((int64_t)64 * lda * esz < (1ll << 31) && (int64_t)64 * ldb * esz < (1ll << 31),
                  "lako_gemm_tn: leading dimension too large");
-  hipStream_t s = (hipStream_t)stream;
   if (in_dtype == LAKO_BF16) launch_tn<bf16_t>(a, s);
   else launch_tn<float>(a, s);
   LAKO_LAUNCH_CHECK();
   return LAKO_OK;
+}
+
+// Development knob (not part of the training path): select kernel variants for A/B measurements.
+extern "C" int lako_set_tuning(const char* key, int value) {
+  if (key && !strcmp(key, "gemm_nt_variant")) {
+    g_nt_variant = value;
+    return LAKO_OK;
+  }
+  if (key && !strcmp(key, "gemm_tn_big")) {
+    g_tn_big = value;
+    return LAKO_OK;
+  }
+  if (key && !strcmp(key, "gemm_nt_persistent")) {
+    g_nt_persistent = value;
+    return LAKO_OK;
+  }
+  lako_set_error("lako_set_tuning: unknown key");
+  return LAKO_E_BADARG;
 }

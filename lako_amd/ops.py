@@ -90,6 +90,9 @@ class HipOps:
     def zero_(self, t: torch.Tensor):
         t.zero_()
 
+    def set_tuning(self, key: str, value: int):
+        check(self.lib.lako_set_tuning(key.encode(), int(value)), "lako_set_tuning")
+
     # ---- GEMMs -----------------------------------------------------------------------------
     def gemm_nt(self, A, B, Cm, *, alpha=1.0, relu=False, resid=None, aux=None, aux_scale=1.0, drop=None,
                 atomic=False):

@@ -89,7 +89,8 @@ def test_gemm_nt_epilogues(ops, ref, dt):
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("K,M,N,split", [(500, 264, 136, 0), (108, 64, 32, 1), (4096, 768, 768, 0), (130, 128, 128, 3),
-                                         (64, 96, 2304, 0)])
+                                         (64, 96, 2304, 0), (1000, 520, 264, 0), (777, 256, 768, 5),
+                                         (6400, 2304, 768, 0)])
 def test_gemm_tn(ops, ref, dt, K, M, N, split):
     T = DT[dt]
     A, B = rnd(K, M, dtype=T, seed=8), rnd(K, N, dtype=T, seed=9)

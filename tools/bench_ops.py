@@ -16,6 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--only", default="gemm,tn,attn,norm,misc")
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--variants", default="-1", help="gemm_nt tile variants to time, e.g. 0,1,2")
 args = ap.parse_args()
 only = set(args.only.split(","))
 T = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -46,7 +47,10 @@ def timeit(name, fn, flops=0.0, bytes_=0.0):
 
 
 drop = (0.1, 1, 2)
-if "gemm" in only:
+for variant in ([int(v) for v in args.variants.split(",")] if "gemm" in only else []):
+    ops.set_tuning("gemm_nt_variant", variant % 10)
+    ops.set_tuning("gemm_nt_persistent", 0 if variant >= 10 else 1)
+    print(f"--- gemm_nt variant {variant % 10} (-1 auto, 0 128x128, 1 256x128, 2 256x256) persistent={variant < 10}", flush=True)
     for nm, (M, Nn, K), kw in [
         ("nt qkv   [Me,768]x[2304,768]", (Me, 3 * inner, d), {}),
         ("nt o+res [Me,768]x[768,768]", (Me, d, inner), dict(resid=True, drop=drop)),
@@ -73,7 +77,9 @@ if "gemm" in only:
         timeit(nm, lambda: ops.gemm_nt(A, Bm, C, **k2), flops=2.0 * M * Nn * K)
         del A, Bm, C, k2
 
-if "tn" in only:
+for big in ([1, 0] if "tn" in only else []):
+    ops.set_tuning("gemm_tn_big", big)
+    print(f"--- gemm_tn 256x256 kernel {'on' if big else 'off (128x128)'}", flush=True)
     for nm, (K, M, Nn) in [
         ("tn dWqkv [Me,2304]^T x [Me,768]", (Me, 3 * inner, d)),
         ("tn dWo   [Me,768]^T x [Me,768]", (Me, d, inner)),
