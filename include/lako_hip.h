@@ -119,7 +119,9 @@ typedef struct {
   int causal, causal_off;  /* causal: key j visible iff j <= i + causal_off */
   int Bn, H, Lq, Lk, d_head;
   int dtype;
-  lako_dropout_t drop; /* on the probabilities; idx = ((b*H + h)*Lq + i)*Lk + j */
+  lako_dropout_t drop; /* on the probabilities.  Attention uses a cheaper draw than the element-wise sites: keys 2c and
+                          2c+1 of score row (b,h,i) share hash32(key ^ (((b*H+h)*Lq+i)*ceil(Lk/2) + c)); the even key
+                          takes the low, the odd key the high 16 bits; keep iff half >= round(p*65536) */
   float* scores_out;   /* optional [Bn, H, Lq, Lk] fp32 raw pre-softmax scores (+bias, masked keys = 0):
                           the quantity src/model.py:316-329 stores for get_crossattention_scores */
 } lako_attn_fwd_t;

@@ -13,6 +13,11 @@
 // 2 cross-lane shuffles, and (b) the tile is directly the B operand of the following product that
 // contracts over the LDS-side index (P·V, dSᵀ·K, Pᵀ·dO, dSᵀ·Q) — its A operand is a transposed read of the
 // LDS image (ds_read_b64_tr_b16 for bf16, plain dwords for fp32).  No P/dS round trip through LDS.
+//
+// The kernels are VALU-bound, not MFMA-bound (≈50 score elements per lane per 16-query block), so the
+// element-wise path is kept branch-free and short: the relative-position bias and the additive key
+// mask (0 / −FLT_MAX / −inf, exactly HF's "scores + finfo.min") are folded into the MFMA accumulator
+// INIT, the causal mask is one select, and dropout draws two 16-bit keep decisions from one 32-bit hash.
 // bf16: v_mfma_f32_16x16x32_bf16; fp32 (parity mode): v_mfma_f32_16x16x4_f32.
 #include <float.h>
 
@@ -31,7 +36,6 @@ template <typename T, int DK> struct AC {
 };
 
 struct AttnArgs {
-  // LDS-side / register-side tensors are selected per kernel from these
   const char *q, *k, *v, *o, *dout;
   char *out, *dq, *dk, *dv;
   float* stats;        // [Bn, H, Lq, 4] = (row max, 1 / row sum, delta = rowsum(dO∘O) [written by the dQ pass], -)
@@ -42,9 +46,10 @@ struct AttnArgs {
   int64_t qsb, qst, ksb, kst, vsb, vst, osb, ost;  // strides in elements
   int R, rel_off, causal, causal_off;
   int Bn, H, Lq, Lk;
-  int chunk_rows;   // LDS-side rows per chunk (multiple of 32, <= CH_MAX)
+  int chunk_rows;     // LDS-side rows per chunk (multiple of 32, <= CH_MAX)
   int blocks_per_wg;  // register-side 16-row blocks per workgroup
-  uint32_t drop_thresh, drop_key;
+  int bn_per_wg;      // dQ pass: batch rows walked by one workgroup (bias-gradient register accumulation)
+  uint32_t drop_t16, drop_key;   // attention dropout: keep iff 16-bit half >= drop_t16 (0 = off)
   float drop_scale;
 };
 
@@ -67,13 +72,16 @@ template <> struct Mma16<float> {
   }
 };
 
-// Stage rows [r0, r0 + nrows) of a strided [L, ·] tensor (row = `stride` elements, DK used) into a
-// padded LDS image; rows >= L are zero-filled (so padded keys/queries contribute exact zeros).
+// Attention-probability dropout: elements (row, 2c) and (row, 2c+1) share hash(key, row·⌈Lk/2⌉ + c); the even
+// key takes the low 16 bits, the odd key the high 16 bits; keep iff half >= round(p·65536).
+// (tests/ref_ops.py carries the same integer recipe.)
+__device__ __forceinline__ uint32_t pair_hash(uint32_t key, uint32_t pair_idx) { return lako_hash32(pair_idx ^ key); }
+
+// Stage rows [r0, r0 + nrows) of a strided [L, ·] tensor into a padded LDS image; rows >= L are
+// zero-filled (so padded keys/queries contribute exact zeros).  8 independent loads in flight per thread.
 template <typename T, int DK>
 __device__ __forceinline__ void stage_image(char* img, const char* base, int64_t stride, int r0, int nrows, int L) {
   using C = AC<T, DK>;
-  // 8 independent 16-B loads in flight per thread before the first LDS write (a load→store chain per
-  // element would pay one HBM round trip per 16 bytes)
   const int total = nrows * C::CPR;
   for (int idx0 = threadIdx.x; idx0 < total; idx0 += 256 * 8) {
     u32x4 v[8];
@@ -107,13 +115,13 @@ __device__ __forceinline__ void load_reg_frags(FragArr<AC<T, DK>::NF>& f, const 
   }
 }
 
-// tile[LDS row = row0 + 4g + r][reg-side = lane & 15] = Σ_d X[row0 + ·][d] · Y[·][d]
+// tile[LDS row = row0 + 4g + r][reg-side = lane & 15] = init + Σ_d X[row0 + ·][d] · Y[·][d]
 template <typename T, int DK>
-__device__ __forceinline__ f32x4 score_tile(const char* img, int row0, const FragArr<AC<T, DK>::NF>& yf, int lane) {
+__device__ __forceinline__ f32x4 score_tile(const char* img, int row0, const FragArr<AC<T, DK>::NF>& yf, int lane,
+                                            f32x4 acc) {
   using C = AC<T, DK>;
   const int g = lane >> 4;
   const char* rp = img + (row0 + (lane & 15)) * C::ROWB + g * 16;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < C::NF; ++i) {
     u32x4 xf = *reinterpret_cast<const u32x4*>(rp + i * 64);
@@ -172,22 +180,33 @@ __device__ __forceinline__ float group_sum(float v) {
   v += __shfl_xor(v, 16, 64);
   return v + __shfl_xor(v, 32, 64);
 }
+__device__ __forceinline__ int clampi(int x, int lo, int hi) { return min(max(x, lo), hi); }
 
-// LDS carve (all offsets multiples of 16):  img1 | img2 | aux floats
+// additive key mask of LDS-side chunk rows: 0 attend, −FLT_MAX padding key (HF: scores + finfo.min), −inf beyond Lk
+__device__ __forceinline__ void stage_key_add(float* kadd, const uint8_t* key_mask, int b, int kc0, int nk, int Lk) {
+  for (int i = threadIdx.x; i < nk; i += 256) {
+    const int j = kc0 + i;
+    float f = 0.f;
+    if (j >= Lk) f = -INFINITY;
+    else if (key_mask && !key_mask[(int64_t)b * Lk + j]) f = -FLT_MAX;
+    kadd[i] = f;
+  }
+}
+
 template <typename T, int DK> __host__ __device__ constexpr int img_bytes(int ch) { return ch * AC<T, DK>::ROWB; }
 
 // =============================================================================================
 // forward
 // =============================================================================================
-template <typename T, int DK>
+template <typename T, int DK, bool CAPTURE>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   using C = AC<T, DK>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int CH = a.chunk_rows;
   char* Kimg = smem;
   char* Vimg = smem + img_bytes<T, DK>(CH);
-  float* kflag = reinterpret_cast<float*>(smem + 2 * img_bytes<T, DK>(CH));  // [CH] 0 ok, 1 masked, 2 beyond Lk
-  float* bias_l = kflag + CH;                                                // [R]
+  float* kadd = reinterpret_cast<float*>(smem + 2 * img_bytes<T, DK>(CH));  // [CH]
+  float* bias_l = kadd + CH;                                                // [R]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, l15 = lane & 15;
@@ -203,12 +222,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   const bool has_bias = a.rel_bias != nullptr;
   if (has_bias)
     for (int i = threadIdx.x; i < a.R; i += 256) bias_l[i] = a.rel_bias[(int64_t)h * a.R + i];
+  const int hk = (a.Lk + 1) >> 1;   // dropout pairs per score row
 
   // Key-split mode: a workgroup that owns a single 16-query block (cross-attention, decode steps) lets its
   // 4 waves share that block and split every key chunk between them (tile pair tp → wave tp & 3); the
   // partial (max, sum, O) of the 4 waves are merged through LDS at the end.
   const bool ksplit = nqb == 1 && a.Lk > 64;   // host reserves the merge scratch only when Lq <= 16
-  float* mrg = bias_l + ((a.R + 3) & ~3);   // [4 waves][16 queries][DK + 2] (ksplit only)
+  float* mrg = bias_l + ((a.R + 3) & ~3);      // [4 waves][16 queries][DK + 2] (ksplit only)
 
   for (int qb0 = qb_begin; qb0 < qb_end; qb0 += 4) {
     const int qb = ksplit ? qb0 : qb0 + wave;
@@ -220,6 +240,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     f32x4 oacc[C::NDB];
 #pragma unroll
     for (int db = 0; db < C::NDB; ++db) oacc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int jmax = a.causal ? qi + a.causal_off : 0x7fffffff;       // keys j > jmax are causally masked
+    const uint32_t prow = (uint32_t)((b * a.H + h) * a.Lq + qi) * (uint32_t)hk;  // dropout pair index of (qi, key 0)
 
     for (int ch = 0; ch < nchunks; ++ch) {
       const int kc0 = ch * CH;
@@ -228,64 +250,73 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         __syncthreads();
         stage_image<T, DK>(Kimg, kbase, a.kst, kc0, nk, a.Lk);
         stage_image<T, DK>(Vimg, vbase, a.vst, kc0, nk, a.Lk);
-        for (int i = threadIdx.x; i < nk; i += 256) {
-          int j = kc0 + i;
-          float f = 0.f;
-          if (j >= a.Lk) f = 2.f;
-          else if (a.key_mask && !a.key_mask[(int64_t)b * a.Lk + j]) f = 1.f;
-          kflag[i] = f;
-        }
+        stage_key_add(kadd, a.key_mask, b, kc0, nk, a.Lk);
         __syncthreads();
       }
       if (!active) continue;
       const int ntile = nk >> 4;
 #define MINE(t) ((t) < ntile && (!ksplit || (((t) >> 1) & 3) == wave))
       f32x4 s[16];
-#pragma unroll
-      for (int t = 0; t < 16; ++t)
-        if (MINE(t)) s[t] = score_tile<T, DK>(Kimg, t * 16, qf, lane);
-      float cmax = -INFINITY;
+      // scores = (bias + key mask) + Q·Kᵀ : the additive terms are the accumulator init
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
         if (MINE(t)) {
-          const f32x4 kf = *reinterpret_cast<const f32x4*>(kflag + t * 16 + 4 * g);
+          f32x4 init = *reinterpret_cast<const f32x4*>(kadd + t * 16 + 4 * g);
+          if (has_bias) {
+            const int bi0 = kc0 + t * 16 + 4 * g - qi + a.rel_off;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int j = kc0 + t * 16 + 4 * g + r;
-            float val = s[t][r];
-            if (has_bias) {
-              int bi = j - qi + a.rel_off;
-              if (bi >= 0 && bi < a.R) val += bias_l[bi];
-            }
-            bool masked = kf[r] == 1.f || (a.causal && j > qi + a.causal_off);
-            if (a.scores_out && qi < a.Lq && j < a.Lk)
-              a.scores_out[(((int64_t)b * a.H + h) * a.Lq + qi) * a.Lk + j] = masked ? 0.f : val;
-            if (masked) val = -FLT_MAX;
-            if (kf[r] == 2.f) val = -INFINITY;
-            s[t][r] = val;
-            cmax = fmaxf(cmax, val);
+            for (int r = 0; r < 4; ++r) init[r] += bias_l[clampi(bi0 + r, 0, a.R - 1)];
           }
+          s[t] = score_tile<T, DK>(Kimg, t * 16, qf, lane, init);
         }
       }
+      if (a.causal) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+          if (MINE(t)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[t][r] = (kc0 + t * 16 + 4 * g + r > jmax) ? -FLT_MAX : s[t][r];
+          }
+      }
+      if constexpr (CAPTURE) {   // separate instantiation (score capture at decode step 0): raw scores, masked keys → 0
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+          if (MINE(t)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int j = kc0 + t * 16 + 4 * g + r;
+              if (qi < a.Lq && j < a.Lk)
+                a.scores_out[(((int64_t)b * a.H + h) * a.Lq + qi) * a.Lk + j] = s[t][r] <= -FLT_MAX ? 0.f : s[t][r];
+            }
+          }
+      }
+      float cmax = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < 16; ++t)
+        if (MINE(t)) cmax = fmaxf(fmaxf(cmax, fmaxf(s[t][0], s[t][1])), fmaxf(s[t][2], s[t][3]));
       cmax = group_max(cmax);
       if (cmax == -INFINITY) continue;      // ksplit: this wave owns no valid key of this chunk (wave-uniform)
       const float m_new = fmaxf(m, cmax);
       const float alpha = __expf(m - m_new);  // m = -inf on the first chunk → 0
       float psum = 0.f;
-      const uint64_t didx0 = (((uint64_t)b * a.H + h) * a.Lq + (uint64_t)qi) * (uint64_t)a.Lk;
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
         if (MINE(t)) {
+          f32x4 p;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float p = __expf(s[t][r] - m_new);
-            psum += p;
-            if (a.drop_thresh) {
-              const int j = kc0 + t * 16 + 4 * g + r;
-              p = lako_keep(a.drop_key, didx0 + (uint64_t)j, a.drop_thresh) ? p * a.drop_scale : 0.f;
-            }
-            s[t][r] = p;
+            p[r] = __expf(s[t][r] - m_new);
+            psum += p[r];
           }
+          if (a.drop_t16) {
+            const uint32_t pi = prow + (uint32_t)((kc0 + t * 16 + 4 * g) >> 1);
+            const uint32_t h0 = pair_hash(a.drop_key, pi), h1 = pair_hash(a.drop_key, pi + 1);
+            p[0] = (h0 & 0xffffu) >= a.drop_t16 ? p[0] * a.drop_scale : 0.f;
+            p[1] = (h0 >> 16) >= a.drop_t16 ? p[1] * a.drop_scale : 0.f;
+            p[2] = (h1 & 0xffffu) >= a.drop_t16 ? p[2] * a.drop_scale : 0.f;
+            p[3] = (h1 >> 16) >= a.drop_t16 ? p[3] * a.drop_scale : 0.f;
+          }
+          s[t] = p;
         }
       }
       psum = group_sum(psum);
@@ -360,15 +391,17 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   const int CH = a.chunk_rows;
   char* X1 = smem;                               // MODE 0: K   MODE 1: Q
   char* X2 = smem + img_bytes<T, DK>(CH);        // MODE 0: V   MODE 1: dO
-  float* aux0 = reinterpret_cast<float*>(smem + 2 * img_bytes<T, DK>(CH));  // MODE 0: kflag   MODE 1: row max
-  float* aux1 = aux0 + CH;                       // MODE 1: 1/rowsum
+  float* aux0 = reinterpret_cast<float*>(smem + 2 * img_bytes<T, DK>(CH));  // MODE 0: key add   MODE 1: row max
+  float* aux1 = aux0 + CH;                       // MODE 1: 1/rowsum (0 for padded query rows)
   float* aux2 = aux1 + CH;                       // MODE 1: delta
   float* bias_l = aux2 + CH;                     // [R]
   float* drel_l = bias_l + a.R;                  // [R] (MODE 0)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, l15 = lane & 15;
-  const int b = blockIdx.z, h = blockIdx.y;
+  const int h = blockIdx.y;
+  const int bn_per = MODE == 0 ? a.bn_per_wg : 1;
+  const int b_begin = blockIdx.z * bn_per, b_end = min(a.Bn, b_begin + bn_per);
   const int LX = MODE == 0 ? a.Lk : a.Lq;  // LDS side length
   const int LY = MODE == 0 ? a.Lq : a.Lk;  // register side length
   const int nyb = (LY + 15) >> 4;
@@ -376,31 +409,42 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   const int yb_end = min(nyb, yb_begin + a.blocks_per_wg);
   const int nchunks = (LX + CH - 1) / CH;
   const int64_t hoff = (int64_t)h * DK;
-  const char* qbase = a.q + ((int64_t)b * a.qsb + hoff) * C::ES;
-  const char* kbase = a.k + ((int64_t)b * a.ksb + hoff) * C::ES;
-  const char* vbase = a.v + ((int64_t)b * a.vsb + hoff) * C::ES;
-  const char* obase = a.o + ((int64_t)b * a.osb + hoff) * C::ES;
-  const char* dobase = a.dout + ((int64_t)b * a.osb + hoff) * C::ES;
-  float* stats = a.stats + ((int64_t)b * a.H + h) * a.Lq * 4;
   const bool has_bias = a.rel_bias != nullptr;
   const bool want_drel = MODE == 0 && a.drel != nullptr;
   if (has_bias)
     for (int i = threadIdx.x; i < a.R; i += 256) bias_l[i] = a.rel_bias[(int64_t)h * a.R + i];
   if (want_drel)
     for (int i = threadIdx.x; i < a.R; i += 256) drel_l[i] = 0.f;
+  const int hk = (a.Lk + 1) >> 1;
 
   // key-split (dQ pass only): a workgroup owning one query block shares it between its 4 waves, which split the
   // keys (tile pair tp → wave tp & 3); the partial dQ tiles are summed through LDS at the end.
   const bool ksplit = MODE == 0 && nyb == 1 && a.Lk > 64;   // merge scratch reserved only when Lq <= 16
-  float* mrg = drel_l + ((a.R + 3) & ~3);   // [4][16][DK] (ksplit only)
+  float* mrg = drel_l + ((a.R + 3) & ~3);                   // [4][16][DK] (ksplit only)
 
+  // Bias gradient (dQ pass): d rel_bias[key − query] = Σ_batch Σ_(q,k) dS.  LDS float atomics per score
+  // element are ~40 cycles per wave-instruction, so when one round covers the workgroup's query blocks
+  // (each wave keeps ONE query block) the dS tiles are summed in registers over the workgroup's batch rows
+  // (tile position → fixed diagonal offsets) and reduced over diagonals once at the end.
+  const bool fast_drel = want_drel && nchunks == 1 && (yb_end - yb_begin) <= 4;
+  f32x4 dsacc[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) dsacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int b = b_begin; b < b_end; ++b) {
+  const char* qbase = a.q + ((int64_t)b * a.qsb + hoff) * C::ES;
+  const char* kbase = a.k + ((int64_t)b * a.ksb + hoff) * C::ES;
+  const char* vbase = a.v + ((int64_t)b * a.vsb + hoff) * C::ES;
+  const char* obase = a.o + ((int64_t)b * a.osb + hoff) * C::ES;
+  const char* dobase = a.dout + ((int64_t)b * a.osb + hoff) * C::ES;
+  float* stats = a.stats + ((int64_t)b * a.H + h) * a.Lq * 4;
   for (int yb0 = yb_begin; yb0 < yb_end; yb0 += 4) {
     const int yb = ksplit ? yb0 : yb0 + wave;
     const bool active = yb < yb_end;
     const int yi = active ? yb * 16 + l15 : LY;  // this lane's register-side row (query in MODE 0, key in MODE 1)
     u32x4 y1[C::NF], y2[C::NF];
-    float m_q = 0.f, invl_q = 0.f, delta_q = 0.f;
-    bool key_masked = false;
+    float m_q = 0.f, invl_q = 0.f, delta_q = 0.f;   // MODE 0: this lane's query statistics (inv = 0 ⇒ p = 0)
+    float kadd_lane = 0.f;                           // MODE 1: this lane's key mask term
     if constexpr (MODE == 0) {
       load_reg_frags<T, DK>(y1, qbase, a.qst, yi, a.Lq, lane);
       load_reg_frags<T, DK>(y2, dobase, a.ost, yi, a.Lq, lane);
@@ -428,7 +472,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
     } else {
       load_reg_frags<T, DK>(y1, kbase, a.kst, yi, a.Lk, lane);
       load_reg_frags<T, DK>(y2, vbase, a.vst, yi, a.Lk, lane);
-      if (a.key_mask && yi < a.Lk) key_masked = !a.key_mask[(int64_t)b * a.Lk + yi];
+      if (yi >= a.Lk) kadd_lane = -INFINITY;
+      else if (a.key_mask && !a.key_mask[(int64_t)b * a.Lk + yi]) kadd_lane = -FLT_MAX;
     }
     f32x4 acc1[C::NDB], acc2[C::NDB];  // MODE 0: dQ (acc1)   MODE 1: dK (acc1), dV (acc2)
 #pragma unroll
@@ -445,77 +490,92 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
         if constexpr (MODE == 0) {
           stage_image<T, DK>(X1, kbase, a.kst, x0, nx, a.Lk);
           stage_image<T, DK>(X2, vbase, a.vst, x0, nx, a.Lk);
-          for (int i = threadIdx.x; i < nx; i += 256) {
-            int j = x0 + i;
-            float f = 0.f;
-            if (j >= a.Lk) f = 2.f;
-            else if (a.key_mask && !a.key_mask[(int64_t)b * a.Lk + j]) f = 1.f;
-            aux0[i] = f;
-          }
+          stage_key_add(aux0, a.key_mask, b, x0, nx, a.Lk);
         } else {
           stage_image<T, DK>(X1, qbase, a.qst, x0, nx, a.Lq);
           stage_image<T, DK>(X2, dobase, a.ost, x0, nx, a.Lq);
           for (int i = threadIdx.x; i < nx; i += 256) {
-            int qi = x0 + i;
-            float mm = 0.f, il = 0.f, dl = 0.f;
-            if (qi < a.Lq) {
-              const f32x4 st4 = *reinterpret_cast<const f32x4*>(stats + qi * 4);
-              mm = st4[0];
-              il = st4[1];
-              dl = st4[2];                     // delta = rowsum(dO∘O), written by the dQ pass
-            }
-            aux0[i] = mm;
-            aux1[i] = il;
-            aux2[i] = dl;
+            const int qi = x0 + i;
+            f32x4 st4 = {0.f, 0.f, 0.f, 0.f};
+            if (qi < a.Lq) st4 = *reinterpret_cast<const f32x4*>(stats + qi * 4);
+            aux0[i] = st4[0];
+            aux1[i] = st4[1];   // 0 for padded rows ⇒ p = 0 there
+            aux2[i] = st4[2];   // delta = rowsum(dO∘O), written by the dQ pass
           }
         }
         __syncthreads();
       }
       if (!active) continue;
       const int npair = nx >> 5;
-      for (int tp = 0; tp < npair; ++tp) {
+#pragma unroll
+      for (int tp = 0; tp < 8; ++tp) {
+        if (tp >= npair) continue;
         if (ksplit && (tp & 3) != wave) continue;
         f32x4 pt[2], ds[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const int row0 = tp * 32 + t * 16;
-          f32x4 sv = score_tile<T, DK>(X1, row0, y1, lane);
-          f32x4 dp = score_tile<T, DK>(X2, row0, y2, lane);
-          f32x4 fl = {0.f, 0.f, 0.f, 0.f}, mq = {0.f, 0.f, 0.f, 0.f}, il = mq, dl = mq;
-          if constexpr (MODE == 0) fl = *reinterpret_cast<const f32x4*>(aux0 + row0 + 4 * g);
-          else {
+          const int x_first = x0 + row0 + 4 * g;          // LDS-side index of element r = 0
+          // additive terms as accumulator init: bias + key mask
+          f32x4 init = {kadd_lane, kadd_lane, kadd_lane, kadd_lane};
+          if constexpr (MODE == 0) init = *reinterpret_cast<const f32x4*>(aux0 + row0 + 4 * g);
+          int bi0 = 0;
+          if (has_bias) {
+            bi0 = (MODE == 0 ? x_first - yi : yi - x_first) + a.rel_off;   // key − query + off of element r = 0
+#pragma unroll
+            for (int r = 0; r < 4; ++r) init[r] += bias_l[clampi(MODE == 0 ? bi0 + r : bi0 - r, 0, a.R - 1)];
+          }
+          f32x4 sv = score_tile<T, DK>(X1, row0, y1, lane, init);
+          f32x4 dp = score_tile<T, DK>(X2, row0, y2, lane, f32x4{0.f, 0.f, 0.f, 0.f});
+          f32x4 mq, il, dl;
+          if constexpr (MODE == 0) {
+            mq = f32x4{m_q, m_q, m_q, m_q};
+            il = f32x4{invl_q, invl_q, invl_q, invl_q};
+            dl = f32x4{delta_q, delta_q, delta_q, delta_q};
+          } else {
             mq = *reinterpret_cast<const f32x4*>(aux0 + row0 + 4 * g);
             il = *reinterpret_cast<const f32x4*>(aux1 + row0 + 4 * g);
             dl = *reinterpret_cast<const f32x4*>(aux2 + row0 + 4 * g);
           }
+          if (a.causal) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int xi = x0 + row0 + 4 * g + r;
-            const int key = MODE == 0 ? xi : yi;
-            const int qi = MODE == 0 ? yi : xi;
-            const bool valid = key < a.Lk && qi < a.Lq;
-            float val = sv[r];
-            int bi = key - qi + a.rel_off;
-            const bool bi_ok = bi >= 0 && bi < a.R;
-            if (has_bias && bi_ok) val += bias_l[bi];
-            bool masked = (MODE == 0 ? fl[r] == 1.f : key_masked) || (a.causal && key > qi + a.causal_off);
-            if (masked) val = -FLT_MAX;
-            const float mm = MODE == 0 ? m_q : mq[r];
-            const float inv = MODE == 0 ? invl_q : il[r];
-            const float dlt = MODE == 0 ? delta_q : dl[r];
-            float p = valid ? __expf(val - mm) * inv : 0.f;
-            float dpd = dp[r];
-            float pd = p;
-            if (a.drop_thresh) {
-              uint64_t idx = (((uint64_t)b * a.H + h) * a.Lq + (uint64_t)qi) * (uint64_t)a.Lk + (uint64_t)key;
-              bool keep = lako_keep(a.drop_key, idx, a.drop_thresh);
-              dpd = keep ? dpd * a.drop_scale : 0.f;
-              pd = keep ? p * a.drop_scale : 0.f;
+            for (int r = 0; r < 4; ++r) {
+              const int key = MODE == 0 ? x_first + r : yi, qi = MODE == 0 ? yi : x_first + r;
+              sv[r] = key > qi + a.causal_off ? -FLT_MAX : sv[r];
             }
-            float d = p * (dpd - dlt);
-            pt[t][r] = pd;
-            ds[t][r] = d;
-            if (want_drel && valid && bi_ok && d != 0.f) atomicAdd(&drel_l[bi], d);
+          }
+          f32x4 p;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) p[r] = __expf(sv[r] - mq[r]) * il[r];
+          f32x4 pd = p, dpd = dp;
+          if (a.drop_t16) {
+            if constexpr (MODE == 0) {   // 4 consecutive keys of one query: two pair hashes
+              const uint32_t pi = (uint32_t)((b * a.H + h) * a.Lq + yi) * (uint32_t)hk + (uint32_t)(x_first >> 1);
+              const uint32_t h0 = pair_hash(a.drop_key, pi), h1 = pair_hash(a.drop_key, pi + 1);
+              const bool k0 = (h0 & 0xffffu) >= a.drop_t16, k1 = (h0 >> 16) >= a.drop_t16,
+                         k2 = (h1 & 0xffffu) >= a.drop_t16, k3 = (h1 >> 16) >= a.drop_t16;
+              pd[0] = k0 ? p[0] * a.drop_scale : 0.f; dpd[0] = k0 ? dp[0] * a.drop_scale : 0.f;
+              pd[1] = k1 ? p[1] * a.drop_scale : 0.f; dpd[1] = k1 ? dp[1] * a.drop_scale : 0.f;
+              pd[2] = k2 ? p[2] * a.drop_scale : 0.f; dpd[2] = k2 ? dp[2] * a.drop_scale : 0.f;
+              pd[3] = k3 ? p[3] * a.drop_scale : 0.f; dpd[3] = k3 ? dp[3] * a.drop_scale : 0.f;
+            } else {                      // one key, 4 consecutive queries: one hash per element
+              const uint32_t half = (uint32_t)(yi & 1) * 16u;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const uint32_t pi = (uint32_t)((b * a.H + h) * a.Lq + x_first + r) * (uint32_t)hk + (uint32_t)(yi >> 1);
+                const bool kp = ((pair_hash(a.drop_key, pi) >> half) & 0xffffu) >= a.drop_t16;
+                pd[r] = kp ? p[r] * a.drop_scale : 0.f;
+                dpd[r] = kp ? dp[r] * a.drop_scale : 0.f;
+              }
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ds[t][r] = p[r] * (dpd[r] - dl[r]);
+          pt[t] = pd;
+          if (MODE == 0 && fast_drel) dsacc[2 * tp + t] += ds[t];
+          else if (want_drel) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(&drel_l[clampi(bi0 + r, 0, a.R - 1)], ds[t][r]);
           }
         }
         if constexpr (MODE == 0) {
@@ -559,6 +619,18 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
           store4(vp + db * 16 + 4 * g, acc2[db]);
         }
       }
+    }
+  }
+  }  // batch rows of this workgroup
+  if (MODE == 0 && fast_drel) {
+    // this wave's query block is the same for every batch row: yi = (yb_begin + wave)*16 + l15
+    const int yq = (yb_begin + wave) * 16 + l15;
+    if (yb_begin + wave < yb_end) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          atomicAdd(&drel_l[clampi(t * 16 + 4 * g + r - yq + a.rel_off, 0, a.R - 1)], dsacc[t][r]);
     }
   }
   if (want_drel) {
@@ -610,10 +682,16 @@ int run_fwd(AttnArgs& a, hipStream_t s) {
   const int nqb = (a.Lq + 15) / 16;
   a.blocks_per_wg = pick_blocks_per_wg(nqb, (int64_t)a.Bn * a.H);
   const int lds = lds_bytes_fwd<T, DK>(a.chunk_rows, a.R, nqb == 1);
-  static int cur = 0;
-  set_lds_attr(&attn_fwd_kernel<T, DK>, lds, cur);
   dim3 grid((nqb + a.blocks_per_wg - 1) / a.blocks_per_wg, a.H, a.Bn);
-  hipLaunchKernelGGL((attn_fwd_kernel<T, DK>), grid, dim3(256), lds, s, a);
+  if (a.scores_out) {
+    static int curc = 0;
+    set_lds_attr(&attn_fwd_kernel<T, DK, true>, lds, curc);
+    hipLaunchKernelGGL((attn_fwd_kernel<T, DK, true>), grid, dim3(256), lds, s, a);
+  } else {
+    static int cur = 0;
+    set_lds_attr(&attn_fwd_kernel<T, DK, false>, lds, cur);
+    hipLaunchKernelGGL((attn_fwd_kernel<T, DK, false>), grid, dim3(256), lds, s, a);
+  }
   return 0;
 }
 
@@ -624,14 +702,22 @@ int run_bwd(AttnArgs& a, hipStream_t s) {
     q.chunk_rows = pick_chunk(a.Lk);
     const int nqb = (a.Lq + 15) / 16;
     q.blocks_per_wg = pick_blocks_per_wg(nqb, (int64_t)a.Bn * a.H);
+    q.bn_per_wg = 1;
+    if (a.drel && a.Lk <= CH_MAX) {
+      // bias gradient: one query block per wave, several batch rows per workgroup (register accumulation of dS)
+      q.blocks_per_wg = 4;
+      const int64_t wgs = (int64_t)a.Bn * a.H * ((nqb + 3) / 4);
+      q.bn_per_wg = (int)(wgs / 1024 > 1 ? wgs / 1024 : 1);
+    }
     const int lds = lds_bytes_bwd<T, DK>(q.chunk_rows, a.R, nqb == 1);
     static int cur0 = 0;
     set_lds_attr(&attn_bwd_kernel<T, DK, 0>, lds, cur0);
-    dim3 grid((nqb + q.blocks_per_wg - 1) / q.blocks_per_wg, a.H, a.Bn);
+    dim3 grid((nqb + q.blocks_per_wg - 1) / q.blocks_per_wg, a.H, (a.Bn + q.bn_per_wg - 1) / q.bn_per_wg);
     hipLaunchKernelGGL((attn_bwd_kernel<T, DK, 0>), grid, dim3(256), lds, s, q);
   }
   {  // dK/dV pass
     AttnArgs k = a;
+    k.bn_per_wg = 1;
     k.chunk_rows = pick_chunk(a.Lq);
     const int nkb = (a.Lk + 15) / 16;
     k.blocks_per_wg = pick_blocks_per_wg(nkb, (int64_t)a.Bn * a.H);
@@ -660,7 +746,22 @@ int check_common(const char* fn, int Bn, int H, int Lq, int Lk, int d_head, int 
   }
   if (rel_bias && !(R > 0 && R <= 4096)) { lako_set_error("%s: bad R=%d", fn, R); return LAKO_E_BADARG; }
   if (!(p >= 0.f && p < 1.f)) { lako_set_error("%s: dropout p out of range", fn); return LAKO_E_BADARG; }
+  if (p > 0.f && (int64_t)Bn * H * Lq * ((Lk + 1) / 2) >= (1ll << 32)) {
+    lako_set_error("%s: dropout pair index exceeds 32 bits", fn);
+    return LAKO_E_UNSUPPORTED;
+  }
   return LAKO_OK;
+}
+
+void set_drop(AttnArgs& a, const lako_dropout_t& d) {
+  a.drop_t16 = 0;
+  a.drop_scale = 1.0f;
+  if (d.p > 0.f) {
+    uint32_t t = (uint32_t)((double)d.p * 65536.0 + 0.5);
+    a.drop_t16 = t < 1 ? 1 : (t > 65535 ? 65535 : t);
+    a.drop_scale = 1.0f / (1.0f - d.p);
+  }
+  a.drop_key = lako_drop_key(d.seed, d.site);
 }
 
 }  // namespace
@@ -699,9 +800,7 @@ extern "C" int lako_attn_fwd(const lako_attn_fwd_t* p, lako_stream_t stream) {
   a.causal = p->causal;
   a.causal_off = p->causal_off;
   a.Bn = p->Bn; a.H = p->H; a.Lq = p->Lq; a.Lk = p->Lk;
-  a.drop_thresh = p->drop.p > 0.f ? lako_drop_thresh(p->drop.p) : 0u;
-  a.drop_scale = p->drop.p > 0.f ? 1.0f / (1.0f - p->drop.p) : 1.0f;
-  a.drop_key = lako_drop_key(p->drop.seed, p->drop.site);
+  set_drop(a, p->drop);
   ATTN_DISPATCH(p->dtype, p->d_head, run_fwd, a, (hipStream_t)stream);
   LAKO_LAUNCH_CHECK();
   return LAKO_OK;
@@ -723,7 +822,7 @@ extern "C" int lako_attn_bwd(const lako_attn_bwd_t* p, lako_stream_t stream) {
   a.dq = (char*)p->dq_out;
   a.dk = (char*)p->dk_out;
   a.dv = (char*)p->dv_out;
-  a.stats = const_cast<float*>(p->lse);
+  a.stats = p->lse;
   a.rel_bias = p->rel_bias;
   a.drel = p->drel;
   a.key_mask = p->key_mask;
@@ -734,9 +833,7 @@ extern "C" int lako_attn_bwd(const lako_attn_bwd_t* p, lako_stream_t stream) {
   a.causal = p->causal;
   a.causal_off = p->causal_off;
   a.Bn = p->Bn; a.H = p->H; a.Lq = p->Lq; a.Lk = p->Lk;
-  a.drop_thresh = p->drop.p > 0.f ? lako_drop_thresh(p->drop.p) : 0u;
-  a.drop_scale = p->drop.p > 0.f ? 1.0f / (1.0f - p->drop.p) : 1.0f;
-  a.drop_key = lako_drop_key(p->drop.seed, p->drop.site);
+  set_drop(a, p->drop);
   ATTN_DISPATCH(p->dtype, p->d_head, run_bwd, a, (hipStream_t)stream);
   LAKO_LAUNCH_CHECK();
   return LAKO_OK;

@@ -10,7 +10,10 @@ pids=()
 for f in gemm rowops attn; do
   [ -f $f.hip ] || continue
   if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ common.h -nt $f.o ] || [ ../../include/lako_hip.h -nt $f.o ]; then
-    $HIPCC $FLAGS -c $f.hip -o $f.o &
+    extra=""
+    # attention is VALU-bound on the score tiles: keep MFMA results in VGPRs (no v_accvgpr_read/write round trips)
+    [ $f = attn ] && extra="-mllvm -amdgpu-mfma-vgpr-form=1"
+    $HIPCC $FLAGS $extra -c $f.hip -o $f.o &
     pids+=($!)
   fi
   objs+=($f.o)

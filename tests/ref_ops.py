@@ -161,9 +161,16 @@ class RefOps:
         l = p.sum(-1)
         pn = p / l[..., None]
         if _on(drop):
-            idx = torch.arange(B * H * Lq * Lk, device=dev, dtype=torch.int64).view(B, H, Lq, Lk)
-            keep, scale = keep_mask(drop, idx)
-            pn = torch.where(keep, pn * scale, torch.zeros_like(pn))
+            # attention-probability dropout (csrc/attn.hip pair_hash): keys 2c, 2c+1 of a score row share one hash
+            pr, seed, site = drop
+            hk = (Lk + 1) // 2
+            rows = torch.arange(B * H * Lq, device=dev, dtype=torch.int64).view(B, H, Lq, 1)
+            pi = (rows * hk + (j >> 1)) & M32
+            hsh = hash32(pi ^ drop_key(int(seed) & M32, int(site) & M32))
+            half = torch.where((j & 1).bool(), hsh >> 16, hsh & 0xFFFF)
+            t16 = min(max(int(float(np.float32(pr)) * 65536.0 + 0.5), 1), 65535)
+            scale = float(np.float32(1.0) / (np.float32(1.0) - np.float32(pr)))
+            pn = torch.where(half >= t16, pn * scale, torch.zeros_like(pn))
         out = torch.einsum("bhqk,bkhd->bqhd", pn, v)
         return out, m, 1.0 / l, raw
 

@@ -113,8 +113,10 @@ if "attn" in only:
                  rel_bias=rel, rel_off=L - 1, key_mask=km, drop=drop)
     dctx, dqkv = rnd(BN * L, inner), torch.empty(BN * L, 3 * inner, dtype=T, device=dev)
     drel = torch.zeros_like(rel)
-    for nm, kw in [("attn_bwd enc plain", {}), ("attn_bwd enc bias+mask+drop+drel",
-                                                  dict(rel_bias=rel, rel_off=L - 1, key_mask=km, drop=drop, drel=drel))]:
+    bm = dict(rel_bias=rel, rel_off=L - 1, key_mask=km)
+    for nm, kw in [("attn_bwd enc plain", {}), ("attn_bwd enc bias+mask", bm), ("attn_bwd enc bias+mask+drop", dict(bm, drop=drop)),
+                   ("attn_bwd enc bias+mask+drel", dict(bm, drel=drel)),
+                   ("attn_bwd enc bias+mask+drop+drel", dict(bm, drop=drop, drel=drel))]:
         timeit(nm, lambda: ops.attn_bwd(heads(qkv, BN, L, 0), heads(qkv, BN, L, inner), heads(qkv, BN, L, 2 * inner),
                                         heads(ctx, BN, L, 0), heads(dctx, BN, L, 0), st, heads(dqkv, BN, L, 0),
                                         heads(dqkv, BN, L, inner), heads(dqkv, BN, L, 2 * inner), **kw), flops=2.5 * fl)
