@@ -1,0 +1,92 @@
+"""CPU checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, and exports exactly the
+entry points include/lako_hip.h declares (no compute calls — there is no GPU here); the Python binding table
+covers every one of them; argument validation returns error codes instead of crashing."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "lako_hip.h")
+LIB = os.path.join(ROOT, "lako_amd", "liblako_hip.so")
+
+
+def header_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\bint\s+(lako_\w+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(LIB):
+        subprocess.run(["bash", os.path.join(ROOT, "lako_amd", "csrc", "build.sh")], check=True)
+    return ctypes.CDLL(LIB)
+
+
+def test_header_declares_the_expected_surface():
+    fns = header_functions()
+    for must in ("lako_gemm_nt", "lako_gemm_tn", "lako_attn_fwd", "lako_attn_bwd", "lako_rmsnorm_fwd",
+                 "lako_rmsnorm_bwd", "lako_embed_fwd", "lako_embed_bwd", "lako_ce_fwd_bwd", "lako_adamw_step",
+                 "lako_sumsq", "lako_greedy_step", "lako_relpos_expand", "lako_relpos_reduce", "lako_last_error"):
+        assert must in fns
+
+
+def test_library_exports_every_declared_symbol(lib):
+    out = subprocess.run(["nm", "-D", "--defined-only", LIB], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\bT\s+(lako_\w+)", out))
+    declared = set(header_functions())
+    assert declared <= exported, f"declared but not exported: {sorted(declared - exported)}"
+    assert exported <= declared, f"exported but not declared in the header: {sorted(exported - declared)}"
+    for name in declared:
+        getattr(lib, name)
+
+
+def test_binding_table_matches_header():
+    from lako_amd import _lib
+    assert sorted(_lib.SIGNATURES) == header_functions()
+
+
+def test_struct_layouts_match_header_order():
+    """ctypes field order must follow the C structs (same names, same order)."""
+    from lako_amd import _lib
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    for cname, py in (("lako_gemm_nt_t", _lib.GemmNT), ("lako_attn_fwd_t", _lib.AttnFwd), ("lako_attn_bwd_t", _lib.AttnBwd),
+                      ("lako_dropout_t", _lib.Dropout)):
+        body = re.search(r"typedef struct \{([^{}]*)\}\s*" + cname, src, re.S).group(1)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            decl = re.sub(r"^(const\s+)?(void|float|int64_t|int|uint8_t|uint32_t|lako_dropout_t)\b", "", decl)
+            names += [n.strip(" *") for n in decl.split(",")]
+        assert names == [f[0] for f in py._fields_], (cname, names)
+
+
+def test_bad_arguments_return_error_codes(lib):
+    """Validation happens on the host before any launch, so it can be exercised without a GPU."""
+    from lako_amd import _lib
+    _lib._lib = None
+    L = _lib.load()
+    assert L.lako_version() == 1
+    p = _lib.GemmNT()               # all zeros: M = N = K = 0
+    rc = L.lako_gemm_nt(ctypes.byref(p), None)
+    assert rc == -1
+    buf = ctypes.create_string_buffer(256)
+    n = L.lako_last_error(buf, 256)
+    assert n > 0 and b"lako_gemm_nt" in buf.value
+    a = _lib.AttnFwd()
+    a.Bn, a.H, a.Lq, a.Lk, a.d_head, a.dtype = 1, 1, 4, 4, 48, 1      # unsupported head dim
+    assert L.lako_attn_fwd(ctypes.byref(a), None) == -4
+    assert L.lako_rmsnorm_fwd(None, None, None, None, 4, 12, 1e-6, 1, _lib.NO_DROP, None) == -1   # d % 8 != 0
+    assert L.lako_set_tuning(b"no_such_knob", 1) == -1
+
+
+def test_product_fails_loudly_without_library(monkeypatch, tmp_path):
+    from lako_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(_lib.LakoError, match="no CPU fallback"):
+        _lib.load(str(tmp_path / "missing.so"))

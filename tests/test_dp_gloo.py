@@ -1,0 +1,105 @@
+"""Data-parallel path on CPU: world_size 2 over gloo (the N > 1 path of bench.py / train_reader.py).
+
+Each rank holds a full replica and its own half of the batch; gradients are SUM all-reduced in the buckets
+the engine reports as they complete during backward (lako_amd.dist.GradSync), the 1/world factor is folded
+into the fused optimizer step, and the clip uses the post-all-reduce global norm.  Expected result: the
+same weights as a single process that averages the two half-batch gradients by hand.  (Host logic only —
+the kernels are replaced by the fp32 test double, tests/ref_ops.py.)"""
+import os
+import socket
+import types
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from lako_amd import FiDConfig, FiDT5
+from lako_amd import util as U
+from tests.ref_ops import RefOps
+from tests.util_golden import load_case
+
+
+def _cfg(dims):
+    return FiDConfig(vocab_size=dims.vocab_size, d_model=dims.d_model, d_kv=dims.d_kv, d_ff=dims.d_ff,
+                     num_layers=dims.num_layers, num_decoder_layers=dims.num_decoder_layers, num_heads=dims.num_heads,
+                     dropout_rate=0.0)
+
+
+def _opt(model):
+    o = types.SimpleNamespace(optim="adamw", lr=5e-3, weight_decay=1e-2, scheduler="linear", scheduler_steps=None,
+                              total_steps=10, warmup_steps=2, fixed_lr=False)
+    return U.set_optim(o, model)
+
+
+def _batches():
+    from oracle import fid_t5_oracle as O
+    z, dims, w = load_case("tiny_a")
+    B, N, L = z["input_ids"].shape
+    T = z["labels"].shape[1]
+    return dims, w, [O.synthetic_batch(4, N, L, T, dims.vocab_size, seed=900 + k) for k in range(2)]
+
+
+def _worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        dims, w, batches = _batches()
+        model = FiDT5(_cfg(dims), dtype=torch.float32, _ops=RefOps())
+        if rank == 0:
+            model.load_t5(w)                    # rank 1 starts from different weights on purpose:
+        from lako_amd.dist import GradSync, broadcast_parameters
+        model._get_engine()
+        broadcast_parameters(model)             # … the broadcast must make the replicas identical
+        sync = GradSync(model, bucket_bytes=1 << 12)     # tiny buckets → several all-reduces per backward
+        optimizer, scheduler = _opt(model)
+        model.train()
+        n_calls = 0
+        for ids, mask, labels in batches:
+            half = slice(rank * 2, rank * 2 + 2)
+            loss = model(input_ids=ids[half], attention_mask=mask[half], labels=labels[half])[0]
+            loss.backward()
+            n_calls += len(sync.handles) + (1 if sync._pending else 0)
+            gn = U.clip_grad_norm_(model, 0.5)
+            optimizer.step()
+            scheduler.step()
+            model.zero_grad()
+        assert n_calls >= 4, "gradients must travel in several buckets, launched during backward"
+        if rank == 0:
+            torch.save({"P": model._engine.P.clone(), "gn": float(gn)}, out_path)
+        # every rank must end with identical weights
+        ref = model._engine.P.clone()
+        dist.broadcast(ref, 0)
+        assert torch.equal(ref, model._engine.P)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_matches_manual_average(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "dp.pt")
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    # single-process expectation: average the two half-batch gradients by hand
+    dims, w, batches = _batches()
+    model = FiDT5(_cfg(dims), dtype=torch.float32, _ops=RefOps())
+    model.load_t5(w)
+    optimizer, scheduler = _opt(model)
+    model.train()
+    eng = model._get_engine()
+    for ids, mask, labels in batches:
+        acc = torch.zeros_like(eng.G)
+        for r in range(2):
+            half = slice(r * 2, r * 2 + 2)
+            model(input_ids=ids[half], attention_mask=mask[half], labels=labels[half])[0].backward()
+            acc += eng.G
+            model.zero_grad()
+        eng.G.copy_(acc / 2)
+        gn = U.clip_grad_norm_(model, 0.5)
+        optimizer.step()
+        scheduler.step()
+        model.zero_grad()
+    torch.testing.assert_close(got["P"], eng.P, atol=2e-6, rtol=1e-5)
+    assert abs(got["gn"] - float(gn)) < 1e-5 * max(1.0, float(gn))
