@@ -32,6 +32,7 @@ struct NtArgs {
   int flags;
   uint32_t drop_thresh, drop_key;
   int tiles_m, tiles_n;
+  int stagger;
 };
 
 // bijective XCD-aware remap (blocks b and b+8 share an XCD): give each XCD a contiguous id range
@@ -131,16 +132,23 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
       const char* As = smem + cur * BUF;
       const char* Bs = As + A_BYTES;
       char* An = smem + (cur ^ 1) * BUF;
-      if (t + 1 < nk) {
-        int koff = (t + 1) * TKB;
-        stage_rows<BM, NW>(An, Abase + koff, rows_a, lda_b, kbytes - koff, wave, lane);
-        stage_rows<BN, NW>(An + A_BYTES, Bbase + koff, rows_b, ldb_b, kbytes - koff, wave, lane);
-      } else if (has_next) {
-        stage_rows<BM, NW>(An, a.A + (int64_t)nm0 * lda_b, min(BM, a.M - nm0), lda_b, kbytes, wave, lane);
-        stage_rows<BN, NW>(An + A_BYTES, a.B + (int64_t)nn0 * ldb_b, min(BN, a.N - nn0), ldb_b, kbytes, wave, lane);
-      }
+      auto prefetch = [&]() {
+        if (t + 1 < nk) {
+          int koff = (t + 1) * TKB;
+          stage_rows<BM, NW>(An, Abase + koff, rows_a, lda_b, kbytes - koff, wave, lane);
+          stage_rows<BN, NW>(An + A_BYTES, Bbase + koff, rows_b, ldb_b, kbytes - koff, wave, lane);
+        } else if (has_next) {
+          stage_rows<BM, NW>(An, a.A + (int64_t)nm0 * lda_b, min(BM, a.M - nm0), lda_b, kbytes, wave, lane);
+          stage_rows<BN, NW>(An + A_BYTES, a.B + (int64_t)nn0 * ldb_b, min(BN, a.N - nn0), ldb_b, kbytes, wave, lane);
+        }
+      };
+      // STAGGER: waves w and w + NW/2 share a SIMD.  The first half issues its LDS-DMA before the K-step's
+      // MFMAs, the second half between the two K-halves, so one wave's DMA issue overlaps its partner's MFMAs.
+      const bool late = a.stagger && NW == 8 && wave >= NW / 2;
+      if (!late) prefetch();
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh) {
+        if (late && kh == 1) prefetch();
         u32x4 af[MT], bf[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) bf[nt] = read_frag_rows(Bs, (wc * NT + nt) * 16 + r16, kh * 4 + g);
@@ -207,6 +215,151 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
     n0 = nn0;
     rows_a = min(BM, a.M - m0);
     rows_b = min(BN, a.N - n0);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// NT, bf16, 256×256 tile / 8 waves, DEEP pipeline.  PMC counters of the 2-buffer kernel above show the
+// MFMA pipe 35 % busy and the waves parked 42 % of the time in s_waitcnt/s_barrier: with two 64 KiB
+// buffers the LDS-DMA prefetch distance is ONE K-step (≈1 µs), too short for the ≈20 % of requests that
+// miss L2.  Here K advances in 64-BYTE slices (one 16×16×32 MFMA deep) through a 4-slot LDS ring of
+// 32 KiB stages: three slices are in flight while one is consumed, retired by a COUNTED s_waitcnt vmcnt
+// and a raw s_barrier (never vmcnt(0) in steady state).  The stream of stages is continuous across the
+// persistent workgroup's tiles, so a tile's epilogue overlaps the next tile's first three slices.
+// LDS image of a stage: [256 rows][64 B]; 16-B chunk c of row r sits at c ^ (((r >> 2) & 1) << 1)
+// (conflict-free for the ds_read_b128 lane groups); applied on the DMA source address and on the read.
+// ---------------------------------------------------------------------------------------------
+constexpr int PSB = 64, PA_BYTES = 256 * PSB, PSTAGE = 2 * PA_BYTES, PNST = 4;
+
+__device__ __forceinline__ void stage_rows64(char* lds, const char* base, int rows_valid, int64_t ld_bytes,
+                                             int kbytes_left, int wave, int lane) {
+  uint32_t nrec = (rows_valid > 0 && kbytes_left > 0)
+                      ? (uint32_t)((int64_t)(rows_valid - 1) * ld_bytes + (kbytes_left < PSB ? kbytes_left : PSB))
+                      : 0u;
+  auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)nrec, 0x00020000);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int inst = wave + i * 8;                  // 16 wave-instructions of 16 rows each
+    const int row = inst * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ (((row >> 2) & 1) << 1);
+    const bool ok = (row < rows_valid) && (c * 16 < kbytes_left);
+    const uint32_t voff = ok ? (uint32_t)(row * ld_bytes + c * 16) : 0xFFFFFFF0u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds + inst * 1024), 16, (int)voff, 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ u32x4 read_frag64(const char* lds, int row, int g) {
+  return *reinterpret_cast<const u32x4*>(lds + row * PSB + ((g ^ (((row >> 2) & 1) << 1)) * 16));
+}
+
+template <typename TO>
+__global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(NtArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int nwg = a.tiles_m * a.tiles_n;
+  const int64_t lda_b = a.lda * 2, ldb_b = a.ldb * 2;
+  const int kbytes = a.K * 2;
+  const int nk = (kbytes + PSB - 1) / PSB;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int G = gridDim.x;
+  const int v = xcd_remap(blockIdx.x, G);
+  const int my_tiles = (nwg - v + G - 1) / G;
+  const int total = my_tiles * nk;          // stages this workgroup streams
+
+  // issue cursor
+  int i_tile = v, i_k = 0;
+  auto issue = [&](int s) {
+    if (s >= total) return;
+    const int m0 = (i_tile / a.tiles_n) * 256, n0 = (i_tile % a.tiles_n) * 256;
+    char* buf = smem + (s & (PNST - 1)) * PSTAGE;
+    const int koff = i_k * PSB;
+    stage_rows64(buf, a.A + (int64_t)m0 * lda_b + koff, min(256, a.M - m0), lda_b, kbytes - koff, wave, lane);
+    stage_rows64(buf + PA_BYTES, a.B + (int64_t)n0 * ldb_b + koff, min(256, a.N - n0), ldb_b, kbytes - koff, wave, lane);
+    if (++i_k == nk) {
+      i_k = 0;
+      i_tile += G;
+    }
+  };
+  issue(0);
+  issue(1);
+  issue(2);
+
+  f32x4 acc[4][8];  // [nt][mt]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int c_tile = v, c_k = 0;
+
+  for (int t = 0; t < total; ++t) {
+    // retire stage t: this wave's 4 DMA ops of it are the oldest outstanding; younger stages stay in flight
+    const int younger = min(total - 1 - t, 2);
+    if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();            // every wave's part of stage t has landed; stage t-1 is fully consumed
+    asm volatile("" ::: "memory");
+    issue(t + 3);                            // refill the slot stage t-1 occupied
+    const char* As = smem + (t & (PNST - 1)) * PSTAGE;
+    const char* Bs = As + PA_BYTES;
+    u32x4 af[8], bf[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) bf[nt] = read_frag64(Bs, (wc * 4 + nt) * 16 + r16, g);
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) af[mt] = read_frag64(As, (wr * 8 + mt) * 16 + r16, g);
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[nt][mt] = Mma<bf16_t>::run(bf[nt], af[mt], acc[nt][mt]);
+
+    if (++c_k < nk) continue;
+    // ---- tile finished: epilogue (registers only; the ring keeps streaming the next tile) -------------
+    c_k = 0;
+    const int m0 = (c_tile / a.tiles_n) * 256, n0 = (c_tile % a.tiles_n) * 256;
+    c_tile += G;
+    TO* C = reinterpret_cast<TO*>(a.C);
+    const TO* R = reinterpret_cast<const TO*>(a.resid);
+    const bf16_t* X = reinterpret_cast<const bf16_t*>(a.aux);
+    const bool relu = a.flags & LAKO_EPI_RELU, has_res = a.flags & LAKO_EPI_RESID,
+               auxm = a.flags & LAKO_EPI_AUXMASK, atomic = a.flags & LAKO_EPI_ATOMIC;
+    const bool drop = a.drop_thresh != 0;
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+      const int m = m0 + (wr * 8 + mt) * 16 + r16;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + (wc * 4 + nt) * 16 + 4 * g;
+        f32x4 vv = acc[nt][mt] * a.alpha;
+        acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (m >= a.M || n >= a.N) continue;
+        if (relu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) vv[r] = fmaxf(vv[r], 0.f);
+        }
+        if (auxm) {
+          f32x4 x = load4(X + (int64_t)m * a.ldaux + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) vv[r] = x[r] > 0.f ? vv[r] * a.aux_scale : 0.f;
+        }
+        if (drop) {
+          uint64_t idx = (uint64_t)m * (uint64_t)a.N + (uint64_t)n;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) vv[r] = lako_keep(a.drop_key, idx + r, a.drop_thresh) ? vv[r] * a.drop_scale : 0.f;
+        }
+        if (has_res) vv += load4(R + (int64_t)m * a.ldr + n);
+        TO* cp = C + (int64_t)m * a.ldc + n;
+        if constexpr (sizeof(TO) == 4) {
+          if (atomic) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(reinterpret_cast<float*>(cp) + r, vv[r]);
+            continue;
+          }
+        }
+        store4(cp, vv);
+      }
+    }
   }
 }
 
@@ -448,14 +601,19 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(TnArgs a) {
     const int cur = t & 1;
     const char* As = smem + cur * 2 * TN2_IMG;
     const char* Bs = As + TN2_IMG;
-    if (t + 1 < nk) {
-      char* An = smem + (cur ^ 1) * 2 * TN2_IMG;
-      const int kr = (t + 1) * 64;
-      stage_cols256(An, Abase + (int64_t)kr * lda_b, krows - kr, lda_b, acols_b, wave, lane);
-      stage_cols256(An + TN2_IMG, Bbase + (int64_t)kr * ldb_b, krows - kr, ldb_b, bcols_b, wave, lane);
-    }
+    auto prefetch = [&]() {
+      if (t + 1 < nk) {
+        char* An = smem + (cur ^ 1) * 2 * TN2_IMG;
+        const int kr = (t + 1) * 64;
+        stage_cols256(An, Abase + (int64_t)kr * lda_b, krows - kr, lda_b, acols_b, wave, lane);
+        stage_cols256(An + TN2_IMG, Bbase + (int64_t)kr * ldb_b, krows - kr, ldb_b, bcols_b, wave, lane);
+      }
+    };
+    const bool late = wave >= 4;   // stagger the DMA issue of the two waves that share a SIMD (see gemm_nt_kernel)
+    if (!late) prefetch();
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
+      if (late && kk == 1) prefetch();
       u32x4 af[8], bf[4];
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) bf[nt] = read_frag_tr256(Bs, kk, wc * 64 + nt * 16, lane);
@@ -493,6 +651,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(TnArgs a) {
 }
 
 int g_tn_big = 1;
+int g_nt_stagger = 1;
 int g_nt_persistent = 1;
 int g_nt_variant = -1;   // -1 auto; 0: 128x128/4 waves; 1: 256x128/8 waves; 2: 256x256/8 waves (lako_set_tuning)
 
@@ -507,6 +666,7 @@ void launch_nt_cfg(NtArgs a, hipStream_t s) {
   }
   a.tiles_m = cdiv(a.M, BM);
   a.tiles_n = cdiv(a.N, BN);
+  a.stagger = g_nt_stagger;
   // persistent grid: resident workgroups only (LDS-limited: 160 KiB / CU), 256 CUs
   const int per_cu = (160 * 1024) / LDS > 0 ? (160 * 1024) / LDS : 1;
   int grid = a.tiles_m * a.tiles_n;
@@ -521,6 +681,24 @@ int launch_nt(const NtArgs& a, hipStream_t s) {
     // big tiles once there is enough work to fill the chip with them (>= 1 tile per CU), else 128x128
     const int64_t t256 = (int64_t)cdiv(a.M, 256) * cdiv(a.N, 256);
     v = (t256 >= 256 && sizeof(T) == 2) ? 2 : 0;
+  }
+  if (v == 3) {
+    if constexpr (sizeof(T) == 2) {
+      static bool attr_done = false;
+      if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_pipe_kernel<TO>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, PNST * PSTAGE);
+        attr_done = true;
+      }
+      NtArgs b = a;
+      b.tiles_m = cdiv(a.M, 256);
+      b.tiles_n = cdiv(a.N, 256);
+      int grid = b.tiles_m * b.tiles_n;
+      if (grid > 256) grid = 256;
+      hipLaunchKernelGGL((gemm_nt_pipe_kernel<TO>), dim3(grid), dim3(512), PNST * PSTAGE, s, b);
+      return 0;
+    }
+    v = 2;
   }
   if (v == 2) launch_nt_cfg<T, TO, 2, 4, 8, 4>(a, s);
   else if (v == 1) launch_nt_cfg<T, TO, 4, 2, 4, 4>(a, s);
@@ -673,6 +851,10 @@ extern "C" int lako_gemm_tn(const void* A, const void* B, float* C, int64_t M, i
 extern "C" int lako_set_tuning(const char* key, int value) {
   if (key && !strcmp(key, "gemm_nt_variant")) {
     g_nt_variant = value;
+    return LAKO_OK;
+  }
+  if (key && !strcmp(key, "gemm_nt_stagger")) {
+    g_nt_stagger = value;
     return LAKO_OK;
   }
   if (key && !strcmp(key, "gemm_tn_big")) {

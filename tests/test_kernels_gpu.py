@@ -62,6 +62,29 @@ def test_gemm_nt_plain(ops, ref, dt, M, N, K):
         close(C, Cr, T, f"gemm_nt {dt}->{out_t} {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("M,N,K", [(1024, 768, 768), (700, 520, 200), (256, 256, 32), (2048, 2304, 768), (300, 264, 3072)])
+def test_gemm_nt_tile_variants(ops, ref, variant, M, N, K):
+    """every tile variant of the bf16 NT kernel (0: 128², 1: 256×128, 2: 256² 2-buffer, 3: 256² 4-slot ring),
+    persistent and one-tile-per-workgroup grids, ragged edges, fused epilogues."""
+    T = torch.bfloat16
+    A, B = rnd(M, K, dtype=T, seed=41), rnd(N, K, dtype=T, seed=42)
+    R = rnd(M, N, dtype=T, seed=43)
+    try:
+        for persistent in (1, 0):
+            ops.set_tuning("gemm_nt_variant", variant)
+            ops.set_tuning("gemm_nt_persistent", persistent)
+            for kw in (dict(), dict(relu=True, drop=(0.1, 5, 6)), dict(resid=R, drop=(0.1, 7, 8), alpha=0.5)):
+                C = torch.empty(M, N, dtype=T, device=dev())
+                Cr = torch.zeros(M, N, device=dev())
+                ops.gemm_nt(A, B, C, **kw)
+                ref.gemm_nt(A, B, Cr, **kw)
+                close(C, Cr, T, f"gemm_nt variant {variant} persistent {persistent} {list(kw)} {M}x{N}x{K}")
+    finally:
+        ops.set_tuning("gemm_nt_variant", -1)
+        ops.set_tuning("gemm_nt_persistent", 1)
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_gemm_nt_epilogues(ops, ref, dt):
     T = DT[dt]

@@ -49,8 +49,10 @@ def timeit(name, fn, flops=0.0, bytes_=0.0):
 drop = (0.1, 1, 2)
 for variant in ([int(v) for v in args.variants.split(",")] if "gemm" in only else []):
     ops.set_tuning("gemm_nt_variant", variant % 10)
-    ops.set_tuning("gemm_nt_persistent", 0 if variant >= 10 else 1)
-    print(f"--- gemm_nt variant {variant % 10} (-1 auto, 0 128x128, 1 256x128, 2 256x256) persistent={variant < 10}", flush=True)
+    ops.set_tuning("gemm_nt_persistent", 0 if 10 <= variant < 20 else 1)
+    ops.set_tuning("gemm_nt_stagger", 0 if variant >= 20 else 1)
+    print(f"--- gemm_nt variant {variant % 10} (-1 auto, 0 128x128, 1 256x128, 2 256x256, 3 ring) "
+          f"persistent={not 10 <= variant < 20} stagger={variant < 20}", flush=True)
     for nm, (M, Nn, K), kw in [
         ("nt qkv   [Me,768]x[2304,768]", (Me, 3 * inner, d), {}),
         ("nt o+res [Me,768]x[768,768]", (Me, d, inner), dict(resid=True, drop=drop)),
