@@ -167,8 +167,13 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dist = os.environ.get("LAKO_FORCE_DIST") == "1"   # exercise the RCCL path even at world size 1
+    use_dist = world > 1 or force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
 
     cfg = FiDConfig.named(args.model, dropout_rate=args.dropout)
@@ -185,10 +190,10 @@ def main():
                                 total_steps=max(total * 4, 100), warmup_steps=max(int(total * 4 * 0.06), 1),
                                 fixed_lr=False)
     optimizer, scheduler = U.set_optim(opt, model)
-    if world > 1:
+    if use_dist:
         from lako_amd.dist import GradSync, broadcast_parameters
         broadcast_parameters(model)
-        GradSync(model)
+        GradSync(model, force=force_dist)
     ops = model._get_engine().ops
 
     B, N, L, T = args.batch, args.n_passages, args.seq_len, args.target_len
@@ -206,7 +211,7 @@ def main():
         loss_acc.add_(loss.detach())
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -222,7 +227,7 @@ def main():
     elapsed = time.perf_counter() - t0
     probe = ops.probe_summary()
     ops.probe = None
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -262,7 +267,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -12,6 +12,8 @@
 // bank-conflict swizzle is applied to the per-lane SOURCE address and again on the fragment read.
 // bf16 uses v_mfma_f32_16x16x32_bf16, fp32 uses the exact-f32 v_mfma_f32_16x16x4_f32 (parity mode).
 // Workgroup ids are remapped so that the tiles sharing an A row-panel run on one XCD (one L2).
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -171,6 +173,39 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
   const bool relu = a.flags & LAKO_EPI_RELU, has_res = a.flags & LAKO_EPI_RESID,
              auxm = a.flags & LAKO_EPI_AUXMASK, atomic = a.flags & LAKO_EPI_ATOMIC;
   const bool drop = a.drop_thresh != 0;
+  // pass 1: issue EVERY residual / aux load of the wave's sub-tiles before the first use (a load → wait → use
+  // chain per sub-tile would pay one memory round trip per 16×16 block); addresses clamped in-bounds
+  // (kept packed: 2 registers per sub-tile when both dtypes are bf16)
+  constexpr bool PACKED = sizeof(T) == 2 && sizeof(TO) == 2;
+  using SideT = typename std::conditional<PACKED, bf16x4, f32x4>::type;
+  constexpr bool PREFETCH = PACKED || MT * NT <= 16;   // fp32 side inputs of the 256² tile would not fit in registers
+  SideT side[PREFETCH ? NT : 1][PREFETCH ? MT : 1];
+  if (PREFETCH && (has_res || auxm)) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = min(m0 + (wr * MT + mt) * 16 + r16, a.M - 1);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n = min(n0 + (wc * NT + nt) * 16 + 4 * g, a.N - 4);
+        if constexpr (PACKED) {
+          side[nt][mt] = has_res ? *reinterpret_cast<const bf16x4*>(R + (int64_t)m * a.ldr + n)
+                                 : *reinterpret_cast<const bf16x4*>(X + (int64_t)m * a.ldaux + n);
+        } else if constexpr (PREFETCH) {
+          side[nt][mt] = has_res ? load4(R + (int64_t)m * a.ldr + n) : load4(X + (int64_t)m * a.ldaux + n);
+        }
+      }
+    }
+  }
+  auto side_f32 = [&](int nt, int mt, int m, int n) -> f32x4 {
+    if constexpr (PACKED) {
+      const bf16x4 q = side[nt][mt];
+      return f32x4{(float)q[0], (float)q[1], (float)q[2], (float)q[3]};
+    } else if constexpr (PREFETCH) {
+      return side[nt][mt];
+    } else {
+      return has_res ? load4(R + (int64_t)m * a.ldr + n) : load4(X + (int64_t)m * a.ldaux + n);
+    }
+  };
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = m0 + (wr * MT + mt) * 16 + r16;
@@ -185,7 +220,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
       }
       if (auxm) {
-        f32x4 x = load4(X + (int64_t)m * a.ldaux + n);
+        const f32x4 x = side_f32(nt, mt, m, n);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = x[r] > 0.f ? v[r] * a.aux_scale : 0.f;
       }
@@ -194,10 +229,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = lako_keep(a.drop_key, idx + r, a.drop_thresh) ? v[r] * a.drop_scale : 0.f;
       }
-      if (has_res) {
-        f32x4 x = load4(R + (int64_t)m * a.ldr + n);
-        v += x;
-      }
+      if (has_res) v += side_f32(nt, mt, m, n);
       TO* cp = C + (int64_t)m * a.ldc + n;
       if constexpr (sizeof(TO) == 4) {
         if (atomic) {

@@ -16,7 +16,8 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, model, group=None, bucket_bytes: int = 64 << 20):
+    def __init__(self, model, group=None, bucket_bytes: int = 64 << 20, force: bool = False):
+        self.force = force          # issue the collectives even at world size 1 (single-GPU test of the RCCL path)
         self.model = model
         self.group = group
         self.world_size = dist.get_world_size(group)
@@ -36,7 +37,7 @@ class GradSync:
         self.handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _on_ready(self, lo: int, hi: int):
-        if self.world_size == 1:
+        if self.world_size == 1 and not self.force:
             return
         if self._pending is not None and self._pending[1] == lo:
             self._pending = (self._pending[0], hi)          # contiguous with the previous range: coalesce

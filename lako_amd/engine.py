@@ -135,6 +135,7 @@ class _Ctx:
     mask_u8: torch.Tensor = None
     labels: torch.Tensor = None
     dec_ids: torch.Tensor = None
+    ckpt: bool = False
     ws: dict = field(default_factory=dict)
 
 
@@ -254,34 +255,47 @@ class Engine:
     # ------------------------------------------------------------------------------------------
     # forward
     # ------------------------------------------------------------------------------------------
-    def _encode(self, ws, ids_flat, mask_u8, BN, L, p, seed, save: bool):
+    def _enc_layer_fwd(self, ws, i, j, h, h_out, BN, L, mask_u8, rel, dr):
+        """One encoder block (HF5:448-509): RMSNorm → fused QKV → attention → O+residual → RMSNorm → FFN+residual.
+        Intermediates are written to the workspace slot `j` (per layer when everything is kept, slot 0 when the
+        layer is recomputed in backward or nothing is kept)."""
         cfg, ops = self.cfg, self.ops
-        d, f, inner, H = cfg.d_model, cfg.d_ff, cfg.inner_dim, cfg.num_heads
+        d, f, inner, H, eps = cfg.d_model, cfg.d_ff, cfg.inner_dim, cfg.num_heads, cfg.layer_norm_epsilon
+        Me, lw = BN * L, self.enc[i]
+        xn1 = self._buf(ws, f"e.xn1.{j}", (Me, d))
+        ops.rmsnorm_fwd(h, lw["ln1"].p, xn1, self._buf(ws, f"e.rs1.{j}", (Me,), torch.float32), eps)
+        qkv = self._buf(ws, f"e.qkv.{j}", (Me, 3 * inner))
+        ops.gemm_nt(xn1, lw["qkv"].w, qkv)
+        ctx = self._buf(ws, f"e.ctx.{j}", (Me, inner))
+        ops.attn_fwd(self._heads(qkv, BN, L, 0), self._heads(qkv, BN, L, inner), self._heads(qkv, BN, L, 2 * inner),
+                     self._heads(ctx, BN, L, 0), self._buf(ws, f"e.st.{j}", (BN, H, L, 4), torch.float32),
+                     rel_bias=rel, rel_off=L - 1, key_mask=mask_u8, drop=dr(_enc_site(i, 0)))
+        h1 = self._buf(ws, f"e.h1.{j}", (Me, d))
+        ops.gemm_nt(ctx, lw["o"].w, h1, resid=h, drop=dr(_enc_site(i, 1)))
+        xn2 = self._buf(ws, f"e.xn2.{j}", (Me, d))
+        ops.rmsnorm_fwd(h1, lw["ln2"].p, xn2, self._buf(ws, f"e.rs2.{j}", (Me,), torch.float32), eps)
+        a1 = self._buf(ws, f"e.a1.{j}", (Me, f))
+        ops.gemm_nt(xn2, lw["wi"].w, a1, relu=True, drop=dr(_enc_site(i, 2)))
+        if h_out is not None:
+            ops.gemm_nt(a1, lw["wo"].w, h_out, resid=h1, drop=dr(_enc_site(i, 3)))
+
+    def _encode(self, ws, ids_flat, mask_u8, BN, L, p, seed, save):
+        """save: True  — keep every intermediate of every layer (training; 288 GB of HBM make this the default);
+                 "ckpt" — keep only each block's input and recompute the block in backward (`set_checkpoint(True)`,
+                          the reference's CheckpointWrapper, src/model.py:237-283);
+                 False — keep nothing (generate)."""
+        cfg, ops = self.cfg, self.ops
+        d, H = cfg.d_model, cfg.num_heads
         Me, Le, eps = BN * L, cfg.num_layers, cfg.layer_norm_epsilon
         dr = (lambda site: (p, seed, site)) if p > 0 else (lambda site: None)
-        ix = (lambda i: i) if save else (lambda i: 0)
+        ix = (lambda i: i) if save is True else (lambda i: 0)
         hx = (lambda i: i) if save else (lambda i: i % 2)
         ops.embed_fwd(ids_flat, self.shared.w, self._buf(ws, f"e.h{hx(0)}", (Me, d)), dr(S_ENC_EMBED))
         rel = self._buf(ws, "e.rel", (H, 2 * L - 1), torch.float32)
         ops.relpos_expand(self.enc_rel.p, self._lut(L, L, True), rel)
         for i in range(Le):
-            lw, j = self.enc[i], ix(i)
-            h = ws[f"e.h{hx(i)}"]
-            xn1 = self._buf(ws, f"e.xn1.{j}", (Me, d))
-            ops.rmsnorm_fwd(h, lw["ln1"].p, xn1, self._buf(ws, f"e.rs1.{j}", (Me,), torch.float32), eps)
-            qkv = self._buf(ws, f"e.qkv.{j}", (Me, 3 * inner))
-            ops.gemm_nt(xn1, lw["qkv"].w, qkv)
-            ctx = self._buf(ws, f"e.ctx.{j}", (Me, inner))
-            ops.attn_fwd(self._heads(qkv, BN, L, 0), self._heads(qkv, BN, L, inner), self._heads(qkv, BN, L, 2 * inner),
-                         self._heads(ctx, BN, L, 0), self._buf(ws, f"e.st.{j}", (BN, H, L, 4), torch.float32),
-                         rel_bias=rel, rel_off=L - 1, key_mask=mask_u8, drop=dr(_enc_site(i, 0)))
-            h1 = self._buf(ws, f"e.h1.{j}", (Me, d))
-            ops.gemm_nt(ctx, lw["o"].w, h1, resid=h, drop=dr(_enc_site(i, 1)))
-            xn2 = self._buf(ws, f"e.xn2.{j}", (Me, d))
-            ops.rmsnorm_fwd(h1, lw["ln2"].p, xn2, self._buf(ws, f"e.rs2.{j}", (Me,), torch.float32), eps)
-            a1 = self._buf(ws, f"e.a1.{j}", (Me, f))
-            ops.gemm_nt(xn2, lw["wi"].w, a1, relu=True, drop=dr(_enc_site(i, 2)))
-            ops.gemm_nt(a1, lw["wo"].w, self._buf(ws, f"e.h{hx(i + 1)}", (Me, d)), resid=h1, drop=dr(_enc_site(i, 3)))
+            self._enc_layer_fwd(ws, i, ix(i), ws[f"e.h{hx(i)}"], self._buf(ws, f"e.h{hx(i + 1)}", (Me, d)), BN, L,
+                                mask_u8, rel, dr)
         enc_out = self._buf(ws, "e.out", (Me, d))
         ops.rmsnorm_fwd(ws[f"e.h{hx(Le)}"], self.enc_final.p, enc_out, self._buf(ws, "e.rsf", (Me,), torch.float32),
                         eps, dr(S_ENC_FINAL))
@@ -307,7 +321,8 @@ class Engine:
         ctx.labels = labels.reshape(-1).contiguous()
         dr = (lambda site: (p, seed, site)) if p > 0 else (lambda site: None)
         eps = cfg.layer_norm_epsilon
-        enc_out, kv = self._encode(ws, ctx.ids, ctx.mask_u8, B * N, L, p, seed, save=True)
+        ctx.ckpt = bool(self.use_checkpoint and training)
+        enc_out, kv = self._encode(ws, ctx.ids, ctx.mask_u8, B * N, L, p, seed, save="ckpt" if ctx.ckpt else True)
         # ---- decoder ------------------------------------------------------------------------
         Md, S, Ld = B * T, N * L, cfg.num_decoder_layers
         enc_mask = ctx.mask_u8.view(B, S)
@@ -458,24 +473,28 @@ class Engine:
         ops.zero_(drel_e)
         for i in reversed(range(Le)):
             lw = self.enc[i]
-            self._ffn_bwd(lw, deh, ws[f"e.a1.{i}"], ws[f"e.xn2.{i}"], ws[f"e.h1.{i}"], ws[f"e.rs2.{i}"], lw["ln2"], p,
+            j = i
+            if ctx.ckpt:   # recompute this block's intermediates from its saved input (same seeds → same dropout masks)
+                j = 0
+                self._enc_layer_fwd(ws, i, 0, ws[f"e.h{i}"], None, BN, L, ctx.mask_u8, ws["e.rel"], dr)
+            self._ffn_bwd(lw, deh, ws[f"e.a1.{j}"], ws[f"e.xn2.{j}"], ws[f"e.h1.{j}"], ws[f"e.rs2.{j}"], lw["ln2"], p,
                           dr(_enc_site(i, 3)), tmp)
             dy = deh
             if p > 0:
                 ops.dropout_apply(deh, dy := self._buf(tmp, f"dy.{Me}", (Me, d)), dr(_enc_site(i, 1)))
-            ops.gemm_tn(dy, ws[f"e.ctx.{i}"], lw["o"].g)
+            ops.gemm_tn(dy, ws[f"e.ctx.{j}"], lw["o"].g)
             dctx = self._buf(tmp, f"dctx.{Me}", (Me, inner))
             ops.gemm_nt(dy, lw["o"].wt, dctx)
-            qkv = ws[f"e.qkv.{i}"]
+            qkv = ws[f"e.qkv.{j}"]
             dqkv = self._buf(tmp, f"dqkv.{Me}", (Me, 3 * inner))
             ops.attn_bwd(self._heads(qkv, BN, L, 0), self._heads(qkv, BN, L, inner), self._heads(qkv, BN, L, 2 * inner),
-                         self._heads(ws[f"e.ctx.{i}"], BN, L, 0), self._heads(dctx, BN, L, 0), ws[f"e.st.{i}"],
+                         self._heads(ws[f"e.ctx.{j}"], BN, L, 0), self._heads(dctx, BN, L, 0), ws[f"e.st.{j}"],
                          self._heads(dqkv, BN, L, 0), self._heads(dqkv, BN, L, inner),
                          self._heads(dqkv, BN, L, 2 * inner), rel_bias=ws["e.rel"], drel=drel_e, rel_off=L - 1,
                          key_mask=ctx.mask_u8, drop=dr(_enc_site(i, 0)))
-            ops.gemm_tn(dqkv, ws[f"e.xn1.{i}"], lw["qkv"].g)
+            ops.gemm_tn(dqkv, ws[f"e.xn1.{j}"], lw["qkv"].g)
             ops.gemm_nt(dqkv, lw["qkv"].wt, dxe)
-            ops.rmsnorm_bwd(dxe, ws[f"e.h{i}"], lw["ln1"].p, ws[f"e.rs1.{i}"], deh, deh, lw["ln1"].g)
+            ops.rmsnorm_bwd(dxe, ws[f"e.h{i}"], lw["ln1"].p, ws[f"e.rs1.{j}"], deh, deh, lw["ln1"].g)
             self._ready(f"enc.{i}.qkv", f"enc.{i}.ln2")
         ops.embed_bwd(ctx.ids, deh, self.shared.g, dr(S_ENC_EMBED))
         ops.relpos_reduce(drel_e, self._lut(L, L, True), self.enc_rel.g)

@@ -211,8 +211,9 @@ class FiDT5(nn.Module):
         return eng.generate(input_ids, attention_mask, max_length)
 
     def set_checkpoint(self, use_checkpoint):
-        """src/model.py:84-90.  With 288 GB of HBM per GPU activation recompute is never required
-        (SURVEY.md A.7); the flag is kept for API parity and recorded on the engine."""
+        """src/model.py:84-90: recompute each encoder block in backward from its saved input instead of keeping its
+        intermediates (the reference's CheckpointWrapper + torch.utils.checkpoint, :237-283).  With 288 GB of HBM per
+        GPU this is never required — it trades one extra encoder forward for ~13 GB at config 2."""
         self._use_checkpoint = bool(use_checkpoint)
         if self._engine is not None:
             self._engine.use_checkpoint = self._use_checkpoint

@@ -175,3 +175,24 @@ def test_dropout_training_is_deterministic_and_unbiased():
     assert abs(res[0][0] - float(z["loss"])) < 0.5   # same ballpark as the no-dropout loss
     m.eval()
     assert abs(m(input_ids=ids, attention_mask=mask, labels=labels)[0].item() - float(z["loss"])) < 2e-5
+
+
+def test_set_checkpoint_recompute_matches(tmp_path):
+    """set_checkpoint(True): encoder blocks are recomputed in backward (src/model.py:84-90,237-283) — with and without
+    dropout the loss and every gradient must equal the keep-everything schedule bit for bit (same seeds → same masks)."""
+    z, dims, w = load_case("mid_a")
+    ids, mask, labels = (torch.from_numpy(z[k]) for k in ("input_ids", "attention_mask", "labels"))
+    for p in (0.0, 0.1):
+        res = []
+        for ck in (False, True):
+            m = FiDT5(cfg_of(dims, p), dtype=torch.float32, seed=11, _ops=RefOps())
+            m.load_t5(w)
+            m.set_checkpoint(ck)
+            m.train()
+            loss = m(input_ids=ids, attention_mask=mask, labels=labels)[0]
+            loss.backward()
+            res.append((loss.item(), m._engine.G.clone(), len([k for k in m._engine._ws_cache[("train", *ids.shape, labels.shape[1])]
+                                                               if k.startswith("e.a1.")])))
+        assert res[0][0] == res[1][0]
+        torch.testing.assert_close(res[0][1], res[1][1], atol=1e-6, rtol=1e-5)
+        assert res[0][2] == dims.num_layers and res[1][2] == 1      # only one FFN activation buffer is live when recomputing

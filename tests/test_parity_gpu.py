@@ -225,5 +225,50 @@ def test_config2_dropout_determinism():
         res.append((loss.item(), m._engine.G.double().norm().item()))
         del m
         torch.cuda.empty_cache()
-    assert res[0][0] == res[1][0]                              # forward is bit-deterministic
-    assert abs(res[0][1] - res[1][1]) < 1e-3 * res[0][1]       # backward sums with float atomics: order noise only
+    # same seed → same dropout masks.  Activations are bit-deterministic; the loss scalar sums the rows with a float
+    # atomic and the gradients accumulate with float atomics, so both may differ by summation-order rounding only
+    assert abs(res[0][0] - res[1][0]) < 1e-6 * abs(res[0][0])
+    assert abs(res[0][1] - res[1][1]) < 1e-3 * res[0][1]
+
+
+def test_checkpoint_recompute_on_gpu():
+    """set_checkpoint(True) on the HIP path, bf16 + dropout: identical loss, gradients equal up to atomic-order noise."""
+    z, dims, w = load_case("mid_a")
+    ids, mask, labels = dev(z["input_ids"], z["attention_mask"], z["labels"])
+    res = []
+    for ck in (False, True):
+        m = FiDT5(cfg_of(dims, 0.1), dtype=torch.bfloat16, seed=5)
+        m.load_t5(w)
+        m = m.cuda().train()
+        m.set_checkpoint(ck)
+        loss = m(input_ids=ids, attention_mask=mask, labels=labels)[0]
+        loss.backward()
+        res.append((loss.item(), m._engine.G.clone()))
+    assert abs(res[0][0] - res[1][0]) < 1e-6 * max(1.0, abs(res[0][0]))
+    torch.testing.assert_close(res[0][1], res[1][1], atol=1e-4, rtol=1e-3)
+
+
+def test_bf16_training_overfits_a_fixed_batch():
+    """End-to-end sanity of the bf16 train step (fused AdamW, bf16 + transposed weight shadows, dropout on):
+    T5-small on one fixed synthetic batch must drive the loss far below its starting value."""
+    cfg = FiDConfig.named("small", dropout_rate=0.1)
+    torch.manual_seed(0)
+    m = FiDT5(cfg, dtype=torch.bfloat16, seed=1)
+    with torch.no_grad():
+        m._params_by_plain["shared.weight"].mul_(0.05)
+    m = m.cuda().train()
+    ids, mask, labels = dev(*O.synthetic_batch(4, 3, 64, 6, cfg.vocab_size, seed=77))
+    opt = types.SimpleNamespace(optim="adamw", lr=1e-3, weight_decay=0.0, scheduler="fixed", fixed_lr=True,
+                                scheduler_steps=None, total_steps=100, warmup_steps=0)
+    optimizer, scheduler = U.set_optim(opt, m)
+    first = None
+    for k in range(80):
+        loss = m(input_ids=ids, attention_mask=mask, labels=labels)[0]
+        loss.backward()
+        U.clip_grad_norm_(m, 1.0)
+        optimizer.step()
+        scheduler.step()
+        m.zero_grad()
+        first = first if first is not None else loss.item()
+    last = loss.item()
+    assert first > 8.0 and last < 0.25 * first, (first, last)     # ln(32128) = 10.4 at random init
