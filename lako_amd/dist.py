@@ -2,31 +2,49 @@
 train_reader.py never wraps the model in DDP).
 
 One process per GPU; `torch.distributed` backend "nccl" is RCCL on ROCm and rides xGMI inside a node.
-The engine lays gradients out in the order they complete during backward and reports finished ranges
-through `Engine.grad_hook`; each range becomes one asynchronous SUM all-reduce issued while the rest of
-backward is still running (decoder + cross-K/V bucket first, then one bucket per encoder layer, the
-tied embedding last).  `finish()` makes the compute stream wait for all of them; the 1/world factor is
-folded into the fused optimizer step (lako_adamw_step grad_scale), so gradients are never rescaled in
-a separate pass.
+The engine lays gradients out in ONE flat fp32 buffer, in the order they complete during backward, and
+reports finished ranges through `Engine.grad_hook`.  Two modes:
+
+  "deferred" (default)  one SUM all-reduce of the whole flat buffer after backward.  892 MB at T5-base:
+                        ≈5 ms on an 8-GPU xGMI ring against a ≈73 ms step.  Chosen as the default because the
+                        big GEMM kernels fill the chip with exactly one workgroup per CU (128 KiB LDS, ≈240
+                        VGPRs): RCCL kernels running concurrently on their own stream would take CUs away and
+                        stretch every such kernel by a whole scheduling round.
+  "overlap"             one asynchronous all-reduce per finished range (decoder + cross-K/V first, then per
+                        encoder layer, coalesced to `bucket_bytes`), issued while backward is still running;
+                        `LAKO_DP_MODE=overlap`.  Correct (2-rank gloo test) — to be measured on 8 GPUs.
+
+`finish()` makes the compute stream wait for the collectives; the 1/world factor is folded into the fused
+optimizer step (lako_adamw_step grad_scale) and into the clip norm, so gradients are never rescaled in a
+separate pass.
 """
 from __future__ import annotations
 
-import torch
+import os
+
 import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, model, group=None, bucket_bytes: int = 64 << 20, force: bool = False):
+    def __init__(self, model, group=None, bucket_bytes: int = 64 << 20, force: bool = False, mode: str | None = None):
         self.force = force          # issue the collectives even at world size 1 (single-GPU test of the RCCL path)
         self.model = model
         self.group = group
         self.world_size = dist.get_world_size(group)
         self.bucket_bytes = bucket_bytes
+        self.mode = mode or os.environ.get("LAKO_DP_MODE", "deferred")
+        if self.mode not in ("deferred", "overlap"):
+            raise ValueError(f"unknown DP mode {self.mode!r}")
         self.handles = []
         self._pending = None
+        self._dirty = False
         eng = model._get_engine()
         eng.grad_hook = self._on_ready
         model._grad_sync = self
+
+    @property
+    def active(self):
+        return self.world_size > 1 or self.force
 
     def _flush(self):
         if self._pending is None:
@@ -37,7 +55,10 @@ class GradSync:
         self.handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _on_ready(self, lo: int, hi: int):
-        if self.world_size == 1 and not self.force:
+        if not self.active:
+            return
+        self._dirty = True
+        if self.mode == "deferred":
             return
         if self._pending is not None and self._pending[1] == lo:
             self._pending = (self._pending[0], hi)          # contiguous with the previous range: coalesce
@@ -48,6 +69,12 @@ class GradSync:
             self._flush()
 
     def finish(self):
+        if not self.active or not self._dirty:
+            return
+        self._dirty = False
+        if self.mode == "deferred":
+            dist.all_reduce(self.model._engine.G, op=dist.ReduceOp.SUM, group=self.group)
+            return
         self._flush()
         for h in self.handles:
             h.wait()

@@ -39,7 +39,7 @@ def _batches():
     return dims, w, [O.synthetic_batch(4, N, L, T, dims.vocab_size, seed=900 + k) for k in range(2)]
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, mode):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -51,7 +51,7 @@ def _worker(rank, world, port, out_path):
         from lako_amd.dist import GradSync, broadcast_parameters
         model._get_engine()
         broadcast_parameters(model)             # … the broadcast must make the replicas identical
-        sync = GradSync(model, bucket_bytes=1 << 12)     # tiny buckets → several all-reduces per backward
+        sync = GradSync(model, bucket_bytes=1 << 12, mode=mode)     # overlap: tiny buckets → several all-reduces
         optimizer, scheduler = _opt(model)
         model.train()
         n_calls = 0
@@ -64,7 +64,8 @@ def _worker(rank, world, port, out_path):
             optimizer.step()
             scheduler.step()
             model.zero_grad()
-        assert n_calls >= 4, "gradients must travel in several buckets, launched during backward"
+        if mode == "overlap":
+            assert n_calls >= 4, "gradients must travel in several buckets, launched during backward"
         if rank == 0:
             torch.save({"P": model._engine.P.clone(), "gn": float(gn)}, out_path)
         # every rank must end with identical weights
@@ -75,12 +76,16 @@ def _worker(rank, world, port, out_path):
         dist.destroy_process_group()
 
 
-def test_two_rank_data_parallel_matches_manual_average(tmp_path):
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("mode", ["deferred", "overlap"])
+def test_two_rank_data_parallel_matches_manual_average(tmp_path, mode):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = str(tmp_path / "dp.pt")
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, out, mode), nprocs=2, join=True)
     got = torch.load(out)
     # single-process expectation: average the two half-batch gradients by hand
     dims, w, batches = _batches()
