@@ -30,6 +30,7 @@ class Options:
                        help="train on synthetic OKVQA-shaped batches of this shape (no tokenizer / data files needed)")
         p.add_argument("--dtype", type=str, default="bf16", choices=["bf16", "f32"], help="compute dtype of the kernels")
         p.add_argument("--steps", type=int, default=None, help="stop after this many optimizer steps")
+        p.add_argument("--tokenizer", type=str, default=None, help="local T5 tokenizer directory (default t5-<model_size>)")
 
     def add_optim_options(self):
         p = self.parser

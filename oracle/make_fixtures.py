@@ -287,9 +287,43 @@ def make_tables():
     print("tables ok")
 
 
+EXAMPLES = [
+    {"question": "what is the man holding", "target": "umbrella", "answer": {"umbrella": 1.0}, "img_id": 1,
+     "caption": "a man in the rain . street sign", "fact": [{"sentence": "umbrella is used for rain .", "id": 3},
+                                                            {"sentence": "rain is wet .", "id": 9},
+                                                            {"sentence": "a man is a person .", "id": 4}]},
+    {"question": "which sport is this", "target": "tennis", "answer": {"tennis": 1.0, "badminton": 0.3}, "img_id": 2,
+     "caption": "two people with rackets", "fact": [{"sentence": "racket is used for tennis .", "id": 5},
+                                                    {"sentence": "tennis is a sport .", "id": 6}]},
+    {"question": "what animal is shown", "answers": ["cat"], "answer": {"cat": 1.0}, "img_id": 3,
+     "caption": "a cat on a sofa", "fact": [{"sentence": "cat is a pet .", "id": 7}]},
+]
+
+
+def make_collate():
+    """Golden outputs of the reference's own Dataset + Collator (src/data.py) with the stub tokenizer."""
+    import src.data as rd
+    from tests.stub_tokenizer import StubTokenizer
+    out = {}
+    for stream in (1, 2):
+        for use_fact in ("yes", "no"):
+            for ans_len in (-1, 3):
+                opt = types.SimpleNamespace(n_context=2, fact_use_way="concate", use_fact=use_fact)
+                ds = rd.Dataset(EXAMPLES, opt)
+                col = rd.Collator(12, StubTokenizer(), answer_maxlength=ans_len, stream=stream)
+                index, tid, tmask, pid, pmask = col([ds[i] for i in range(len(ds))])
+                key = f"s{stream}_{use_fact}_{ans_len}"
+                out.update({key + "/index": index.numpy(), key + "/target_ids": tid.numpy(),
+                            key + "/target_mask": tmask.numpy(), key + "/passage_ids": pid.numpy(),
+                            key + "/passage_masks": pmask.numpy()})
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "collate.npz"), **out)
+    print("collate ok", sorted({k.split("/")[0] for k in out}))
+
+
 if __name__ == "__main__":
     tiny = O.T5Dims.named("tiny")
     make_tables()
+    make_collate()
     make_case("tiny_a", tiny, B=3, N=3, L=12, T=5, seed=1, full_pad=(1, 2))
     make_case("tiny_fact", tiny, B=3, N=2, L=24, T=4, seed=2, fact_case=True)
     make_case("tiny_eos", tiny, B=4, N=3, L=12, T=6, seed=5, pretrain=150)

@@ -8,8 +8,8 @@ gradients are all-reduced over RCCL (the reference itself never synchronises gra
     python train_reader.py --model_size base --per_gpu_batch_size 16 --n_context 10 --text_maxlength 200 \
         --optim adamw --scheduler linear --weight_decay 1e-4 --lr 4e-5 --epochs 1 --synthetic 16,20,200,8 --steps 20
 
-Round 1 ships the synthetic data source (`--synthetic B,N,L,T`); the tokenizer / JSON pipeline of
-src/data.py is the next row of the scope table (§8 f2)."""
+Data: `--synthetic B,N,L,T` or the reference's JSON files through lako_amd.data (Dataset/Collator
+restated from src/data.py; needs a T5 tokenizer on disk: `--tokenizer PATH`, default `t5-<model_size>`)."""
 from __future__ import annotations
 
 import logging
@@ -36,6 +36,22 @@ def synthetic_loader(opt, cfg, device, n_batches):
     assert B == opt.per_gpu_batch_size, "--synthetic B must equal --per_gpu_batch_size"
     for i in range(n_batches):
         yield synthetic_batch(B, N, L, T, cfg.vocab_size, seed=opt.seed + opt.global_rank * 7919 + i, device=device)
+
+
+def json_loader(opt, path, tokenizer, device, shuffle):
+    """train_reader.py:40-48 / :123-131: DataLoader over the reference's JSON examples."""
+    import json
+
+    from torch.utils.data import DataLoader, RandomSampler, SequentialSampler
+
+    from lako_amd.data import Collator, Dataset
+    with open(path) as f:
+        ds = Dataset(json.load(f), opt)
+    col = Collator(opt.text_maxlength, tokenizer, answer_maxlength=opt.answer_maxlength, stream=opt.stream)
+    dl = DataLoader(ds, sampler=RandomSampler(ds) if shuffle else SequentialSampler(ds),
+                    batch_size=opt.per_gpu_batch_size, drop_last=shuffle, num_workers=2, collate_fn=col)
+    for _, labels, _, ids, mask in dl:
+        yield ids.to(device, non_blocking=True), mask.to(device, non_blocking=True), labels.to(device, non_blocking=True)
 
 
 def evaluate(model, batches, opt):
@@ -71,9 +87,15 @@ def main():
     logging.basicConfig(level=logging.INFO if opt.is_main else logging.WARN, format="[%(asctime)s] %(message)s")
     torch.manual_seed(opt.seed)
 
+    tokenizer = None
     if opt.synthetic is None:
-        raise SystemExit("round 1 ships the synthetic source only: pass --synthetic B,N,L,T "
-                         "(the tokenizer/JSON pipeline of src/data.py is scope row f2)")
+        if opt.train_data == "none":
+            raise SystemExit("pass --synthetic B,N,L,T or --train_data/--eval_data JSON files")
+        import transformers
+        try:
+            tokenizer = transformers.T5Tokenizer.from_pretrained(opt.tokenizer or ("t5-" + opt.model_size))
+        except Exception as e:      # no network in the build container: a local tokenizer directory is required
+            raise SystemExit(f"cannot load a T5 tokenizer ({e}); pass --tokenizer /path/to/t5-tokenizer or use --synthetic")
     cfg = FiDConfig.named(opt.model_size, dropout_rate=opt.dropout)
     dtype = torch.bfloat16 if opt.dtype == "bf16" else torch.float32
     if opt.model_path == "none":
@@ -84,6 +106,16 @@ def main():
         model = FiDT5.from_pretrained(opt.model_path, dtype=dtype, seed=opt.seed + opt.global_rank)
     model = model.cuda(local_rank)
     model.set_checkpoint(opt.use_checkpoint)
+
+    def train_batches(n):
+        if tokenizer is None:
+            return synthetic_loader(opt, cfg, opt.device, n)
+        return json_loader(opt, opt.train_data, tokenizer, opt.device, True)
+
+    def eval_batches():
+        if tokenizer is None:
+            return list(synthetic_loader(opt, cfg, opt.device, 2))
+        return json_loader(opt, opt.eval_data, tokenizer, opt.device, False)
 
     steps_per_epoch = opt.steps or 100
     opt.total_steps = steps_per_epoch * opt.epochs
@@ -101,7 +133,7 @@ def main():
         curr_loss = torch.zeros((), device=opt.device)
         t0 = time.time()
         n = 0
-        for ids, mask, labels in synthetic_loader(opt, cfg, opt.device, steps_per_epoch):
+        for ids, mask, labels in train_batches(steps_per_epoch):
             step += 1
             train_loss = model(input_ids=ids, attention_mask=mask, labels=labels)[0]
             train_loss.backward()
@@ -116,7 +148,7 @@ def main():
                 break
         torch.cuda.synchronize()
         dt = time.time() - t0
-        dev_em = evaluate(model, list(synthetic_loader(opt, cfg, opt.device, 2)), opt)
+        dev_em = evaluate(model, eval_batches(), opt)
         if opt.is_main:
             logger.info(f"epoch {epoch} |step {step} |train loss: {curr_loss.item() / max(n, 1):.3f} |"
                         f"evaluation: {100 * dev_em:.2f}EM |lr: {scheduler.get_last_lr()[0]:.5f} |"
