@@ -35,6 +35,7 @@ struct NtArgs {
   uint32_t drop_thresh, drop_key;
   int tiles_m, tiles_n;
   int stagger;
+  int wide_epi;   // 256² bf16 tile: LDS-transposed epilogue with 16-B row-major stores (needs N, ldc, ldr, ldaux % 8 == 0)
 };
 
 // bijective XCD-aware remap (blocks b and b+8 share an XCD): give each XCD a contiguous id range
@@ -173,12 +174,67 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
   const bool relu = a.flags & LAKO_EPI_RELU, has_res = a.flags & LAKO_EPI_RESID,
              auxm = a.flags & LAKO_EPI_AUXMASK, atomic = a.flags & LAKO_EPI_ATOMIC;
   const bool drop = a.drop_thresh != 0;
+  if constexpr (sizeof(T) == 2 && sizeof(TO) == 2 && MT == 8 && NT == 4) {
+    if (a.wide_epi) {
+      // WIDE epilogue (256² bf16 tile).  In the accumulator layout a lane owns 4 consecutive columns of 32
+      // different sub-tiles: 32 eight-byte stores per lane that land as 32-B granules — store-ISSUE bound, ≈9 µs
+      // per tile, i.e. 5 K-steps' worth when K = 768.  Instead each wave transposes its 128×64 fp32 tile through
+      // its private 8 KiB of the free LDS buffer, 32 rows at a time (XOR-swizzled 16-B chunks), and leaves with
+      // row-major data: 8 consecutive columns per lane, 8 rows × 128 B per wave-instruction, 16-B stores (16 store
+      // instructions per wave instead of 32).  Only for epilogues WITHOUT a residual / aux operand (host-selected).
+      char* ep = smem + (cur ^ 1) * BUF + wave * 8192;
+      const int cj = lane & 7, n = n0 + wc * 64 + cj * 8;
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const int mt = 2 * pass + mi, row_l = mi * 16 + r16;
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            f32x4 v = acc[nt][mt] * a.alpha;
+            if (relu) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            *reinterpret_cast<f32x4*>(ep + row_l * 256 + (((nt * 4 + g) ^ (row_l & 15)) * 16)) = v;
+          }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int row_l = it * 8 + (lane >> 3);
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(ep + row_l * 256 + (((2 * cj) ^ (row_l & 15)) * 16));
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(ep + row_l * 256 + (((2 * cj + 1) ^ (row_l & 15)) * 16));
+          const int m = m0 + wr * 128 + pass * 32 + row_l;
+          if (m < a.M && n < a.N) {
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            if (drop) {
+              const uint64_t idx = (uint64_t)m * (uint64_t)a.N + (uint64_t)n;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = lako_keep(a.drop_key, idx + e, a.drop_thresh) ? v[e] * a.drop_scale : 0.f;
+            }
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+            *reinterpret_cast<bf16x8*>(C + (int64_t)m * a.ldc + n) = o;
+          }
+        }
+      }
+      if (!has_next) break;
+      __syncthreads();   // the next tile's first prefetch DMA-writes the buffer the waves just used as scratch
+      tile = next_tile;
+      m0 = nm0;
+      n0 = nn0;
+      rows_a = min(BM, a.M - m0);
+      rows_b = min(BN, a.N - n0);
+      continue;
+    }
+  }
   // pass 1: issue EVERY residual / aux load of the wave's sub-tiles before the first use (a load → wait → use
   // chain per sub-tile would pay one memory round trip per 16×16 block); addresses clamped in-bounds
   // (kept packed: 2 registers per sub-tile when both dtypes are bf16)
   constexpr bool PACKED = sizeof(T) == 2 && sizeof(TO) == 2;
   using SideT = typename std::conditional<PACKED, bf16x4, f32x4>::type;
-  constexpr bool PREFETCH = PACKED || MT * NT <= 16;   // fp32 side inputs of the 256² tile would not fit in registers
+  constexpr bool PREFETCH = MT * NT <= 16;   // 256² tile: 64 more live registers would spill next to the wide epilogue (measured equal without)
   SideT side[PREFETCH ? NT : 1][PREFETCH ? MT : 1];
   if (PREFETCH && (has_res || auxm)) {
 #pragma unroll
@@ -187,7 +243,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int n = min(n0 + (wc * NT + nt) * 16 + 4 * g, a.N - 4);
-        if constexpr (PACKED) {
+        if constexpr (PACKED && PREFETCH) {
           side[nt][mt] = has_res ? *reinterpret_cast<const bf16x4*>(R + (int64_t)m * a.ldr + n)
                                  : *reinterpret_cast<const bf16x4*>(X + (int64_t)m * a.ldaux + n);
         } else if constexpr (PREFETCH) {
@@ -197,7 +253,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
     }
   }
   auto side_f32 = [&](int nt, int mt, int m, int n) -> f32x4 {
-    if constexpr (PACKED) {
+    if constexpr (PREFETCH && PACKED) {
       const bf16x4 q = side[nt][mt];
       return f32x4{(float)q[0], (float)q[1], (float)q[2], (float)q[3]};
     } else if constexpr (PREFETCH) {
@@ -683,6 +739,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(TnArgs a) {
 }
 
 int g_tn_big = 1;
+int g_nt_wide_epi = 1;
 int g_nt_stagger = 1;
 int g_nt_persistent = 1;
 int g_nt_variant = -1;   // -1 auto; 0: 128x128/4 waves; 1: 256x128/8 waves; 2: 256x256/8 waves (lako_set_tuning)
@@ -699,6 +756,10 @@ void launch_nt_cfg(NtArgs a, hipStream_t s) {
   a.tiles_m = cdiv(a.M, BM);
   a.tiles_n = cdiv(a.N, BN);
   a.stagger = g_nt_stagger;
+  // measured (tools/bench_ops.py --variants 2,32): +6…12 % on plain stores, a LOSS when a residual / aux operand must
+  // be fetched in the row-major layout too — those keep the accumulator-layout epilogue
+  a.wide_epi = g_nt_wide_epi && !(a.flags & (LAKO_EPI_ATOMIC | LAKO_EPI_RESID | LAKO_EPI_AUXMASK)) && a.N % 8 == 0 &&
+               a.ldc % 8 == 0 && reinterpret_cast<uintptr_t>(a.C) % 16 == 0;
   // persistent grid: resident workgroups only (LDS-limited: 160 KiB / CU), 256 CUs
   const int per_cu = (160 * 1024) / LDS > 0 ? (160 * 1024) / LDS : 1;
   int grid = a.tiles_m * a.tiles_n;
@@ -883,6 +944,10 @@ extern "C" int lako_gemm_tn(const void* A, const void* B, float* C, int64_t M, i
 extern "C" int lako_set_tuning(const char* key, int value) {
   if (key && !strcmp(key, "gemm_nt_variant")) {
     g_nt_variant = value;
+    return LAKO_OK;
+  }
+  if (key && !strcmp(key, "gemm_nt_wide_epi")) {
+    g_nt_wide_epi = value;
     return LAKO_OK;
   }
   if (key && !strcmp(key, "gemm_nt_stagger")) {

@@ -17,6 +17,8 @@ ap.add_argument("--only", default="gemm,tn,attn,norm,misc")
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--variants", default="-1", help="gemm_nt tile variants to time, e.g. 0,1,2")
+ap.add_argument("--vendor", action="store_true", help="also time torch.matmul (hipBLASLt / rocBLAS) on the GEMM shapes: a yardstick, "
+                "never part of the product path")
 args = ap.parse_args()
 only = set(args.only.split(","))
 T = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -50,9 +52,10 @@ drop = (0.1, 1, 2)
 for variant in ([int(v) for v in args.variants.split(",")] if "gemm" in only else []):
     ops.set_tuning("gemm_nt_variant", variant % 10)
     ops.set_tuning("gemm_nt_persistent", 0 if 10 <= variant < 20 else 1)
-    ops.set_tuning("gemm_nt_stagger", 0 if variant >= 20 else 1)
+    ops.set_tuning("gemm_nt_stagger", 0 if 20 <= variant < 30 else 1)
+    ops.set_tuning("gemm_nt_wide_epi", 0 if variant >= 30 else 1)
     print(f"--- gemm_nt variant {variant % 10} (-1 auto, 0 128x128, 1 256x128, 2 256x256, 3 ring) "
-          f"persistent={not 10 <= variant < 20} stagger={variant < 20}", flush=True)
+          f"persistent={not 10 <= variant < 20} stagger={not 20 <= variant < 30} wide_epi={variant < 30}", flush=True)
     for nm, (M, Nn, K), kw in [
         ("nt qkv   [Me,768]x[2304,768]", (Me, 3 * inner, d), {}),
         ("nt o+res [Me,768]x[768,768]", (Me, d, inner), dict(resid=True, drop=drop)),
@@ -78,6 +81,23 @@ for variant in ([int(v) for v in args.variants.split(",")] if "gemm" in only els
             k2["drop"] = kw["drop"]
         timeit(nm, lambda: ops.gemm_nt(A, Bm, C, **k2), flops=2.0 * M * Nn * K)
         del A, Bm, C, k2
+
+if args.vendor:
+    print("--- vendor yardstick: torch.matmul, plain bf16 GEMM without any fused epilogue", flush=True)
+    for nm, (M, Nn, K) in [("nt [Me,768]x[2304,768]", (Me, 3 * inner, d)), ("nt [Me,768]x[768,768]", (Me, d, inner)),
+                           ("nt [Me,768]x[3072,768]", (Me, f, d)), ("nt [Me,3072]x[768,3072]", (Me, d, f)),
+                           ("nt [Me,768]x[18432,768]", (Me, Ld * 2 * inner, d)), ("nt [Me,18432]x[768,18432]", (Me, d, Ld * 2 * inner)),
+                           ("nt 4096^3", (4096,) * 3), ("nt 8192^3", (8192,) * 3)]:
+        A, Bm = rnd(M, K), rnd(Nn, K)
+        C = torch.empty(M, Nn, dtype=T, device=dev)
+        timeit("vendor " + nm, lambda: torch.matmul(A, Bm.t(), out=C), flops=2.0 * M * Nn * K)
+        del A, Bm, C
+    for nm, (K, M, Nn) in [("tn [Me,2304]^T x [Me,768]", (Me, 3 * inner, d)), ("tn [Me,768]^T x [Me,768]", (Me, d, inner)),
+                           ("tn [Me,3072]^T x [Me,768]", (Me, f, d)), ("tn [Me,18432]^T x [Me,768]", (Me, Ld * 2 * inner, d))]:
+        A, Bm = rnd(K, M), rnd(K, Nn)
+        C = torch.empty(M, Nn, dtype=T, device=dev)
+        timeit("vendor " + nm, lambda: torch.matmul(A.t(), Bm, out=C), flops=2.0 * M * Nn * K)
+        del A, Bm, C
 
 for big in ([1, 0] if "tn" in only else []):
     ops.set_tuning("gemm_tn_big", big)
