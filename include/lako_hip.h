@@ -175,7 +175,11 @@ int lako_greedy_step(const float* logits, int64_t V, int B, int64_t* seq, int64_
                      uint8_t* done, int32_t* n_done, int64_t eos_id, int64_t pad_id, lako_stream_t stream);
 
 /* Development knob for A/B measurements (tools/bench_ops.py); training never calls it.
- * "gemm_nt_variant": -1 auto (default), 0 = 128x128 tile / 4 waves, 1 = 256x128 / 8 waves, 2 = 256x256 / 8 waves */
+ * "gemm_nt_variant": -1 auto (default), 0 = 128x128 tile / 4 waves, 1 = 256x128 / 8 waves, 2 = 256x256 / 8 waves,
+ *                    3 = 256x256 4-slot ring;  "gemm_nt_persistent" 0/1;  "gemm_nt_stagger" 0/1;
+ * "gemm_nt_wide_epi" 0/1 (LDS-transposed epilogue for plain bf16 stores);  "gemm_nt_group_m": tile-rows per band of
+ * the banded tile order (0 = row-major, >0 applied when the output is >= 16 tiles wide, <0 forces |value|);
+ * "gemm_tn_big" 0/1 (256x256 weight-gradient kernel).  Unknown key: LAKO_E_BADARG. */
 int lako_set_tuning(const char* key, int value);
 
 #ifdef __cplusplus

@@ -35,6 +35,8 @@ struct NtArgs {
   uint32_t drop_thresh, drop_key;
   int tiles_m, tiles_n;
   int stagger;
+  int debug;      // timing experiments only (bench_ops): bit 0 = skip the K-loop LDS-DMA, bit 1 = all workgroups stream tile (0,0), bit 2 = never wait for the DMA, bit 3 = no epilogue stores (results are garbage)
+  int group_m;    // >0: tile ids walk bands of group_m tile-rows column-major (an XCD's 32 resident tiles form a ≈group_m × 32/group_m block)
   int wide_epi;   // 256² bf16 tile: LDS-transposed epilogue with 16-B row-major stores (needs N, ldc, ldr, ldaux % 8 == 0)
 };
 
@@ -43,6 +45,21 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   int q = nwg >> 3, r = nwg & 7, x = bid & 7;
   int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
   return base + (bid >> 3);
+}
+
+// tile id → (tile row, tile col).  Row-major ids make the 32 tiles resident on one XCD a 1×32 strip when tiles_n ≥ 32:
+// 33 distinct operand panels for 32 tiles.  Banded ids (group_m rows per band, column-major inside the band) make
+// them a group_m × (32/group_m) block: 12 panels at group_m = 4 or 8, so ≥ 80 % of the LDS-DMA requests can hit L2.
+__device__ __forceinline__ void tile_coords(int tile, int tiles_m, int tiles_n, int group_m, int& tm, int& tn) {
+  if (group_m <= 0) {
+    tm = tile / tiles_n;
+    tn = tile % tiles_n;
+    return;
+  }
+  const int band = group_m * tiles_n, b = tile / band, r = tile - b * band;
+  const int rows = min(group_m, tiles_m - b * group_m);
+  tm = b * group_m + r % rows;
+  tn = r / rows;
 }
 
 template <typename T> struct Mma;
@@ -83,6 +100,25 @@ __device__ __forceinline__ void stage_rows(char* lds_tile, const char* base, int
   }
 }
 
+// the same, one 1-KiB piece at a time (piece i of this wave), so that the K-loop can deal the pieces out between MFMAs
+template <int NWAVES>
+__device__ __forceinline__ void stage_piece(char* lds_tile, __amdgpu_buffer_rsrc_t rsrc, int rows_valid, int64_t ld_bytes,
+                                            int kbytes_left, int wave, int lane, int i) {
+  int inst = wave + i * NWAVES;
+  int row = inst * 8 + (lane >> 3);
+  int cp = lane & 7;
+  int c = cp ^ ((row >> 1) & 7);
+  bool ok = (row < rows_valid) && (c * 16 < kbytes_left);
+  uint32_t voff = ok ? (uint32_t)(row * ld_bytes + c * 16) : 0xFFFFFFF0u;
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + inst * 1024), 16, (int)voff, 0, 0, 0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t slice_rsrc(const char* base, int rows_valid, int64_t ld_bytes, int kbytes_left) {
+  uint32_t nrec = (rows_valid > 0 && kbytes_left > 0)
+                      ? (uint32_t)((int64_t)(rows_valid - 1) * ld_bytes + (kbytes_left < TKB ? kbytes_left : TKB))
+                      : 0u;
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)nrec, 0x00020000);
+}
+
 __device__ __forceinline__ u32x4 read_frag_rows(const char* lds_tile, int row, int chunk) {
   int cp = chunk ^ ((row >> 1) & 7);
   return *reinterpret_cast<const u32x4*>(lds_tile + row * TKB + cp * 16);
@@ -91,7 +127,7 @@ __device__ __forceinline__ u32x4 read_frag_rows(const char* lds_tile, int row, i
 // Workgroup tile = (WM·MT·16) × (WN·NT·16); WM×WN waves, each owning MT×NT MFMA 16×16 tiles.
 //   <2,2,4,4> 128×128, 4 waves, 64 KiB LDS (2 workgroups / CU)      — small / skinny problems
 //   <2,4,8,4> 256×256, 8 waves, 128 KiB LDS (1 workgroup / CU)      — half the LDS+L2 bytes per FLOP
-template <typename T, typename TO, int WM, int WN, int MT, int NT>
+template <typename T, typename TO, int WM, int WN, int MT, int NT, bool SPREAD>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
   constexpr int NW = WM * WN, BM = WM * MT * 16, BN = WN * NT * 16;
   constexpr int A_BYTES = BM * TKB, B_BYTES = BN * TKB, BUF = A_BYTES + B_BYTES;
@@ -110,7 +146,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
   // last K-step of the current tile, so neither its HBM latency nor this tile's epilogue stalls the MFMAs.
   // v = xcd_remap(blockIdx): workgroups of one XCD get consecutive tile ids (they share A row-panels in L2).
   int tile = xcd_remap(blockIdx.x, gridDim.x);
-  int m0 = (tile / a.tiles_n) * BM, n0 = (tile % a.tiles_n) * BN;
+  int tm_, tn_;
+  tile_coords(tile, a.tiles_m, a.tiles_n, a.group_m, tm_, tn_);
+  int m0 = tm_ * BM, n0 = tn_ * BN;
   int rows_a = min(BM, a.M - m0), rows_b = min(BN, a.N - n0);
   stage_rows<BM, NW>(smem, a.A + (int64_t)m0 * lda_b, rows_a, lda_b, kbytes, wave, lane);
   stage_rows<BN, NW>(smem + A_BYTES, a.B + (int64_t)n0 * ldb_b, rows_b, ldb_b, kbytes, wave, lane);
@@ -121,9 +159,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
   while (true) {
     const int next_tile = tile + gridDim.x;
     const bool has_next = next_tile < nwg;
-    const int nm0 = has_next ? (next_tile / a.tiles_n) * BM : 0, nn0 = has_next ? (next_tile % a.tiles_n) * BN : 0;
-    const char* Abase = a.A + (int64_t)m0 * lda_b;
-    const char* Bbase = a.B + (int64_t)n0 * ldb_b;
+    tile_coords(has_next ? next_tile : 0, a.tiles_m, a.tiles_n, a.group_m, tm_, tn_);
+    const int nm0 = tm_ * BM, nn0 = tn_ * BN;
+    // debug bit 1: every workgroup streams tile (0, 0)'s operands — all requests hit L2 (timing experiment)
+    const char* Abase = a.A + ((a.debug & 2) ? 0 : (int64_t)m0 * lda_b);
+    const char* Bbase = a.B + ((a.debug & 2) ? 0 : (int64_t)n0 * ldb_b);
 
     f32x4 acc[NT][MT];  // element r of lane (l&15, g): C[m = mt*16 + (l&15)][n = nt*16 + 4g + r]
 #pragma unroll
@@ -135,35 +175,83 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
       const char* As = smem + cur * BUF;
       const char* Bs = As + A_BYTES;
       char* An = smem + (cur ^ 1) * BUF;
-      auto prefetch = [&]() {
-        if (t + 1 < nk) {
-          int koff = (t + 1) * TKB;
-          stage_rows<BM, NW>(An, Abase + koff, rows_a, lda_b, kbytes - koff, wave, lane);
-          stage_rows<BN, NW>(An + A_BYTES, Bbase + koff, rows_b, ldb_b, kbytes - koff, wave, lane);
-        } else if (has_next) {
-          stage_rows<BM, NW>(An, a.A + (int64_t)nm0 * lda_b, min(BM, a.M - nm0), lda_b, kbytes, wave, lane);
-          stage_rows<BN, NW>(An + A_BYTES, a.B + (int64_t)nn0 * ldb_b, min(BN, a.N - nn0), ldb_b, kbytes, wave, lane);
-        }
+      // source of the NEXT K-slice: this tile's slice t+1, or the first slice of the workgroup's next tile
+      const bool more_k = t + 1 < nk;
+      const bool pf = !(a.debug & 1) && (more_k || has_next);
+      const int koff = more_k ? (t + 1) * TKB : 0;
+      const int pf_rows_a = more_k ? rows_a : min(BM, a.M - nm0), pf_rows_b = more_k ? rows_b : min(BN, a.N - nn0);
+      const char* pf_a = more_k ? Abase + koff : a.A + (int64_t)nm0 * lda_b;
+      const char* pf_b = more_k ? Bbase + koff : a.B + (int64_t)nn0 * ldb_b;
+      const auto rsrc_a = slice_rsrc(pf_a, pf_rows_a, lda_b, kbytes - koff);
+      const auto rsrc_b = slice_rsrc(pf_b, pf_rows_b, ldb_b, kbytes - koff);
+      constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;    // 1-KiB DMA pieces per wave and K-step
+      auto piece = [&](int j) {
+        if (!pf) return;
+        if (j < PA) stage_piece<NW>(An, rsrc_a, pf_rows_a, lda_b, kbytes - koff, wave, lane, j);
+        else if (j < PA + PB) stage_piece<NW>(An + A_BYTES, rsrc_b, pf_rows_b, ldb_b, kbytes - koff, wave, lane, j - PA);
       };
-      // STAGGER: waves w and w + NW/2 share a SIMD.  The first half issues its LDS-DMA before the K-step's
-      // MFMAs, the second half between the two K-halves, so one wave's DMA issue overlaps its partner's MFMAs.
-      const bool late = a.stagger && NW == 8 && wave >= NW / 2;
-      if (!late) prefetch();
+      auto prefetch = [&]() {
+#pragma unroll
+        for (int j = 0; j < PA + PB; ++j) piece(j);
+      };
+      // DMA placement.  One LDS-DMA piece costs its wave ≈60 cycles of issue among bare MFMAs but 100–185 inside a
+      // burst next to the fragment reads (MI355X_MICROARCH.md, cycle constants), and a K-step has only 1024 MFMA cycles
+      // per wave.  spread = 1: the PA+PB pieces go out one per row of MFMAs in the first K-half.
+      // spread = 0 (burst): STAGGER — waves w and w + NW/2 share a SIMD; the first half issues its burst before the
+      // K-step's fragment reads, the second half after the first MT/4 rows of MFMAs.
+      constexpr bool spread = SPREAD;
+      const bool late = !spread && a.stagger && NW == 8 && wave >= NW / 2;
+      if (!spread && !late) prefetch();
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh) {
-        if (late && kh == 1) prefetch();
         u32x4 af[MT], bf[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) bf[nt] = read_frag_rows(Bs, (wc * NT + nt) * 16 + r16, kh * 4 + g);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) af[mt] = read_frag_rows(As, (wr * MT + mt) * 16 + r16, kh * 4 + g);
+        // all fragment reads of the K-half go out back to back; left alone, the machine scheduler folds every
+        // A fragment into ONE register quad (read → s_waitcnt lgkmcnt(0) → 4 MFMAs, MT times per K-half),
+        // exposing a full LDS round trip per 64 MFMA cycles
+        __builtin_amdgcn_sched_barrier(0);
+        auto mma_rows = [&](int lo, int hi) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+          for (int mt = lo; mt < hi; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) acc[nt][mt] = Mma<T>::run(bf[nt], af[mt], acc[nt][mt]);
+            for (int nt = 0; nt < NT; ++nt) acc[nt][mt] = Mma<T>::run(bf[nt], af[mt], acc[nt][mt]);
+        };
+        constexpr int Q = MT / 4;
+        if (kh == 0) {
+          if constexpr (spread) {
+            constexpr int PER = (PA + PB + MT - 1) / MT;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              mma_rows(mt, mt + 1);
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int q = 0; q < PER; ++q) piece(mt * PER + q);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          } else {
+            mma_rows(0, Q);
+            if (late) {
+              __builtin_amdgcn_sched_barrier(0);
+              prefetch();
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            mma_rows(Q, MT);
+          }
+        } else {
+          // the wait for the next K-slice and the barrier sit Q rows of MFMAs before the end of the step: late enough
+          // that the DMA had the step to land (the scheduler would hoist them to the top of this K-half), early
+          // enough that the barrier round trip is covered by MFMAs already queued
+          mma_rows(0, MT - Q);
+          __builtin_amdgcn_sched_barrier(0);
+          if (!(a.debug & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          __builtin_amdgcn_sched_barrier(0);
+          mma_rows(MT - Q, MT);
+        }
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
       cur ^= 1;
     }
 
@@ -215,7 +303,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
             bf16x8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-            *reinterpret_cast<bf16x8*>(C + (int64_t)m * a.ldc + n) = o;
+            if (!(a.debug & 8)) *reinterpret_cast<bf16x8*>(C + (int64_t)m * a.ldc + n) = o;
           }
         }
       }
@@ -294,7 +382,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
           continue;
         }
       }
-      store4(cp, v);
+      if (!(a.debug & 8)) store4(cp, v);
     }
   }
     if (!has_next) break;
@@ -740,6 +828,9 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(TnArgs a) {
 
 int g_tn_big = 1;
 int g_nt_wide_epi = 1;
+int g_nt_group_m = 8;
+int g_nt_debug = 0;
+int g_nt_spread = 0;   // measured equal to slightly slower than the burst + stagger placement (tools/bench_ops.py --variants 2,102)
 int g_nt_stagger = 1;
 int g_nt_persistent = 1;
 int g_nt_variant = -1;   // -1 auto; 0: 128x128/4 waves; 1: 256x128/8 waves; 2: 256x256/8 waves (lako_set_tuning)
@@ -749,13 +840,18 @@ void launch_nt_cfg(NtArgs a, hipStream_t s) {
   constexpr int BM = WM * MT * 16, BN = WN * NT * 16, LDS = 2 * (BM + BN) * TKB;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, TO, WM, WN, MT, NT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, TO, WM, WN, MT, NT, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, TO, WM, WN, MT, NT, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_done = true;
   }
   a.tiles_m = cdiv(a.M, BM);
   a.tiles_n = cdiv(a.N, BN);
   a.stagger = g_nt_stagger;
+  a.debug = g_nt_debug;
+  // narrow outputs already give an XCD a compact block; a negative knob forces |value| on every shape (tests)
+  a.group_m = g_nt_group_m < 0 ? -g_nt_group_m : (a.tiles_n >= 16 ? g_nt_group_m : 0);
   // measured (tools/bench_ops.py --variants 2,32): +6…12 % on plain stores, a LOSS when a residual / aux operand must
   // be fetched in the row-major layout too — those keep the accumulator-layout epilogue
   a.wide_epi = g_nt_wide_epi && !(a.flags & (LAKO_EPI_ATOMIC | LAKO_EPI_RESID | LAKO_EPI_AUXMASK)) && a.N % 8 == 0 &&
@@ -764,7 +860,9 @@ void launch_nt_cfg(NtArgs a, hipStream_t s) {
   const int per_cu = (160 * 1024) / LDS > 0 ? (160 * 1024) / LDS : 1;
   int grid = a.tiles_m * a.tiles_n;
   if (g_nt_persistent && grid > 256 * per_cu) grid = 256 * per_cu;
-  hipLaunchKernelGGL((gemm_nt_kernel<T, TO, WM, WN, MT, NT>), dim3(grid), dim3(WM * WN * 64), LDS, s, a);
+  if ((g_nt_debug >> 8) > 0 && grid > (g_nt_debug >> 8)) grid = g_nt_debug >> 8;   // timing experiment: fewer resident workgroups
+  if (g_nt_spread) hipLaunchKernelGGL((gemm_nt_kernel<T, TO, WM, WN, MT, NT, true>), dim3(grid), dim3(WM * WN * 64), LDS, s, a);
+  else hipLaunchKernelGGL((gemm_nt_kernel<T, TO, WM, WN, MT, NT, false>), dim3(grid), dim3(WM * WN * 64), LDS, s, a);
 }
 
 template <typename T, typename TO>
@@ -945,6 +1043,18 @@ extern "C" int lako_set_tuning(const char* key, int value) {
   if (key && !strcmp(key, "gemm_nt_variant")) {
     g_nt_variant = value;
     return LAKO_OK;
+  }
+  if (key && !strcmp(key, "gemm_nt_spread")) {
+    g_nt_spread = value;
+    return 0;
+  }
+  if (key && !strcmp(key, "gemm_nt_debug")) {
+    g_nt_debug = value;
+    return 0;
+  }
+  if (key && !strcmp(key, "gemm_nt_group_m")) {
+    g_nt_group_m = value;
+    return 0;
   }
   if (key && !strcmp(key, "gemm_nt_wide_epi")) {
     g_nt_wide_epi = value;

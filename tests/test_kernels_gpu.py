@@ -71,18 +71,23 @@ def test_gemm_nt_tile_variants(ops, ref, variant, M, N, K):
     A, B = rnd(M, K, dtype=T, seed=41), rnd(N, K, dtype=T, seed=42)
     R = rnd(M, N, dtype=T, seed=43)
     try:
-        for persistent in (1, 0):
+        # (persistent grid, LDS-transposed wide epilogue, banded tile order forced with 3 tile-rows per band)
+        for persistent, wide, group_m in ((1, 1, 8), (0, 0, 0), (1, 1, -3), (0, 1, -2)):
             ops.set_tuning("gemm_nt_variant", variant)
             ops.set_tuning("gemm_nt_persistent", persistent)
+            ops.set_tuning("gemm_nt_wide_epi", wide)
+            ops.set_tuning("gemm_nt_group_m", group_m)
             for kw in (dict(), dict(relu=True, drop=(0.1, 5, 6)), dict(resid=R, drop=(0.1, 7, 8), alpha=0.5)):
                 C = torch.empty(M, N, dtype=T, device=dev())
                 Cr = torch.zeros(M, N, device=dev())
                 ops.gemm_nt(A, B, C, **kw)
                 ref.gemm_nt(A, B, Cr, **kw)
-                close(C, Cr, T, f"gemm_nt variant {variant} persistent {persistent} {list(kw)} {M}x{N}x{K}")
+                close(C, Cr, T, f"gemm_nt variant {variant} persistent {persistent} wide {wide} group_m {group_m} {list(kw)} {M}x{N}x{K}")
     finally:
         ops.set_tuning("gemm_nt_variant", -1)
         ops.set_tuning("gemm_nt_persistent", 1)
+        ops.set_tuning("gemm_nt_wide_epi", 1)
+        ops.set_tuning("gemm_nt_group_m", 8)
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])

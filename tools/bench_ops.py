@@ -53,9 +53,13 @@ for variant in ([int(v) for v in args.variants.split(",")] if "gemm" in only els
     ops.set_tuning("gemm_nt_variant", variant % 10)
     ops.set_tuning("gemm_nt_persistent", 0 if 10 <= variant < 20 else 1)
     ops.set_tuning("gemm_nt_stagger", 0 if 20 <= variant < 30 else 1)
-    ops.set_tuning("gemm_nt_wide_epi", 0 if variant >= 30 else 1)
+    ops.set_tuning("gemm_nt_wide_epi", 0 if 30 <= variant < 40 else 1)
+    ops.set_tuning("gemm_nt_debug", {7: 1, 8: 2, 9: 4, 14: 8, 11: 128 << 8, 12: 64 << 8, 13: (128 << 8) | 1}.get(variant // 10, 0))   # 7x: no K-loop DMA; 8x: every DMA hits L2 (timing experiments, wrong results)
+    ops.set_tuning("gemm_nt_spread", 1 if variant // 10 == 10 else 0)      # 10x: one DMA piece per MFMA row instead of the burst
+    ops.set_tuning("gemm_nt_group_m", {4: 0, 5: 4, 6: 16}.get(variant // 10, 8))
     print(f"--- gemm_nt variant {variant % 10} (-1 auto, 0 128x128, 1 256x128, 2 256x256, 3 ring) "
-          f"persistent={not 10 <= variant < 20} stagger={not 20 <= variant < 30} wide_epi={variant < 30}", flush=True)
+          f"persistent={not 10 <= variant < 20} stagger={not 20 <= variant < 30} wide_epi={not 30 <= variant < 40} "
+          f"group_m={ {4: 0, 5: 4, 6: 16}.get(variant // 10, 8)}", flush=True)
     for nm, (M, Nn, K), kw in [
         ("nt qkv   [Me,768]x[2304,768]", (Me, 3 * inner, d), {}),
         ("nt o+res [Me,768]x[768,768]", (Me, d, inner), dict(resid=True, drop=drop)),
@@ -67,8 +71,11 @@ for variant in ([int(v) for v in args.variants.split(",")] if "gemm" in only els
         ("nt lmhead[128,768]x[32128,768] f32 out", (Md, V, d), dict(f32=True)),
         ("nt square 4096^3", (4096, 4096, 4096), {}),
         ("nt square 8192^3", (8192, 8192, 8192), {}),
+        ("nt square 8192^3, row stride 8192+64", (8192, 8192, 8192), dict(pad=64)),
+        ("nt kvall, row stride 768+64", (Me, Ld * 2 * inner, d), dict(pad=64)),
     ]:
-        A, Bm = rnd(M, K), rnd(Nn, K)
+        pad = kw.get("pad", 0)       # row stride K + pad elements: breaks power-of-two strides (L2 channel spread)
+        A, Bm = rnd(M, K + pad)[:, :K], rnd(Nn, K + pad)[:, :K]
         C = torch.empty(M, Nn, dtype=torch.float32 if kw.get("f32") else T, device=dev)
         k2 = {}
         if kw.get("resid"):
