@@ -19,6 +19,31 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
+// LDS-DMA (buffer_load_dwordx4 … lds: 64 lanes × 16 B straight into LDS at lds_dst + 16·lane) issued as inline asm.
+// hipcc's waitcnt pass puts `s_waitcnt vmcnt(0)` in front of every LDS read it cannot prove disjoint from the
+// destination of a *builtin* LDS-DMA (seen before each ds_read_b64_tr_b16 of the TN kernel), which makes the prefetch
+// synchronous.  The asm form is outside that bookkeeping: the caller owns the wait (s_waitcnt vmcnt) and the barrier.
+// lds_dst and the descriptor must be wave-uniform.  M0 is compiler-reserved: saved and restored in the statement.
+typedef uint32_t lako_u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ lako_u32x4_t lds_dma_rsrc(const void* base, uint32_t num_bytes) {
+  const uint64_t b = reinterpret_cast<uint64_t>(base);
+  lako_u32x4_t r;
+  r[0] = __builtin_amdgcn_readfirstlane((uint32_t)b);
+  r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32) & 0xFFFFu);
+  r[2] = __builtin_amdgcn_readfirstlane(num_bytes);
+  r[3] = 0x00020000u;
+  return r;
+}
+__device__ __forceinline__ void lds_dma16(const void* lds_dst, lako_u32x4_t rsrc, uint32_t voff) {
+  const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)LDS_PTR(lds_dst));
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(dst), "s"(rsrc)
+      : "memory");
+}
+
 // ---------------------------------------------------------------------------------------------
 // error plumbing (never throws, never exits; see include/lako_hip.h)
 // ---------------------------------------------------------------------------------------------

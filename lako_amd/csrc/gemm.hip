@@ -569,7 +569,7 @@ __device__ __forceinline__ void stage_cols(char* lds_tile, const char* base, int
   uint32_t nrec = (krows_valid > 0 && colbytes_valid > 0)
                       ? (uint32_t)((int64_t)(krows_valid - 1) * ld_bytes + min(colbytes_valid, G::ROWB))
                       : 0u;
-  auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)nrec, 0x00020000);
+  const auto rsrc = lds_dma_rsrc(base, nrec);   // asm LDS-DMA: see common.h (the builtin makes hipcc wait vmcnt(0) before the tr reads)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int inst = wave * 4 + i;
@@ -585,7 +585,7 @@ __device__ __forceinline__ void stage_cols(char* lds_tile, const char* base, int
     }
     bool ok = (row < krows_valid) && (cb < colbytes_valid);
     uint32_t voff = ok ? (uint32_t)(row * ld_bytes + cb) : 0xFFFFFFF0u;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + inst * 1024), 16, (int)voff, 0, 0, 0);
+    lds_dma16(lds_tile + inst * 1024, rsrc, voff);
   }
 }
 
@@ -713,7 +713,7 @@ __device__ __forceinline__ void stage_cols256(char* img, const char* base, int k
   uint32_t nrec = (krows_valid > 0 && colbytes_valid > 0)
                       ? (uint32_t)((int64_t)(krows_valid - 1) * ld_bytes + min(colbytes_valid, TN2_ROWB))
                       : 0u;
-  auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)nrec, 0x00020000);
+  const auto rsrc = lds_dma_rsrc(base, nrec);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int inst = wave + i * 8;            // 32 wave-instructions of 2 rows each
@@ -722,7 +722,7 @@ __device__ __forceinline__ void stage_cols256(char* img, const char* base, int k
     const int cb = (cp ^ (tn_key(row) << 1)) * 16;
     const bool ok = (row < krows_valid) && (cb < colbytes_valid);
     const uint32_t voff = ok ? (uint32_t)(row * ld_bytes + cb) : 0xFFFFFFF0u;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(img + inst * 1024), 16, (int)voff, 0, 0, 0);
+    lds_dma16(img + inst * 1024, rsrc, voff);
   }
 }
 
@@ -785,23 +785,42 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(TnArgs a) {
         stage_cols256(An + TN2_IMG, Bbase + (int64_t)kr * ldb_b, krows - kr, ldb_b, bcols_b, wave, lane);
       }
     };
-    const bool late = wave >= 4;   // stagger the DMA issue of the two waves that share a SIMD (see gemm_nt_kernel)
+    // K-step schedule as in gemm_nt_kernel: fragment reads of a K-half back to back (sched_barrier: the machine
+    // scheduler would fold them into one register quad and wait per read), the second half of the workgroup issues
+    // its DMA after two rows of MFMAs, and the wait + barrier sit two rows before the end of the step
+    const bool late = wave >= 4;
     if (!late) prefetch();
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      if (late && kk == 1) prefetch();
       u32x4 af[8], bf[4];
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) bf[nt] = read_frag_tr256(Bs, kk, wc * 64 + nt * 16, lane);
 #pragma unroll
       for (int mt = 0; mt < 8; ++mt) af[mt] = read_frag_tr256(As, kk, wr * 128 + mt * 16, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      auto mma_rows = [&](int lo, int hi) {
 #pragma unroll
-      for (int mt = 0; mt < 8; ++mt)
+        for (int mt = lo; mt < hi; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = Mma<bf16_t>::run(af[mt], bf[nt], acc[mt][nt]);
+          for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = Mma<bf16_t>::run(af[mt], bf[nt], acc[mt][nt]);
+      };
+      if (kk == 0) {
+        mma_rows(0, 2);
+        if (late) {
+          __builtin_amdgcn_sched_barrier(0);
+          prefetch();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        mma_rows(2, 8);
+      } else {
+        mma_rows(0, 6);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        mma_rows(6, 8);
+      }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
   }
 
   // epilogue: per wave a private 16×64 fp32 slab in LDS (staging buffers are free after the last barrier)
