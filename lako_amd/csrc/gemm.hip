@@ -124,10 +124,91 @@ __device__ __forceinline__ u32x4 read_frag_rows(const char* lds_tile, int row, i
   return *reinterpret_cast<const u32x4*>(lds_tile + row * TKB + cp * 16);
 }
 
+// Generic epilogue in the accumulator layout (element r of lane (l&15, g) of sub-tile (mt, nt) is
+// C[m0 + (wr·MT + mt)·16 + (l&15)][n0 + (wc·NT + nt)·16 + 4g + r]): alpha, ReLU, aux mask, dropout, residual, store / atomic.
+template <typename T, typename TO, int WM, int WN, int MT, int NT>
+__device__ __forceinline__ void nt_store_tile(const NtArgs& a, f32x4 (&acc)[NT][MT], int m0, int n0, int wr, int wc, int lane) {
+  const int r16 = lane & 15, g = lane >> 4;
+  TO* C = reinterpret_cast<TO*>(a.C);
+  const TO* R = reinterpret_cast<const TO*>(a.resid);
+  const T* X = reinterpret_cast<const T*>(a.aux);
+  const bool relu = a.flags & LAKO_EPI_RELU, has_res = a.flags & LAKO_EPI_RESID,
+             auxm = a.flags & LAKO_EPI_AUXMASK, atomic = a.flags & LAKO_EPI_ATOMIC;
+  const bool drop = a.drop_thresh != 0;
+  // pass 1: issue EVERY residual / aux load of the wave's sub-tiles before the first use (a load → wait → use
+  // chain per sub-tile would pay one memory round trip per 16×16 block); addresses clamped in-bounds
+  // (kept packed: 2 registers per sub-tile when both dtypes are bf16)
+  constexpr bool PACKED = sizeof(T) == 2 && sizeof(TO) == 2;
+  using SideT = typename std::conditional<PACKED, bf16x4, f32x4>::type;
+  constexpr bool PREFETCH = MT * NT <= 16;   // 256² tile: 64 more live registers would spill next to the wide epilogue (measured equal without)
+  SideT side[PREFETCH ? NT : 1][PREFETCH ? MT : 1];
+  if (PREFETCH && (has_res || auxm)) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = min(m0 + (wr * MT + mt) * 16 + r16, a.M - 1);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n = min(n0 + (wc * NT + nt) * 16 + 4 * g, a.N - 4);
+        if constexpr (PACKED && PREFETCH) {
+          side[nt][mt] = has_res ? *reinterpret_cast<const bf16x4*>(R + (int64_t)m * a.ldr + n)
+                                 : *reinterpret_cast<const bf16x4*>(X + (int64_t)m * a.ldaux + n);
+        } else if constexpr (PREFETCH) {
+          side[nt][mt] = has_res ? load4(R + (int64_t)m * a.ldr + n) : load4(X + (int64_t)m * a.ldaux + n);
+        }
+      }
+    }
+  }
+  auto side_f32 = [&](int nt, int mt, int m, int n) -> f32x4 {
+    if constexpr (PREFETCH && PACKED) {
+      const bf16x4 q = side[nt][mt];
+      return f32x4{(float)q[0], (float)q[1], (float)q[2], (float)q[3]};
+    } else if constexpr (PREFETCH) {
+      return side[nt][mt];
+    } else {
+      return has_res ? load4(R + (int64_t)m * a.ldr + n) : load4(X + (int64_t)m * a.ldaux + n);
+    }
+  };
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m0 + (wr * MT + mt) * 16 + r16;
+    if (m >= a.M) continue;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n0 + (wc * NT + nt) * 16 + 4 * g;
+      if (n >= a.N) continue;  // N % 4 == 0: a group of 4 is all in or all out
+      f32x4 v = acc[nt][mt] * a.alpha;
+      if (relu) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      if (auxm) {
+        const f32x4 x = side_f32(nt, mt, m, n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = x[r] > 0.f ? v[r] * a.aux_scale : 0.f;
+      }
+      if (drop) {
+        uint64_t idx = (uint64_t)m * (uint64_t)a.N + (uint64_t)n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = lako_keep(a.drop_key, idx + r, a.drop_thresh) ? v[r] * a.drop_scale : 0.f;
+      }
+      if (has_res) v += side_f32(nt, mt, m, n);
+      TO* cp = C + (int64_t)m * a.ldc + n;
+      if constexpr (sizeof(TO) == 4) {
+        if (atomic) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) atomicAdd(reinterpret_cast<float*>(cp) + r, v[r]);
+          continue;
+        }
+      }
+      if (!(a.debug & 8)) store4(cp, v);
+    }
+  }
+}
+
 // Workgroup tile = (WM·MT·16) × (WN·NT·16); WM×WN waves, each owning MT×NT MFMA 16×16 tiles.
 //   <2,2,4,4> 128×128, 4 waves, 64 KiB LDS (2 workgroups / CU)      — small / skinny problems
 //   <2,4,8,4> 256×256, 8 waves, 128 KiB LDS (1 workgroup / CU)      — half the LDS+L2 bytes per FLOP
-template <typename T, typename TO, int WM, int WN, int MT, int NT, bool SPREAD>
+template <typename T, typename TO, int WM, int WN, int MT, int NT>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
   constexpr int NW = WM * WN, BM = WM * MT * 16, BN = WN * NT * 16;
   constexpr int A_BYTES = BM * TKB, B_BYTES = BN * TKB, BUF = A_BYTES + B_BYTES;
@@ -194,14 +275,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
 #pragma unroll
         for (int j = 0; j < PA + PB; ++j) piece(j);
       };
-      // DMA placement.  One LDS-DMA piece costs its wave ≈60 cycles of issue among bare MFMAs but 100–185 inside a
-      // burst next to the fragment reads (MI355X_MICROARCH.md, cycle constants), and a K-step has only 1024 MFMA cycles
-      // per wave.  spread = 1: the PA+PB pieces go out one per row of MFMAs in the first K-half.
-      // spread = 0 (burst): STAGGER — waves w and w + NW/2 share a SIMD; the first half issues its burst before the
-      // K-step's fragment reads, the second half after the first MT/4 rows of MFMAs.
-      constexpr bool spread = SPREAD;
-      const bool late = !spread && a.stagger && NW == 8 && wave >= NW / 2;
-      if (!spread && !late) prefetch();
+      // DMA placement: STAGGER — waves w and w + NW/2 share a SIMD; the first half issues its burst before the
+      // K-step's fragment reads, the second half after the first MT/4 rows of MFMAs.  (Dealing the pieces out one per
+      // row of MFMAs instead measured equal to 3 % slower: the L2→LDS path, not the issue slot, is the limit.)
+      const bool late = a.stagger && NW == 8 && wave >= NW / 2;
+      if (!late) prefetch();
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh) {
         u32x4 af[MT], bf[NT];
@@ -221,25 +299,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
         };
         constexpr int Q = MT / 4;
         if (kh == 0) {
-          if constexpr (spread) {
-            constexpr int PER = (PA + PB + MT - 1) / MT;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-              mma_rows(mt, mt + 1);
-              __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-              for (int q = 0; q < PER; ++q) piece(mt * PER + q);
-              __builtin_amdgcn_sched_barrier(0);
-            }
-          } else {
-            mma_rows(0, Q);
-            if (late) {
-              __builtin_amdgcn_sched_barrier(0);
-              prefetch();
-              __builtin_amdgcn_sched_barrier(0);
-            }
-            mma_rows(Q, MT);
+          mma_rows(0, Q);
+          if (late) {
+            __builtin_amdgcn_sched_barrier(0);
+            prefetch();
+            __builtin_amdgcn_sched_barrier(0);
           }
+          mma_rows(Q, MT);
         } else {
           // the wait for the next K-slice and the barrier sit Q rows of MFMAs before the end of the step: late enough
           // that the DMA had the step to land (the scheduler would hoist them to the top of this K-half), early
@@ -317,74 +383,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
       continue;
     }
   }
-  // pass 1: issue EVERY residual / aux load of the wave's sub-tiles before the first use (a load → wait → use
-  // chain per sub-tile would pay one memory round trip per 16×16 block); addresses clamped in-bounds
-  // (kept packed: 2 registers per sub-tile when both dtypes are bf16)
-  constexpr bool PACKED = sizeof(T) == 2 && sizeof(TO) == 2;
-  using SideT = typename std::conditional<PACKED, bf16x4, f32x4>::type;
-  constexpr bool PREFETCH = MT * NT <= 16;   // 256² tile: 64 more live registers would spill next to the wide epilogue (measured equal without)
-  SideT side[PREFETCH ? NT : 1][PREFETCH ? MT : 1];
-  if (PREFETCH && (has_res || auxm)) {
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int m = min(m0 + (wr * MT + mt) * 16 + r16, a.M - 1);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int n = min(n0 + (wc * NT + nt) * 16 + 4 * g, a.N - 4);
-        if constexpr (PACKED && PREFETCH) {
-          side[nt][mt] = has_res ? *reinterpret_cast<const bf16x4*>(R + (int64_t)m * a.ldr + n)
-                                 : *reinterpret_cast<const bf16x4*>(X + (int64_t)m * a.ldaux + n);
-        } else if constexpr (PREFETCH) {
-          side[nt][mt] = has_res ? load4(R + (int64_t)m * a.ldr + n) : load4(X + (int64_t)m * a.ldaux + n);
-        }
-      }
-    }
-  }
-  auto side_f32 = [&](int nt, int mt, int m, int n) -> f32x4 {
-    if constexpr (PREFETCH && PACKED) {
-      const bf16x4 q = side[nt][mt];
-      return f32x4{(float)q[0], (float)q[1], (float)q[2], (float)q[3]};
-    } else if constexpr (PREFETCH) {
-      return side[nt][mt];
-    } else {
-      return has_res ? load4(R + (int64_t)m * a.ldr + n) : load4(X + (int64_t)m * a.ldaux + n);
-    }
-  };
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int m = m0 + (wr * MT + mt) * 16 + r16;
-    if (m >= a.M) continue;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int n = n0 + (wc * NT + nt) * 16 + 4 * g;
-      if (n >= a.N) continue;  // N % 4 == 0: a group of 4 is all in or all out
-      f32x4 v = acc[nt][mt] * a.alpha;
-      if (relu) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-      }
-      if (auxm) {
-        const f32x4 x = side_f32(nt, mt, m, n);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = x[r] > 0.f ? v[r] * a.aux_scale : 0.f;
-      }
-      if (drop) {
-        uint64_t idx = (uint64_t)m * (uint64_t)a.N + (uint64_t)n;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = lako_keep(a.drop_key, idx + r, a.drop_thresh) ? v[r] * a.drop_scale : 0.f;
-      }
-      if (has_res) v += side_f32(nt, mt, m, n);
-      TO* cp = C + (int64_t)m * a.ldc + n;
-      if constexpr (sizeof(TO) == 4) {
-        if (atomic) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) atomicAdd(reinterpret_cast<float*>(cp) + r, v[r]);
-          continue;
-        }
-      }
-      if (!(a.debug & 8)) store4(cp, v);
-    }
-  }
+  nt_store_tile<T, TO, WM, WN, MT, NT>(a, acc, m0, n0, wr, wc, lane);
     if (!has_next) break;
     tile = next_tile;
     m0 = nm0;
@@ -392,6 +391,73 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
     rows_a = min(BM, a.M - m0);
     rows_b = min(BN, a.N - n0);
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// NT, SKINNY problems (the decoder's 128-row GEMMs, the LM head): a handful of 128×128 tiles, so every workgroup
+// is alone on its CU and nothing hides the global→LDS latency of the 2-buffer kernel above — ≈2 µs per K-step,
+// 16–30 µs per GEMM of ≈0.5 GFLOP, 145 of them per training step.  Here the K-slices run through a 4-slot ring
+// (32 KiB per slot): three slices are always in flight, retired by a COUNTED s_waitcnt (every slice is exactly
+// RING_P wave-instructions per wave — slices past K are issued too, fully out of bounds, they move no bytes),
+// one barrier per K-step.  2×2 waves of 64×64; generic epilogue.
+// ---------------------------------------------------------------------------------------------
+constexpr int RING_NST = 4, RING_BM = 128, RING_STAGE = 2 * RING_BM * TKB, RING_P = 2 * RING_BM / 8 / 4;
+static_assert(RING_P == 8, "the counted waits below assume 8 DMA pieces per wave and slice");
+
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void gemm_nt_ring_kernel(NtArgs a) {
+  constexpr int WM = 2, WN = 2, MT = 4, NT = 4, NW = 4, A_BYTES = RING_BM * TKB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave / WN, wc = wave % WN;
+  const int64_t lda_b = a.lda * sizeof(T), ldb_b = a.ldb * sizeof(T);
+  const int kbytes = a.K * (int)sizeof(T);
+  const int nk = (kbytes + TKB - 1) / TKB;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int tile = blockIdx.x;
+  const int m0 = (tile / a.tiles_n) * RING_BM, n0 = (tile % a.tiles_n) * RING_BM;
+  const int rows_a = min(RING_BM, a.M - m0), rows_b = min(RING_BM, a.N - n0);
+  const char* Abase = a.A + (int64_t)m0 * lda_b;
+  const char* Bbase = a.B + (int64_t)n0 * ldb_b;
+  auto issue = [&](int t) {     // slice t → slot t % RING_NST (all out of bounds once t >= nk)
+    char* slot = smem + (t % RING_NST) * RING_STAGE;
+    const int koff = t * TKB;
+    stage_rows<RING_BM, NW>(slot, Abase + koff, rows_a, lda_b, kbytes - koff, wave, lane);
+    stage_rows<RING_BM, NW>(slot + A_BYTES, Bbase + koff, rows_b, ldb_b, kbytes - koff, wave, lane);
+  };
+#pragma unroll
+  for (int t = 0; t < RING_NST - 1; ++t) issue(t);
+
+  f32x4 acc[NT][MT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int t = 0; t < nk; ++t) {
+    // slices t+1, t+2 may stay in flight: 2 × RING_P wave-instructions; then every wave's pieces of slice t are in
+    // LDS and every wave has finished reading slice t-1, whose slot the next issue overwrites
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue(t + RING_NST - 1);
+    const char* As = smem + (t % RING_NST) * RING_STAGE;
+    const char* Bs = As + A_BYTES;
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      u32x4 af[MT], bf[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bf[nt] = read_frag_rows(Bs, (wc * NT + nt) * 16 + r16, kh * 4 + g);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) af[mt] = read_frag_rows(As, (wr * MT + mt) * 16 + r16, kh * 4 + g);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt][mt] = Mma<T>::run(bf[nt], af[mt], acc[nt][mt]);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the (empty) slices issued past K
+  nt_store_tile<T, TO, WM, WN, MT, NT>(a, acc, m0, n0, wr, wc, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -849,7 +915,7 @@ int g_tn_big = 1;
 int g_nt_wide_epi = 1;
 int g_nt_group_m = 8;
 int g_nt_debug = 0;
-int g_nt_spread = 0;   // measured equal to slightly slower than the burst + stagger placement (tools/bench_ops.py --variants 2,102)
+int g_nt_ring = 1;      // skinny problems go to gemm_nt_ring_kernel ("gemm_nt_ring" 0 disables; variant 4 forces it)
 int g_nt_stagger = 1;
 int g_nt_persistent = 1;
 int g_nt_variant = -1;   // -1 auto; 0: 128x128/4 waves; 1: 256x128/8 waves; 2: 256x256/8 waves (lako_set_tuning)
@@ -859,9 +925,7 @@ void launch_nt_cfg(NtArgs a, hipStream_t s) {
   constexpr int BM = WM * MT * 16, BN = WN * NT * 16, LDS = 2 * (BM + BN) * TKB;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, TO, WM, WN, MT, NT, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, TO, WM, WN, MT, NT, false>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, TO, WM, WN, MT, NT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_done = true;
   }
@@ -880,8 +944,7 @@ void launch_nt_cfg(NtArgs a, hipStream_t s) {
   int grid = a.tiles_m * a.tiles_n;
   if (g_nt_persistent && grid > 256 * per_cu) grid = 256 * per_cu;
   if ((g_nt_debug >> 8) > 0 && grid > (g_nt_debug >> 8)) grid = g_nt_debug >> 8;   // timing experiment: fewer resident workgroups
-  if (g_nt_spread) hipLaunchKernelGGL((gemm_nt_kernel<T, TO, WM, WN, MT, NT, true>), dim3(grid), dim3(WM * WN * 64), LDS, s, a);
-  else hipLaunchKernelGGL((gemm_nt_kernel<T, TO, WM, WN, MT, NT, false>), dim3(grid), dim3(WM * WN * 64), LDS, s, a);
+  hipLaunchKernelGGL((gemm_nt_kernel<T, TO, WM, WN, MT, NT>), dim3(grid), dim3(WM * WN * 64), LDS, s, a);
 }
 
 template <typename T, typename TO>
@@ -909,6 +972,21 @@ int launch_nt(const NtArgs& a, hipStream_t s) {
       return 0;
     }
     v = 2;
+  }
+  if (v == 4 || (g_nt_variant < 0 && g_nt_ring && (int64_t)cdiv(a.M, RING_BM) * cdiv(a.N, RING_BM) <= 256)) {
+    // skinny: at most one 128² tile per CU → the 4-slot ring hides the global→LDS latency inside the workgroup
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_ring_kernel<T, TO>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, RING_NST * RING_STAGE);
+      attr_done = true;
+    }
+    NtArgs b = a;
+    b.tiles_m = cdiv(a.M, RING_BM);
+    b.tiles_n = cdiv(a.N, RING_BM);
+    b.debug = 0;
+    hipLaunchKernelGGL((gemm_nt_ring_kernel<T, TO>), dim3(b.tiles_m * b.tiles_n), dim3(256), RING_NST * RING_STAGE, s, b);
+    return 0;
   }
   if (v == 2) launch_nt_cfg<T, TO, 2, 4, 8, 4>(a, s);
   else if (v == 1) launch_nt_cfg<T, TO, 4, 2, 4, 4>(a, s);
@@ -1063,8 +1141,8 @@ extern "C" int lako_set_tuning(const char* key, int value) {
     g_nt_variant = value;
     return LAKO_OK;
   }
-  if (key && !strcmp(key, "gemm_nt_spread")) {
-    g_nt_spread = value;
+  if (key && !strcmp(key, "gemm_nt_ring")) {
+    g_nt_ring = value;
     return 0;
   }
   if (key && !strcmp(key, "gemm_nt_debug")) {

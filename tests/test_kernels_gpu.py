@@ -62,10 +62,11 @@ def test_gemm_nt_plain(ops, ref, dt, M, N, K):
         close(C, Cr, T, f"gemm_nt {dt}->{out_t} {M}x{N}x{K}")
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
-@pytest.mark.parametrize("M,N,K", [(1024, 768, 768), (700, 520, 200), (256, 256, 32), (2048, 2304, 768), (300, 264, 3072)])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("M,N,K", [(1024, 768, 768), (700, 520, 200), (256, 256, 32), (2048, 2304, 768), (300, 264, 3072), (128, 768, 72)])
 def test_gemm_nt_tile_variants(ops, ref, variant, M, N, K):
-    """every tile variant of the bf16 NT kernel (0: 128², 1: 256×128, 2: 256² 2-buffer, 3: 256² 4-slot ring),
+    """every tile variant of the bf16 NT kernel (0: 128², 1: 256×128, 2: 256² 2-buffer, 3: 256² 4-slot ring, 4: the 128²
+    4-slot ring that skinny problems are dispatched to),
     persistent and one-tile-per-workgroup grids, ragged edges, fused epilogues."""
     T = torch.bfloat16
     A, B = rnd(M, K, dtype=T, seed=41), rnd(N, K, dtype=T, seed=42)

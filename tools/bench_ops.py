@@ -55,9 +55,8 @@ for variant in ([int(v) for v in args.variants.split(",")] if "gemm" in only els
     ops.set_tuning("gemm_nt_stagger", 0 if 20 <= variant < 30 else 1)
     ops.set_tuning("gemm_nt_wide_epi", 0 if 30 <= variant < 40 else 1)
     ops.set_tuning("gemm_nt_debug", {7: 1, 8: 2, 9: 4, 14: 8, 11: 128 << 8, 12: 64 << 8, 13: (128 << 8) | 1}.get(variant // 10, 0))   # 7x: no K-loop DMA; 8x: every DMA hits L2 (timing experiments, wrong results)
-    ops.set_tuning("gemm_nt_spread", 1 if variant // 10 == 10 else 0)      # 10x: one DMA piece per MFMA row instead of the burst
     ops.set_tuning("gemm_nt_group_m", {4: 0, 5: 4, 6: 16}.get(variant // 10, 8))
-    print(f"--- gemm_nt variant {variant % 10} (-1 auto, 0 128x128, 1 256x128, 2 256x256, 3 ring) "
+    print(f"--- gemm_nt variant {variant % 10} (-1 auto, 0 128x128, 1 256x128, 2 256x256, 3 ring256, 4 ring128) "
           f"persistent={not 10 <= variant < 20} stagger={not 20 <= variant < 30} wide_epi={not 30 <= variant < 40} "
           f"group_m={ {4: 0, 5: 4, 6: 16}.get(variant // 10, 8)}", flush=True)
     for nm, (M, Nn, K), kw in [
@@ -69,6 +68,10 @@ for variant in ([int(v) for v in args.variants.split(",")] if "gemm" in only els
         ("nt dxkv  [Me,18432]x[768,18432]", (Me, d, Ld * 2 * inner), {}),
         ("nt dpre  [Me,768]x[3072,768] auxmask", (Me, f, d), dict(aux=True)),
         ("nt lmhead[128,768]x[32128,768] f32 out", (Md, V, d), dict(f32=True)),
+        ("nt dec qkv [128,768]x[2304,768]", (Md, 3 * inner, d), {}),
+        ("nt dec o+res [128,768]x[768,768]", (Md, d, inner), dict(resid=True, drop=drop)),
+        ("nt dec wi  [128,768]x[3072,768] relu+drop", (Md, f, d), dict(relu=True, drop=drop)),
+        ("nt dec wo  [128,3072]x[768,3072] res+drop", (Md, d, f), dict(resid=True, drop=drop)),
         ("nt square 4096^3", (4096, 4096, 4096), {}),
         ("nt square 8192^3", (8192, 8192, 8192), {}),
         ("nt square 8192^3, row stride 8192+64", (8192, 8192, 8192), dict(pad=64)),
