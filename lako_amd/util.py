@@ -6,14 +6,22 @@
   AdamW                            the HF<=4 `transformers.AdamW(correct_bias=False)` src/util.py:225 builds
   clip_grad_norm_(model, max_norm) train_reader.py:76 (torch.nn.utils.clip_grad_norm_)
   average_main / weighted_average  src/util.py:248-275 (scalar reduces to rank 0)
+  save / load / symlink_force      src/util.py:63-71,105-146 (checkpoint directory: save_pretrained files +
+                                   optimizer.pth.tar + `latest` symlink)
 
 The optimizer is fused: one kernel launch updates the whole flat fp32 parameter buffer (clip coefficient,
 Adam moments without bias correction, decoupled weight decay) and writes the low-precision shadow.
 """
 from __future__ import annotations
 
+import errno
+import logging
+import os
+
 import torch
 import torch.distributed as dist
+
+logger = logging.getLogger(__name__)
 
 
 def _model_of(params):
@@ -171,3 +179,55 @@ def weighted_average(x, count, opt):
     dist.reduce(t_loss, 0, op=dist.ReduceOp.SUM)
     dist.reduce(t_total, 0, op=dist.ReduceOp.SUM)
     return (t_loss / t_total).item(), t_total.item()
+
+
+# ---- checkpoint directory (src/util.py:63-71, 105-146) -------------------------------------------------------
+def symlink_force(target, link_name):
+    """`ln -sf`: replace an existing link (src/util.py:63-71)."""
+    try:
+        os.symlink(target, link_name)
+    except OSError as e:
+        if e.errno != errno.EEXIST:
+            raise
+        os.remove(link_name)
+        os.symlink(target, link_name)
+
+
+def save(model, optimizer, scheduler, step, best_eval_metric, opt, dir_path, name):
+    """<dir_path>/checkpoint/<name>/ = save_pretrained files + optimizer.pth.tar {step, optimizer, scheduler, opt,
+    best_eval_metric}; <dir_path>/checkpoint/latest → that directory (src/util.py:105-121).  The optimizer entry
+    carries the fused AdamW's flat moment buffers (AdamW.state_dict)."""
+    model_to_save = model.module if hasattr(model, "module") else model
+    path = os.path.join(dir_path, "checkpoint")
+    epoch_path = os.path.join(path, name)
+    os.makedirs(epoch_path, exist_ok=True)
+    model_to_save.save_pretrained(epoch_path)
+    checkpoint = {"step": step, "optimizer": optimizer.state_dict(), "scheduler": scheduler.state_dict(), "opt": opt,
+                  "best_eval_metric": best_eval_metric}
+    torch.save(checkpoint, os.path.join(epoch_path, "optimizer.pth.tar"))
+    symlink_force(epoch_path, os.path.join(path, "latest"))
+
+
+def load(model_class, dir_path, opt, reset_params=False, **model_kw):
+    """Inverse of save (src/util.py:124-146): returns (model, optimizer, scheduler, opt_checkpoint, step,
+    best_eval_metric).  `reset_params=True` keeps the weights but builds a fresh optimizer / scheduler from `opt`
+    (what train_reader.py:255 does when --model_path is given).  Accepts the older key `best_dev_em`."""
+    epoch_path = os.path.realpath(dir_path)
+    optimizer_path = os.path.join(epoch_path, "optimizer.pth.tar")
+    logger.info("Loading %s", epoch_path)
+    model = model_class.from_pretrained(epoch_path, **model_kw)
+    device = getattr(opt, "device", None)
+    if device is not None and torch.device(device).type == "cuda":
+        model = model.to(device)
+    logger.info("loading checkpoint %s", optimizer_path)
+    checkpoint = torch.load(optimizer_path, map_location="cpu", weights_only=False)
+    opt_checkpoint = checkpoint["opt"]
+    step = checkpoint["step"]
+    best_eval_metric = checkpoint["best_eval_metric"] if "best_eval_metric" in checkpoint else checkpoint["best_dev_em"]
+    if not reset_params:
+        optimizer, scheduler = set_optim(opt_checkpoint, model)
+        scheduler.load_state_dict(checkpoint["scheduler"])
+        optimizer.load_state_dict(checkpoint["optimizer"])
+    else:
+        optimizer, scheduler = set_optim(opt, model)
+    return model, optimizer, scheduler, opt_checkpoint, step, best_eval_metric

@@ -320,10 +320,44 @@ def make_collate():
     print("collate ok", sorted({k.split("/")[0] for k in out}))
 
 
+EVAL_STRINGS = [
+    # (prediction, gold dict {answer: soft score})
+    ("The Eiffel Tower", {"eiffel tower": 1.0, "tower": 0.6}),
+    ("a red, fire-truck!", {"red fire truck": 0.3, "firetruck": 1.0, "red firetruck": 0.6}),
+    ("an apple", {"apple pie": 1.0, "banana": 0.3}),
+    ("ski", {"skiing": 1.0, "snowboarding": 0.6}),
+    ("", {"nothing": 1.0}),
+    ("New   York\tCity", {"new york city": 1.0, "nyc": 0.6}),
+    ("theatre", {"the theatre": 0.6, "a theater": 1.0}),
+    ("it's 3.5%", {"its 35": 1.0}),
+    ("Café au lait", {"cafe au lait": 1.0, "café au lait": 0.3}),
+    ("frisbee", {"frisbee": 1.0, "Frisbee.": 0.6, "disc": 0.3}),
+    ("ÅNGSTRÖM unit", {"ångström unit": 1.0}),
+    ("the", {"a": 1.0}),
+]
+
+
+def make_evaluation():
+    """Golden values of the reference's answer metrics (src/evaluation.py: normalize_answer, ems, includ_ems) on
+    fixed strings; the predictions / golds are data of this repository."""
+    import json
+    import src.evaluation as rev
+    rows = []
+    for pred, golds in EVAL_STRINGS:
+        rows.append({"prediction": pred, "golds": golds,
+                     "normalized": rev.normalize_answer(pred),
+                     "golds_normalized": {k: rev.normalize_answer(k) for k in golds},
+                     "ems": float(rev.ems(pred, golds)), "includ_ems": float(rev.includ_ems(pred, golds))})
+    with open(os.path.join(ROOT, "tests", "golden", "evaluation.json"), "w") as f:
+        json.dump(rows, f, indent=1, ensure_ascii=False)
+    print("wrote evaluation.json", len(rows))
+
+
 if __name__ == "__main__":
     tiny = O.T5Dims.named("tiny")
     make_tables()
     make_collate()
+    make_evaluation()
     make_case("tiny_a", tiny, B=3, N=3, L=12, T=5, seed=1, full_pad=(1, 2))
     make_case("tiny_fact", tiny, B=3, N=2, L=24, T=4, seed=2, fact_case=True)
     make_case("tiny_eos", tiny, B=4, N=3, L=12, T=6, seed=5, pretrain=150)

@@ -1,0 +1,102 @@
+"""§8 f3: checkpoint directory format (src/util.py:105-146) and the answer metrics (src/evaluation.py:130-167).
+
+The metric golden values were produced by the reference's own functions (oracle/make_fixtures.py::make_evaluation).
+The checkpoint tests run the host logic on the fp32 test double (tests/ref_ops.py): train 2 steps → save → load →
+the resumed run must continue exactly like the uninterrupted one (weights, AdamW moments, scheduler position)."""
+import json
+import os
+import types
+
+import torch
+
+from lako_amd import FiDT5
+from lako_amd import evaluation as E
+from lako_amd import util as U
+from tests.ref_ops import RefOps
+from tests.test_engine_cpu import build
+
+
+def test_answer_metrics_match_reference():
+    with open(os.path.join(os.path.dirname(__file__), "golden", "evaluation.json")) as f:
+        rows = json.load(f)
+    assert len(rows) >= 10
+    for r in rows:
+        assert E.normalize_answer(r["prediction"]) == r["normalized"]
+        for k, v in r["golds_normalized"].items():
+            assert E.normalize_answer(k) == v
+        assert float(E.ems(r["prediction"], r["golds"])) == r["ems"]
+        assert float(E.includ_ems(r["prediction"], r["golds"])) == r["includ_ems"]
+
+
+def test_stem_ems_and_stopword_mode():
+    class Tok:
+        def tokenize(self, s):
+            return s.split()
+
+    class Stem:
+        def stem(self, w):
+            return w[:-3] if w.endswith("ing") else w
+    golds = {"skiing": 1.0, "snowboarding": 0.6, "sledding": 0.3}
+    assert E.stem_ems("ski", golds, Tok(), Stem()) == 1.0            # best-scored gold sharing a stem wins
+    assert E.stem_ems("people snowboard", golds, Tok(), Stem()) == 0.6
+    assert E.stem_ems("swimming", golds, Tok(), Stem()) == 0
+    assert E.normalize_answer("what is the dog", dele_sw=True, stop_words=["what", "is"]) == "dog"
+
+
+def _opt():
+    return types.SimpleNamespace(optim="adamw", lr=3e-3, weight_decay=1e-2, scheduler="linear", scheduler_steps=None,
+                                 total_steps=8, warmup_steps=2, fixed_lr=False, device="cpu")
+
+
+def _steps(model, optimizer, scheduler, batches):
+    model.train()
+    for ids, mask, labels in batches:
+        model(input_ids=ids, attention_mask=mask, labels=labels)[0].backward()
+        U.clip_grad_norm_(model, 1.0)
+        optimizer.step()
+        scheduler.step()
+        model.zero_grad()
+
+
+def test_save_load_resume_is_exact(tmp_path):
+    from oracle import fid_t5_oracle as O
+    z, dims, w, model = build("tiny_a")
+    B, N, L = z["input_ids"].shape
+    T = z["labels"].shape[1]
+    batches = [O.synthetic_batch(B, N, L, T, dims.vocab_size, seed=700 + k) for k in range(4)]
+    optimizer, scheduler = U.set_optim(_opt(), model)
+    _steps(model, optimizer, scheduler, batches[:2])
+    U.save(model, optimizer, scheduler, 2, 0.25, _opt(), str(tmp_path), "step-2")
+    ck = tmp_path / "checkpoint"
+    assert (ck / "step-2" / "optimizer.pth.tar").exists() and (ck / "step-2" / "config.json").exists()
+    assert os.path.islink(ck / "latest") and os.path.realpath(ck / "latest") == os.path.realpath(ck / "step-2")
+    _steps(model, optimizer, scheduler, batches[2:])                      # the uninterrupted run
+
+    m2, o2, s2, opt_ck, step, best = U.load(FiDT5, str(ck / "latest"), _opt(), dtype=torch.float32, _ops=RefOps())
+    assert step == 2 and best == 0.25 and opt_ck.lr == 3e-3
+    assert s2.last_epoch == 2 and abs(s2.get_last_lr()[0] - scheduler.get_last_lr()[0]) > 0   # position restored, not final
+    _steps(m2, o2, s2, batches[2:])
+    assert torch.equal(m2._engine.P, model._engine.P)
+    assert torch.equal(m2._engine.opt_m, model._engine.opt_m) and torch.equal(m2._engine.opt_v, model._engine.opt_v)
+    assert s2.get_last_lr() == scheduler.get_last_lr()
+
+    # a second save under the same link name replaces the symlink (symlink_force)
+    U.save(m2, o2, s2, 4, 0.5, _opt(), str(tmp_path), "step-4")
+    assert os.path.realpath(ck / "latest") == os.path.realpath(ck / "step-4")
+
+    # reset_params: weights kept, optimizer and scheduler fresh (train_reader.py:255)
+    m3, o3, s3, _, step3, best3 = U.load(FiDT5, str(ck / "step-2"), _opt(), reset_params=True, dtype=torch.float32,
+                                         _ops=RefOps())
+    assert step3 == 2 and s3.last_epoch == 0 and m3._get_engine().opt_m is None
+
+
+def test_load_accepts_legacy_metric_key(tmp_path):
+    _, _, _, model = build("tiny_a")
+    optimizer, scheduler = U.set_optim(_opt(), model)
+    U.save(model, optimizer, scheduler, 7, 0.1, _opt(), str(tmp_path), "best_dev")
+    fp = tmp_path / "checkpoint" / "best_dev" / "optimizer.pth.tar"
+    ck = torch.load(fp, weights_only=False)
+    ck["best_dev_em"] = ck.pop("best_eval_metric")
+    torch.save(ck, fp)
+    *_, step, best = U.load(FiDT5, str(tmp_path / "checkpoint" / "best_dev"), _opt(), dtype=torch.float32, _ops=RefOps())
+    assert (step, best) == (7, 0.1)

@@ -38,37 +38,48 @@ def synthetic_loader(opt, cfg, device, n_batches):
         yield synthetic_batch(B, N, L, T, cfg.vocab_size, seed=opt.seed + opt.global_rank * 7919 + i, device=device)
 
 
-def json_loader(opt, path, tokenizer, device, shuffle):
-    """train_reader.py:40-48 / :123-131: DataLoader over the reference's JSON examples."""
+def json_dataset(opt, path):
     import json
 
+    from lako_amd.data import Dataset
+    with open(path) as f:
+        return Dataset(json.load(f), opt)
+
+
+def json_loader(opt, ds, tokenizer, device, shuffle, with_index=False):
+    """train_reader.py:40-48 / :123-131: DataLoader over the reference's JSON examples."""
     from torch.utils.data import DataLoader, RandomSampler, SequentialSampler
 
-    from lako_amd.data import Collator, Dataset
-    with open(path) as f:
-        ds = Dataset(json.load(f), opt)
+    from lako_amd.data import Collator
     col = Collator(opt.text_maxlength, tokenizer, answer_maxlength=opt.answer_maxlength, stream=opt.stream)
     dl = DataLoader(ds, sampler=RandomSampler(ds) if shuffle else SequentialSampler(ds),
                     batch_size=opt.per_gpu_batch_size, drop_last=shuffle, num_workers=2, collate_fn=col)
-    for _, labels, _, ids, mask in dl:
-        yield ids.to(device, non_blocking=True), mask.to(device, non_blocking=True), labels.to(device, non_blocking=True)
+    for idx, labels, _, ids, mask in dl:
+        batch = (ids.to(device, non_blocking=True), mask.to(device, non_blocking=True), labels.to(device, non_blocking=True))
+        yield (idx,) + batch if with_index else batch
 
 
-def evaluate(model, batches, opt):
-    """Greedy decode + exact match of the generated ids against the label ids (train_reader.py:123-169; the string
-    metrics of src/evaluation.py operate on detokenised text and are out of the hot path)."""
+def evaluate(model, batches, opt, tokenizer=None, dataset=None):
+    """Greedy decode (max_length 50) and score (train_reader.py:123-169).  With a tokenizer and the JSON dataset:
+    the reference's soft exact match `ems(decoded answer, example['answer'])` (src/evaluation.py:158).  On synthetic
+    batches (no tokenizer, no strings): exact match of the generated ids against the label ids."""
+    from lako_amd import evaluation as E
     model.eval()
-    hit = total = 0
+    scores = []
     with torch.no_grad():
-        for ids, mask, labels in batches:
+        for batch in batches:
+            idx, (ids, mask, labels) = (batch[0], batch[1:]) if len(batch) == 4 else (None, batch)
             out = model.generate(input_ids=ids, attention_mask=mask, max_length=50)
-            for b in range(ids.shape[0]):
-                gold = [t for t in labels[b].tolist() if t not in (-100, 0, 1)]
-                pred = [t for t in out[b].tolist() if t not in (0, 1)]
-                hit += int(gold == pred)
-                total += 1
+            if tokenizer is not None and dataset is not None:
+                for k, ans in enumerate(tokenizer.batch_decode(out, skip_special_tokens=True)):
+                    scores.append(float(E.ems(ans, dataset.get_example(int(idx[k]))["answer"])))
+            else:
+                for b in range(ids.shape[0]):
+                    gold = [t for t in labels[b].tolist() if t not in (-100, 0, 1)]
+                    pred = [t for t in out[b].tolist() if t not in (0, 1)]
+                    scores.append(float(gold == pred))
     model.train()
-    score, total = U.weighted_average(hit / max(total, 1), total, opt)
+    score, _ = U.weighted_average(sum(scores) / max(len(scores), 1), len(scores), opt)
     return score
 
 
@@ -98,29 +109,41 @@ def main():
             raise SystemExit(f"cannot load a T5 tokenizer ({e}); pass --tokenizer /path/to/t5-tokenizer or use --synthetic")
     cfg = FiDConfig.named(opt.model_size, dropout_rate=opt.dropout)
     dtype = torch.bfloat16 if opt.dtype == "bf16" else torch.float32
-    if opt.model_path == "none":
-        model = FiDT5(cfg, dtype=dtype, seed=opt.seed + opt.global_rank)
-        with torch.no_grad():
-            model._params_by_plain["shared.weight"].mul_(0.05)      # random-init stand-in for t5-* weights
-    else:
-        model = FiDT5.from_pretrained(opt.model_path, dtype=dtype, seed=opt.seed + opt.global_rank)
-    model = model.cuda(local_rank)
-    model.set_checkpoint(opt.use_checkpoint)
+    train_ds = eval_ds = None
+    if tokenizer is not None:
+        train_ds, eval_ds = json_dataset(opt, opt.train_data), json_dataset(opt, opt.eval_data)
 
     def train_batches(n):
         if tokenizer is None:
             return synthetic_loader(opt, cfg, opt.device, n)
-        return json_loader(opt, opt.train_data, tokenizer, opt.device, True)
+        return json_loader(opt, train_ds, tokenizer, opt.device, True)
 
     def eval_batches():
         if tokenizer is None:
             return list(synthetic_loader(opt, cfg, opt.device, 2))
-        return json_loader(opt, opt.eval_data, tokenizer, opt.device, False)
+        return json_loader(opt, eval_ds, tokenizer, opt.device, False, with_index=True)
 
-    steps_per_epoch = opt.steps or 100
+    # train_reader.py:255-262: steps/epoch from the dataset, warm-up = 6 % of all steps
+    steps_per_epoch = opt.steps or (len(train_ds) // opt.per_gpu_batch_size if train_ds is not None else 100)
     opt.total_steps = steps_per_epoch * opt.epochs
     opt.warmup_steps = int(opt.total_steps * 0.06)
-    optimizer, scheduler = U.set_optim(opt, model)
+    step, best = 0, 0.0
+    if opt.model_path == "none":
+        model = FiDT5(cfg, dtype=dtype, seed=opt.seed + opt.global_rank)
+        with torch.no_grad():
+            model._params_by_plain["shared.weight"].mul_(0.05)      # random-init stand-in for t5-* weights
+        model = model.cuda(local_rank)
+        optimizer, scheduler = U.set_optim(opt, model)
+    elif os.path.exists(os.path.join(os.path.realpath(opt.model_path), "optimizer.pth.tar")):
+        # a checkpoint directory written by util.save: weights kept, fresh optimizer / scheduler (train_reader.py:255)
+        model, optimizer, scheduler, _, step, best = U.load(FiDT5, opt.model_path, opt, reset_params=True, dtype=dtype,
+                                                            seed=opt.seed + opt.global_rank)
+        model = model.cuda(local_rank)
+        logger.info(f"model loaded from {opt.model_path} (step {step}, best {best})")
+    else:
+        model = FiDT5.from_pretrained(opt.model_path, dtype=dtype, seed=opt.seed + opt.global_rank).cuda(local_rank)
+        optimizer, scheduler = U.set_optim(opt, model)
+    model.set_checkpoint(opt.use_checkpoint)
     if opt.is_distributed:
         from lako_amd.dist import GradSync, broadcast_parameters
         broadcast_parameters(model)
@@ -128,7 +151,6 @@ def main():
 
     torch.manual_seed(opt.global_rank + opt.seed)
     model.train()
-    step, best = 0, 0.0
     for epoch in range(1, opt.epochs + 1):
         curr_loss = torch.zeros((), device=opt.device)
         t0 = time.time()
@@ -148,15 +170,14 @@ def main():
                 break
         torch.cuda.synchronize()
         dt = time.time() - t0
-        dev_em = evaluate(model, eval_batches(), opt)
+        dev_em = evaluate(model, eval_batches(), opt, tokenizer, eval_ds)
         if opt.is_main:
             logger.info(f"epoch {epoch} |step {step} |train loss: {curr_loss.item() / max(n, 1):.3f} |"
                         f"evaluation: {100 * dev_em:.2f}EM |lr: {scheduler.get_last_lr()[0]:.5f} |"
                         f"{n * ids.shape[0] * opt.world_size / dt:.1f} samples/s")
-            if dev_em > best:
+            if dev_em > best:      # train_reader.py:104-107
                 best = dev_em
-                path = os.path.join(opt.checkpoint_dir, opt.name, "checkpoint", "best_dev")
-                model.save_pretrained(path)
+                U.save(model, optimizer, scheduler, step, best, opt, os.path.join(opt.checkpoint_dir, opt.name), "best_dev")
         if opt.steps and step >= opt.steps:
             break
     if opt.is_distributed:
