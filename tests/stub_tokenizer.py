@@ -14,7 +14,22 @@ class StubTokenizer:
         out = []
         for w in text.replace(":", " : ").replace(".", " . ").split():
             out.append({"</s>": 1, ".": 5, ":": 10}.get(w, 11 + zlib.crc32(w.encode()) % 50))
+            self._seen[out[-1]] = w
         return out
+
+    _seen: dict = {}
+
+    def batch_decode(self, sequences, skip_special_tokens=True):
+        """ids → text through the words seen so far (unknown ids print as <id>); 0 / 1 are pad / EOS."""
+        texts = []
+        for seq in sequences:
+            words = []
+            for t in (seq.tolist() if hasattr(seq, "tolist") else seq):
+                if skip_special_tokens and t in (0, 1):
+                    continue
+                words.append(self._seen.get(int(t), f"<{int(t)}>"))
+            texts.append(" ".join(words))
+        return texts
 
     def batch_encode_plus(self, texts, max_length=None, pad_to_max_length=True, return_tensors="pt", truncation=False):
         seqs = [self._ids(t) for t in texts]

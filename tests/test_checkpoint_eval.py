@@ -100,3 +100,46 @@ def test_load_accepts_legacy_metric_key(tmp_path):
     torch.save(ck, fp)
     *_, step, best = U.load(FiDT5, str(tmp_path / "checkpoint" / "best_dev"), _opt(), dtype=torch.float32, _ops=RefOps())
     assert (step, best) == (7, 0.1)
+
+
+def test_test_reader_evaluate_writes_scores_and_results(tmp_path):
+    """test_reader.py::evaluate on the fp32 test double: greedy decode, the three metrics, results JSON, and the
+    per-fact cross-attention scores written back into the examples (test_reader.py:62-76,107-122)."""
+    import copy
+    import importlib.util
+    from torch.utils.data import DataLoader, SequentialSampler
+
+    from lako_amd import FiDConfig
+    from lako_amd.data import Collator, Dataset
+    from tests.stub_tokenizer import StubTokenizer
+    from tests.test_data_pipeline import EXAMPLES
+    spec = importlib.util.spec_from_file_location("reader_eval", os.path.join(os.path.dirname(__file__), "..", "test_reader.py"))
+    tr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tr)
+
+    cfg = FiDConfig(vocab_size=64, d_model=32, d_kv=32, d_ff=64, num_layers=2, num_decoder_layers=2, num_heads=2, dropout_rate=0.0)
+    model = FiDT5(cfg, dtype=torch.float32, seed=3, _ops=RefOps())
+    for style in ("mean", "max"):
+        for ans_attention in ("no", "yes"):
+            opt = types.SimpleNamespace(n_context=2, fact_use_way="concate", use_fact="yes", stream=2, write_results=True,
+                                        write_crossattention_scores=True, ans_attention=ans_attention,
+                                        attention_score_style=style, use_last_half_layer_attention="no", dataset="okvqa",
+                                        model_size="tiny", per_gpu_batch_size=2, text_maxlength=24, is_distributed=False,
+                                        eval_data="dev.json", version="v1", device="cpu")
+            ds = Dataset(copy.deepcopy(EXAMPLES), opt)
+            tok = StubTokenizer()
+            dl = DataLoader(ds, sampler=SequentialSampler(ds), batch_size=2, collate_fn=Collator(24, tok, stream=2))
+            em, stem_em, inc_em, total = tr.evaluate(model, ds, dl, tok, opt, str(tmp_path), stop_words=["is", "a"])
+            assert total == 3 and 0.0 <= em <= inc_em <= 1.0 and 0.0 <= stem_em <= 1.0
+            for ex in ds.data:
+                n = min(opt.n_context, len(ex["fact"]))
+                got = [f["score"] for f in ex["fact"][:n]]
+                assert all(0.0 <= s <= 1.0 for s in got) and sum(got) <= 1.0 + 1e-9
+                if ans_attention == "yes" or n == opt.n_context:
+                    assert abs(sum(got) - 1.0) < 1e-9           # softmax over exactly the scored facts
+                assert all("score" not in f for f in ex["fact"][n:])
+    res = os.listdir(tmp_path / "test_results")
+    assert len(res) == 1 and res[0].startswith("okvqa_tiny_batch_2_maxLen_24_stream_2_content_2_")
+    rows = json.load(open(tmp_path / "test_results" / res[0]))
+    assert len(rows) == 3 and {"question", "answer", "real answers", "score", "include_score", "stem_score"} <= set(rows[0])
+    assert tr.scores_file_name(opt) == "dev_full_attention_of_tiny_with_max_v1.json"
