@@ -161,6 +161,12 @@ int lako_adamw_step(float* p, const float* g, float* m, float* v, void* shadow, 
                     float grad_scale, int shadow_dtype, lako_stream_t stream);
 /* dst[c][r] = (dtype) src[r][c]  — transposed low-precision weight copies used by the dX GEMMs */
 int lako_transpose_cast(const float* src, void* dst, int64_t rows, int64_t cols, int dtype, lako_stream_t stream);
+/* the same for a whole table of matrices in one launch (all weights after an optimizer step): matrix i is
+ * src_base + desc[4i] ([rows = desc[4i+2]][cols = desc[4i+3]], fp32) → dst_base + desc[4i+1] ([cols][rows], dtype);
+ * tile_prefix[i] = number of 64×64 tiles of matrices 0..i-1, total_tiles = their sum over all n matrices.
+ * desc / tile_prefix are DEVICE arrays; offsets in elements, multiples of 4 (16-byte aligned sources). */
+int lako_transpose_cast_batched(const float* src_base, void* dst_base, const int64_t* desc, const int32_t* tile_prefix,
+                                int n, int total_tiles, int dtype, lako_stream_t stream);
 int lako_cast(const float* src, void* dst, int64_t n, int dtype, lako_stream_t stream);
 
 /* ---- small helpers ------------------------------------------------------------------------------ */

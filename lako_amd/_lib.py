@@ -72,6 +72,7 @@ SIGNATURES = {
     "lako_sumsq": [vp, i64, vp, vp],
     "lako_adamw_step": [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, f32, f32, i32, vp],
     "lako_transpose_cast": [vp, vp, i64, i64, i32, vp],
+    "lako_transpose_cast_batched": [vp, vp, vp, vp, i32, i32, i32, vp],
     "lako_cast": [vp, vp, i64, i32, vp],
     "lako_dropout_apply": [vp, vp, i64, i32, Dropout, vp],
     "lako_shift_right": [vp, vp, i32, i32, vp],

@@ -258,6 +258,57 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __rest
   }
 }
 
+// All weight matrices of the model in ONE launch (122 matrices at T5-base: one launch instead of 122 of ≈8 µs each).
+// desc[i] = {src offset, dst offset (elements), rows, cols}; tile_prefix[i] = first 64×64 tile of matrix i.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_cast_batched_kernel(const float* __restrict__ src_base, T* __restrict__ dst_base,
+                                                                     const int64_t* __restrict__ desc,
+                                                                     const int32_t* __restrict__ tile_prefix, int n) {
+  __shared__ float tile[64][65];
+  int lo = 0, hi = n - 1;                      // last i with tile_prefix[i] <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tile_prefix[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const int64_t* dd = desc + 4 * lo;
+  const float* src = src_base + dd[0];
+  T* dst = dst_base + dd[1];
+  const int64_t rows = dd[2], cols = dd[3];
+  const int t = blockIdx.x - tile_prefix[lo];
+  const int tiles_c = (int)((cols + 63) >> 6);
+  const int64_t r0 = (int64_t)(t / tiles_c) * 64, c0 = (int64_t)(t % tiles_c) * 64;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;   // 16 × 16; a thread reads 4 consecutive floats
+  const bool vec = (cols % 4 == 0) && (rows % 4 == 0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t r = r0 + ty + 16 * j, c = c0 + 4 * tx;
+    if (vec && r < rows && c + 3 < cols) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src + r * cols + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tile[ty + 16 * j][4 * tx + e] = v[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tile[ty + 16 * j][4 * tx + e] = (r < rows && c + e < cols) ? src[r * cols + c + e] : 0.f;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t c = c0 + ty + 16 * j, r = r0 + 4 * tx;    // dst row c, 4 consecutive r
+    if (c >= cols) continue;
+    if (vec && r + 3 < rows) {
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = tile[4 * tx + e][ty + 16 * j];
+      store4(dst + c * rows + r, v);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (r + e < rows) dst[c * rows + r + e] = (T)tile[4 * tx + e][ty + 16 * j];
+    }
+  }
+}
+
 // ---- cross-entropy --------------------------------------------------------------------------
 __global__ void ce_init_kernel(float* loss_out, const int64_t* labels, int64_t M) {
   // single block: count valid labels
@@ -558,6 +609,19 @@ extern "C" int lako_transpose_cast(const float* src, void* dst, int64_t rows, in
   LAKO_CHECK_ARG(grid.y < 65536, "lako_transpose_cast: too many rows");
   DISPATCH_T(dtype, hipLaunchKernelGGL((transpose_cast_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, src, (T*)dst,
                                        rows, cols));
+  LAKO_LAUNCH_CHECK();
+  return LAKO_OK;
+}
+
+extern "C" int lako_transpose_cast_batched(const float* src_base, void* dst_base, const int64_t* desc,
+                                           const int32_t* tile_prefix, int n, int total_tiles, int dtype,
+                                           lako_stream_t stream) {
+  CHECK_DTYPE("lako_transpose_cast_batched", dtype);
+  LAKO_CHECK_ARG(n > 0 && total_tiles > 0 && desc && tile_prefix, "lako_transpose_cast_batched: empty table");
+  LAKO_CHECK_ALIGN(src_base, 16);
+  LAKO_CHECK_ALIGN(dst_base, 16);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((transpose_cast_batched_kernel<T>), dim3((unsigned)total_tiles), dim3(256), 0,
+                                       (hipStream_t)stream, src_base, (T*)dst_base, desc, tile_prefix, n));
   LAKO_LAUNCH_CHECK();
   return LAKO_OK;
 }

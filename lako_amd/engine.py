@@ -162,6 +162,7 @@ class Engine:
         self.step_count = 0
         self.use_checkpoint = False
         self._ws_cache: dict = {}
+        self._tr_table = None
         self._lut_cache: dict = {}
         self.ctx: _Ctx | None = None
         self.grad_hook = None    # callable(lo, hi): gradients G[lo:hi] are final (data-parallel overlap)
@@ -213,13 +214,24 @@ class Engine:
                 out[name] = v[r0:r0 + nr] if len(b.shape) == 2 else v
         return out
 
+    def refresh_transposed(self):
+        """WT ← transposed compute-dtype copies of every GEMM weight in P, one launch over a static table."""
+        if self._tr_table is None:
+            mats = [b for b in self.blocks if b.transpose]
+            desc, prefix, total = [], [], 0
+            for b in mats:
+                desc += [b.off, b.toff, b.shape[0], b.shape[1]]
+                prefix.append(total)
+                total += -(-b.shape[0] // 64) * -(-b.shape[1] // 64)
+            self._tr_table = (torch.tensor(desc, dtype=torch.int64, device=self.device),
+                              torch.tensor(prefix, dtype=torch.int32, device=self.device), len(mats), total)
+        self.ops.transpose_cast_batched(self.P, self.WT, *self._tr_table)
+
     def refresh_shadows(self):
         """Re-derive the compute-dtype copies (W, WT) from the fp32 master after it changed."""
         if self.W is not self.P:
             self.ops.cast(self.P, self.W)
-        for b in self.blocks:
-            if b.transpose:
-                self.ops.transpose_cast(self._view(self.P, b), self._view(self.WT, b, True))
+        self.refresh_transposed()
         self.shadows_stale = False
 
     def zero_grad(self):

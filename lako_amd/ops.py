@@ -233,6 +233,13 @@ class HipOps:
         rows, cols = src.shape
         self._timed("transpose_cast", 0.0, lambda: check(self.lib.lako_transpose_cast(_p(src), _p(dst), rows, cols, _dt(dst), self._stream()), "lako_transpose_cast"))
 
+    def transpose_cast_batched(self, src_flat, dst_flat, desc, tile_prefix, n, total_tiles):
+        """every [rows, cols] fp32 matrix of the table → its [cols, rows] compute-dtype copy, one launch (desc and
+        tile_prefix are device tensors: see lako_transpose_cast_batched in include/lako_hip.h)"""
+        self._timed("transpose_cast", 0.0, lambda: check(self.lib.lako_transpose_cast_batched(
+            _p(src_flat), _p(dst_flat), _p(desc), _p(tile_prefix), int(n), int(total_tiles), _dt(dst_flat), self._stream()),
+            "lako_transpose_cast_batched"))
+
     def cast(self, src, dst):
         self._timed("cast", 0.0, lambda: check(self.lib.lako_cast(_p(src), _p(dst), src.numel(), _dt(dst), self._stream()), "lako_cast"))
 

@@ -73,9 +73,7 @@ class AdamW(torch.optim.Optimizer):
                            gnorm_sq=eng.gnorm_sq if clip is not None else None,
                            max_norm=clip if clip is not None else 0.0, grad_scale=scale)
         model._pending_clip = None
-        for b in eng.blocks:
-            if b.transpose:
-                eng.ops.transpose_cast(eng._view(eng.P, b), eng._view(eng.WT, b, True))
+        eng.refresh_transposed()
         eng.shadows_stale = False
 
     def state_dict(self):

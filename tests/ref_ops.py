@@ -231,6 +231,12 @@ class RefOps:
     def transpose_cast(self, src, dst):
         dst.copy_(src.t())
 
+    def transpose_cast_batched(self, src_flat, dst_flat, desc, tile_prefix, n, total_tiles):
+        d = desc.view(-1, 4).tolist()
+        assert len(d) == n
+        for so, do, rows, cols in d:
+            dst_flat[do:do + rows * cols].view(cols, rows).copy_(src_flat[so:so + rows * cols].view(rows, cols).t())
+
     def cast(self, src, dst):
         dst.copy_(src.view(dst.shape))
 

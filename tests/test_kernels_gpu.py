@@ -339,6 +339,24 @@ def test_optimizer(ops, ref):
         d2 = torch.empty(70 * 200, dtype=T, device=dev())
         ops.cast(src.view(-1), d2)
         assert torch.equal(d2, src.view(-1).to(T))
+    # batched form: a table of matrices in one launch — ragged (non-multiple-of-64 / of-4) and aligned shapes
+    shapes = [(70, 200), (64, 64), (3, 5), (128, 768), (257, 36), (1, 64)]
+    offs, total = [], 0
+    for r, c in shapes:
+        offs.append(total)
+        total += (r * c + 3) // 4 * 4
+    flat = rnd(total, seed=32)
+    desc, prefix, tiles = [], [], 0
+    for (r, c), o in zip(shapes, offs):
+        desc += [o, o, r, c]
+        prefix.append(tiles)
+        tiles += -(-r // 64) * -(-c // 64)
+    for T in (torch.float32, torch.bfloat16):
+        out = torch.full((total,), 7.0, dtype=T, device=dev())
+        ops.transpose_cast_batched(flat, out, torch.tensor(desc, device=dev()), torch.tensor(prefix, dtype=torch.int32, device=dev()),
+                                   len(shapes), tiles)
+        for (r, c), o in zip(shapes, offs):
+            assert torch.equal(out[o:o + r * c].view(c, r), flat[o:o + r * c].view(r, c).t().to(T)), (r, c, T)
 
 
 def test_int_helpers(ops, ref):
