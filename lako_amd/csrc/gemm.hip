@@ -14,6 +14,8 @@
 // Workgroup ids are remapped so that the tiles sharing an A row-panel run on one XCD (one L2).
 #include <type_traits>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -36,6 +38,7 @@ struct NtArgs {
   int tiles_m, tiles_n;
   int stagger;
   int debug;      // timing experiments only (bench_ops): bit 0 = skip the K-loop LDS-DMA, bit 1 = all workgroups stream tile (0,0), bit 2 = never wait for the DMA, bit 3 = no epilogue stores (results are garbage)
+  int split_k, k_chunk;   // ring kernel with LAKO_EPI_ATOMIC only: K split over split_k workgroups per tile, k_chunk BYTES each
   int group_m;    // >0: tile ids walk bands of group_m tile-rows column-major (an XCD's 32 resident tiles form a ≈group_m × 32/group_m block)
   int wide_epi;   // 256² bf16 tile: LDS-transposed epilogue with 16-B row-major stores (needs N, ldc, ldr, ldaux % 8 == 0)
 };
@@ -412,14 +415,17 @@ __global__ __launch_bounds__(256) void gemm_nt_ring_kernel(NtArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave / WN, wc = wave % WN;
   const int64_t lda_b = a.lda * sizeof(T), ldb_b = a.ldb * sizeof(T);
-  const int kbytes = a.K * (int)sizeof(T);
-  const int nk = (kbytes + TKB - 1) / TKB;
   const int r16 = lane & 15, g = lane >> 4;
-  const int tile = blockIdx.x;
+  const int ntile = a.tiles_m * a.tiles_n;
+  const int tile = blockIdx.x % ntile, split = blockIdx.x / ntile;
+  // split-K (atomic fp32 accumulation only): this workgroup owns K bytes [kb0, kb0 + kbytes)
+  const int kb0 = split * a.k_chunk;
+  const int kbytes = min(a.K * (int)sizeof(T), kb0 + a.k_chunk) - kb0;
+  const int nk = (kbytes + TKB - 1) / TKB;
   const int m0 = (tile / a.tiles_n) * RING_BM, n0 = (tile % a.tiles_n) * RING_BM;
   const int rows_a = min(RING_BM, a.M - m0), rows_b = min(RING_BM, a.N - n0);
-  const char* Abase = a.A + (int64_t)m0 * lda_b;
-  const char* Bbase = a.B + (int64_t)n0 * ldb_b;
+  const char* Abase = a.A + (int64_t)m0 * lda_b + kb0;
+  const char* Bbase = a.B + (int64_t)n0 * ldb_b + kb0;
   auto issue = [&](int t) {     // slice t → slot t % RING_NST (all out of bounds once t >= nk)
     char* slot = smem + (t % RING_NST) * RING_STAGE;
     const int koff = t * TKB;
@@ -985,7 +991,15 @@ int launch_nt(const NtArgs& a, hipStream_t s) {
     b.tiles_m = cdiv(a.M, RING_BM);
     b.tiles_n = cdiv(a.N, RING_BM);
     b.debug = 0;
-    hipLaunchKernelGGL((gemm_nt_ring_kernel<T, TO>), dim3(b.tiles_m * b.tiles_n), dim3(256), RING_NST * RING_STAGE, s, b);
+    const int tiles = b.tiles_m * b.tiles_n, nk_all = cdiv(a.K * (int)sizeof(T), TKB);
+    b.split_k = 1;
+    // a few tiles with a very long K (LM-head backward: 6 tiles × 502 K-steps) would run on 6 CUs: with fp32 atomic
+    // accumulation the K range may be cut into pieces of >= 8 K-steps over idle CUs (alpha is linear, no other epilogue)
+    if (a.flags == LAKO_EPI_ATOMIC && sizeof(TO) == 4 && tiles < 128 && nk_all >= 32)
+      b.split_k = std::max(1, std::min(256 / tiles, nk_all / 8));
+    b.k_chunk = cdiv(nk_all, b.split_k) * TKB;
+    b.split_k = cdiv(nk_all * TKB, b.k_chunk);
+    hipLaunchKernelGGL((gemm_nt_ring_kernel<T, TO>), dim3(tiles * b.split_k), dim3(256), RING_NST * RING_STAGE, s, b);
     return 0;
   }
   if (v == 2) launch_nt_cfg<T, TO, 2, 4, 8, 4>(a, s);

@@ -426,7 +426,13 @@ class Engine:
         alpha = d ** -0.5
         dh = self._buf(tmp, "d.dh", (Md, d))
         dout = self._buf(tmp, f"dxn.{Md}", (Md, d))
-        ops.gemm_nt(dlog, self.shared.wt, dout, alpha=alpha)
+        # K = vocabulary (32128) for an [Md, d] output of a handful of tiles: accumulate in fp32 with atomics so that the
+        # library may split K over the idle CUs (gemm_nt_ring_kernel), then round once to the compute dtype
+        dout32 = dout if dout.dtype == torch.float32 else self._buf(tmp, "d.dout32", (Md, d), torch.float32)
+        ops.zero_(dout32)
+        ops.gemm_nt(dlog, self.shared.wt, dout32, alpha=alpha, atomic=True)
+        if dout32 is not dout:
+            ops.cast(dout32.view(-1), dout.view(-1))
         ops.gemm_tn(dlog, ws["d.out"], self.shared.g, alpha=alpha)
         ops.rmsnorm_bwd(dout, ws[f"d.h{Ld}"], self.dec_final.p, ws["d.rsf"], None, dh, self.dec_final.g, dr(S_DEC_FINAL))
         dkv = self._buf(tmp, "dkv", (Me, self.kv_all.w.shape[0]))

@@ -92,6 +92,19 @@ def test_gemm_nt_tile_variants(ops, ref, variant, M, N, K):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(128, 768, 32128), (40, 264, 5000), (128, 132, 2048)])
+def test_gemm_nt_split_k_atomic(ops, ref, dt, M, N, K):
+    """few tiles × very long K with fp32 atomic accumulation: the ring kernel splits K over workgroups (LM-head backward)."""
+    T = DT[dt]
+    A, B = rnd(M, K, dtype=T, seed=61) * 0.25, rnd(N, K, dtype=T, seed=62) * 0.25
+    C = rnd(M, N, seed=63)
+    Cr = C.clone()
+    ops.gemm_nt(A, B, C, alpha=0.5, atomic=True)
+    ref.gemm_nt(A, B, Cr, alpha=0.5, atomic=True)
+    close(C, Cr, T, f"gemm_nt split-K atomic {dt} {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_gemm_nt_epilogues(ops, ref, dt):
     T = DT[dt]
     M, N, K = 200, 136, 96
