@@ -183,14 +183,28 @@ __device__ __forceinline__ float group_sum(float v) {
 __device__ __forceinline__ int clampi(int x, int lo, int hi) { return min(max(x, lo), hi); }
 
 // additive key mask of LDS-side chunk rows: 0 attend, −FLT_MAX padding key (HF: scores + finfo.min), −inf beyond Lk
-__device__ __forceinline__ void stage_key_add(float* kadd, const uint8_t* key_mask, int b, int kc0, int nk, int Lk) {
-  for (int i = threadIdx.x; i < nk; i += 256) {
-    const int j = kc0 + i;
-    float f = 0.f;
-    if (j >= Lk) f = -INFINITY;
-    else if (key_mask && !key_mask[(int64_t)b * Lk + j]) f = -FLT_MAX;
-    kadd[i] = f;
+// pair_any[tp] (tp < 8) = 1 when tile pair tp (keys kc0 + 32·tp … + 31) holds at least one attendable key.  A masked
+// key's probability is EXACTLY 0 whenever its row has one attendable key (exp(−FLT_MAX − m) = 0), so tile pairs
+// without any can be skipped; a sequence with no attendable key at all keeps every tile (HF: uniform attention).
+__device__ __forceinline__ void stage_key_add(float* kadd, const uint8_t* key_mask, int b, int kc0, int nk, int Lk,
+                                              int* pair_any) {
+  static_assert(CH_MAX <= 256, "one key per thread");
+  const int i = threadIdx.x, j = kc0 + i;
+  float f = 0.f;
+  if (j >= Lk) f = -INFINITY;
+  else if (key_mask && !key_mask[(int64_t)b * Lk + j]) f = -FLT_MAX;
+  if (i < nk) kadd[i] = f;
+  const uint64_t bal = __ballot(i < nk && f == 0.f);
+  if ((threadIdx.x & 63) == 0) {
+    pair_any[2 * (threadIdx.x >> 6)] = (uint32_t)bal != 0u;
+    pair_any[2 * (threadIdx.x >> 6) + 1] = (uint32_t)(bal >> 32) != 0u;
   }
+}
+__device__ __forceinline__ int pair_bits(const int* pair_any) {
+  int bits = 0;
+#pragma unroll
+  for (int tp = 0; tp < 8; ++tp) bits |= (pair_any[tp] != 0) << tp;
+  return __builtin_amdgcn_readfirstlane(bits);
 }
 
 template <typename T, int DK> __host__ __device__ constexpr int img_bytes(int ch) { return ch * AC<T, DK>::ROWB; }
@@ -228,7 +242,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   // 4 waves share that block and split every key chunk between them (tile pair tp → wave tp & 3); the
   // partial (max, sum, O) of the 4 waves are merged through LDS at the end.
   const bool ksplit = nqb == 1 && a.Lk > 64;   // host reserves the merge scratch only when Lq <= 16
-  float* mrg = bias_l + ((a.R + 3) & ~3);      // [4 waves][16 queries][DK + 2] (ksplit only)
+  int* pair_any = reinterpret_cast<int*>(bias_l + ((a.R + 3) & ~3));   // [8]
+  float* mrg = reinterpret_cast<float*>(pair_any + 8);                 // [4 waves][16 queries][DK + 2] (ksplit only)
+  int okbits = 0xff;   // tile pairs of the staged chunk worth computing (single-chunk sequences only)
 
   for (int qb0 = qb_begin; qb0 < qb_end; qb0 += 4) {
     const int qb = ksplit ? qb0 : qb0 + wave;
@@ -250,12 +266,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         __syncthreads();
         stage_image<T, DK>(Kimg, kbase, a.kst, kc0, nk, a.Lk);
         stage_image<T, DK>(Vimg, vbase, a.vst, kc0, nk, a.Lk);
-        stage_key_add(kadd, a.key_mask, b, kc0, nk, a.Lk);
+        stage_key_add(kadd, a.key_mask, b, kc0, nk, a.Lk, pair_any);
         __syncthreads();
+        if (!CAPTURE && nchunks == 1) {
+          okbits = pair_bits(pair_any);
+          if (okbits == 0) okbits = 0xff;   // fully padded sequence: uniform attention over every key, like the reference
+        }
       }
       if (!active) continue;
       const int ntile = nk >> 4;
-#define MINE(t) ((t) < ntile && (!ksplit || (((t) >> 1) & 3) == wave))
+#define MINE(t) ((t) < ntile && ((okbits >> ((t) >> 1)) & 1) && (!ksplit || (((t) >> 1) & 3) == wave))
       f32x4 s[16];
       // scores = (bias + key mask) + Q·Kᵀ : the additive terms are the accumulator init
 #pragma unroll
@@ -420,7 +440,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   // key-split (dQ pass only): a workgroup owning one query block shares it between its 4 waves, which split the
   // keys (tile pair tp → wave tp & 3); the partial dQ tiles are summed through LDS at the end.
   const bool ksplit = MODE == 0 && nyb == 1 && a.Lk > 64;   // merge scratch reserved only when Lq <= 16
-  float* mrg = drel_l + ((a.R + 3) & ~3);                   // [4][16][DK] (ksplit only)
+  int* pair_any = reinterpret_cast<int*>(drel_l + ((a.R + 3) & ~3));   // [8] (MODE 0), [0] = sequence has a key (MODE 1)
+  float* mrg = reinterpret_cast<float*>(pair_any + 8);                 // [4][16][DK] (ksplit only)
+  int okbits = 0xff;          // MODE 0: tile pairs of the staged keys worth computing (see stage_key_add)
 
   // Bias gradient (dQ pass): d rel_bias[key − query] = Σ_batch Σ_(q,k) dS.  LDS float atomics per score
   // element are ~40 cycles per wave-instruction, so when one round covers the workgroup's query blocks
@@ -438,6 +460,17 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   const char* obase = a.o + ((int64_t)b * a.osb + hoff) * C::ES;
   const char* dobase = a.dout + ((int64_t)b * a.osb + hoff) * C::ES;
   float* stats = a.stats + ((int64_t)b * a.H + h) * a.Lq * 4;
+  bool seq_any = true;        // MODE 1: does this sequence have an attendable key at all?
+  if (MODE == 1 && a.key_mask) {
+    __syncthreads();
+    if (threadIdx.x == 0) pair_any[0] = 0;
+    __syncthreads();
+    bool mine = false;
+    for (int j = threadIdx.x; j < a.Lk; j += 256) mine |= a.key_mask[(int64_t)b * a.Lk + j] != 0;
+    if (__ballot(mine) != 0 && (threadIdx.x & 63) == 0) pair_any[0] = 1;
+    __syncthreads();
+    seq_any = pair_any[0] != 0;
+  }
   for (int yb0 = yb_begin; yb0 < yb_end; yb0 += 4) {
     const int yb = ksplit ? yb0 : yb0 + wave;
     const bool active = yb < yb_end;
@@ -475,6 +508,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
       if (yi >= a.Lk) kadd_lane = -INFINITY;
       else if (a.key_mask && !a.key_mask[(int64_t)b * a.Lk + yi]) kadd_lane = -FLT_MAX;
     }
+    // MODE 1: a block of 16 keys none of which is attendable has dK = dV = 0 exactly (p = 0 for them on every row
+    // that has an attendable key): nothing to compute, the zero accumulators are stored
+    const bool compute = active && !(MODE == 1 && seq_any && __ballot(kadd_lane == 0.f) == 0);
     f32x4 acc1[C::NDB], acc2[C::NDB];  // MODE 0: dQ (acc1)   MODE 1: dK (acc1), dV (acc2)
 #pragma unroll
     for (int db = 0; db < C::NDB; ++db) {
@@ -490,7 +526,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
         if constexpr (MODE == 0) {
           stage_image<T, DK>(X1, kbase, a.kst, x0, nx, a.Lk);
           stage_image<T, DK>(X2, vbase, a.vst, x0, nx, a.Lk);
-          stage_key_add(aux0, a.key_mask, b, x0, nx, a.Lk);
+          stage_key_add(aux0, a.key_mask, b, x0, nx, a.Lk, pair_any);
         } else {
           stage_image<T, DK>(X1, qbase, a.qst, x0, nx, a.Lq);
           stage_image<T, DK>(X2, dobase, a.ost, x0, nx, a.Lq);
@@ -504,12 +540,17 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
           }
         }
         __syncthreads();
+        if (MODE == 0 && nchunks == 1) {
+          okbits = pair_bits(pair_any);
+          if (okbits == 0) okbits = 0xff;   // fully padded sequence: every key takes part (uniform attention)
+        }
       }
-      if (!active) continue;
+      if (!compute) continue;
       const int npair = nx >> 5;
 #pragma unroll
       for (int tp = 0; tp < 8; ++tp) {
         if (tp >= npair) continue;
+        if (MODE == 0 && !((okbits >> tp) & 1)) continue;
         if (ksplit && (tp & 3) != wave) continue;
         f32x4 pt[2], ds[2];
 #pragma unroll
@@ -644,11 +685,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
 
 template <typename T, int DK>
 int lds_bytes_fwd(int ch, int R, bool merge) {
-  return 2 * img_bytes<T, DK>(ch) + (ch + R + 8 + (merge ? 4 * 16 * (DK + 2) : 0)) * 4;
+  return 2 * img_bytes<T, DK>(ch) + (ch + R + 16 + (merge ? 4 * 16 * (DK + 2) : 0)) * 4;
 }
 template <typename T, int DK>
 int lds_bytes_bwd(int ch, int R, bool merge) {
-  return 2 * img_bytes<T, DK>(ch) + (3 * ch + 2 * R + 8 + (merge ? 4 * 16 * DK : 0)) * 4;
+  return 2 * img_bytes<T, DK>(ch) + (3 * ch + 2 * R + 16 + (merge ? 4 * 16 * DK : 0)) * 4;
 }
 
 inline int pick_chunk(int L) {
