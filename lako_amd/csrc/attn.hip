@@ -246,12 +246,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   float* mrg = reinterpret_cast<float*>(pair_any + 8);                 // [4 waves][16 queries][DK + 2] (ksplit only)
   int okbits = 0xff;   // tile pairs of the staged chunk worth computing (single-chunk sequences only)
 
+  // The Q fragments of round r+1 are requested before round r is computed: a round is only ≈7 tile pairs long, a
+  // load → wait → compute chain per round would expose one global round trip (≈2 µs) per ≈2 µs of work.
+  u32x4 qf_next[C::NF];
+  auto request_q = [&](int qb0n) {
+    const int qbn = ksplit ? qb0n : qb0n + wave;
+    load_reg_frags<T, DK>(qf_next, qbase, a.qst, (qb0n < qb_end && qbn < qb_end) ? qbn * 16 + l15 : a.Lq, a.Lq, lane);
+  };
+  request_q(qb_begin);
   for (int qb0 = qb_begin; qb0 < qb_end; qb0 += 4) {
     const int qb = ksplit ? qb0 : qb0 + wave;
     const bool active = qb < qb_end;
     const int qi = qb * 16 + l15;  // this lane's query
     u32x4 qf[C::NF];
-    load_reg_frags<T, DK>(qf, qbase, a.qst, active ? qi : a.Lq, a.Lq, lane);
+#pragma unroll
+    for (int i = 0; i < C::NF; ++i) qf[i] = qf_next[i];
+    request_q(qb0 + 4);
     float m = -INFINITY, lsum = 0.f;
     f32x4 oacc[C::NDB];
 #pragma unroll
@@ -453,6 +463,34 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
 #pragma unroll
   for (int t = 0; t < 16; ++t) dsacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // register-side operands of the NEXT round (possibly the next batch row's first) are requested before this round is
+  // computed — see attn_fwd_kernel
+  u32x4 n1[C::NF], n2[C::NF], n3[C::NF];
+  float ns0 = 0.f, ns1 = 0.f, nkadd = 0.f;
+  auto request = [&](int bb, int ybb0) {
+    const int ybn = ksplit ? ybb0 : ybb0 + wave;
+    const bool act = bb < b_end && ybb0 < yb_end && ybn < yb_end;
+    const int yin = act ? ybn * 16 + l15 : LY;
+    if constexpr (MODE == 0) {
+      load_reg_frags<T, DK>(n1, a.q + ((int64_t)bb * a.qsb + hoff) * C::ES, a.qst, yin, a.Lq, lane);
+      load_reg_frags<T, DK>(n2, a.dout + ((int64_t)bb * a.osb + hoff) * C::ES, a.ost, yin, a.Lq, lane);
+      load_reg_frags<T, DK>(n3, a.o + ((int64_t)bb * a.osb + hoff) * C::ES, a.ost, yin, a.Lq, lane);
+      ns0 = ns1 = 0.f;
+      if (yin < a.Lq) {
+        const float* st = a.stats + (((int64_t)bb * a.H + h) * a.Lq + yin) * 4;
+        ns0 = st[0];
+        ns1 = st[1];
+      }
+    } else {
+      load_reg_frags<T, DK>(n1, a.k + ((int64_t)bb * a.ksb + hoff) * C::ES, a.kst, yin, a.Lk, lane);
+      load_reg_frags<T, DK>(n2, a.v + ((int64_t)bb * a.vsb + hoff) * C::ES, a.vst, yin, a.Lk, lane);
+      nkadd = 0.f;
+      if (yin >= a.Lk) nkadd = -INFINITY;
+      else if (a.key_mask && !a.key_mask[(int64_t)bb * a.Lk + yin]) nkadd = -FLT_MAX;
+    }
+  };
+  request(b_begin, yb_begin);
+
   for (int b = b_begin; b < b_end; ++b) {
   const char* qbase = a.q + ((int64_t)b * a.qsb + hoff) * C::ES;
   const char* kbase = a.k + ((int64_t)b * a.ksb + hoff) * C::ES;
@@ -478,11 +516,18 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
     u32x4 y1[C::NF], y2[C::NF];
     float m_q = 0.f, invl_q = 0.f, delta_q = 0.f;   // MODE 0: this lane's query statistics (inv = 0 ⇒ p = 0)
     float kadd_lane = 0.f;                           // MODE 1: this lane's key mask term
+    u32x4 of[C::NF];
+#pragma unroll
+    for (int i = 0; i < C::NF; ++i) {
+      y1[i] = n1[i];
+      y2[i] = n2[i];
+      if constexpr (MODE == 0) of[i] = n3[i];
+    }
+    const float st_m = ns0, st_il = ns1;
+    kadd_lane = nkadd;
+    if (yb0 + 4 < yb_end) request(b, yb0 + 4);
+    else request(b + 1, yb_begin);
     if constexpr (MODE == 0) {
-      load_reg_frags<T, DK>(y1, qbase, a.qst, yi, a.Lq, lane);
-      load_reg_frags<T, DK>(y2, dobase, a.ost, yi, a.Lq, lane);
-      u32x4 of[C::NF];
-      load_reg_frags<T, DK>(of, obase, a.ost, yi, a.Lq, lane);
       float part = 0.f;
 #pragma unroll
       for (int i = 0; i < C::NF; ++i) {
@@ -498,15 +543,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
       }
       delta_q = group_sum(part);
       if (yi < a.Lq) {
-        m_q = stats[yi * 4];
-        invl_q = stats[yi * 4 + 1];
+        m_q = st_m;
+        invl_q = st_il;
         if (g == 0) stats[yi * 4 + 2] = delta_q;   // handed to the dK/dV pass (launched after this one)
       }
-    } else {
-      load_reg_frags<T, DK>(y1, kbase, a.kst, yi, a.Lk, lane);
-      load_reg_frags<T, DK>(y2, vbase, a.vst, yi, a.Lk, lane);
-      if (yi >= a.Lk) kadd_lane = -INFINITY;
-      else if (a.key_mask && !a.key_mask[(int64_t)b * a.Lk + yi]) kadd_lane = -FLT_MAX;
     }
     // MODE 1: a block of 16 keys none of which is attendable has dK = dV = 0 exactly (p = 0 for them on every row
     // that has an attendable key): nothing to compute, the zero accumulators are stored
