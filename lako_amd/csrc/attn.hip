@@ -72,10 +72,24 @@ template <> struct Mma16<float> {
   }
 };
 
-// Attention-probability dropout: elements (row, 2c) and (row, 2c+1) share hash(key, row·⌈Lk/2⌉ + c); the even
-// key takes the low 16 bits, the odd key the high 16 bits; keep iff half >= round(p·65536).
-// (tests/ref_ops.py carries the same integer recipe.)
-__device__ __forceinline__ uint32_t pair_hash(uint32_t key, uint32_t pair_idx) { return lako_hash32(pair_idx ^ key); }
+// Attention-probability dropout: the four elements (row, 4c … 4c+3) of a score row share ONE hash,
+//   h = hash32(key ^ (row·⌈Lk/4⌉ + c)),  w = h · 0x9E3779B1 (low 32 bits);
+// their 16-bit draws are h>>16, h&0xffff, w>>16, w&0xffff; keep iff draw >= round(p·65536).  Compared without
+// extracting the fields: x>>16 >= t  ⟺  x >= t<<16,  x&0xffff >= t  ⟺  x<<16 >= t<<16.
+// (tests/ref_ops.py carries the same integer recipe; measured keep rate / neighbour correlations: DESIGN.md §4.)
+struct QuadDraw { uint32_t h, w; };
+__device__ __forceinline__ QuadDraw quad_hash(uint32_t key, uint32_t quad_idx) {
+  QuadDraw d;
+  d.h = lako_hash32(quad_idx ^ key);
+  d.w = d.h * 0x9E3779B1u;
+  return d;
+}
+__device__ __forceinline__ void quad_keep(QuadDraw d, uint32_t t_hi, bool (&k)[4]) {
+  k[0] = d.h >= t_hi;
+  k[1] = (d.h << 16) >= t_hi;
+  k[2] = d.w >= t_hi;
+  k[3] = (d.w << 16) >= t_hi;
+}
 
 // Stage rows [r0, r0 + nrows) of a strided [L, ·] tensor into a padded LDS image; rows >= L are
 // zero-filled (so padded keys/queries contribute exact zeros).  8 independent loads in flight per thread.
@@ -236,7 +250,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   const bool has_bias = a.rel_bias != nullptr;
   if (has_bias)
     for (int i = threadIdx.x; i < a.R; i += 256) bias_l[i] = a.rel_bias[(int64_t)h * a.R + i];
-  const int hk = (a.Lk + 1) >> 1;   // dropout pairs per score row
+  const int hq = (a.Lk + 3) >> 2;   // dropout quads per score row
+  const uint32_t t_hi = a.drop_t16 << 16;
 
   // Key-split mode: a workgroup that owns a single 16-query block (cross-attention, decode steps) lets its
   // 4 waves share that block and split every key chunk between them (tile pair tp → wave tp & 3); the
@@ -267,7 +282,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
     for (int db = 0; db < C::NDB; ++db) oacc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int jmax = a.causal ? qi + a.causal_off : 0x7fffffff;       // keys j > jmax are causally masked
-    const uint32_t prow = (uint32_t)((b * a.H + h) * a.Lq + qi) * (uint32_t)hk;  // dropout pair index of (qi, key 0)
+    const uint32_t prow = (uint32_t)((b * a.H + h) * a.Lq + qi) * (uint32_t)hq;  // dropout quad index of (qi, key 0)
 
     for (int ch = 0; ch < nchunks; ++ch) {
       const int kc0 = ch * CH;
@@ -339,12 +354,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
             psum += p[r];
           }
           if (a.drop_t16) {
-            const uint32_t pi = prow + (uint32_t)((kc0 + t * 16 + 4 * g) >> 1);
-            const uint32_t h0 = pair_hash(a.drop_key, pi), h1 = pair_hash(a.drop_key, pi + 1);
-            p[0] = (h0 & 0xffffu) >= a.drop_t16 ? p[0] * a.drop_scale : 0.f;
-            p[1] = (h0 >> 16) >= a.drop_t16 ? p[1] * a.drop_scale : 0.f;
-            p[2] = (h1 & 0xffffu) >= a.drop_t16 ? p[2] * a.drop_scale : 0.f;
-            p[3] = (h1 >> 16) >= a.drop_t16 ? p[3] * a.drop_scale : 0.f;
+            bool kp[4];
+            quad_keep(quad_hash(a.drop_key, prow + (uint32_t)((kc0 + t * 16 + 4 * g) >> 2)), t_hi, kp);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[r] = kp[r] ? p[r] * a.drop_scale : 0.f;
           }
           s[t] = p;
         }
@@ -445,7 +458,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
     for (int i = threadIdx.x; i < a.R; i += 256) bias_l[i] = a.rel_bias[(int64_t)h * a.R + i];
   if (want_drel)
     for (int i = threadIdx.x; i < a.R; i += 256) drel_l[i] = 0.f;
-  const int hk = (a.Lk + 1) >> 1;
+  const int hq = (a.Lk + 3) >> 2;
+  const uint32_t t_hi = a.drop_t16 << 16;
 
   // key-split (dQ pass only): a workgroup owning one query block shares it between its 4 waves, which split the
   // keys (tile pair tp → wave tp & 3); the partial dQ tiles are summed through LDS at the end.
@@ -630,24 +644,24 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
           for (int r = 0; r < 4; ++r) p[r] = __expf(sv[r] - mq[r]) * il[r];
           f32x4 pd = p, dpd = dp;
           if (a.drop_t16) {
-            if constexpr (MODE == 0) {   // 4 consecutive keys of one query: two pair hashes
-              const uint32_t pi = (uint32_t)((b * a.H + h) * a.Lq + yi) * (uint32_t)hk + (uint32_t)(x_first >> 1);
-              const uint32_t h0 = pair_hash(a.drop_key, pi), h1 = pair_hash(a.drop_key, pi + 1);
-              const bool k0 = (h0 & 0xffffu) >= a.drop_t16, k1 = (h0 >> 16) >= a.drop_t16,
-                         k2 = (h1 & 0xffffu) >= a.drop_t16, k3 = (h1 >> 16) >= a.drop_t16;
-              pd[0] = k0 ? p[0] * a.drop_scale : 0.f; dpd[0] = k0 ? dp[0] * a.drop_scale : 0.f;
-              pd[1] = k1 ? p[1] * a.drop_scale : 0.f; dpd[1] = k1 ? dp[1] * a.drop_scale : 0.f;
-              pd[2] = k2 ? p[2] * a.drop_scale : 0.f; dpd[2] = k2 ? dp[2] * a.drop_scale : 0.f;
-              pd[3] = k3 ? p[3] * a.drop_scale : 0.f; dpd[3] = k3 ? dp[3] * a.drop_scale : 0.f;
-            } else {                      // one key, 4 consecutive queries: one hash per element
-              const uint32_t half = (uint32_t)(yi & 1) * 16u;
+            bool kp[4];
+            if constexpr (MODE == 0) {   // 4 consecutive keys of one query: one quad
+              quad_keep(quad_hash(a.drop_key, (uint32_t)((b * a.H + h) * a.Lq + yi) * (uint32_t)hq + (uint32_t)(x_first >> 2)),
+                        t_hi, kp);
+            } else {                      // one key, 4 consecutive queries: this lane's draw of four different quads
+              const bool use_w = (yi & 2) != 0;
+              const uint32_t sh = (uint32_t)(yi & 1) * 16u;
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                const uint32_t pi = (uint32_t)((b * a.H + h) * a.Lq + x_first + r) * (uint32_t)hk + (uint32_t)(yi >> 1);
-                const bool kp = ((pair_hash(a.drop_key, pi) >> half) & 0xffffu) >= a.drop_t16;
-                pd[r] = kp ? p[r] * a.drop_scale : 0.f;
-                dpd[r] = kp ? dp[r] * a.drop_scale : 0.f;
+                const QuadDraw d = quad_hash(a.drop_key, (uint32_t)((b * a.H + h) * a.Lq + x_first + r) * (uint32_t)hq +
+                                                             (uint32_t)(yi >> 2));
+                kp[r] = ((use_w ? d.w : d.h) << sh) >= t_hi;
               }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              pd[r] = kp[r] ? p[r] * a.drop_scale : 0.f;
+              dpd[r] = kp[r] ? dp[r] * a.drop_scale : 0.f;
             }
           }
 #pragma unroll

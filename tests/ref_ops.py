@@ -161,13 +161,16 @@ class RefOps:
         l = p.sum(-1)
         pn = p / l[..., None]
         if _on(drop):
-            # attention-probability dropout (csrc/attn.hip pair_hash): keys 2c, 2c+1 of a score row share one hash
+            # attention-probability dropout (csrc/attn.hip quad_hash): keys 4c … 4c+3 of a score row share one hash h;
+            # draws: h>>16, h&0xffff, w>>16, w&0xffff with w = h·0x9E3779B1 mod 2^32
             pr, seed, site = drop
-            hk = (Lk + 1) // 2
+            hq = (Lk + 3) // 4
             rows = torch.arange(B * H * Lq, device=dev, dtype=torch.int64).view(B, H, Lq, 1)
-            pi = (rows * hk + (j >> 1)) & M32
-            hsh = hash32(pi ^ drop_key(int(seed) & M32, int(site) & M32))
-            half = torch.where((j & 1).bool(), hsh >> 16, hsh & 0xFFFF)
+            qi = (rows * hq + (j >> 2)) & M32
+            hsh = hash32(qi ^ drop_key(int(seed) & M32, int(site) & M32))
+            wsh = _mul32(hsh, 0x9E3779B1)
+            word = torch.where((j & 2).bool(), wsh, hsh)
+            half = torch.where((j & 1).bool(), word & 0xFFFF, word >> 16)
             t16 = min(max(int(float(np.float32(pr)) * 65536.0 + 0.5), 1), 65535)
             scale = float(np.float32(1.0) / (np.float32(1.0) - np.float32(pr)))
             pn = torch.where(half >= t16, pn * scale, torch.zeros_like(pn))
