@@ -21,6 +21,8 @@
 // bf16: v_mfma_f32_16x16x32_bf16; fp32 (parity mode): v_mfma_f32_16x16x4_f32.
 #include <float.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -52,6 +54,15 @@ struct AttnArgs {
   uint32_t drop_t16, drop_key;   // attention dropout: keep iff 16-bit half >= drop_t16 (0 = off)
   float drop_scale;
 };
+
+// f(integral_constant<int, 0>) … f(integral_constant<int, N-1>): a compile-time-indexed unrolled loop
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
 
 template <int N> using FragArr = u32x4[N];
 template <int N> using AccArr = f32x4[N];
@@ -223,6 +234,93 @@ __device__ __forceinline__ int pair_bits(const int* pair_any) {
 
 template <typename T, int DK> __host__ __device__ constexpr int img_bytes(int ch) { return ch * AC<T, DK>::ROWB; }
 
+// One staged key chunk for one wave's 16 queries: scores → online softmax → P·V for NP tile pairs, with NO runtime
+// branch inside (the caller dispatches on the pair count): per-tile `if`s cut the unrolled code into basic blocks
+// of one LDS-read → wait → MFMA chain each, nothing overlapped.  Pair p is tile pair tp = tp0 + p·tstride of the
+// chunk (key-split mode: tp0 = wave, tstride = 4).
+struct FwdRow {          // per-lane state of one query row across chunks
+  float m, lsum;
+};
+template <typename T, int DK, bool CAPTURE, int NP>
+__device__ __forceinline__ void fwd_chunk(const AttnArgs& a, const char* Kimg, const char* Vimg, const float* kadd,
+                                          const float* bias_l, const FragArr<AC<T, DK>::NF>& qf, FwdRow& st,
+                                          AccArr<AC<T, DK>::NDB>& oacc, int b, int h, int qi, int kc0, int tp0, int tstride,
+                                          uint32_t prow, uint32_t t_hi, int jmax, int lane) {
+  using C = AC<T, DK>;
+  const int g = lane >> 4;
+  const bool has_bias = bias_l != nullptr;
+  f32x4 s[2 * NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int row0 = (tp0 + p * tstride) * 32 + u * 16;     // first key of the tile inside the chunk
+      f32x4 init = *reinterpret_cast<const f32x4*>(kadd + row0 + 4 * g);
+      if (has_bias) {
+        const int bi0 = kc0 + row0 + 4 * g - qi + a.rel_off;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) init[r] += bias_l[clampi(bi0 + r, 0, a.R - 1)];
+      }
+      s[2 * p + u] = score_tile<T, DK>(Kimg, row0, qf, lane, init);
+    }
+  }
+  if (a.causal) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int j0 = kc0 + (tp0 + p * tstride) * 32 + u * 16 + 4 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[2 * p + u][r] = (j0 + r > jmax) ? -FLT_MAX : s[2 * p + u][r];
+      }
+  }
+  if constexpr (CAPTURE) {   // score capture at decode step 0: raw scores, masked keys → 0
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int j0 = kc0 + (tp0 + p * tstride) * 32 + u * 16 + 4 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (qi < a.Lq && j0 + r < a.Lk)
+            a.scores_out[(((int64_t)b * a.H + h) * a.Lq + qi) * a.Lk + j0 + r] =
+                s[2 * p + u][r] <= -FLT_MAX ? 0.f : s[2 * p + u][r];
+      }
+  }
+  float cmax = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < 2 * NP; ++t) cmax = fmaxf(fmaxf(cmax, fmaxf(s[t][0], s[t][1])), fmaxf(s[t][2], s[t][3]));
+  cmax = group_max(cmax);
+  if (cmax == -INFINITY) return;           // every key of these tiles lies beyond Lk (wave-uniform)
+  const float m_new = fmaxf(st.m, cmax);
+  const float alpha = __expf(st.m - m_new);  // m = -inf on the first chunk → 0
+  float psum = 0.f;
+#pragma unroll
+  for (int t = 0; t < 2 * NP; ++t) {
+    f32x4 pr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      pr[r] = __expf(s[t][r] - m_new);
+      psum += pr[r];
+    }
+    if (a.drop_t16) {
+      const int row0 = (tp0 + (t >> 1) * tstride) * 32 + (t & 1) * 16;
+      bool kp[4];
+      quad_keep(quad_hash(a.drop_key, prow + (uint32_t)((kc0 + row0 + 4 * g) >> 2)), t_hi, kp);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pr[r] = kp[r] ? pr[r] * a.drop_scale : 0.f;
+    }
+    s[t] = pr;
+  }
+  psum = group_sum(psum);
+  st.lsum = st.lsum * alpha + psum;
+  st.m = m_new;
+#pragma unroll
+  for (int db = 0; db < C::NDB; ++db) oacc[db] *= alpha;
+#pragma unroll
+  for (int p = 0; p < NP; ++p) pv_accumulate<T, DK>(oacc, s[2 * p], s[2 * p + 1], Vimg, (tp0 + p * tstride) * 32, lane);
+}
+
 // =============================================================================================
 // forward
 // =============================================================================================
@@ -299,78 +397,28 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         }
       }
       if (!active) continue;
-      const int ntile = nk >> 4;
-#define MINE(t) ((t) < ntile && ((okbits >> ((t) >> 1)) & 1) && (!ksplit || (((t) >> 1) & 3) == wave))
-      f32x4 s[16];
-      // scores = (bias + key mask) + Q·Kᵀ : the additive terms are the accumulator init
-#pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        if (MINE(t)) {
-          f32x4 init = *reinterpret_cast<const f32x4*>(kadd + t * 16 + 4 * g);
-          if (has_bias) {
-            const int bi0 = kc0 + t * 16 + 4 * g - qi + a.rel_off;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) init[r] += bias_l[clampi(bi0 + r, 0, a.R - 1)];
-          }
-          s[t] = score_tile<T, DK>(Kimg, t * 16, qf, lane, init);
-        }
+      // pairs of this wave in this chunk: all up to the last one that holds an attendable key (single-chunk
+      // sequences; fully masked pairs inside that prefix are computed, their probabilities come out as exact zeros),
+      // or — key-split mode — pairs wave, wave + 4
+      const int npair = nk >> 5;
+      int np, tp0 = 0, tstride = 1;
+      if (ksplit) {
+        tp0 = wave;
+        tstride = 4;
+        np = npair > wave ? (npair - wave + 3) >> 2 : 0;
+      } else {
+        np = min(npair, 32 - __builtin_clz(okbits & 0xff));
       }
-      if (a.causal) {
-#pragma unroll
-        for (int t = 0; t < 16; ++t)
-          if (MINE(t)) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s[t][r] = (kc0 + t * 16 + 4 * g + r > jmax) ? -FLT_MAX : s[t][r];
-          }
+      FwdRow st{m, lsum};
+      const float* bl = has_bias ? bias_l : nullptr;
+#define CHUNK(N) case N: fwd_chunk<T, DK, CAPTURE, N>(a, Kimg, Vimg, kadd, bl, qf, st, oacc, b, h, qi, kc0, tp0, tstride, prow, t_hi, jmax, lane); break;
+      switch (np) {
+        CHUNK(1) CHUNK(2) CHUNK(3) CHUNK(4) CHUNK(5) CHUNK(6) CHUNK(7) CHUNK(8)
+        default: break;
       }
-      if constexpr (CAPTURE) {   // separate instantiation (score capture at decode step 0): raw scores, masked keys → 0
-#pragma unroll
-        for (int t = 0; t < 16; ++t)
-          if (MINE(t)) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int j = kc0 + t * 16 + 4 * g + r;
-              if (qi < a.Lq && j < a.Lk)
-                a.scores_out[(((int64_t)b * a.H + h) * a.Lq + qi) * a.Lk + j] = s[t][r] <= -FLT_MAX ? 0.f : s[t][r];
-            }
-          }
-      }
-      float cmax = -INFINITY;
-#pragma unroll
-      for (int t = 0; t < 16; ++t)
-        if (MINE(t)) cmax = fmaxf(fmaxf(cmax, fmaxf(s[t][0], s[t][1])), fmaxf(s[t][2], s[t][3]));
-      cmax = group_max(cmax);
-      if (cmax == -INFINITY) continue;      // ksplit: this wave owns no valid key of this chunk (wave-uniform)
-      const float m_new = fmaxf(m, cmax);
-      const float alpha = __expf(m - m_new);  // m = -inf on the first chunk → 0
-      float psum = 0.f;
-#pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        if (MINE(t)) {
-          f32x4 p;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            p[r] = __expf(s[t][r] - m_new);
-            psum += p[r];
-          }
-          if (a.drop_t16) {
-            bool kp[4];
-            quad_keep(quad_hash(a.drop_key, prow + (uint32_t)((kc0 + t * 16 + 4 * g) >> 2)), t_hi, kp);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) p[r] = kp[r] ? p[r] * a.drop_scale : 0.f;
-          }
-          s[t] = p;
-        }
-      }
-      psum = group_sum(psum);
-      lsum = lsum * alpha + psum;
-      m = m_new;
-#pragma unroll
-      for (int db = 0; db < C::NDB; ++db) oacc[db] *= alpha;
-#pragma unroll
-      for (int tp = 0; tp < 8; ++tp)
-        if (MINE(2 * tp)) pv_accumulate<T, DK>(oacc, s[2 * tp], s[2 * tp + 1], Vimg, tp * 32, lane);
-#undef MINE
+#undef CHUNK
+      m = st.m;
+      lsum = st.lsum;
     }
     if (ksplit) {
       // merge the 4 waves' partial softmax states (all waves hold the SAME 16 queries)
@@ -426,6 +474,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 
 // =============================================================================================
 // backward.  MODE 0: dQ pass (keys in LDS, wave owns queries)   MODE 1: dK/dV pass (queries in LDS)
+// (The branch-free per-pair-count dispatch of fwd_chunk was tried here too: 8 copies of this much larger pair body
+// ran 35 % SLOWER — 256 VGPRs and an instruction footprint beyond the I-cache — so the pair loop keeps its `continue`s.)
 // =============================================================================================
 template <typename T, int DK, int MODE>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
