@@ -30,6 +30,20 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+def gemm_traffic_bytes(args):
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC profile (separate rocprofv3 --pmc passes
+    over tools/gemm_probe.py, FETCH_SIZE doubled as the gfx950 guide prescribes; profiles/r01b_gemm_traffic.json):
+    the mean over the probe's four config-2 encoder GEMM shapes.  null for any other workload or when the file is absent —
+    counters cannot be collected from inside a timed run."""
+    if (args.model, args.batch, args.n_passages, args.seq_len, args.dtype) != ("base", 16, 20, 200, "bf16"):
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01b_gemm_traffic.json")) as f:
+            return json.load(f)["nt_mean_traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 PEAK_BF16_TFLOPS = 2500.0      # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (no 2:1 sparsity)
 PEAK_F32_TFLOPS = 157.3
 
@@ -252,7 +266,7 @@ def main():
                        "answer_len": T, "dropout": args.dropout, "parallelism": f"dp{world}",
                        "master_weights": "fp32", "final_mean_loss": round(final_loss, 4)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": None,
+                         "frac": round(achieved / peak, 4), "traffic": gemm_traffic_bytes(args),
                          "kernel": "gemm_nt_kernel<bf16,bf16>" if args.dtype == "bf16" else "gemm_nt_kernel<f32,f32>",
                          "launches_per_step": n_l, "avg_launch_us": round(t_ms * 1e3 / max(n_l, 1), 2),
                          "step_mfma_frac": round(world * B / (elapsed / args.steps) * fl / 1e12 / (peak * world), 4),
