@@ -75,6 +75,20 @@ int lako_gemm_nt(const lako_gemm_nt_t* p, lako_stream_t stream);
 int lako_gemm_tn(const void* A, const void* B, float* C, int64_t M, int64_t N, int64_t K, int64_t lda,
                  int64_t ldb, int64_t ldc, int in_dtype, float alpha, int split_k, lako_stream_t stream);
 
+/* Several weight gradients in ONE launch: C_i[M_i,N_i] += alpha_i * A_iᵀ·B_i for i < n_items (<= LAKO_TN_GROUP_MAX), all with
+ * the same K (= tokens) and input dtype.  The four dW of a transformer layer fill the chip with ~3 K-splits instead of 7-28
+ * each, and every split costs one fp32 atomic pass over the output (≈1.3 TB/s chip-wide).  Falls back to one lako_gemm_tn
+ * per item for shapes the 256x256 kernel does not take (fp32 inputs, M or N < 256).  `items` is a HOST array. */
+#define LAKO_TN_GROUP_MAX 8
+typedef struct {
+  const void* a; /* [K, M] row-major, lda */
+  const void* b; /* [K, N] row-major, ldb */
+  float* c;      /* [M, N] fp32, ldc */
+  int64_t M, N, lda, ldb, ldc;
+  float alpha;
+} lako_gemm_tn_item_t;
+int lako_gemm_tn_grouped(const lako_gemm_tn_item_t* items, int n_items, int64_t K, int in_dtype, lako_stream_t stream);
+
 /* ---- T5LayerNorm (RMSNorm, HF5:59-72): y = dropout(x * rsqrt(mean(x²) + eps) * w) ----------------
  * rstd [rows] fp32 is written for the backward.  w is fp32 [d]. */
 int lako_rmsnorm_fwd(const void* x, const float* w, void* y, float* rstd, int64_t rows, int d, float eps,

@@ -34,6 +34,14 @@ class GemmNT(C.Structure):
                 ("ldr", i64), ("aux", vp), ("ldaux", i64), ("aux_scale", f32), ("drop", Dropout)]
 
 
+class GemmTNItem(C.Structure):
+    _fields_ = [("a", vp), ("b", vp), ("c", vp), ("M", i64), ("N", i64), ("lda", i64), ("ldb", i64), ("ldc", i64),
+                ("alpha", f32)]
+
+
+TN_GROUP_MAX = 8
+
+
 class AttnFwd(C.Structure):
     _fields_ = [("q", vp), ("k", vp), ("v", vp), ("out", vp), ("lse", vp),
                 ("q_stride_b", i64), ("q_stride_t", i64), ("k_stride_b", i64), ("k_stride_t", i64),
@@ -60,6 +68,7 @@ SIGNATURES = {
     "lako_last_error": [C.c_char_p, C.c_size_t],
     "lako_gemm_nt": [C.POINTER(GemmNT), vp],
     "lako_gemm_tn": [vp, vp, vp, i64, i64, i64, i64, i64, i64, i32, f32, i32, vp],
+    "lako_gemm_tn_grouped": [C.POINTER(GemmTNItem), i32, i64, i32, vp],
     "lako_rmsnorm_fwd": [vp, vp, vp, vp, i64, i32, f32, i32, Dropout, vp],
     "lako_rmsnorm_bwd": [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, Dropout, vp],
     "lako_embed_fwd": [vp, vp, vp, i64, i32, i64, i32, Dropout, vp],

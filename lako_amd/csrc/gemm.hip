@@ -626,6 +626,16 @@ struct TnArgs {
   int64_t lda, ldb, ldc;
   float alpha;
   int tiles_m, tiles_n, split_k, k_chunk;  // k_chunk: rows of K per split (multiple of 64)
+  int no_atomics;   // timing experiment (gemm_tn_big = 2): skip the accumulation
+  // grouped launch (gemm_tn256_kernel): n_items > 0 → tile id t belongs to the last item with tile_start <= t
+  int n_items;
+  struct Item {
+    const char *A, *B;
+    float* C;
+    int M, N, tiles_n, tile_start;
+    int64_t lda, ldb, ldc;
+    float alpha;
+  } items[LAKO_TN_GROUP_MAX];
 };
 
 template <typename T> struct TnGeom;
@@ -819,18 +829,33 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(TnArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave >> 2, wc = wave & 3;
-  const int ntile = a.tiles_m * a.tiles_n;
+  const int ntile = a.tiles_m * a.tiles_n;               // grouped: the tiles of all items
   const int flat = xcd_remap(blockIdx.x, gridDim.x);   // one XCD ← consecutive (split, tile) ids
-  const int split = flat / ntile, tid = flat % ntile;
-  const int tile_m = tid / a.tiles_n, tile_n = tid % a.tiles_n;
+  const int split = flat / ntile;
+  int tid = flat % ntile;
+  // the problem this tile belongs to (one problem, or up to LAKO_TN_GROUP_MAX weight gradients sharing K = tokens: with
+  // more tiles per launch fewer K-splits fill the chip, and every split costs one fp32 atomic pass over the output)
+  TnArgs::Item it;
+  if (a.n_items > 0) {
+    int i = 0;
+#pragma unroll
+    for (int j = 1; j < LAKO_TN_GROUP_MAX; ++j)
+      if (j < a.n_items && a.items[j].tile_start <= tid) i = j;
+    it = a.items[i];
+    tid -= it.tile_start;
+  } else {
+    it.A = a.A; it.B = a.B; it.C = a.C; it.M = a.M; it.N = a.N; it.tiles_n = a.tiles_n;
+    it.lda = a.lda; it.ldb = a.ldb; it.ldc = a.ldc; it.alpha = a.alpha;
+  }
+  const int tile_m = tid / it.tiles_n, tile_n = tid % it.tiles_n;
   const int m0 = tile_m * 256, n0 = tile_n * 256;
   const int k_begin = split * a.k_chunk;
   const int k_end = min(a.K, k_begin + a.k_chunk);
   if (k_begin >= k_end) return;
-  const int64_t lda_b = a.lda * 2, ldb_b = a.ldb * 2;
-  const int acols_b = (a.M - m0) * 2, bcols_b = (a.N - n0) * 2;
-  const char* Abase = a.A + (int64_t)k_begin * lda_b + (int64_t)m0 * 2;
-  const char* Bbase = a.B + (int64_t)k_begin * ldb_b + (int64_t)n0 * 2;
+  const int64_t lda_b = it.lda * 2, ldb_b = it.ldb * 2;
+  const int acols_b = (it.M - m0) * 2, bcols_b = (it.N - n0) * 2;
+  const char* Abase = it.A + (int64_t)k_begin * lda_b + (int64_t)m0 * 2;
+  const char* Bbase = it.B + (int64_t)k_begin * ldb_b + (int64_t)n0 * 2;
   const int krows = k_end - k_begin;
   const int nk = (krows + 63) / 64;
 
@@ -904,14 +929,14 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(TnArgs a) {
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) slab[(4 * g + r) * 64 + nt * 16 + r16] = acc[mt][nt][r] * a.alpha;
+      for (int r = 0; r < 4; ++r) slab[(4 * g + r) * 64 + nt * 16 + r16] = acc[mt][nt][r] * it.alpha;
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes have landed
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int row = 0; row < 16; ++row) {
       const float v = slab[row * 64 + lane];
       const int m = m0 + wr * 128 + mt * 16 + row;
-      if (m < a.M && n < a.N) atomicAdd(a.C + (int64_t)m * a.ldc + n, v);
+      if (m < it.M && n < it.N && !a.no_atomics) atomicAdd(it.C + (int64_t)m * it.ldc + n, v);
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -1089,6 +1114,7 @@ extern "C" int lako_gemm_tn(const void* A, const void* B, float* C, int64_t M, i
   LAKO_CHECK_ALIGN(B, 16);
   LAKO_CHECK_ALIGN(C, 4);
   TnArgs a;
+  a.n_items = 0;
   a.A = (const char*)A;
   a.B = (const char*)B;
   a.C = C;
@@ -1116,6 +1142,7 @@ extern "C" int lako_gemm_tn(const void* A, const void* B, float* C, int64_t M, i
     int chunk = cdiv(cdiv(K, sk), 64) * 64;
     a.split_k = cdiv(K, chunk);
     a.k_chunk = chunk;
+    a.no_atomics = g_tn_big == 2;
     LAKO_CHECK_ARG((int64_t)64 * lda * 2 < (1ll << 31) && (int64_t)64 * ldb * 2 < (1ll << 31),
                    "lako_gemm_tn: leading dimension too large");
     static bool attr_done = false;
@@ -1150,6 +1177,62 @@ extern "C" int lako_gemm_tn(const void* A, const void* B, float* C, int64_t M, i
 }
 
 // Development knob (not part of the training path): select kernel variants for A/B measurements.
+extern "C" int lako_gemm_tn_grouped(const lako_gemm_tn_item_t* items, int n_items, int64_t K, int in_dtype,
+                                    lako_stream_t stream) {
+  LAKO_CHECK_ARG(items && n_items >= 1 && n_items <= LAKO_TN_GROUP_MAX, "lako_gemm_tn_grouped: 1..%d items", LAKO_TN_GROUP_MAX);
+  LAKO_CHECK_ARG(K > 0 && K < (1 << 30), "lako_gemm_tn_grouped: bad K");
+  bool big = in_dtype == LAKO_BF16 && g_tn_big;
+  for (int i = 0; i < n_items; ++i) big = big && items[i].M >= 256 && items[i].N >= 256;
+  if (!big || n_items == 1) {   // shapes the 256×256 kernel does not take: one launch per problem
+    for (int i = 0; i < n_items; ++i) {
+      int rc = lako_gemm_tn(items[i].a, items[i].b, items[i].c, items[i].M, items[i].N, K, items[i].lda, items[i].ldb,
+                            items[i].ldc, in_dtype, items[i].alpha, 0, stream);
+      if (rc != LAKO_OK) return rc;
+    }
+    return LAKO_OK;
+  }
+  TnArgs a;
+  a.n_items = n_items;
+  a.K = (int)K;
+  a.no_atomics = g_tn_big == 2;
+  int tiles = 0;
+  for (int i = 0; i < n_items; ++i) {
+    const lako_gemm_tn_item_t& p = items[i];
+    LAKO_CHECK_ARG(p.a && p.b && p.c && p.M > 0 && p.N > 0, "lako_gemm_tn_grouped: item %d: null operand / empty problem", i);
+    LAKO_CHECK_ARG((p.M * 2) % 16 == 0 && (p.N * 2) % 16 == 0 && (p.lda * 2) % 16 == 0 && (p.ldb * 2) % 16 == 0,
+                   "lako_gemm_tn_grouped: item %d: M/N/lda/ldb must make 16-byte rows", i);
+    LAKO_CHECK_ARG(p.M < (1 << 30) && p.N < (1 << 30) && (int64_t)64 * p.lda * 2 < (1ll << 31) && (int64_t)64 * p.ldb * 2 < (1ll << 31),
+                   "lako_gemm_tn_grouped: item %d: dims too large", i);
+    LAKO_CHECK_ALIGN(p.a, 16);
+    LAKO_CHECK_ALIGN(p.b, 16);
+    LAKO_CHECK_ALIGN(p.c, 4);
+    TnArgs::Item& d = a.items[i];
+    d.A = (const char*)p.a; d.B = (const char*)p.b; d.C = p.c; d.M = (int)p.M; d.N = (int)p.N;
+    d.lda = p.lda; d.ldb = p.ldb; d.ldc = p.ldc; d.alpha = p.alpha;
+    d.tiles_n = cdiv((int)p.N, 256);
+    d.tile_start = tiles;
+    tiles += cdiv((int)p.M, 256) * d.tiles_n;
+  }
+  a.tiles_m = tiles;     // the kernel only uses the product
+  a.tiles_n = 1;
+  int sk = (256 + tiles / 2) / tiles;
+  const int max_split = cdiv(K, 64 * 4);
+  if (sk > max_split) sk = max_split;
+  if (sk < 1) sk = 1;
+  const int chunk = cdiv(cdiv(K, sk), 64) * 64;
+  a.split_k = cdiv(K, chunk);
+  a.k_chunk = chunk;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              4 * TN2_IMG);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(gemm_tn256_kernel, dim3(tiles * a.split_k), dim3(512), 4 * TN2_IMG, (hipStream_t)stream, a);
+  LAKO_LAUNCH_CHECK();
+  return LAKO_OK;
+}
+
 extern "C" int lako_set_tuning(const char* key, int value) {
   if (key && !strcmp(key, "gemm_nt_variant")) {
     g_nt_variant = value;

@@ -391,19 +391,27 @@ class Engine:
             a, b = self.by_name[first_block], self.by_name[last_block]
             self.grad_hook(a.off, b.off + -(-b.numel // ALIGN) * ALIGN)
 
-    def _ffn_bwd(self, lw, dh, a1, xn, h_in, rs, ln, p, drop_out, tmp):
-        """residual FFN sublayer backward; dh is updated in place to the gradient wrt the sublayer input."""
+    def _ffn_bwd(self, lw, dh, a1, xn, h_in, rs, ln, p, drop_out, tmp, dw=None):
+        """residual FFN sublayer backward; dh is updated in place to the gradient wrt the sublayer input.
+        `dw`: list collecting the weight-gradient problems for one grouped launch (encoder layers with dropout: their
+        operands live in per-layer scratch that stays untouched until the layer's backward is complete)."""
         ops = self.ops
         M, d = dh.shape
         f = a1.shape[1]
         dy = dh
         if p > 0:
-            dy = self._buf(tmp, f"dy.{M}", (M, d))
+            dy = self._buf(tmp, f"dy.ffn.{M}" if dw is not None else f"dy.{M}", (M, d))
             ops.dropout_apply(dh, dy, drop_out)
-        ops.gemm_tn(dy, a1, lw["wo"].g)
+        if dw is not None and p > 0:
+            dw.append((dy, a1, lw["wo"].g, 1.0))
+        else:
+            ops.gemm_tn(dy, a1, lw["wo"].g)
         dpre = self._buf(tmp, f"dpre.{M}", (M, f))
         ops.gemm_nt(dy, lw["wo"].wt, dpre, aux=a1, aux_scale=1.0 / (1.0 - p))   # ∘ [relu'>0] ∘ dropout
-        ops.gemm_tn(dpre, xn, lw["wi"].g)
+        if dw is not None:
+            dw.append((dpre, xn, lw["wi"].g, 1.0))
+        else:
+            ops.gemm_tn(dpre, xn, lw["wi"].g)
         dxn = self._buf(tmp, f"dxn.{M}", (M, d))
         ops.gemm_nt(dpre, lw["wi"].wt, dxn)
         ops.rmsnorm_bwd(dxn, h_in, ln.p, rs, dh, dh, ln.g)
@@ -495,12 +503,18 @@ class Engine:
             if ctx.ckpt:   # recompute this block's intermediates from its saved input (same seeds → same dropout masks)
                 j = 0
                 self._enc_layer_fwd(ws, i, 0, ws[f"e.h{i}"], None, BN, L, ctx.mask_u8, ws["e.rel"], dr)
+            # the layer's four weight gradients (K = all tokens, small M×N) go out as ONE grouped launch at the end of the
+            # layer: 108 tiles fill the chip with ~2 K-splits, where four separate launches need 7–28 splits each and
+            # pay one fp32 atomic pass over the output per split
+            dw = []
             self._ffn_bwd(lw, deh, ws[f"e.a1.{j}"], ws[f"e.xn2.{j}"], ws[f"e.h1.{j}"], ws[f"e.rs2.{j}"], lw["ln2"], p,
-                          dr(_enc_site(i, 3)), tmp)
+                          dr(_enc_site(i, 3)), tmp, dw)
             dy = deh
             if p > 0:
                 ops.dropout_apply(deh, dy := self._buf(tmp, f"dy.{Me}", (Me, d)), dr(_enc_site(i, 1)))
-            ops.gemm_tn(dy, ws[f"e.ctx.{j}"], lw["o"].g)
+                dw.append((dy, ws[f"e.ctx.{j}"], lw["o"].g, 1.0))
+            else:
+                ops.gemm_tn(dy, ws[f"e.ctx.{j}"], lw["o"].g)     # dy aliases deh, which the next ops rewrite
             dctx = self._buf(tmp, f"dctx.{Me}", (Me, inner))
             ops.gemm_nt(dy, lw["o"].wt, dctx)
             qkv = ws[f"e.qkv.{j}"]
@@ -510,9 +524,10 @@ class Engine:
                          self._heads(dqkv, BN, L, 0), self._heads(dqkv, BN, L, inner),
                          self._heads(dqkv, BN, L, 2 * inner), rel_bias=ws["e.rel"], drel=drel_e, rel_off=L - 1,
                          key_mask=ctx.mask_u8, drop=dr(_enc_site(i, 0)))
-            ops.gemm_tn(dqkv, ws[f"e.xn1.{j}"], lw["qkv"].g)
+            dw.append((dqkv, ws[f"e.xn1.{j}"], lw["qkv"].g, 1.0))
             ops.gemm_nt(dqkv, lw["qkv"].wt, dxe)
             ops.rmsnorm_bwd(dxe, ws[f"e.h{i}"], lw["ln1"].p, ws[f"e.rs1.{j}"], deh, deh, lw["ln1"].g)
+            ops.gemm_tn_grouped(dw)
             self._ready(f"enc.{i}.qkv", f"enc.{i}.ln2")
         ops.embed_bwd(ctx.ids, deh, self.shared.g, dr(S_ENC_EMBED))
         ops.relpos_reduce(drel_e, self._lut(L, L, True), self.enc_rel.g)

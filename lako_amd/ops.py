@@ -129,6 +129,30 @@ class HipOps:
         self._timed("gemm_tn", 2.0 * M * N * K, lambda: check(self.lib.lako_gemm_tn(_p(A), _p(B), _p(Cm), M, N, K, lda, ldb, ldc, _dt(A), float(alpha), int(split_k),
                                     self._stream()), "lako_gemm_tn"))
 
+    def gemm_tn_grouped(self, problems):
+        """[(A [K, M], B [K, N], C [M, N] fp32, alpha), …] with one K: every C += alpha·Aᵀ·B, one launch per
+        TN_GROUP_MAX problems (see lako_gemm_tn_grouped in include/lako_hip.h)."""
+        from ._lib import TN_GROUP_MAX, GemmTNItem
+        for g0 in range(0, len(problems), TN_GROUP_MAX):
+            grp = problems[g0:g0 + TN_GROUP_MAX]
+            arr = (GemmTNItem * len(grp))()
+            K0, flops = None, 0.0
+            for it, (A, B, Cm, alpha) in zip(arr, grp):
+                K, M, lda = _rowmajor2d(A, "gemm_tn_grouped A")
+                K2, N, ldb = _rowmajor2d(B, "gemm_tn_grouped B")
+                M2, N2, ldc = _rowmajor2d(Cm, "gemm_tn_grouped C")
+                if K != K2 or M != M2 or N != N2 or A.dtype != B.dtype or Cm.dtype != torch.float32 or A.dtype != grp[0][0].dtype:
+                    raise LakoError(f"gemm_tn_grouped: shape/dtype mismatch A{tuple(A.shape)} B{tuple(B.shape)} C{tuple(Cm.shape)}")
+                if K0 is None:
+                    K0 = K
+                elif K != K0:
+                    raise LakoError("gemm_tn_grouped: all problems must share K")
+                it.a, it.b, it.c = _p(A), _p(B), _p(Cm)
+                it.M, it.N, it.lda, it.ldb, it.ldc, it.alpha = M, N, lda, ldb, ldc, float(alpha)
+                flops += 2.0 * M * N * K
+            self._timed("gemm_tn", flops, lambda: check(self.lib.lako_gemm_tn_grouped(arr, len(grp), K0, _dt(grp[0][0]), self._stream()),
+                                                        "lako_gemm_tn_grouped"))
+
     # ---- norm / embedding / dropout ---------------------------------------------------------------
     def rmsnorm_fwd(self, x, w, y, rstd, eps, drop=None):
         rows, d = x.shape

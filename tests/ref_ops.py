@@ -96,6 +96,10 @@ class RefOps:
     def gemm_tn(self, A, B, Cm, *, alpha=1.0, split_k=0):
         Cm += (f(A).t() @ f(B)) * alpha
 
+    def gemm_tn_grouped(self, problems):
+        for A, B, Cm, alpha in problems:
+            self.gemm_tn(A, B, Cm, alpha=alpha)
+
     # ---- norm / embedding / dropout ------------------------------------------------------------
     def rmsnorm_fwd(self, x, w, y, rstd, eps, drop=None):
         xf = f(x)

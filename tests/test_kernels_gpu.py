@@ -91,6 +91,27 @@ def test_gemm_nt_tile_variants(ops, ref, variant, M, N, K):
         ops.set_tuning("gemm_nt_group_m", 8)
 
 
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+def test_gemm_tn_grouped(ops, ref, dt):
+    """several weight gradients sharing K in one launch (256×256 kernel, bf16) or its per-item fallback (fp32, small
+    shapes); accumulates into C like lako_gemm_tn."""
+    T = DT[dt]
+    K = 3000
+    for shapes in ([(768, 2304), (768, 768), (3072, 768), (768, 3072)], [(256, 264), (520, 256)], [(256, 256), (64, 304)],
+                   [(304, 256)] * 9):
+        probs, want = [], []
+        for i, (M, N) in enumerate(shapes):
+            A, B = rnd(K, M, dtype=T, seed=70 + i) * 0.25, rnd(K, N, dtype=T, seed=90 + i) * 0.25
+            C0 = rnd(M, N, seed=110 + i)
+            Cr = C0.clone()
+            ref.gemm_tn(A, B, Cr, alpha=0.5 + i)
+            probs.append((A, B, C0, 0.5 + i))
+            want.append(Cr)
+        ops.gemm_tn_grouped(probs)
+        for (A, B, Cg, _), Cr, (M, N) in zip(probs, want, shapes):
+            close(Cg, Cr, T, f"gemm_tn_grouped {dt} {M}x{N}")
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("M,N,K", [(128, 768, 32128), (40, 264, 5000), (128, 132, 2048)])
 def test_gemm_nt_split_k_atomic(ops, ref, dt, M, N, K):

@@ -109,9 +109,9 @@ if args.vendor:
         timeit("vendor " + nm, lambda: torch.matmul(A.t(), Bm, out=C), flops=2.0 * M * Nn * K)
         del A, Bm, C
 
-for big in ([1, 0] if "tn" in only else []):
+for big in ([1, 2, 0] if "tn" in only else []):
     ops.set_tuning("gemm_tn_big", big)
-    print(f"--- gemm_tn 256x256 kernel {'on' if big else 'off (128x128)'}", flush=True)
+    print(f"--- gemm_tn 256x256 kernel {['off (128x128)', 'on', 'on, accumulation atomics skipped (timing experiment)'][big]}", flush=True)
     for nm, (K, M, Nn) in [
         ("tn dWqkv [Me,2304]^T x [Me,768]", (Me, 3 * inner, d)),
         ("tn dWo   [Me,768]^T x [Me,768]", (Me, d, inner)),
@@ -124,6 +124,19 @@ for big in ([1, 0] if "tn" in only else []):
         C = torch.zeros(M, Nn, device=dev)
         timeit(nm, lambda: ops.gemm_tn(A, Bm, C), flops=2.0 * M * Nn * K)
         del A, Bm, C
+
+if "tn" in only:
+    print("--- gemm_tn grouped: the four weight gradients of an encoder layer in one launch", flush=True)
+    dys = [rnd(Me, 3 * inner), rnd(Me, d), rnd(Me, f), rnd(Me, d)]
+    xs = [rnd(Me, d), rnd(Me, inner), rnd(Me, d), rnd(Me, f)]
+    cs = [torch.zeros(a.shape[1], b.shape[1], device=dev) for a, b in zip(dys, xs)]
+    fl4 = sum(2.0 * Me * a.shape[1] * b.shape[1] for a, b in zip(dys, xs))
+    for big in (1, 2):
+        ops.set_tuning("gemm_tn_big", big)
+        timeit(f"tn layer: 4 separate launches{' (no atomics)' if big == 2 else ''}", lambda: [ops.gemm_tn(a, b, c) for a, b, c in zip(dys, xs, cs)], flops=fl4)
+        timeit(f"tn layer: 1 grouped launch{' (no atomics)' if big == 2 else ''}", lambda: ops.gemm_tn_grouped([(a, b, c, 1.0) for a, b, c in zip(dys, xs, cs)]), flops=fl4)
+    ops.set_tuning("gemm_tn_big", 1)
+    del dys, xs, cs
 
 if "attn" in only:
     BN = B * N
