@@ -943,6 +943,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(TnArgs a) {
 }
 
 int g_tn_big = 1;
+int g_tn_split = 0;   // > 0: force the number of K-splits of the 256x256 TN kernel (A/B measurements)
 int g_nt_wide_epi = 1;
 int g_nt_group_m = 8;
 int g_nt_debug = 0;
@@ -1136,6 +1137,7 @@ extern "C" int lako_gemm_tn(const void* A, const void* B, float* C, int64_t M, i
     if (sk <= 0) {   // one workgroup per CU (128 KiB LDS): aim at ~256 workgroups, >= 4 K-steps per split
       sk = (256 + tiles / 2) / tiles;
       const int max_split = cdiv(K, 64 * 4);
+      if (g_tn_split > 0) sk = g_tn_split;
       if (sk > max_split) sk = max_split;
       if (sk < 1) sk = 1;
     }
@@ -1217,6 +1219,7 @@ extern "C" int lako_gemm_tn_grouped(const lako_gemm_tn_item_t* items, int n_item
   a.tiles_n = 1;
   int sk = (256 + tiles / 2) / tiles;
   const int max_split = cdiv(K, 64 * 4);
+  if (g_tn_split > 0) sk = g_tn_split;
   if (sk > max_split) sk = max_split;
   if (sk < 1) sk = 1;
   const int chunk = cdiv(cdiv(K, sk), 64) * 64;
@@ -1257,6 +1260,10 @@ extern "C" int lako_set_tuning(const char* key, int value) {
   if (key && !strcmp(key, "gemm_nt_stagger")) {
     g_nt_stagger = value;
     return LAKO_OK;
+  }
+  if (key && !strcmp(key, "gemm_tn_split")) {
+    g_tn_split = value;
+    return 0;
   }
   if (key && !strcmp(key, "gemm_tn_big")) {
     g_tn_big = value;

@@ -136,7 +136,14 @@ if "tn" in only:
         timeit(f"tn layer: 4 separate launches{' (no atomics)' if big == 2 else ''}", lambda: [ops.gemm_tn(a, b, c) for a, b, c in zip(dys, xs, cs)], flops=fl4)
         timeit(f"tn layer: 1 grouped launch{' (no atomics)' if big == 2 else ''}", lambda: ops.gemm_tn_grouped([(a, b, c, 1.0) for a, b, c in zip(dys, xs, cs)]), flops=fl4)
     ops.set_tuning("gemm_tn_big", 1)
-    del dys, xs, cs
+    A, Bm = rnd(Me, Ld * 2 * inner), rnd(Me, d)
+    Ck = torch.zeros(Ld * 2 * inner, d, device=dev)
+    for sp in (0, 2, 3, 5, 7, 9, 14):
+        ops.set_tuning("gemm_tn_split", sp)
+        timeit(f"tn layer grouped, K-splits {sp or 'auto'}", lambda: ops.gemm_tn_grouped([(a, b, c, 1.0) for a, b, c in zip(dys, xs, cs)]), flops=fl4)
+        timeit(f"tn dWkv, K-splits {sp or 'auto'}", lambda: ops.gemm_tn(A, Bm, Ck), flops=2.0 * Me * Ld * 2 * inner * d)
+    ops.set_tuning("gemm_tn_split", 0)
+    del dys, xs, cs, A, Bm, Ck
 
 if "attn" in only:
     BN = B * N
