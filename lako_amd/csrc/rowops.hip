@@ -202,10 +202,13 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
   for (int64_t t = wid; t < n_tok; t += nw) {
     int64_t id = ids[t];
     if (id < 0 || id >= vocab) id = 0;
-    // one dword per lane per instruction: 256 contiguous bytes per wave atomic (full-rate shape)
+    // one dword per lane per instruction: 256 contiguous bytes per wave atomic (full-rate shape).  Wave-instructions
+    // whose 64 values are all zero are skipped: adding 0 changes nothing, and the gradient at padded positions is
+    // exactly 0 — a quarter of the config-2 tokens, every one of them aimed at the SAME table row (pad id 0).
     for (int c = lane; c < d; c += 64) {
       float v = (float)dout[t * d + c];
       if (dr.thresh) v = lako_keep(dr.key, (uint64_t)t * d + c, dr.thresh) ? v * dr.scale : 0.f;
+      if (__ballot(v != 0.f) == 0) continue;
       atomicAdd(dtable + id * d + c, v);
     }
   }
