@@ -133,11 +133,18 @@ typedef struct {
   int causal, causal_off;  /* causal: key j visible iff j <= i + causal_off */
   int Bn, H, Lq, Lk, d_head;
   int dtype;
-  lako_dropout_t drop; /* on the probabilities.  Attention uses a cheaper draw than the element-wise sites: keys 2c and
-                          2c+1 of score row (b,h,i) share hash32(key ^ (((b*H+h)*Lq+i)*ceil(Lk/2) + c)); the even key
-                          takes the low, the odd key the high 16 bits; keep iff half >= round(p*65536) */
+  lako_dropout_t drop; /* on the probabilities.  Attention uses a cheaper draw than the element-wise sites: keys 4c … 4c+3
+                          of score row (b,h,i) share h = hash32(key ^ (((b*H+h)*Lq+i)*ceil(Lk/4) + c)), w = h*0x9E3779B1;
+                          their 16-bit draws are h>>16, h&0xffff, w>>16, w&0xffff; keep iff draw >= round(p*65536) */
   float* scores_out;   /* optional [Bn, H, Lq, Lk] fp32 raw pre-softmax scores (+bias, masked keys = 0):
                           the quantity src/model.py:316-329 stores for get_crossattention_scores */
+  /* RAGGED sequences (optional; NULL = the padded layout above).  q_off / k_off: device int32 [Bn + 1] row offsets into ONE
+   * packed [rows, H*d_head] buffer: sequence b owns rows [off[b], off[b+1]) (addressing ptr + (off[b] + t)*stride_t + …, the
+   * batch stride is ignored); `out` follows q_off.  Lq / Lk are then the MAXIMUM lengths: the statistics buffer and the dropout
+   * draws stay indexed in padded coordinates, so a ragged call reproduces the padded call on the rows that exist.  Keys
+   * carry no padding in this form (key_mask must be NULL); score capture is not available. */
+  const int32_t* q_off;
+  const int32_t* k_off;
 } lako_attn_fwd_t;
 int lako_attn_fwd(const lako_attn_fwd_t* p, lako_stream_t stream);
 
@@ -154,6 +161,8 @@ typedef struct {
   int Bn, H, Lq, Lk, d_head;
   int dtype;
   lako_dropout_t drop;
+  const int32_t* q_off; /* ragged sequences, as in lako_attn_fwd_t (dq follows q_off; dk, dv follow k_off) */
+  const int32_t* k_off;
 } lako_attn_bwd_t;
 int lako_attn_bwd(const lako_attn_bwd_t* p, lako_stream_t stream);
 

@@ -45,6 +45,9 @@ struct AttnArgs {
   float* drel;
   const uint8_t* key_mask;
   float* scores_out;
+  // ragged (unpadded) sequences: rows of sequence b are rows [off[b], off[b+1]) of ONE packed [rows, H·dk] buffer (the batch
+  // stride is ignored); Lq / Lk are then the maxima (grid sizing, statistics and dropout indexing stay in padded coordinates)
+  const int32_t *q_off, *k_off;
   int64_t qsb, qst, ksb, kst, vsb, vst, osb, ost;  // strides in elements
   int R, rel_off, causal, causal_off;
   int Bn, H, Lq, Lk;
@@ -212,12 +215,12 @@ __device__ __forceinline__ int clampi(int x, int lo, int hi) { return min(max(x,
 // key's probability is EXACTLY 0 whenever its row has one attendable key (exp(−FLT_MAX − m) = 0), so tile pairs
 // without any can be skipped; a sequence with no attendable key at all keeps every tile (HF: uniform attention).
 __device__ __forceinline__ void stage_key_add(float* kadd, const uint8_t* key_mask, int b, int kc0, int nk, int Lk,
-                                              int* pair_any) {
+                                              int mask_ld, int* pair_any) {
   static_assert(CH_MAX <= 256, "one key per thread");
   const int i = threadIdx.x, j = kc0 + i;
   float f = 0.f;
   if (j >= Lk) f = -INFINITY;
-  else if (key_mask && !key_mask[(int64_t)b * Lk + j]) f = -FLT_MAX;
+  else if (key_mask && !key_mask[(int64_t)b * mask_ld + j]) f = -FLT_MAX;
   if (i < nk) kadd[i] = f;
   const uint64_t bal = __ballot(i < nk && f == 0.f);
   if ((threadIdx.x & 63) == 0) {
@@ -337,14 +340,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, l15 = lane & 15;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int nqb = (a.Lq + 15) >> 4;
+  const int nqb = (a.Lq + 15) >> 4;                        // padded maximum (grid, key-split decision)
+  // this sequence's own lengths and row offsets (ragged mode) — bounds use Lq / Lk, index hashing a.Lq / a.Lk
+  const int q0 = a.q_off ? a.q_off[b] : 0, k0 = a.k_off ? a.k_off[b] : 0;
+  const int Lq = a.q_off ? a.q_off[b + 1] - q0 : a.Lq, Lk = a.k_off ? a.k_off[b + 1] - k0 : a.Lk;
   const int qb_begin = blockIdx.x * a.blocks_per_wg;
-  const int qb_end = min(nqb, qb_begin + a.blocks_per_wg);
-  const int nchunks = (a.Lk + CH - 1) / CH;
-  const char* qbase = a.q + ((int64_t)b * a.qsb + (int64_t)h * DK) * C::ES;
-  const char* kbase = a.k + ((int64_t)b * a.ksb + (int64_t)h * DK) * C::ES;
-  const char* vbase = a.v + ((int64_t)b * a.vsb + (int64_t)h * DK) * C::ES;
-  char* obase = a.out + ((int64_t)b * a.osb + (int64_t)h * DK) * C::ES;
+  const int qb_end = min((Lq + 15) >> 4, qb_begin + a.blocks_per_wg);
+  const int nchunks = (Lk + CH - 1) / CH;
+  const int64_t hoff = (int64_t)h * DK;
+  const char* qbase = a.q + ((a.q_off ? (int64_t)q0 * a.qst : (int64_t)b * a.qsb) + hoff) * C::ES;
+  const char* kbase = a.k + ((a.k_off ? (int64_t)k0 * a.kst : (int64_t)b * a.ksb) + hoff) * C::ES;
+  const char* vbase = a.v + ((a.k_off ? (int64_t)k0 * a.vst : (int64_t)b * a.vsb) + hoff) * C::ES;
+  char* obase = a.out + ((a.q_off ? (int64_t)q0 * a.ost : (int64_t)b * a.osb) + hoff) * C::ES;
   const bool has_bias = a.rel_bias != nullptr;
   if (has_bias)
     for (int i = threadIdx.x; i < a.R; i += 256) bias_l[i] = a.rel_bias[(int64_t)h * a.R + i];
@@ -364,7 +371,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   u32x4 qf_next[C::NF];
   auto request_q = [&](int qb0n) {
     const int qbn = ksplit ? qb0n : qb0n + wave;
-    load_reg_frags<T, DK>(qf_next, qbase, a.qst, (qb0n < qb_end && qbn < qb_end) ? qbn * 16 + l15 : a.Lq, a.Lq, lane);
+    load_reg_frags<T, DK>(qf_next, qbase, a.qst, (qb0n < qb_end && qbn < qb_end) ? qbn * 16 + l15 : Lq, Lq, lane);
   };
   request_q(qb_begin);
   for (int qb0 = qb_begin; qb0 < qb_end; qb0 += 4) {
@@ -384,12 +391,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 
     for (int ch = 0; ch < nchunks; ++ch) {
       const int kc0 = ch * CH;
-      const int nk = min(CH, ((a.Lk - kc0 + 31) >> 5) << 5);  // rows used in this chunk (multiple of 32)
+      const int nk = min(CH, ((Lk - kc0 + 31) >> 5) << 5);  // rows used in this chunk (multiple of 32)
       if (nchunks > 1 || qb0 == qb_begin) {
         __syncthreads();
-        stage_image<T, DK>(Kimg, kbase, a.kst, kc0, nk, a.Lk);
-        stage_image<T, DK>(Vimg, vbase, a.vst, kc0, nk, a.Lk);
-        stage_key_add(kadd, a.key_mask, b, kc0, nk, a.Lk, pair_any);
+        stage_image<T, DK>(Kimg, kbase, a.kst, kc0, nk, Lk);
+        stage_image<T, DK>(Vimg, vbase, a.vst, kc0, nk, Lk);
+        stage_key_add(kadd, a.key_mask, b, kc0, nk, Lk, a.Lk, pair_any);
         __syncthreads();
         if (!CAPTURE && nchunks == 1) {
           okbits = pair_bits(pair_any);
@@ -458,7 +465,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         m = M;
       }
     }
-    if (active && qi < a.Lq && (!ksplit || wave == 0)) {
+    if (active && qi < Lq && (!ksplit || wave == 0)) {
       const float inv = 1.0f / lsum;
       T* op = reinterpret_cast<T*>(obase + (int64_t)qi * a.ost * C::ES);
 #pragma unroll
@@ -495,12 +502,21 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   const int h = blockIdx.y;
   const int bn_per = MODE == 0 ? a.bn_per_wg : 1;
   const int b_begin = blockIdx.z * bn_per, b_end = min(a.Bn, b_begin + bn_per);
-  const int LX = MODE == 0 ? a.Lk : a.Lq;  // LDS side length
-  const int LY = MODE == 0 ? a.Lq : a.Lk;  // register side length
-  const int nyb = (LY + 15) >> 4;
+  const int LXm = MODE == 0 ? a.Lk : a.Lq;  // LDS side length      } padded maxima: grid-uniform decisions
+  const int LYm = MODE == 0 ? a.Lq : a.Lk;  // register side length }
+  const int nyb = (LYm + 15) >> 4;
   const int yb_begin = blockIdx.x * a.blocks_per_wg;
   const int yb_end = min(nyb, yb_begin + a.blocks_per_wg);
-  const int nchunks = (LX + CH - 1) / CH;
+  const int nchunks_m = (LXm + CH - 1) / CH;
+  // ragged mode: row offset and length of sequence bb on the query / key side
+  auto seq_q = [&](int bb, int& o0, int& len) { o0 = a.q_off ? a.q_off[bb] : 0; len = a.q_off ? a.q_off[bb + 1] - o0 : a.Lq; };
+  auto seq_k = [&](int bb, int& o0, int& len) { o0 = a.k_off ? a.k_off[bb] : 0; len = a.k_off ? a.k_off[bb + 1] - o0 : a.Lk; };
+  auto base_q = [&](const char* ptr, int bb, int o0, int64_t sb, int64_t st) {
+    return ptr + ((a.q_off ? (int64_t)o0 * st : (int64_t)bb * sb) + (int64_t)h * DK) * C::ES;
+  };
+  auto base_k = [&](const char* ptr, int bb, int o0, int64_t sb, int64_t st) {
+    return ptr + ((a.k_off ? (int64_t)o0 * st : (int64_t)bb * sb) + (int64_t)h * DK) * C::ES;
+  };
   const int64_t hoff = (int64_t)h * DK;
   const bool has_bias = a.rel_bias != nullptr;
   const bool want_drel = MODE == 0 && a.drel != nullptr;
@@ -522,7 +538,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   // element are ~40 cycles per wave-instruction, so when one round covers the workgroup's query blocks
   // (each wave keeps ONE query block) the dS tiles are summed in registers over the workgroup's batch rows
   // (tile position → fixed diagonal offsets) and reduced over diagonals once at the end.
-  const bool fast_drel = want_drel && nchunks == 1 && (yb_end - yb_begin) <= 4;
+  const bool fast_drel = want_drel && nchunks_m == 1 && (yb_end - yb_begin) <= 4;
   f32x4 dsacc[16];
 #pragma unroll
   for (int t = 0; t < 16; ++t) dsacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -531,36 +547,49 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   // computed — see attn_fwd_kernel
   u32x4 n1[C::NF], n2[C::NF], n3[C::NF];
   float ns0 = 0.f, ns1 = 0.f, nkadd = 0.f;
+  int req_b = -1, req_yb = -1;     // what n1 … currently hold
   auto request = [&](int bb, int ybb0) {
+    req_b = bb;
+    req_yb = ybb0;
+    int o0 = 0, len = 0;
+    if (bb < b_end) {
+      if (MODE == 0) seq_q(bb, o0, len);
+      else seq_k(bb, o0, len);
+    }
     const int ybn = ksplit ? ybb0 : ybb0 + wave;
-    const bool act = bb < b_end && ybb0 < yb_end && ybn < yb_end;
-    const int yin = act ? ybn * 16 + l15 : LY;
+    const bool act = bb < b_end && ybb0 < yb_end && ybn * 16 < len;
+    const int yin = act ? ybn * 16 + l15 : len;
     if constexpr (MODE == 0) {
-      load_reg_frags<T, DK>(n1, a.q + ((int64_t)bb * a.qsb + hoff) * C::ES, a.qst, yin, a.Lq, lane);
-      load_reg_frags<T, DK>(n2, a.dout + ((int64_t)bb * a.osb + hoff) * C::ES, a.ost, yin, a.Lq, lane);
-      load_reg_frags<T, DK>(n3, a.o + ((int64_t)bb * a.osb + hoff) * C::ES, a.ost, yin, a.Lq, lane);
+      load_reg_frags<T, DK>(n1, base_q(a.q, bb, o0, a.qsb, a.qst), a.qst, yin, len, lane);
+      load_reg_frags<T, DK>(n2, base_q(a.dout, bb, o0, a.osb, a.ost), a.ost, yin, len, lane);
+      load_reg_frags<T, DK>(n3, base_q(a.o, bb, o0, a.osb, a.ost), a.ost, yin, len, lane);
       ns0 = ns1 = 0.f;
-      if (yin < a.Lq) {
+      if (yin < len) {
         const float* st = a.stats + (((int64_t)bb * a.H + h) * a.Lq + yin) * 4;
         ns0 = st[0];
         ns1 = st[1];
       }
     } else {
-      load_reg_frags<T, DK>(n1, a.k + ((int64_t)bb * a.ksb + hoff) * C::ES, a.kst, yin, a.Lk, lane);
-      load_reg_frags<T, DK>(n2, a.v + ((int64_t)bb * a.vsb + hoff) * C::ES, a.vst, yin, a.Lk, lane);
+      load_reg_frags<T, DK>(n1, base_k(a.k, bb, o0, a.ksb, a.kst), a.kst, yin, len, lane);
+      load_reg_frags<T, DK>(n2, base_k(a.v, bb, o0, a.vsb, a.vst), a.vst, yin, len, lane);
       nkadd = 0.f;
-      if (yin >= a.Lk) nkadd = -INFINITY;
+      if (yin >= len) nkadd = -INFINITY;
       else if (a.key_mask && !a.key_mask[(int64_t)bb * a.Lk + yin]) nkadd = -FLT_MAX;
     }
   };
-  request(b_begin, yb_begin);
 
   for (int b = b_begin; b < b_end; ++b) {
-  const char* qbase = a.q + ((int64_t)b * a.qsb + hoff) * C::ES;
-  const char* kbase = a.k + ((int64_t)b * a.ksb + hoff) * C::ES;
-  const char* vbase = a.v + ((int64_t)b * a.vsb + hoff) * C::ES;
-  const char* obase = a.o + ((int64_t)b * a.osb + hoff) * C::ES;
-  const char* dobase = a.dout + ((int64_t)b * a.osb + hoff) * C::ES;
+  int q0, k0, Lq, Lk;
+  seq_q(b, q0, Lq);
+  seq_k(b, k0, Lk);
+  const int LX = MODE == 0 ? Lk : Lq, LY = MODE == 0 ? Lq : Lk;   // this sequence's own lengths (bounds)
+  const int ybe = min(yb_end, (LY + 15) >> 4);
+  const int nchunks = (LX + CH - 1) / CH;
+  if (ybe <= yb_begin || LX <= 0) continue;                       // nothing of this sequence in this workgroup
+  const char* qbase = base_q(a.q, b, q0, a.qsb, a.qst);
+  const char* kbase = base_k(a.k, b, k0, a.ksb, a.kst);
+  const char* vbase = base_k(a.v, b, k0, a.vsb, a.vst);
+  const char* dobase = base_q(a.dout, b, q0, a.osb, a.ost);
   float* stats = a.stats + ((int64_t)b * a.H + h) * a.Lq * 4;
   bool seq_any = true;        // MODE 1: does this sequence have an attendable key at all?
   if (MODE == 1 && a.key_mask) {
@@ -568,14 +597,15 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
     if (threadIdx.x == 0) pair_any[0] = 0;
     __syncthreads();
     bool mine = false;
-    for (int j = threadIdx.x; j < a.Lk; j += 256) mine |= a.key_mask[(int64_t)b * a.Lk + j] != 0;
+    for (int j = threadIdx.x; j < Lk; j += 256) mine |= a.key_mask[(int64_t)b * a.Lk + j] != 0;
     if (__ballot(mine) != 0 && (threadIdx.x & 63) == 0) pair_any[0] = 1;
     __syncthreads();
     seq_any = pair_any[0] != 0;
   }
-  for (int yb0 = yb_begin; yb0 < yb_end; yb0 += 4) {
+  for (int yb0 = yb_begin; yb0 < ybe; yb0 += 4) {
     const int yb = ksplit ? yb0 : yb0 + wave;
-    const bool active = yb < yb_end;
+    const bool active = yb < ybe;
+    if (req_b != b || req_yb != yb0) request(b, yb0);   // first round of the launch, or the rows before were empty
     const int yi = active ? yb * 16 + l15 : LY;  // this lane's register-side row (query in MODE 0, key in MODE 1)
     u32x4 y1[C::NF], y2[C::NF];
     float m_q = 0.f, invl_q = 0.f, delta_q = 0.f;   // MODE 0: this lane's query statistics (inv = 0 ⇒ p = 0)
@@ -589,7 +619,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
     }
     const float st_m = ns0, st_il = ns1;
     kadd_lane = nkadd;
-    if (yb0 + 4 < yb_end) request(b, yb0 + 4);
+    if (yb0 + 4 < ybe) request(b, yb0 + 4);
     else request(b + 1, yb_begin);
     if constexpr (MODE == 0) {
       float part = 0.f;
@@ -606,7 +636,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
         }
       }
       delta_q = group_sum(part);
-      if (yi < a.Lq) {
+      if (yi < Lq) {
         m_q = st_m;
         invl_q = st_il;
         if (g == 0) stats[yi * 4 + 2] = delta_q;   // handed to the dK/dV pass (launched after this one)
@@ -628,16 +658,16 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
       if (nchunks > 1 || yb0 == yb_begin) {
         __syncthreads();
         if constexpr (MODE == 0) {
-          stage_image<T, DK>(X1, kbase, a.kst, x0, nx, a.Lk);
-          stage_image<T, DK>(X2, vbase, a.vst, x0, nx, a.Lk);
-          stage_key_add(aux0, a.key_mask, b, x0, nx, a.Lk, pair_any);
+          stage_image<T, DK>(X1, kbase, a.kst, x0, nx, Lk);
+          stage_image<T, DK>(X2, vbase, a.vst, x0, nx, Lk);
+          stage_key_add(aux0, a.key_mask, b, x0, nx, Lk, a.Lk, pair_any);
         } else {
-          stage_image<T, DK>(X1, qbase, a.qst, x0, nx, a.Lq);
-          stage_image<T, DK>(X2, dobase, a.ost, x0, nx, a.Lq);
+          stage_image<T, DK>(X1, qbase, a.qst, x0, nx, Lq);
+          stage_image<T, DK>(X2, dobase, a.ost, x0, nx, Lq);
           for (int i = threadIdx.x; i < nx; i += 256) {
             const int qi = x0 + i;
             f32x4 st4 = {0.f, 0.f, 0.f, 0.f};
-            if (qi < a.Lq) st4 = *reinterpret_cast<const f32x4*>(stats + qi * 4);
+            if (qi < Lq) st4 = *reinterpret_cast<const f32x4*>(stats + qi * 4);
             aux0[i] = st4[0];
             aux1[i] = st4[1];   // 0 for padded rows ⇒ p = 0 there
             aux2[i] = st4[2];   // delta = rowsum(dO∘O), written by the dQ pass
@@ -752,12 +782,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
     }
     if (active && yi < LY && (!ksplit || wave == 0)) {
       if constexpr (MODE == 0) {
-        T* op = reinterpret_cast<T*>(a.dq + ((int64_t)b * a.qsb + (int64_t)yi * a.qst + hoff) * C::ES);
+        T* op = reinterpret_cast<T*>(const_cast<char*>(base_q(a.dq, b, q0, a.qsb, a.qst)) + (int64_t)yi * a.qst * C::ES);
 #pragma unroll
         for (int db = 0; db < C::NDB; ++db) store4(op + db * 16 + 4 * g, acc1[db]);
       } else {
-        T* kp = reinterpret_cast<T*>(a.dk + ((int64_t)b * a.ksb + (int64_t)yi * a.kst + hoff) * C::ES);
-        T* vp = reinterpret_cast<T*>(a.dv + ((int64_t)b * a.vsb + (int64_t)yi * a.vst + hoff) * C::ES);
+        T* kp = reinterpret_cast<T*>(const_cast<char*>(base_k(a.dk, b, k0, a.ksb, a.kst)) + (int64_t)yi * a.kst * C::ES);
+        T* vp = reinterpret_cast<T*>(const_cast<char*>(base_k(a.dv, b, k0, a.vsb, a.vst)) + (int64_t)yi * a.vst * C::ES);
 #pragma unroll
         for (int db = 0; db < C::NDB; ++db) {
           store4(kp + db * 16 + 4 * g, acc1[db]);
@@ -945,6 +975,10 @@ extern "C" int lako_attn_fwd(const lako_attn_fwd_t* p, lako_stream_t stream) {
   a.causal = p->causal;
   a.causal_off = p->causal_off;
   a.Bn = p->Bn; a.H = p->H; a.Lq = p->Lq; a.Lk = p->Lk;
+  a.q_off = p->q_off;
+  a.k_off = p->k_off;
+  LAKO_CHECK_ARG(!(p->scores_out && (p->q_off || p->k_off)), "lako_attn_fwd: score capture needs the padded layout");
+  LAKO_CHECK_ARG(!(p->key_mask && p->k_off), "lako_attn_fwd: ragged keys carry no padding — pass key_mask = NULL");
   set_drop(a, p->drop);
   ATTN_DISPATCH(p->dtype, p->d_head, run_fwd, a, (hipStream_t)stream);
   LAKO_LAUNCH_CHECK();
@@ -978,6 +1012,9 @@ extern "C" int lako_attn_bwd(const lako_attn_bwd_t* p, lako_stream_t stream) {
   a.causal = p->causal;
   a.causal_off = p->causal_off;
   a.Bn = p->Bn; a.H = p->H; a.Lq = p->Lq; a.Lk = p->Lk;
+  a.q_off = p->q_off;
+  a.k_off = p->k_off;
+  LAKO_CHECK_ARG(!(p->key_mask && p->k_off), "lako_attn_bwd: ragged keys carry no padding — pass key_mask = NULL");
   set_drop(a, p->drop);
   ATTN_DISPATCH(p->dtype, p->d_head, run_bwd, a, (hipStream_t)stream);
   LAKO_LAUNCH_CHECK();

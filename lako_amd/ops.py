@@ -185,11 +185,27 @@ class HipOps:
         self._timed("relpos_reduce", 0.0, lambda: check(self.lib.lako_relpos_reduce(_p(drel), _p(lut), _p(dtable), H, drel.shape[1], nb, self._stream()), "lako_relpos_reduce"))
 
     # ---- attention ------------------------------------------------------------------------------
-    def attn_fwd(self, q, k, v, out, stats, *, rel_bias=None, rel_off=0, key_mask=None, causal=False, causal_off=0,
-                 drop=None, scores_out=None):
-        p = AttnFwd()
+    @staticmethod
+    def _ragged(p, q, k, q_off, k_off, max_q, max_k):
+        """ragged sequences (lako_attn_fwd_t.q_off / k_off): q / k arrive as ONE packed [1, rows, H, dk] view each."""
         Bn, Lq, H, dk = q.shape
         Lk = k.shape[1]
+        for off, t, mx, nm in ((q_off, q, max_q, "q"), (k_off, k, max_k, "k")):
+            if off is not None:
+                if off.dtype != torch.int32 or not off.is_contiguous() or t.shape[0] != 1 or mx is None:
+                    raise LakoError(f"attention: {nm}_off must be contiguous int32 [Bn + 1], {nm} a packed [1, rows, H, dk] view, max_{nm} given")
+        if q_off is not None:
+            Bn, Lq, p.q_off = q_off.numel() - 1, int(max_q), q_off.data_ptr()
+        if k_off is not None:
+            Lk, p.k_off = int(max_k), k_off.data_ptr()
+            if q_off is None and k_off.numel() - 1 != Bn:
+                raise LakoError("attention: k_off must have Bn + 1 entries")
+        return Bn, Lq, Lk, H, dk
+
+    def attn_fwd(self, q, k, v, out, stats, *, rel_bias=None, rel_off=0, key_mask=None, causal=False, causal_off=0,
+                 drop=None, scores_out=None, q_off=None, k_off=None, max_q=None, max_k=None):
+        p = AttnFwd()
+        Bn, Lq, Lk, H, dk = self._ragged(p, q, k, q_off, k_off, max_q, max_k)
         p.q, p.k, p.v, p.out, p.lse = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), stats.data_ptr()
         p.q_stride_b, p.q_stride_t = _bthd(q, "attn q")
         p.k_stride_b, p.k_stride_t = _bthd(k, "attn k")
@@ -211,10 +227,9 @@ class HipOps:
         self._timed("attn_fwd", 4.0 * Bn * H * Lq * Lk * dk, lambda: check(self.lib.lako_attn_fwd(C.byref(p), self._stream()), "lako_attn_fwd"))
 
     def attn_bwd(self, q, k, v, out, dout, stats, dq, dk_, dv, *, rel_bias=None, drel=None, rel_off=0, key_mask=None,
-                 causal=False, causal_off=0, drop=None):
+                 causal=False, causal_off=0, drop=None, q_off=None, k_off=None, max_q=None, max_k=None):
         p = AttnBwd()
-        Bn, Lq, H, dk = q.shape
-        Lk = k.shape[1]
+        Bn, Lq, Lk, H, dk = self._ragged(p, q, k, q_off, k_off, max_q, max_k)
         p.q, p.k, p.v, p.out, p.dout, p.lse = (q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
                                                dout.data_ptr(), stats.data_ptr())
         p.dq_out, p.dk_out, p.dv_out = dq.data_ptr(), dk_.data_ptr(), dv.data_ptr()

@@ -181,26 +181,71 @@ class RefOps:
         out = torch.einsum("bhqk,bkhd->bqhd", pn, v)
         return out, m, 1.0 / l, raw
 
+    # Ragged sequences (q_off / k_off, see include/lako_hip.h): by definition the ragged call equals the PADDED call
+    # on the rows that exist, so the double pads the packed [1, rows, H, dk] tensors to [Bn, Lmax, H, dk], derives the
+    # key mask from the lengths, runs the padded math and copies the existing rows back.
+    @staticmethod
+    def _pad(t, off, Lmax):
+        n = off.numel() - 1
+        o = off.tolist()
+        out = torch.zeros(n, Lmax, *t.shape[2:], dtype=torch.float32, device=t.device)
+        for b in range(n):
+            out[b, :o[b + 1] - o[b]] = f(t[0, o[b]:o[b + 1]])
+        return out
+
+    @staticmethod
+    def _unpad_into(dst, src, off):
+        o = off.tolist()
+        for b in range(len(o) - 1):
+            dst[0, o[b]:o[b + 1]] = src[b, :o[b + 1] - o[b]].to(dst.dtype)
+
+    @staticmethod
+    def _len_mask(off, Lmax):
+        lens = (off[1:] - off[:-1]).long()
+        return torch.arange(Lmax, device=off.device)[None, :] < lens[:, None]
+
     def attn_fwd(self, q, k, v, out, stats, *, rel_bias=None, rel_off=0, key_mask=None, causal=False, causal_off=0,
-                 drop=None, scores_out=None):
-        o, m, il, raw = self._attn_core(f(q), f(k), f(v), rel_bias, rel_off, key_mask, causal, causal_off, drop)
-        out.copy_(o)
+                 drop=None, scores_out=None, q_off=None, k_off=None, max_q=None, max_k=None):
+        qf, kf, vf = f(q), f(k), f(v)
+        if q_off is not None:
+            qf = self._pad(q, q_off, max_q)
+        if k_off is not None:
+            assert key_mask is None
+            kf, vf, key_mask = self._pad(k, k_off, max_k), self._pad(v, k_off, max_k), self._len_mask(k_off, max_k)
+        o, m, il, raw = self._attn_core(qf, kf, vf, rel_bias, rel_off, key_mask, causal, causal_off, drop)
+        if q_off is not None:
+            self._unpad_into(out, o, q_off)
+        else:
+            out.copy_(o)
         stats[..., 0] = m
         stats[..., 1] = il
         if scores_out is not None:
             scores_out.copy_(raw)
 
     def attn_bwd(self, q, k, v, out, dout, stats, dq, dk_, dv, *, rel_bias=None, drel=None, rel_off=0, key_mask=None,
-                 causal=False, causal_off=0, drop=None):
+                 causal=False, causal_off=0, drop=None, q_off=None, k_off=None, max_q=None, max_k=None):
+        qp, kp, vp, dop = f(q), f(k), f(v), f(dout)
+        if q_off is not None:
+            qp, dop = self._pad(q, q_off, max_q), self._pad(dout, q_off, max_q)
+        if k_off is not None:
+            assert key_mask is None
+            kp, vp, key_mask = self._pad(k, k_off, max_k), self._pad(v, k_off, max_k), self._len_mask(k_off, max_k)
         with torch.enable_grad():
-            qf, kf, vf = (f(t).detach().clone().requires_grad_(True) for t in (q, k, v))
+            qf, kf, vf = (t.detach().clone().requires_grad_(True) for t in (qp, kp, vp))
             rb = rel_bias.detach().clone().requires_grad_(True) if rel_bias is not None else None
             o, _, _, _ = self._attn_core(qf, kf, vf, rb, rel_off, key_mask, causal, causal_off, drop)
             ins = [qf, kf, vf] + ([rb] if rb is not None else [])
-            gs = torch.autograd.grad(o, ins, f(dout))
-        dq.copy_(gs[0])
-        dk_.copy_(gs[1])
-        dv.copy_(gs[2])
+            gs = torch.autograd.grad(o, ins, dop)
+        if q_off is not None:
+            self._unpad_into(dq, gs[0], q_off)
+        else:
+            dq.copy_(gs[0])
+        if k_off is not None:
+            self._unpad_into(dk_, gs[1], k_off)
+            self._unpad_into(dv, gs[2], k_off)
+        else:
+            dk_.copy_(gs[1])
+            dv.copy_(gs[2])
         if drel is not None:
             drel += gs[3]
 

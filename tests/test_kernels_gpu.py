@@ -329,6 +329,85 @@ def test_attention(ops, ref, dt, case):
 
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("kind", ["self", "self_drop", "cross"])
+def test_attention_ragged_equals_padded(ops, dt, kind):
+    """Ragged sequences (q_off / k_off over packed rows) must reproduce the PADDED call with a key mask on the rows that
+    exist: outputs, softmax statistics, dq / dk / dv and the bias gradient — including an empty sequence."""
+    T = DT[dt]
+    H, dk = 4, 64
+    inner = H * dk
+    if kind == "cross":
+        Bn, Lq, Lmax = 3, 6, 150
+        lens = [150, 0 + 37, 96]
+    else:
+        Bn, Lmax = 5, 70
+        Lq = Lmax
+        lens = [70, 33, 0, 48, 1]
+    drop = (0.1, 5, 9) if kind == "self_drop" else None
+    off = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=dev())
+    rows = int(off[-1])
+    km = (torch.arange(Lmax, device=dev())[None] < torch.tensor(lens, device=dev())[:, None]).to(torch.uint8)
+    rel = rnd(H, 2 * Lmax - 1, seed=44) if kind != "cross" else None
+    bias = dict(rel_bias=rel, rel_off=Lmax - 1) if rel is not None else {}
+
+    def pack(tp):       # [Bn, Lmax, C] padded → [1, rows, C] packed (existing rows only)
+        return torch.cat([tp[b, :lens[b]] for b in range(Bn)], 0)[None].contiguous()
+
+    if kind == "cross":
+        q_p = rnd(Bn, Lq, inner, dtype=T, seed=45, scale=0.5)
+        kv_p = rnd(Bn, Lmax, 2 * inner, dtype=T, seed=46, scale=0.5)
+        kv_r = pack(kv_p)
+        heads = lambda t, c0: t[:, :, c0:c0 + inner].unflatten(2, (H, dk))      # noqa: E731
+        args_p = (heads(q_p, 0), heads(kv_p, 0), heads(kv_p, inner))
+        args_r = (heads(q_p, 0), heads(kv_r, 0), heads(kv_r, inner))
+        rag = dict(k_off=off, max_k=Lmax)
+    else:
+        qkv_p = rnd(Bn, Lmax, 3 * inner, dtype=T, seed=47, scale=0.5)
+        qkv_r = pack(qkv_p)
+        heads = lambda t, c0: t[:, :, c0:c0 + inner].unflatten(2, (H, dk))      # noqa: E731
+        args_p = tuple(heads(qkv_p, c) for c in (0, inner, 2 * inner))
+        args_r = tuple(heads(qkv_r, c) for c in (0, inner, 2 * inner))
+        rag = dict(q_off=off, k_off=off, max_q=Lmax, max_k=Lmax)
+    nq = Lq
+    out_p = torch.zeros(Bn, nq, inner, dtype=T, device=dev())
+    st_p = torch.zeros(Bn, H, nq, 4, device=dev())
+    ops.attn_fwd(*args_p, out_p.unflatten(2, (H, dk)), st_p, key_mask=km, drop=drop, **bias)
+    if kind == "cross":
+        out_r, st_r = torch.zeros_like(out_p), torch.zeros_like(st_p)
+        ops.attn_fwd(*args_r, out_r.unflatten(2, (H, dk)), st_r, drop=drop, **bias, **rag)
+        assert torch.equal(out_r, out_p) and torch.equal(st_r[..., :2], st_p[..., :2])
+    else:
+        out_r = torch.zeros(1, rows, inner, dtype=T, device=dev())
+        st_r = torch.zeros_like(st_p)
+        ops.attn_fwd(*args_r, out_r.unflatten(2, (H, dk)), st_r, drop=drop, **bias, **rag)
+        assert torch.equal(out_r, pack(out_p))
+        for b in range(Bn):
+            assert torch.equal(st_r[b, :, :lens[b], :2], st_p[b, :, :lens[b], :2])
+    # backward
+    dout_p = rnd(Bn, nq, inner, dtype=T, seed=48)
+    if kind != "cross":
+        dout_p = dout_p * km[:, :, None].to(T)            # rows that do not exist carry no gradient
+    drel_p = torch.zeros_like(rel) if rel is not None else None
+    drel_r = torch.zeros_like(rel) if rel is not None else None
+    if kind == "cross":
+        dq_p, dkv_p = torch.zeros_like(q_p), torch.zeros_like(kv_p)
+        ops.attn_bwd(*args_p, out_p.unflatten(2, (H, dk)), dout_p.unflatten(2, (H, dk)), st_p, heads(dq_p, 0), heads(dkv_p, 0),
+                     heads(dkv_p, inner), key_mask=km, drop=drop)
+        dq_r, dkv_r = torch.zeros_like(q_p), torch.zeros_like(kv_r)
+        ops.attn_bwd(*args_r, out_r.unflatten(2, (H, dk)), dout_p.unflatten(2, (H, dk)), st_r, heads(dq_r, 0), heads(dkv_r, 0),
+                     heads(dkv_r, inner), drop=drop, **rag)
+        assert torch.equal(dq_r, dq_p) and torch.equal(dkv_r, pack(dkv_p))
+    else:
+        dqkv_p, dqkv_r = torch.zeros_like(qkv_p), torch.zeros_like(qkv_r)
+        ops.attn_bwd(*args_p, out_p.unflatten(2, (H, dk)), dout_p.unflatten(2, (H, dk)), st_p, heads(dqkv_p, 0),
+                     heads(dqkv_p, inner), heads(dqkv_p, 2 * inner), key_mask=km, drop=drop, drel=drel_p, **bias)
+        ops.attn_bwd(*args_r, out_r.unflatten(2, (H, dk)), pack(dout_p).unflatten(2, (H, dk)), st_r, heads(dqkv_r, 0),
+                     heads(dqkv_r, inner), heads(dqkv_r, 2 * inner), drop=drop, drel=drel_r, **bias, **rag)
+        assert torch.equal(dqkv_r, pack(dqkv_p))
+        close(drel_r, drel_p, torch.float32, "ragged drel", k=5)      # atomics: order differs
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("M,V", [(12, 64), (128, 32128)])
 def test_cross_entropy(ops, ref, dt, M, V):
     T = DT[dt]
