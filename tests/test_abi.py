@@ -61,7 +61,7 @@ def test_struct_layouts_match_header_order():
             decl = decl.strip()
             if not decl:
                 continue
-            decl = re.sub(r"^(const\s+)?(void|float|int64_t|int|uint8_t|uint32_t|lako_dropout_t)\b", "", decl)
+            decl = re.sub(r"^(const\s+)?(void|float|int64_t|int32_t|int|uint8_t|uint32_t|lako_dropout_t)\b", "", decl)
             names += [n.strip(" *") for n in decl.split(",")]
         assert names == [f[0] for f in py._fields_], (cname, names)
 
