@@ -28,6 +28,7 @@
 namespace {
 
 constexpr int CH_MAX = 256;  // LDS-side rows per chunk
+constexpr int OFFS_MAX = 64; // batch rows per workgroup (+1) whose ragged offsets are staged in LDS
 
 template <typename T, int DK> struct AC {
   static constexpr int ES = sizeof(T);
@@ -342,8 +343,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   const int b = blockIdx.z, h = blockIdx.y;
   const int nqb = (a.Lq + 15) >> 4;                        // padded maximum (grid, key-split decision)
   // this sequence's own lengths and row offsets (ragged mode) — bounds use Lq / Lk, index hashing a.Lq / a.Lk
-  const int q0 = a.q_off ? a.q_off[b] : 0, k0 = a.k_off ? a.k_off[b] : 0;
-  const int Lq = a.q_off ? a.q_off[b + 1] - q0 : a.Lq, Lk = a.k_off ? a.k_off[b + 1] - k0 : a.Lk;
+  // (readfirstlane: values loaded from memory are per-lane to the compiler; as loop bounds they would turn every loop
+  //  below into divergent control flow)
+  const int q0 = a.q_off ? __builtin_amdgcn_readfirstlane(a.q_off[b]) : 0;
+  const int k0 = a.k_off ? __builtin_amdgcn_readfirstlane(a.k_off[b]) : 0;
+  const int Lq = a.q_off ? __builtin_amdgcn_readfirstlane(a.q_off[b + 1]) - q0 : a.Lq;
+  const int Lk = a.k_off ? __builtin_amdgcn_readfirstlane(a.k_off[b + 1]) - k0 : a.Lk;
   const int qb_begin = blockIdx.x * a.blocks_per_wg;
   const int qb_end = min((Lq + 15) >> 4, qb_begin + a.blocks_per_wg);
   const int nchunks = (Lk + CH - 1) / CH;
@@ -508,9 +513,23 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   const int yb_begin = blockIdx.x * a.blocks_per_wg;
   const int yb_end = min(nyb, yb_begin + a.blocks_per_wg);
   const int nchunks_m = (LXm + CH - 1) / CH;
-  // ragged mode: row offset and length of sequence bb on the query / key side
-  auto seq_q = [&](int bb, int& o0, int& len) { o0 = a.q_off ? a.q_off[bb] : 0; len = a.q_off ? a.q_off[bb + 1] - o0 : a.Lq; };
-  auto seq_k = [&](int bb, int& o0, int& len) { o0 = a.k_off ? a.k_off[bb] : 0; len = a.k_off ? a.k_off[bb + 1] - o0 : a.Lk; };
+  // ragged mode: row offset and length of sequence bb on the query / key side.  The offsets of the workgroup's batch rows
+  // are staged in LDS once: read from global they would put a dependent load in front of every round's operand requests.
+  int* offs_l = reinterpret_cast<int*>(drel_l + ((a.R + 3) & ~3)) + 8;   // [2][OFFS_MAX], behind pair_any[8]
+  if (threadIdx.x <= b_end - b_begin) {
+    if (a.q_off) offs_l[threadIdx.x] = a.q_off[b_begin + threadIdx.x];
+    if (a.k_off) offs_l[OFFS_MAX + threadIdx.x] = a.k_off[b_begin + threadIdx.x];
+  }
+  __syncthreads();
+  // (readfirstlane: LDS values are per-lane to the compiler; as loop bounds they would make the loops divergent)
+  auto seq_q = [&](int bb, int& o0, int& len) {
+    o0 = a.q_off ? __builtin_amdgcn_readfirstlane(offs_l[bb - b_begin]) : 0;
+    len = a.q_off ? __builtin_amdgcn_readfirstlane(offs_l[bb - b_begin + 1]) - o0 : a.Lq;
+  };
+  auto seq_k = [&](int bb, int& o0, int& len) {
+    o0 = a.k_off ? __builtin_amdgcn_readfirstlane(offs_l[OFFS_MAX + bb - b_begin]) : 0;
+    len = a.k_off ? __builtin_amdgcn_readfirstlane(offs_l[OFFS_MAX + bb - b_begin + 1]) - o0 : a.Lk;
+  };
   auto base_q = [&](const char* ptr, int bb, int o0, int64_t sb, int64_t st) {
     return ptr + ((a.q_off ? (int64_t)o0 * st : (int64_t)bb * sb) + (int64_t)h * DK) * C::ES;
   };
@@ -531,7 +550,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   // keys (tile pair tp → wave tp & 3); the partial dQ tiles are summed through LDS at the end.
   const bool ksplit = MODE == 0 && nyb == 1 && a.Lk > 64;   // merge scratch reserved only when Lq <= 16
   int* pair_any = reinterpret_cast<int*>(drel_l + ((a.R + 3) & ~3));   // [8] (MODE 0), [0] = sequence has a key (MODE 1)
-  float* mrg = reinterpret_cast<float*>(pair_any + 8);                 // [4][16][DK] (ksplit only)
+  float* mrg = reinterpret_cast<float*>(pair_any + 8 + 2 * OFFS_MAX);  // [4][16][DK] (ksplit only; after offs_l)
   int okbits = 0xff;          // MODE 0: tile pairs of the staged keys worth computing (see stage_key_add)
 
   // Bias gradient (dQ pass): d rel_bias[key − query] = Σ_batch Σ_(q,k) dS.  LDS float atomics per score
@@ -547,10 +566,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   // computed — see attn_fwd_kernel
   u32x4 n1[C::NF], n2[C::NF], n3[C::NF];
   float ns0 = 0.f, ns1 = 0.f, nkadd = 0.f;
-  int req_b = -1, req_yb = -1;     // what n1 … currently hold
   auto request = [&](int bb, int ybb0) {
-    req_b = bb;
-    req_yb = ybb0;
     int o0 = 0, len = 0;
     if (bb < b_end) {
       if (MODE == 0) seq_q(bb, o0, len);
@@ -578,14 +594,26 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
     }
   };
 
-  for (int b = b_begin; b < b_end; ++b) {
+  // sequences that have nothing for this workgroup (ragged: shorter than its first block, or empty) are stepped over, so
+  // that the operands requested ahead are always those of the round that runs next
+  auto next_with_work = [&](int bb) {
+    for (; bb < b_end; ++bb) {
+      int oq, lq, ok, lk;
+      seq_q(bb, oq, lq);
+      seq_k(bb, ok, lk);
+      if (((MODE == 0 ? lq : lk) + 15) >> 4 > yb_begin && (MODE == 0 ? lk : lq) > 0) break;
+    }
+    return bb;
+  };
+  int next_b = next_with_work(b_begin);
+  request(next_b, yb_begin);
+  for (int b = next_b; b < b_end; b = next_b) {
   int q0, k0, Lq, Lk;
   seq_q(b, q0, Lq);
   seq_k(b, k0, Lk);
   const int LX = MODE == 0 ? Lk : Lq, LY = MODE == 0 ? Lq : Lk;   // this sequence's own lengths (bounds)
   const int ybe = min(yb_end, (LY + 15) >> 4);
   const int nchunks = (LX + CH - 1) / CH;
-  if (ybe <= yb_begin || LX <= 0) continue;                       // nothing of this sequence in this workgroup
   const char* qbase = base_q(a.q, b, q0, a.qsb, a.qst);
   const char* kbase = base_k(a.k, b, k0, a.ksb, a.kst);
   const char* vbase = base_k(a.v, b, k0, a.vsb, a.vst);
@@ -605,7 +633,6 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   for (int yb0 = yb_begin; yb0 < ybe; yb0 += 4) {
     const int yb = ksplit ? yb0 : yb0 + wave;
     const bool active = yb < ybe;
-    if (req_b != b || req_yb != yb0) request(b, yb0);   // first round of the launch, or the rows before were empty
     const int yi = active ? yb * 16 + l15 : LY;  // this lane's register-side row (query in MODE 0, key in MODE 1)
     u32x4 y1[C::NF], y2[C::NF];
     float m_q = 0.f, invl_q = 0.f, delta_q = 0.f;   // MODE 0: this lane's query statistics (inv = 0 ⇒ p = 0)
@@ -620,7 +647,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
     const float st_m = ns0, st_il = ns1;
     kadd_lane = nkadd;
     if (yb0 + 4 < ybe) request(b, yb0 + 4);
-    else request(b + 1, yb_begin);
+    else request(next_b = next_with_work(b + 1), yb_begin);
     if constexpr (MODE == 0) {
       float part = 0.f;
 #pragma unroll
@@ -823,7 +850,7 @@ int lds_bytes_fwd(int ch, int R, bool merge) {
 }
 template <typename T, int DK>
 int lds_bytes_bwd(int ch, int R, bool merge) {
-  return 2 * img_bytes<T, DK>(ch) + (3 * ch + 2 * R + 16 + (merge ? 4 * 16 * DK : 0)) * 4;
+  return 2 * img_bytes<T, DK>(ch) + (3 * ch + 2 * R + 16 + 2 * OFFS_MAX + (merge ? 4 * 16 * DK : 0)) * 4;
 }
 
 inline int pick_chunk(int L) {
@@ -883,6 +910,7 @@ int run_bwd(AttnArgs& a, hipStream_t s) {
       q.blocks_per_wg = 4;
       const int64_t wgs = (int64_t)a.Bn * a.H * ((nqb + 3) / 4);
       q.bn_per_wg = (int)(wgs / 1024 > 1 ? wgs / 1024 : 1);
+      if (q.bn_per_wg > OFFS_MAX - 1) q.bn_per_wg = OFFS_MAX - 1;   // the kernel stages bn_per_wg + 1 row offsets in LDS
     }
     const int lds = lds_bytes_bwd<T, DK>(q.chunk_rows, a.R, nqb == 1);
     static int cur0 = 0;

@@ -20,6 +20,7 @@ last→first, embedding), so data-parallel buckets can be all-reduced while back
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -123,6 +124,15 @@ def layout_sizes(blocks):
 
 
 @dataclass
+class _Ragged:
+    """Unpadded encoder batch: only the valid tokens of the [B·N, L] passages, packed in (passage, position) order."""
+    M: int                  # number of valid tokens (rows of every encoder buffer)
+    off: torch.Tensor       # int32 [B·N + 1] row offset of each passage
+    soff: torch.Tensor      # int32 [B + 1]   row offset of each sample (its N passages are consecutive)
+    idx: torch.Tensor       # int64 [M] position of each packed token in the flat [B·N·L] input
+
+
+@dataclass
 class _Ctx:
     """What forward leaves behind for backward."""
     B: int = 0
@@ -136,6 +146,8 @@ class _Ctx:
     labels: torch.Tensor = None
     dec_ids: torch.Tensor = None
     ckpt: bool = False
+    rag: object = None      # _Ragged: the encoder ran on the valid tokens only
+    enc_ids: torch.Tensor = None   # the encoder's token ids: all [B·N·L], or the valid ones when rag is set
     ws: dict = field(default_factory=dict)
 
 
@@ -163,6 +175,8 @@ class Engine:
         self.use_checkpoint = False
         self._ws_cache: dict = {}
         self._tr_table = None
+        self._rag_cache: dict = {}
+        self._row_cap: dict = {}     # {rows of the current unpadded batch: padded row count}
         self._lut_cache: dict = {}
         self.ctx: _Ctx | None = None
         self.grad_hook = None    # callable(lo, hi): gradients G[lo:hi] are final (data-parallel overlap)
@@ -249,10 +263,18 @@ class Engine:
         return self._lut_cache[key]
 
     def _buf(self, ws, name, shape, dtype=None):
-        t = ws.get(name)
-        if t is None or tuple(t.shape) != tuple(shape):
-            t = torch.empty(shape, dtype=dtype or self.dtype, device=self.device)
-            ws[name] = t
+        """Workspace tensor `name` of this shape.  The backing allocation only grows: a request with fewer ROWS (the
+        unpadded encoder: the number of valid tokens changes from batch to batch) is a prefix view of it."""
+        shape = tuple(shape)
+        base = ws.get("^" + name)
+        if base is None or tuple(base.shape[1:]) != shape[1:] or base.shape[0] < shape[0] or base.dtype != (dtype or self.dtype):
+            # token-row buffers of an unpadded batch are allocated at the padded row count once, so that a later batch with
+            # more valid tokens never reallocates the workspace in the middle of training
+            rows = max(shape[0], self._row_cap.get(shape[0], 0))
+            base = torch.empty((rows,) + shape[1:], dtype=dtype or self.dtype, device=self.device)
+            ws["^" + name] = base
+        t = base if base.shape[0] == shape[0] else base[:shape[0]]
+        ws[name] = t
         return t
 
     def _workspace(self, key):
@@ -267,21 +289,22 @@ class Engine:
     # ------------------------------------------------------------------------------------------
     # forward
     # ------------------------------------------------------------------------------------------
-    def _enc_layer_fwd(self, ws, i, j, h, h_out, BN, L, mask_u8, rel, dr):
+    def _enc_layer_fwd(self, ws, i, j, h, h_out, BN, L, mask_u8, rel, dr, rag=None):
         """One encoder block (HF5:448-509): RMSNorm → fused QKV → attention → O+residual → RMSNorm → FFN+residual.
         Intermediates are written to the workspace slot `j` (per layer when everything is kept, slot 0 when the
         layer is recomputed in backward or nothing is kept)."""
         cfg, ops = self.cfg, self.ops
         d, f, inner, H, eps = cfg.d_model, cfg.d_ff, cfg.inner_dim, cfg.num_heads, cfg.layer_norm_epsilon
-        Me, lw = BN * L, self.enc[i]
+        Me, lw = (rag.M if rag is not None else BN * L), self.enc[i]
         xn1 = self._buf(ws, f"e.xn1.{j}", (Me, d))
         ops.rmsnorm_fwd(h, lw["ln1"].p, xn1, self._buf(ws, f"e.rs1.{j}", (Me,), torch.float32), eps)
         qkv = self._buf(ws, f"e.qkv.{j}", (Me, 3 * inner))
         ops.gemm_nt(xn1, lw["qkv"].w, qkv)
         ctx = self._buf(ws, f"e.ctx.{j}", (Me, inner))
-        ops.attn_fwd(self._heads(qkv, BN, L, 0), self._heads(qkv, BN, L, inner), self._heads(qkv, BN, L, 2 * inner),
-                     self._heads(ctx, BN, L, 0), self._buf(ws, f"e.st.{j}", (BN, H, L, 4), torch.float32),
-                     rel_bias=rel, rel_off=L - 1, key_mask=mask_u8, drop=dr(_enc_site(i, 0)))
+        hb, ht, akw = self._enc_attn_layout(rag, BN, L, mask_u8)
+        ops.attn_fwd(self._heads(qkv, hb, ht, 0), self._heads(qkv, hb, ht, inner), self._heads(qkv, hb, ht, 2 * inner),
+                     self._heads(ctx, hb, ht, 0), self._buf(ws, f"e.st.{j}", (BN, H, L, 4), torch.float32),
+                     rel_bias=rel, rel_off=L - 1, drop=dr(_enc_site(i, 0)), **akw)
         h1 = self._buf(ws, f"e.h1.{j}", (Me, d))
         ops.gemm_nt(ctx, lw["o"].w, h1, resid=h, drop=dr(_enc_site(i, 1)))
         xn2 = self._buf(ws, f"e.xn2.{j}", (Me, d))
@@ -291,14 +314,22 @@ class Engine:
         if h_out is not None:
             ops.gemm_nt(a1, lw["wo"].w, h_out, resid=h1, drop=dr(_enc_site(i, 3)))
 
-    def _encode(self, ws, ids_flat, mask_u8, BN, L, p, seed, save):
+    @staticmethod
+    def _enc_attn_layout(rag, BN, L, mask_u8):
+        """(batch, time) of the [·, ·, H, dk] head views of the token-major buffers + the attention kwargs: padded
+        [BN, L] with a key mask, or ONE packed run of rows with per-passage offsets."""
+        if rag is None:
+            return BN, L, dict(key_mask=mask_u8)
+        return 1, rag.M, dict(q_off=rag.off, k_off=rag.off, max_q=L, max_k=L)
+
+    def _encode(self, ws, ids_flat, mask_u8, BN, L, p, seed, save, rag=None):
         """save: True  — keep every intermediate of every layer (training; 288 GB of HBM make this the default);
                  "ckpt" — keep only each block's input and recompute the block in backward (`set_checkpoint(True)`,
                           the reference's CheckpointWrapper, src/model.py:237-283);
                  False — keep nothing (generate)."""
         cfg, ops = self.cfg, self.ops
         d, H = cfg.d_model, cfg.num_heads
-        Me, Le, eps = BN * L, cfg.num_layers, cfg.layer_norm_epsilon
+        Me, Le, eps = (rag.M if rag is not None else BN * L), cfg.num_layers, cfg.layer_norm_epsilon
         dr = (lambda site: (p, seed, site)) if p > 0 else (lambda site: None)
         ix = (lambda i: i) if save is True else (lambda i: 0)
         hx = (lambda i: i) if save else (lambda i: i % 2)
@@ -307,7 +338,7 @@ class Engine:
         ops.relpos_expand(self.enc_rel.p, self._lut(L, L, True), rel)
         for i in range(Le):
             self._enc_layer_fwd(ws, i, ix(i), ws[f"e.h{hx(i)}"], self._buf(ws, f"e.h{hx(i + 1)}", (Me, d)), BN, L,
-                                mask_u8, rel, dr)
+                                mask_u8, rel, dr, rag)
         enc_out = self._buf(ws, "e.out", (Me, d))
         ops.rmsnorm_fwd(ws[f"e.h{hx(Le)}"], self.enc_final.p, enc_out, self._buf(ws, "e.rsf", (Me,), torch.float32),
                         eps, dr(S_ENC_FINAL))
@@ -315,6 +346,37 @@ class Engine:
         kv = self._buf(ws, "e.kv", (Me, self.kv_all.w.shape[0]))
         ops.gemm_nt(enc_out, self.kv_all.w, kv)
         return enc_out, kv
+
+    def _ragged_batch(self, attention_mask, B, N, L):
+        """Padded positions never influence the loss, the gradients or the decoded tokens: they are masked as keys in the
+        encoder's self-attention and in the decoder's cross-attention, and nothing else reads them.  When the mask has the
+        tokenizer's form (valid tokens first, then padding) the encoder therefore runs on the valid tokens only — a quarter
+        fewer rows in every GEMM / norm / attention at the OKVQA-like lengths of the benchmark.  Returns None (padded path)
+        for LAKO_UNPAD=0, masks with holes, a sample without any valid token, or when nothing is padded.
+        One host sync per new mask tensor (lengths → host); repeated batches hit the cache."""
+        if os.environ.get("LAKO_UNPAD", "1") == "0":
+            return None
+        key = (attention_mask.data_ptr(), attention_mask._version, B, N, L)
+        hit = self._rag_cache.get(key)
+        if hit is not None:
+            return hit[0]
+        m = attention_mask.reshape(B * N, L).bool()
+        lens = m.sum(1, dtype=torch.int32)
+        prefix = (m == (torch.arange(L, device=m.device)[None, :] < lens[:, None])).all()
+        host = torch.cat([lens, prefix.to(torch.int32)[None]]).cpu()
+        lens_h, ok = host[:-1], bool(host[-1])
+        per_sample = lens_h.view(B, N).sum(1)
+        rag = None
+        if ok and int(per_sample.min()) > 0 and int(lens_h.sum()) < B * N * L:
+            off = torch.zeros(B * N + 1, dtype=torch.int32)
+            off[1:] = torch.cumsum(lens_h, 0)
+            dev = attention_mask.device
+            rag = _Ragged(M=int(off[-1]), off=off.to(dev), soff=off[::N].contiguous().to(dev),
+                          idx=m.reshape(-1).nonzero().reshape(-1))
+        if len(self._rag_cache) >= 16:
+            self._rag_cache.clear()
+        self._rag_cache[key] = (rag, attention_mask)      # holding the tensor keeps (data_ptr, version) unambiguous
+        return rag
 
     def forward_loss(self, input_ids, attention_mask, labels, training: bool):
         """input_ids/attention_mask [B,N,L], labels [B,T] (−100 = ignore) → (loss 0-d fp32, logits [B,T,V] fp32)."""
@@ -334,10 +396,17 @@ class Engine:
         dr = (lambda site: (p, seed, site)) if p > 0 else (lambda site: None)
         eps = cfg.layer_norm_epsilon
         ctx.ckpt = bool(self.use_checkpoint and training)
-        enc_out, kv = self._encode(ws, ctx.ids, ctx.mask_u8, B * N, L, p, seed, save="ckpt" if ctx.ckpt else True)
+        rag = ctx.rag = self._ragged_batch(attention_mask, B, N, L)
+        self._row_cap = {rag.M: B * N * L} if rag is not None else {}
+        enc_ids = ctx.ids if rag is None else ctx.ids[rag.idx]
+        ctx.enc_ids = enc_ids
+        enc_out, kv = self._encode(ws, enc_ids, ctx.mask_u8, B * N, L, p, seed, save="ckpt" if ctx.ckpt else True, rag=rag)
         # ---- decoder ------------------------------------------------------------------------
         Md, S, Ld = B * T, N * L, cfg.num_decoder_layers
-        enc_mask = ctx.mask_u8.view(B, S)
+        if rag is None:      # cross-attention keys: [B, N·L] with the padding mask, or each sample's packed valid tokens
+            kb, kt, ckw = B, S, dict(key_mask=ctx.mask_u8.view(B, S))
+        else:
+            kb, kt, ckw = 1, rag.M, dict(k_off=rag.soff, max_k=S)
         dec_ids = self._buf(ws, "d.ids", (B, T), torch.int64)
         ops.shift_right(labels.contiguous(), dec_ids)
         ctx.dec_ids = dec_ids
@@ -362,10 +431,9 @@ class Engine:
             qc = self._buf(ws, f"d.qc.{i}", (Md, inner))
             ops.gemm_nt(xn2, lw["cq"].w, qc)
             c2 = self._buf(ws, f"d.cctx.{i}", (Md, inner))
-            ops.attn_fwd(self._heads(qc, B, T, 0), self._heads(kv, B, S, 2 * i * inner),
-                         self._heads(kv, B, S, (2 * i + 1) * inner), self._heads(c2, B, T, 0),
-                         self._buf(ws, f"d.cst.{i}", (B, H, T, 4), torch.float32), key_mask=enc_mask,
-                         drop=dr(_dec_site(i, 2)))
+            ops.attn_fwd(self._heads(qc, B, T, 0), self._heads(kv, kb, kt, 2 * i * inner),
+                         self._heads(kv, kb, kt, (2 * i + 1) * inner), self._heads(c2, B, T, 0),
+                         self._buf(ws, f"d.cst.{i}", (B, H, T, 4), torch.float32), drop=dr(_dec_site(i, 2)), **ckw)
             h2 = self._buf(ws, f"d.h2.{i}", (Md, d))
             ops.gemm_nt(c2, lw["co"].w, h2, resid=h1, drop=dr(_dec_site(i, 3)))
             xn3 = self._buf(ws, f"d.xn3.{i}", (Md, d))
@@ -424,10 +492,15 @@ class Engine:
         ws, p, seed = ctx.ws, ctx.p, ctx.seed
         B, N, L, T = ctx.B, ctx.N, ctx.L, ctx.T
         d, f, inner, H, V = cfg.d_model, cfg.d_ff, cfg.inner_dim, cfg.num_heads, cfg.vocab_size
-        Md, Me, S, Ld, Le = B * T, B * N * L, N * L, cfg.num_decoder_layers, cfg.num_layers
+        rag = ctx.rag
+        self._row_cap = {rag.M: B * N * L} if rag is not None else {}
+        Md, Me, S, Ld, Le = B * T, (rag.M if rag is not None else B * N * L), N * L, cfg.num_decoder_layers, cfg.num_layers
         dr = (lambda site: (p, seed, site)) if p > 0 else (lambda site: None)
         tmp = self._workspace(("bwd", B, N, L, T))
-        enc_mask = ctx.mask_u8.view(B, S)
+        if rag is None:
+            kb, kt, ckw = B, S, dict(key_mask=ctx.mask_u8.view(B, S))
+        else:
+            kb, kt, ckw = 1, rag.M, dict(k_off=rag.soff, max_k=S)
         # ---- loss + LM head ------------------------------------------------------------------
         dlog = self._buf(tmp, "dlogits", (Md, V))
         ops.ce_fwd_bwd(ws["d.logits"], ctx.labels, self._buf(tmp, "loss2", (2,), torch.float32), dlog, upstream)
@@ -460,11 +533,11 @@ class Engine:
             dctx = self._buf(tmp, f"dctx.{Md}", (Md, inner))
             ops.gemm_nt(dy, lw["co"].wt, dctx)
             dqc = self._buf(tmp, "d.dqc", (Md, inner))
-            ops.attn_bwd(self._heads(ws[f"d.qc.{i}"], B, T, 0), self._heads(kv, B, S, 2 * i * inner),
-                         self._heads(kv, B, S, (2 * i + 1) * inner), self._heads(ws[f"d.cctx.{i}"], B, T, 0),
+            ops.attn_bwd(self._heads(ws[f"d.qc.{i}"], B, T, 0), self._heads(kv, kb, kt, 2 * i * inner),
+                         self._heads(kv, kb, kt, (2 * i + 1) * inner), self._heads(ws[f"d.cctx.{i}"], B, T, 0),
                          self._heads(dctx, B, T, 0), ws[f"d.cst.{i}"], self._heads(dqc, B, T, 0),
-                         self._heads(dkv, B, S, 2 * i * inner), self._heads(dkv, B, S, (2 * i + 1) * inner),
-                         key_mask=enc_mask, drop=dr(_dec_site(i, 2)))
+                         self._heads(dkv, kb, kt, 2 * i * inner), self._heads(dkv, kb, kt, (2 * i + 1) * inner),
+                         drop=dr(_dec_site(i, 2)), **ckw)
             ops.gemm_tn(dqc, ws[f"d.xn2.{i}"], lw["cq"].g)
             dxn = self._buf(tmp, f"dxn.{Md}", (Md, d))
             ops.gemm_nt(dqc, lw["cq"].wt, dxn)
@@ -502,7 +575,7 @@ class Engine:
             j = i
             if ctx.ckpt:   # recompute this block's intermediates from its saved input (same seeds → same dropout masks)
                 j = 0
-                self._enc_layer_fwd(ws, i, 0, ws[f"e.h{i}"], None, BN, L, ctx.mask_u8, ws["e.rel"], dr)
+                self._enc_layer_fwd(ws, i, 0, ws[f"e.h{i}"], None, BN, L, ctx.mask_u8, ws["e.rel"], dr, rag)
             # the layer's four weight gradients (K = all tokens, small M×N) go out as ONE grouped launch at the end of the
             # layer: 108 tiles fill the chip with ~2 K-splits, where four separate launches need 7–28 splits each and
             # pay one fp32 atomic pass over the output per split
@@ -519,17 +592,18 @@ class Engine:
             ops.gemm_nt(dy, lw["o"].wt, dctx)
             qkv = ws[f"e.qkv.{j}"]
             dqkv = self._buf(tmp, f"dqkv.{Me}", (Me, 3 * inner))
-            ops.attn_bwd(self._heads(qkv, BN, L, 0), self._heads(qkv, BN, L, inner), self._heads(qkv, BN, L, 2 * inner),
-                         self._heads(ws[f"e.ctx.{j}"], BN, L, 0), self._heads(dctx, BN, L, 0), ws[f"e.st.{j}"],
-                         self._heads(dqkv, BN, L, 0), self._heads(dqkv, BN, L, inner),
-                         self._heads(dqkv, BN, L, 2 * inner), rel_bias=ws["e.rel"], drel=drel_e, rel_off=L - 1,
-                         key_mask=ctx.mask_u8, drop=dr(_enc_site(i, 0)))
+            hb, ht, akw = self._enc_attn_layout(rag, BN, L, ctx.mask_u8)
+            ops.attn_bwd(self._heads(qkv, hb, ht, 0), self._heads(qkv, hb, ht, inner), self._heads(qkv, hb, ht, 2 * inner),
+                         self._heads(ws[f"e.ctx.{j}"], hb, ht, 0), self._heads(dctx, hb, ht, 0), ws[f"e.st.{j}"],
+                         self._heads(dqkv, hb, ht, 0), self._heads(dqkv, hb, ht, inner),
+                         self._heads(dqkv, hb, ht, 2 * inner), rel_bias=ws["e.rel"], drel=drel_e, rel_off=L - 1,
+                         drop=dr(_enc_site(i, 0)), **akw)
             dw.append((dqkv, ws[f"e.xn1.{j}"], lw["qkv"].g, 1.0))
             ops.gemm_nt(dqkv, lw["qkv"].wt, dxe)
             ops.rmsnorm_bwd(dxe, ws[f"e.h{i}"], lw["ln1"].p, ws[f"e.rs1.{j}"], deh, deh, lw["ln1"].g)
             ops.gemm_tn_grouped(dw)
             self._ready(f"enc.{i}.qkv", f"enc.{i}.ln2")
-        ops.embed_bwd(ctx.ids, deh, self.shared.g, dr(S_ENC_EMBED))
+        ops.embed_bwd(ctx.enc_ids, deh, self.shared.g, dr(S_ENC_EMBED))
         ops.relpos_reduce(drel_e, self._lut(L, L, True), self.enc_rel.g)
         self._ready("enc.rel", "shared")
         self.step_count += 1   # next forward draws fresh dropout masks

@@ -172,6 +172,22 @@ if "attn" in only:
         timeit(nm, lambda: ops.attn_bwd(heads(qkv, BN, L, 0), heads(qkv, BN, L, inner), heads(qkv, BN, L, 2 * inner),
                                         heads(ctx, BN, L, 0), heads(dctx, BN, L, 0), st, heads(dqkv, BN, L, 0),
                                         heads(dqkv, BN, L, inner), heads(dqkv, BN, L, 2 * inner), **kw), flops=2.5 * fl)
+    # the same encoder attention on RAGGED rows (only the valid tokens, packed) — what the unpadded engine path launches
+    offs = torch.zeros(BN + 1, dtype=torch.int32, device=dev)
+    offs[1:] = torch.cumsum(lens, 0)
+    Mv = int(offs[-1])
+    sel = km.bool().reshape(-1)
+    qkv_r = qkv[sel].contiguous()
+    ctx_r, dctx_r, dqkv_r = torch.empty(Mv, inner, dtype=T, device=dev), dctx[sel].contiguous(), torch.empty(Mv, 3 * inner, dtype=T, device=dev)
+
+    def hr(t, c0):
+        return t.view(1, t.shape[0], t.shape[1])[:, :, c0:c0 + inner].unflatten(2, (H, dk))
+    rg = dict(q_off=offs, k_off=offs, max_q=L, max_k=L, rel_bias=rel, rel_off=L - 1)
+    flr = fl * Mv / (BN * L)
+    timeit(f"attn_fwd enc RAGGED bias+drop ({Mv} of {BN * L} rows)", lambda: ops.attn_fwd(hr(qkv_r, 0), hr(qkv_r, inner), hr(qkv_r, 2 * inner), hr(ctx_r, 0), st, drop=drop, **rg), flops=flr)
+    for nm, kw in [("attn_bwd enc RAGGED bias+drop", dict(drop=drop)), ("attn_bwd enc RAGGED bias+drop+drel", dict(drop=drop, drel=drel))]:
+        timeit(nm, lambda: ops.attn_bwd(hr(qkv_r, 0), hr(qkv_r, inner), hr(qkv_r, 2 * inner), hr(ctx_r, 0), hr(dctx_r, 0), st, hr(dqkv_r, 0),
+                                        hr(dqkv_r, inner), hr(dqkv_r, 2 * inner), **rg, **kw), flops=2.5 * flr)
     # cross attention: T=8 queries over S=4000 keys
     kv = rnd(B * S, 2 * inner, scale=0.5)
     q = rnd(Md, inner, scale=0.5)
