@@ -58,12 +58,28 @@ def train_flops_per_sample(cfg, N, L, T):
     return 3.0 * fwd
 
 
-def synthetic_batch(B, N, L, T, vocab, seed, device):
-    """ids ~ U{2..32099}, per-passage valid length ~ U{ceil(L/2)..L}, labels end in EOS, -100 pad."""
+def executed_train_flops(cfg, lens, T):
+    """The same formula evaluated on the tokens that exist (lens: [B, N] valid lengths): what an implementation that
+    skips padded positions executes — linear terms ∝ Σ len, encoder self-attention ∝ Σ len², cross-attention ∝ Σ len."""
+    d, inner, f, V = cfg.d_model, cfg.inner_dim, cfg.d_ff, cfg.vocab_size
+    Le, Ld = cfg.num_layers, cfg.num_decoder_layers
+    lens = lens.double()
+    tok, sq, B = float(lens.sum()), float((lens * lens).sum()), lens.shape[0]
+    fwd = Le * (tok * (8 * d * inner + 4 * d * f) + 4 * sq * inner) \
+        + Ld * (B * T * (8 * d * inner + 4 * T * inner) + 4 * tok * d * inner + B * 4 * T * d * inner + 4 * T * tok * inner
+                + B * 4 * T * d * f) + B * 2 * T * d * V
+    return 3.0 * fwd
+
+
+def synthetic_batch(B, N, L, T, vocab, seed, device, all_valid=False):
+    """ids ~ U{2..32099}, per-passage valid length ~ U{ceil(L/2)..L} (or all L: the pure-roofline variant),
+    labels end in EOS, -100 pad."""
     g = torch.Generator().manual_seed(seed)
     hi = min(vocab, 32100)
     ids = torch.randint(2, hi, (B, N, L), generator=g)
     lens = torch.randint((L + 1) // 2, L + 1, (B, N), generator=g)
+    if all_valid:
+        lens = torch.full_like(lens, L)
     mask = torch.arange(L)[None, None, :] < lens[..., None]
     ids = ids.masked_fill(~mask, 0)
     labels = torch.randint(2, hi, (B, T), generator=g)
@@ -161,6 +177,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--all-valid", action="store_true", help="every passage has the full text_maxlength tokens (no padding to skip)")
     ap.add_argument("--cpu-batch", type=int, default=1)
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--cpu-seconds", type=float, default=150.0, help="hard deadline for the CPU baseline leg")
@@ -211,7 +228,10 @@ def main():
     ops = model._get_engine().ops
 
     B, N, L, T = args.batch, args.n_passages, args.seq_len, args.target_len
-    batches = [synthetic_batch(B, N, L, T, cfg.vocab_size, seed=rank * 7919 + i, device=device) for i in range(4)]
+    batches = [synthetic_batch(B, N, L, T, cfg.vocab_size, seed=rank * 7919 + i, device=device, all_valid=args.all_valid)
+               for i in range(4)]
+    lens_all = torch.stack([b[1].sum(-1).cpu() for b in batches])            # [4, B, N] valid lengths
+    unpadded = os.environ.get("LAKO_UNPAD", "1") != "0"
     loss_acc = torch.zeros((), device=device)
 
     def step(i):
@@ -250,7 +270,10 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
-        fl = train_flops_per_sample(cfg, N, L, T)
+        fl = train_flops_per_sample(cfg, N, L, T)                                 # nominal: every position of [B, N, L]
+        # what this implementation executes: padded positions are skipped on the unpadded path (exact: DESIGN.md §4)
+        fl_exec = (sum(executed_train_flops(cfg, lens_all[i % 4], T) for i in range(args.warmup, args.warmup + args.steps))
+                   / (args.steps * B)) if unpadded else fl
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         dom = "gemm_nt.11" if args.dtype == "bf16" else "gemm_nt.00"
         n_l, t_ms, f_tot = probe.get(dom, (0, 0.0, 0.0))
@@ -264,13 +287,18 @@ def main():
                                    f"synthetic OKVQA-shaped batches resident in HBM",
                        "per_gpu_batch": B, "global_batch": B * world, "n_passages": N, "text_maxlength": L,
                        "answer_len": T, "dropout": args.dropout, "parallelism": f"dp{world}",
-                       "master_weights": "fp32", "final_mean_loss": round(final_loss, 4)},
+                       "master_weights": "fp32", "final_mean_loss": round(final_loss, 4),
+                       "passage_lengths": "all text_maxlength" if args.all_valid else "U{L/2..L} (SURVEY.md §8d)",
+                       "valid_token_frac": round(float(lens_all.double().mean()) / L, 4),
+                       "padding": "skipped: encoder runs on valid tokens only (results identical)" if unpadded
+                                  else "computed like the reference (LAKO_UNPAD=0)"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": gemm_traffic_bytes(args),
                          "kernel": "gemm_nt_kernel<bf16,bf16>" if args.dtype == "bf16" else "gemm_nt_kernel<f32,f32>",
                          "launches_per_step": n_l, "avg_launch_us": round(t_ms * 1e3 / max(n_l, 1), 2),
-                         "step_mfma_frac": round(world * B / (elapsed / args.steps) * fl / 1e12 / (peak * world), 4),
-                         "train_gflop_per_sample": round(fl / 1e9, 1)},
+                         "step_mfma_frac": round(world * B / (elapsed / args.steps) * fl_exec / 1e12 / (peak * world), 4),
+                         "train_gflop_per_sample": round(fl / 1e9, 1),
+                         "executed_gflop_per_sample": round(fl_exec / 1e9, 1)},
         }
         if args.breakdown:
             tot = sum(v[1] for v in probe.values())

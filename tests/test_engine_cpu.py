@@ -200,3 +200,50 @@ def test_set_checkpoint_recompute_matches(tmp_path):
         assert res[0][0] == res[1][0]
         torch.testing.assert_close(res[0][1], res[1][1], atol=1e-6, rtol=1e-5)
         assert res[0][2] == dims.num_layers and res[1][2] == 1      # only one FFN activation buffer is live when recomputing
+
+
+def _run_fb(model, ids, mask, labels):
+    model.zero_grad()
+    out = model(input_ids=ids, attention_mask=mask, labels=labels)
+    out[0].backward()
+    eng = model._engine
+    return out[0].item(), out.logits.clone(), eng.G.clone(), eng
+
+
+@pytest.mark.parametrize("name", ["tiny_a", "mid_a"])
+def test_unpadded_path_equals_padded_path(name, monkeypatch):
+    """The encoder on valid tokens only (LAKO_UNPAD=1, default) must give the loss, logits and every gradient of the
+    padded computation — including a fully padded passage (tiny_a).  Masks the packing cannot represent fall back to
+    the padded path: holes, or a sample without any valid token."""
+    z, dims, w, model = build(name)
+    ids, mask, labels = (torch.from_numpy(z[k]) for k in ("input_ids", "attention_mask", "labels"))
+    model.train()
+    monkeypatch.setenv("LAKO_UNPAD", "0")
+    l0, lg0, g0, eng = _run_fb(model, ids, mask, labels)
+    assert eng.ctx is None
+    monkeypatch.setenv("LAKO_UNPAD", "1")
+    model(input_ids=ids, attention_mask=mask, labels=labels)
+    assert eng.ctx.rag is not None and eng.ctx.rag.M == int(mask.sum()) < mask.numel()
+    l1, lg1, g1, _ = _run_fb(model, ids, mask, labels)
+    assert abs(l1 - l0) < 1e-6
+    torch.testing.assert_close(lg1, lg0, atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(g1, g0, atol=2e-6, rtol=1e-4)
+    # fallbacks
+    holey = mask.clone()
+    holey[0, 0, 1] = False                     # a hole after a valid token: not a prefix mask
+    model(input_ids=ids, attention_mask=holey, labels=labels)
+    assert eng.ctx.rag is None
+    empty = mask.clone()
+    empty[1] = False                           # a sample without any valid token (HF: uniform attention over padding)
+    model(input_ids=ids, attention_mask=empty, labels=labels)
+    assert eng.ctx.rag is None
+    full = torch.ones_like(mask)               # nothing to skip
+    model(input_ids=ids, attention_mask=full, labels=labels)
+    assert eng.ctx.rag is None
+    # a new batch with MORE valid tokens than any before reuses the workspace allocated at the padded size
+    base = eng._workspace(("train",) + tuple(ids.shape) + (labels.shape[1],))["^e.xn1.0"]
+    more = mask.clone()
+    more[0, 0] = True
+    model(input_ids=ids, attention_mask=more, labels=labels)
+    assert eng.ctx.rag is not None and eng.ctx.rag.M > int(mask.sum())
+    assert eng._workspace(("train",) + tuple(ids.shape) + (labels.shape[1],))["^e.xn1.0"] is base

@@ -308,3 +308,33 @@ def test_train_reader_driver_end_to_end(tmp_path):
                         text=True, timeout=600)
     assert r2.returncode == 0, r2.stderr[-2000:]
     assert "model loaded from" in r2.stderr and "step 5" in r2.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_unpadded_path_equals_padded_path_gpu(dtype, monkeypatch):
+    """HIP path, T5-small shapes with ragged passages (one of them empty): unpadded (default) vs LAKO_UNPAD=0 — same loss,
+    logits and gradients (dropout off: the element-wise dropout draws are indexed by packed rows and differ by design)."""
+    cfg = FiDConfig.named("small", dropout_rate=0.0)
+    model = FiDT5(cfg, dtype=dtype, seed=4).cuda()
+    with torch.no_grad():
+        model._params_by_plain["shared.weight"].mul_(0.05)
+    B, N, L, T = 3, 4, 72, 6
+    ids, mask, labels = dev(*O.synthetic_batch(B, N, L, T, cfg.vocab_size, seed=77))
+    mask[1, 2] = False                                   # a fully padded passage
+    ids = ids.masked_fill(~mask, 0)
+    model.train()
+    res = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("LAKO_UNPAD", flag)
+        model.zero_grad()
+        out = model(input_ids=ids, attention_mask=mask, labels=labels)
+        assert (model._engine.ctx.rag is not None) == (flag == "1")
+        out[0].backward()
+        res.append((out[0].item(), out.logits.float().clone(), model._engine.G.clone()))
+    tol = dict(atol=2e-5, rtol=1e-4) if dtype == torch.float32 else dict(atol=2e-2, rtol=2e-2)
+    assert abs(res[0][0] - res[1][0]) < (1e-5 if dtype == torch.float32 else 2e-3)
+    torch.testing.assert_close(res[1][1], res[0][1], **tol)
+    gscale = res[0][2].abs().max().item()
+    # bf16: the packed keys of the cross-attention are chunked differently (other rounding of the running softmax)
+    assert (res[1][2] - res[0][2]).abs().max().item() < (1e-4 if dtype == torch.float32 else 5e-2) * gscale
