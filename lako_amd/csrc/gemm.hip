@@ -39,6 +39,7 @@ struct NtArgs {
   int stagger;
   int debug;      // timing experiments only (bench_ops): bit 0 = skip the K-loop LDS-DMA, bit 1 = all workgroups stream tile (0,0), bit 2 = never wait for the DMA, bit 3 = no epilogue stores (results are garbage)
   int split_k, k_chunk;   // ring kernel with LAKO_EPI_ATOMIC only: K split over split_k workgroups per tile, k_chunk BYTES each
+  int64_t row0;   // rows [row0, row0 + M) of a larger problem (tail launch): only the dropout element index needs it
   int group_m;    // >0: tile ids walk bands of group_m tile-rows column-major (an XCD's 32 resident tiles form a ≈group_m × 32/group_m block)
   int wide_epi;   // 256² bf16 tile: LDS-transposed epilogue with 16-B row-major stores (needs N, ldc, ldr, ldaux % 8 == 0)
 };
@@ -190,7 +191,7 @@ __device__ __forceinline__ void nt_store_tile(const NtArgs& a, f32x4 (&acc)[NT][
         for (int r = 0; r < 4; ++r) v[r] = x[r] > 0.f ? v[r] * a.aux_scale : 0.f;
       }
       if (drop) {
-        uint64_t idx = (uint64_t)m * (uint64_t)a.N + (uint64_t)n;
+        uint64_t idx = (uint64_t)(a.row0 + m) * (uint64_t)a.N + (uint64_t)n;
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = lako_keep(a.drop_key, idx + r, a.drop_thresh) ? v[r] * a.drop_scale : 0.f;
       }
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
           if (m < a.M && n < a.N) {
             float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             if (drop) {
-              const uint64_t idx = (uint64_t)m * (uint64_t)a.N + (uint64_t)n;
+              const uint64_t idx = (uint64_t)(a.row0 + m) * (uint64_t)a.N + (uint64_t)n;
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = lako_keep(a.drop_key, idx + e, a.drop_thresh) ? v[e] * a.drop_scale : 0.f;
             }
@@ -592,7 +593,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(NtArgs a) {
           for (int r = 0; r < 4; ++r) vv[r] = x[r] > 0.f ? vv[r] * a.aux_scale : 0.f;
         }
         if (drop) {
-          uint64_t idx = (uint64_t)m * (uint64_t)a.N + (uint64_t)n;
+          uint64_t idx = (uint64_t)(a.row0 + m) * (uint64_t)a.N + (uint64_t)n;
 #pragma unroll
           for (int r = 0; r < 4; ++r) vv[r] = lako_keep(a.drop_key, idx + r, a.drop_thresh) ? vv[r] * a.drop_scale : 0.f;
         }
@@ -979,13 +980,38 @@ void launch_nt_cfg(NtArgs a, hipStream_t s) {
   hipLaunchKernelGGL((gemm_nt_kernel<T, TO, WM, WN, MT, NT>), dim3(grid), dim3(WM * WN * 64), LDS, s, a);
 }
 
+int g_nt_tail_split = 1;
+
 template <typename T, typename TO>
-int launch_nt(const NtArgs& a, hipStream_t s) {
+int launch_nt(const NtArgs& a_in, hipStream_t s) {
+  NtArgs a = a_in;
   int v = g_nt_variant;
   if (v < 0) {
     // big tiles once there is enough work to fill the chip with them (>= 1 tile per CU), else 128x128
-    const int64_t t256 = (int64_t)cdiv(a.M, 256) * cdiv(a.N, 256);
+    const int tn = cdiv(a.N, 256);
+    const int64_t t256 = (int64_t)cdiv(a.M, 256) * tn;
     v = (t256 >= 256 && sizeof(T) == 2) ? 2 : 0;
+    // TAIL SPLIT.  256 persistent workgroups walk the 256² tiles in rounds; t256 = 564 (an unpadded batch of ≈48 k
+    // tokens × 768 columns) means 2 full rounds and a third with 52 tiles on 52 CUs: 3 tile-times for 2.2 of work.
+    // The rows of the full rounds go to the 256² kernel, the remaining rows to a second launch with 128² tiles
+    // (4 × as many, 2 workgroups per CU): ≈2.35 tile-times.  Only when the last round would be less than half full.
+    if (v == 2 && g_nt_tail_split && t256 > 256 && !(a.flags & LAKO_EPI_ATOMIC)) {
+      const int64_t full_rows = (t256 / 256) * 256 / tn;             // tile-rows covered by the full rounds
+      const int64_t rest = t256 - full_rows * tn;                    // tiles left for the last round
+      if (rest > 0 && rest < 128 && full_rows > 0) {
+        NtArgs head = a;
+        head.M = (int)(full_rows * 256);
+        launch_nt_cfg<T, TO, 2, 4, 8, 4>(head, s);
+        const int64_t r0 = full_rows * 256;
+        a.M -= (int)r0;
+        a.row0 += r0;
+        a.A += r0 * a.lda * (int64_t)sizeof(T);
+        a.C += r0 * a.ldc * (int64_t)sizeof(TO);
+        if (a.resid) a.resid += r0 * a.ldr * (int64_t)sizeof(TO);
+        if (a.aux) a.aux += r0 * a.ldaux * (int64_t)sizeof(T);
+        v = 0;      // the tail: 128² tiles
+      }
+    }
   }
   if (v == 3) {
     if constexpr (sizeof(T) == 2) {
@@ -1072,6 +1098,7 @@ extern "C" int lako_gemm_nt(const lako_gemm_nt_t* p, lako_stream_t stream) {
   if (p->flags & LAKO_EPI_ATOMIC) LAKO_CHECK_ARG(p->out_dtype == LAKO_F32, "lako_gemm_nt: ATOMIC needs fp32 C");
   LAKO_CHECK_ARG(p->drop.p >= 0.f && p->drop.p < 1.f, "lako_gemm_nt: dropout p out of range");
   NtArgs a;
+  a.row0 = 0;
   a.A = (const char*)p->A;
   a.B = (const char*)p->B;
   a.C = (char*)p->C;
@@ -1240,6 +1267,10 @@ extern "C" int lako_set_tuning(const char* key, int value) {
   if (key && !strcmp(key, "gemm_nt_variant")) {
     g_nt_variant = value;
     return LAKO_OK;
+  }
+  if (key && !strcmp(key, "gemm_nt_tail_split")) {
+    g_nt_tail_split = value;
+    return 0;
   }
   if (key && !strcmp(key, "gemm_nt_ring")) {
     g_nt_ring = value;

@@ -91,6 +91,28 @@ def test_gemm_nt_tile_variants(ops, ref, variant, M, N, K):
         ops.set_tuning("gemm_nt_group_m", 8)
 
 
+def test_gemm_nt_tail_split(ops, ref):
+    """270 tiles of 256² = one full round of the persistent grid + 15 tiles: the rows of the full round go to the 256²
+    kernel, the rest to a second launch with small tiles; dropout draws must use the rows' GLOBAL index."""
+    T = torch.bfloat16
+    M, N, K = 256 * 90, 768, 160
+    A, B = rnd(M, K, dtype=T, seed=81), rnd(N, K, dtype=T, seed=82)
+    R, X = rnd(M, N, dtype=T, seed=83), rnd(M, N, dtype=T, seed=84)
+    try:
+        for split in (1, 0):
+            ops.set_tuning("gemm_nt_tail_split", split)
+            for kw in (dict(), dict(relu=True, drop=(0.1, 5, 6)), dict(resid=R, drop=(0.1, 7, 8), alpha=0.5), dict(aux=X, aux_scale=1.1)):
+                C = torch.empty(M, N, dtype=T, device=dev())
+                Cr = torch.zeros(M, N, device=dev())
+                ops.gemm_nt(A, B, C, **kw)
+                ref.gemm_nt(A, B, Cr, **kw)
+                close(C, Cr, T, f"gemm_nt tail split {split} {list(kw)}")
+                if "drop" in kw:
+                    assert torch.equal(C == 0, Cr.to(T) == 0) or (C == 0).float().mean().item() > 0.05
+    finally:
+        ops.set_tuning("gemm_nt_tail_split", 1)
+
+
 @pytest.mark.parametrize("dt", ["bf16", "f32"])
 def test_gemm_tn_grouped(ops, ref, dt):
     """several weight gradients sharing K in one launch (256×256 kernel, bf16) or its per-item fallback (fp32, small
