@@ -622,8 +622,14 @@ class Engine:
         ws = self._workspace(("gen", B, N, L, max_length))
         ids = input_ids.reshape(-1).contiguous()
         mask_u8 = attention_mask.reshape(B * N, L).to(torch.uint8).contiguous()
-        enc_mask = mask_u8.view(B, S)
-        _, kv = self._encode(ws, ids, mask_u8, B * N, L, 0.0, 0, save=False)
+        # valid tokens only (as in forward_loss) unless the raw scores are captured: those are laid out per padded position
+        rag = None if capture_scores else self._ragged_batch(attention_mask, B, N, L)
+        self._row_cap = {rag.M: B * N * L} if rag is not None else {}
+        if rag is None:
+            kb, kt, ckw = B, S, dict(key_mask=mask_u8.view(B, S))
+        else:
+            ids, kb, kt, ckw = ids[rag.idx], 1, rag.M, dict(k_off=rag.soff, max_k=S)
+        _, kv = self._encode(ws, ids, mask_u8, B * N, L, 0.0, 0, save=False, rag=rag)
         ML = max_length
         seq = self._buf(ws, "g.seq", (B, ML), torch.int64)
         nxt = self._buf(ws, "g.next", (B,), torch.int64)
@@ -655,9 +661,9 @@ class Engine:
                 ops.gemm_nt(c1, lw["o"].w, h1, resid=h)
                 ops.rmsnorm_fwd(h1, lw["ln2"].p, xn, rs, eps)
                 ops.gemm_nt(xn, lw["cq"].w, qc)
-                ops.attn_fwd(qc.view(B, 1, H, dk), self._heads(kv, B, S, 2 * i * inner),
-                             self._heads(kv, B, S, (2 * i + 1) * inner), c2.view(B, 1, H, dk), st, key_mask=enc_mask,
-                             scores_out=scores[i] if (capture_scores and t == 0) else None)
+                ops.attn_fwd(qc.view(B, 1, H, dk), self._heads(kv, kb, kt, 2 * i * inner),
+                             self._heads(kv, kb, kt, (2 * i + 1) * inner), c2.view(B, 1, H, dk), st,
+                             scores_out=scores[i] if (capture_scores and t == 0) else None, **ckw)
                 ops.gemm_nt(c2, lw["co"].w, h2, resid=h1)
                 ops.rmsnorm_fwd(h2, lw["ln3"].p, xn, rs, eps)
                 ops.gemm_nt(xn, lw["wi"].w, a1, relu=True)

@@ -228,6 +228,14 @@ def test_unpadded_path_equals_padded_path(name, monkeypatch):
     assert abs(l1 - l0) < 1e-6
     torch.testing.assert_close(lg1, lg0, atol=1e-5, rtol=1e-5)
     torch.testing.assert_close(g1, g0, atol=2e-6, rtol=1e-4)
+    # greedy decoding: same tokens on both paths
+    model.eval()
+    monkeypatch.setenv("LAKO_UNPAD", "0")
+    t0 = model.generate(input_ids=ids, attention_mask=mask, max_length=8)
+    monkeypatch.setenv("LAKO_UNPAD", "1")
+    t1 = model.generate(input_ids=ids, attention_mask=mask, max_length=8)
+    assert torch.equal(t0, t1)
+    model.train()
     # fallbacks
     holey = mask.clone()
     holey[0, 0, 1] = False                     # a hole after a valid token: not a prefix mask

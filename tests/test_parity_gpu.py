@@ -332,6 +332,13 @@ def test_unpadded_path_equals_padded_path_gpu(dtype, monkeypatch):
         assert (model._engine.ctx.rag is not None) == (flag == "1")
         out[0].backward()
         res.append((out[0].item(), out.logits.float().clone(), model._engine.G.clone()))
+    if dtype == torch.float32:          # greedy decoding: same tokens on both paths (fp32: no rounding-order ties)
+        model.eval()
+        toks = []
+        for flag in ("0", "1"):
+            monkeypatch.setenv("LAKO_UNPAD", flag)
+            toks.append(model.generate(input_ids=ids, attention_mask=mask, max_length=12))
+        assert torch.equal(toks[0], toks[1])
     tol = dict(atol=2e-5, rtol=1e-4) if dtype == torch.float32 else dict(atol=2e-2, rtol=2e-2)
     assert abs(res[0][0] - res[1][0]) < (1e-5 if dtype == torch.float32 else 2e-3)
     torch.testing.assert_close(res[1][1], res[0][1], **tol)
