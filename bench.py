@@ -308,10 +308,19 @@ def main():
             print(f"  sum of kernels {tot:.3f} ms vs step {ms:.3f} ms", file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST thing on stdout: RCCL writes a banner through C stdio, which (on a pipe) would
+        # otherwise surface from libc's buffer only at exit, i.e. after this line
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
