@@ -36,8 +36,9 @@ int lako_version(void);
 /* copies the calling thread's last error message (NUL-terminated) into buf; returns its length */
 int lako_last_error(char* buf, size_t n);
 
-/* stateless dropout: element idx of site `site` is kept iff hash(seed, site, idx) >= p*2^32; kept
- * elements are scaled by 1/(1-p) (torch.nn.Dropout semantics, HF5:725,745,83-94,400).  Forward and
+/* stateless dropout: the four consecutive elements 4q … 4q+3 of site `site` share h = hash32(key(seed, site) ^ q) and
+ * w = h*0x9E3779B1; their 16-bit draws are h>>16, h&0xffff, w>>16, w&0xffff and an element is kept iff its draw >=
+ * round(p*65536); kept elements are scaled by 1/(1-p) (torch.nn.Dropout semantics, HF5:725,745,83-94,400).  Forward and
  * backward kernels regenerate the mask from (seed, site); p == 0 disables. */
 typedef struct {
   float p;

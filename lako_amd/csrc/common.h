@@ -108,17 +108,32 @@ __host__ __device__ __forceinline__ uint32_t lako_hash32(uint32_t x) {
 __host__ __device__ __forceinline__ uint32_t lako_drop_key(uint32_t seed, uint32_t site) {
   return lako_hash32(seed * 0x9E3779B9U + site * 0x85EBCA6BU + 0x1234567U);
 }
-// returns true when the element is KEPT; thresh = round(p * 2^32)
-__host__ __device__ __forceinline__ bool lako_keep(uint32_t key, uint64_t idx, uint32_t thresh) {
-  uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
-  uint32_t h = lako_hash32(lo ^ key ^ (hi * 0x27d4eb2fU));
-  return h >= thresh;
+// Element-wise dropout draws: the four consecutive elements 4q … 4q+3 share ONE hash,
+//   h = hash32(lo(q) ^ key ^ hi(q)·0x27d4eb2f),  w = h · 0x9E3779B1 (low 32 bits),
+// with 16-bit draws h>>16, h&0xffff, w>>16, w&0xffff; an element is KEPT iff its draw >= round(p·65536).
+// `thresh` below is that 16-bit threshold shifted left by 16, so that no field has to be extracted:
+//   x>>16 >= t  ⟺  x >= t<<16,   x&0xffff >= t  ⟺  x<<16 >= t<<16.
+// (one hash per 4 elements instead of per element: the hashes were ≈2 µs of a GEMM tile's epilogue; measured keep rate
+//  and neighbour correlations of this recipe: DESIGN.md §3.)  tests/ref_ops.py carries the same integers.
+__host__ __device__ __forceinline__ void lako_keep4(uint32_t key, uint64_t quad, uint32_t thresh, bool (&k)[4]) {
+  const uint32_t h = lako_hash32((uint32_t)quad ^ key ^ ((uint32_t)(quad >> 32) * 0x27d4eb2fU));
+  const uint32_t w = h * 0x9E3779B1U;
+  k[0] = h >= thresh;
+  k[1] = (h << 16) >= thresh;
+  k[2] = w >= thresh;
+  k[3] = (w << 16) >= thresh;
 }
-static inline uint32_t lako_drop_thresh(float p) {
-  double t = (double)p * 4294967296.0;
-  if (t < 0) t = 0;
-  if (t > 4294967295.0) t = 4294967295.0;
-  return (uint32_t)t;
+// single element idx (callers that hold one element per lane)
+__host__ __device__ __forceinline__ bool lako_keep(uint32_t key, uint64_t idx, uint32_t thresh) {
+  bool k[4];
+  lako_keep4(key, idx >> 2, thresh, k);
+  return k[idx & 3];
+}
+static inline uint32_t lako_drop_thresh(float p) {   // 0 = dropout off
+  double t = (double)p * 65536.0 + 0.5;
+  if (t < 1) t = 1;
+  if (t > 65535.0) t = 65535.0;
+  return (uint32_t)t << 16;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -192,8 +192,10 @@ __device__ __forceinline__ void nt_store_tile(const NtArgs& a, f32x4 (&acc)[NT][
       }
       if (drop) {
         uint64_t idx = (uint64_t)(a.row0 + m) * (uint64_t)a.N + (uint64_t)n;
+        bool kp[4];
+        lako_keep4(a.drop_key, idx >> 2, a.drop_thresh, kp);   // n % 4 == 0: one quad
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = lako_keep(a.drop_key, idx + r, a.drop_thresh) ? v[r] * a.drop_scale : 0.f;
+        for (int r = 0; r < 4; ++r) v[r] = kp[r] ? v[r] * a.drop_scale : 0.f;
       }
       if (has_res) v += side_f32(nt, mt, m, n);
       TO* cp = C + (int64_t)m * a.ldc + n;
@@ -367,8 +369,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
             float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             if (drop) {
               const uint64_t idx = (uint64_t)(a.row0 + m) * (uint64_t)a.N + (uint64_t)n;
+              bool kp[2][4];
+              lako_keep4(a.drop_key, idx >> 2, a.drop_thresh, kp[0]);          // 8 consecutive columns = two quads
+              lako_keep4(a.drop_key, (idx >> 2) + 1, a.drop_thresh, kp[1]);
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = lako_keep(a.drop_key, idx + e, a.drop_thresh) ? v[e] * a.drop_scale : 0.f;
+              for (int e = 0; e < 8; ++e) v[e] = kp[e >> 2][e & 3] ? v[e] * a.drop_scale : 0.f;
             }
             bf16x8 o;
 #pragma unroll
@@ -594,8 +599,10 @@ __global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(NtArgs a) {
         }
         if (drop) {
           uint64_t idx = (uint64_t)(a.row0 + m) * (uint64_t)a.N + (uint64_t)n;
+          bool kp[4];
+          lako_keep4(a.drop_key, idx >> 2, a.drop_thresh, kp);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) vv[r] = lako_keep(a.drop_key, idx + r, a.drop_thresh) ? vv[r] * a.drop_scale : 0.f;
+          for (int r = 0; r < 4; ++r) vv[r] = kp[r] ? vv[r] * a.drop_scale : 0.f;
         }
         if (has_res) vv += load4(R + (int64_t)m * a.ldr + n);
         TO* cp = C + (int64_t)m * a.ldc + n;

@@ -28,6 +28,18 @@ extern "C" int lako_version(void) { return LAKO_ABI_VERSION; }
 
 namespace {
 
+// keep decisions of 8 consecutive elements starting at idx0 (a multiple of 4): two quads
+__device__ __forceinline__ void keep8(uint32_t key, uint64_t idx0, uint32_t thresh, bool (&k)[8]) {
+  bool a[4], b[4];
+  lako_keep4(key, idx0 >> 2, thresh, a);
+  lako_keep4(key, (idx0 >> 2) + 1, thresh, b);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    k[i] = a[i];
+    k[4 + i] = b[i];
+  }
+}
+
 struct DropDev {
   uint32_t thresh, key;
   float scale;
@@ -87,10 +99,12 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const T* __restrict__ 
       float v[8], wv[8];
       load8(xr + c, v);
       load8(w + c, wv);
+      bool kp[8];
+      if (dr.thresh) keep8(dr.key, (uint64_t)row * d + c, dr.thresh, kp);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         float o = wv[i] * (v[i] * rs);
-        if (dr.thresh) o = lako_keep(dr.key, (uint64_t)row * d + c + i, dr.thresh) ? o * dr.scale : 0.f;
+        if (dr.thresh) o = kp[i] ? o * dr.scale : 0.f;
         v[i] = o;
       }
       store8(yr + c, v);
@@ -127,9 +141,11 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* __restrict__ 
       if (c < d) {
         load8(dy + row * d + c, g[it]);
         load8(x + row * d + c, xv[it]);
+        bool kp[8];
+        if (dr.thresh) keep8(dr.key, (uint64_t)row * d + c, dr.thresh, kp);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          if (dr.thresh) g[it][i] = lako_keep(dr.key, (uint64_t)row * d + c + i, dr.thresh) ? g[it][i] * dr.scale : 0.f;
+          if (dr.thresh) g[it][i] = kp[i] ? g[it][i] * dr.scale : 0.f;
           s += wv[it][i] * g[it][i] * xv[it][i];
           dwacc[it][i] += g[it][i] * xv[it][i] * rs;
         }
@@ -184,8 +200,10 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
       float v[8];
       load8(table + id * d + c, v);
       if (dr.thresh) {
+        bool kp[8];
+        keep8(dr.key, (uint64_t)t * d + c, dr.thresh, kp);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = lako_keep(dr.key, (uint64_t)t * d + c + i, dr.thresh) ? v[i] * dr.scale : 0.f;
+        for (int i = 0; i < 8; ++i) v[i] = kp[i] ? v[i] * dr.scale : 0.f;
       }
       store8(out + t * d + c, v);
     }
@@ -223,8 +241,10 @@ __global__ __launch_bounds__(256) void dropout_apply_kernel(const T* __restrict_
   for (; i < n; i += stride) {
     float v[8];
     load8(x + i, v);
+    bool kp[8];
+    keep8(dr.key, (uint64_t)i, dr.thresh, kp);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = lako_keep(dr.key, (uint64_t)i + j, dr.thresh) ? v[j] * dr.scale : 0.f;
+    for (int j = 0; j < 8; ++j) v[j] = kp[j] ? v[j] * dr.scale : 0.f;
     store8(y + i, v);
   }
 }

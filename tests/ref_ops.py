@@ -43,15 +43,20 @@ def drop_key(seed: int, site: int) -> int:
 
 
 def keep_mask(drop, idx: torch.Tensor):
-    """(keep bool tensor, scale) for element indices `idx` (int64) — the integer recipe of csrc/common.h."""
+    """(keep bool tensor, scale) for element indices `idx` (int64) — the integer recipe of csrc/common.h (lako_keep4):
+    elements 4q … 4q+3 share h = hash32(lo(q) ^ key ^ hi(q)·0x27d4eb2f), w = h·0x9E3779B1; 16-bit draws h>>16, h&0xffff,
+    w>>16, w&0xffff; keep iff draw >= round(p·65536)."""
     p, seed, site = drop
-    p32 = float(np.float32(p))
-    thresh = min(int(p32 * 4294967296.0), M32)
+    t16 = min(max(int(float(np.float32(p)) * 65536.0 + 0.5), 1), 65535)
     key = drop_key(int(seed) & M32, int(site) & M32)
-    lo, hi = idx & M32, idx >> 32
+    q, fld = idx >> 2, idx & 3
+    lo, hi = q & M32, q >> 32
     h = hash32(lo ^ key ^ ((hi * 0x27D4EB2F) & M32))
+    w = _mul32(h, 0x9E3779B1)
+    word = torch.where(fld >= 2, w, h)
+    draw = torch.where((fld & 1).bool(), word & 0xFFFF, word >> 16)
     scale = float(np.float32(1.0) / (np.float32(1.0) - np.float32(p)))
-    return h >= thresh, scale
+    return draw >= t16, scale
 
 
 def _on(d):
