@@ -10,7 +10,8 @@ from lako_amd.ops import HipOps  # noqa: E402
 
 ops = HipOps()
 dev = torch.device("cuda:0")
-Me, d, f, inner = 64000, 768, 3072, 768
+Me = int(os.environ.get("LAKO_PROBE_TOKENS", "64000"))     # 64000 = padded config 2; ≈48000 = its valid tokens (unpadded path)
+d, f, inner = 768, 3072, 768
 T = torch.bfloat16
 for (M, N, K) in [(Me, 3 * inner, d), (Me, f, d), (Me, d, f), (Me, d, inner)]:
     A = torch.randn(M, K, device=dev).to(T)
