@@ -522,14 +522,18 @@ class Engine:
         kv = ws["e.kv"]
         for i in reversed(range(Ld)):
             lw = self.dec[i]
+            # the layer's six weight gradients (K = B·T rows: two K-steps each) as one grouped launch at the end of the layer
+            dw = []
             self._ffn_bwd(lw, dh, ws[f"d.a1.{i}"], ws[f"d.xn3.{i}"], ws[f"d.h2.{i}"], ws[f"d.rs3.{i}"], lw["ln3"], p,
-                          dr(_dec_site(i, 5)), tmp)
+                          dr(_dec_site(i, 5)), tmp, dw)
             # cross-attention
             dy = dh
             if p > 0:
-                dy = self._buf(tmp, f"dy.{Md}", (Md, d))
+                dy = self._buf(tmp, f"dy.c.{Md}", (Md, d))
                 ops.dropout_apply(dh, dy, dr(_dec_site(i, 3)))
-            ops.gemm_tn(dy, ws[f"d.cctx.{i}"], lw["co"].g)
+                dw.append((dy, ws[f"d.cctx.{i}"], lw["co"].g, 1.0))
+            else:
+                ops.gemm_tn(dy, ws[f"d.cctx.{i}"], lw["co"].g)
             dctx = self._buf(tmp, f"dctx.{Md}", (Md, inner))
             ops.gemm_nt(dy, lw["co"].wt, dctx)
             dqc = self._buf(tmp, "d.dqc", (Md, inner))
@@ -538,7 +542,7 @@ class Engine:
                          self._heads(dctx, B, T, 0), ws[f"d.cst.{i}"], self._heads(dqc, B, T, 0),
                          self._heads(dkv, kb, kt, 2 * i * inner), self._heads(dkv, kb, kt, (2 * i + 1) * inner),
                          drop=dr(_dec_site(i, 2)), **ckw)
-            ops.gemm_tn(dqc, ws[f"d.xn2.{i}"], lw["cq"].g)
+            dw.append((dqc, ws[f"d.xn2.{i}"], lw["cq"].g, 1.0))
             dxn = self._buf(tmp, f"dxn.{Md}", (Md, d))
             ops.gemm_nt(dqc, lw["cq"].wt, dxn)
             ops.rmsnorm_bwd(dxn, ws[f"d.h1.{i}"], lw["ln2"].p, ws[f"d.rs2.{i}"], dh, dh, lw["ln2"].g)
@@ -546,7 +550,9 @@ class Engine:
             dy = dh
             if p > 0:
                 ops.dropout_apply(dh, dy := self._buf(tmp, f"dy.{Md}", (Md, d)), dr(_dec_site(i, 1)))
-            ops.gemm_tn(dy, ws[f"d.ctx.{i}"], lw["o"].g)
+                dw.append((dy, ws[f"d.ctx.{i}"], lw["o"].g, 1.0))
+            else:
+                ops.gemm_tn(dy, ws[f"d.ctx.{i}"], lw["o"].g)
             ops.gemm_nt(dy, lw["o"].wt, dctx)
             qkv = ws[f"d.qkv.{i}"]
             dqkv = self._buf(tmp, f"dqkv.{Md}", (Md, 3 * inner))
@@ -554,9 +560,10 @@ class Engine:
                          self._heads(ws[f"d.ctx.{i}"], B, T, 0), self._heads(dctx, B, T, 0), ws[f"d.st.{i}"],
                          self._heads(dqkv, B, T, 0), self._heads(dqkv, B, T, inner), self._heads(dqkv, B, T, 2 * inner),
                          rel_bias=ws["d.rel"], drel=drel, rel_off=T - 1, causal=True, drop=dr(_dec_site(i, 0)))
-            ops.gemm_tn(dqkv, ws[f"d.xn1.{i}"], lw["qkv"].g)
+            dw.append((dqkv, ws[f"d.xn1.{i}"], lw["qkv"].g, 1.0))
             ops.gemm_nt(dqkv, lw["qkv"].wt, dxn)
             ops.rmsnorm_bwd(dxn, ws[f"d.h{i}"], lw["ln1"].p, ws[f"d.rs1.{i}"], dh, dh, lw["ln1"].g)
+            ops.gemm_tn_grouped(dw)
         ops.embed_bwd(ctx.dec_ids.view(-1), dh, self.shared.g, dr(S_DEC_EMBED))
         ops.relpos_reduce(drel, self._lut(T, T, False), self.dec_rel.g)
         # ---- cross K/V projection of all decoder layers -----------------------------------------
