@@ -345,3 +345,32 @@ def test_unpadded_path_equals_padded_path_gpu(dtype, monkeypatch):
     gscale = res[0][2].abs().max().item()
     # bf16: the packed keys of the cross-attention are chunked differently (other rounding of the running softmax)
     assert (res[1][2] - res[0][2]).abs().max().item() < (1e-4 if dtype == torch.float32 else 5e-2) * gscale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,L,T", [(1, 1, 5, 1), (2, 3, 17, 3), (1, 7, 33, 2), (3, 1, 250, 9)])
+def test_fp32_edge_shapes_vs_oracle(B, N, L, T):
+    """Shapes at the edges of the kernels' tilings — a single passage, sequences shorter than one 16-row block, one
+    decoder position, one sample, more than one 256-key chunk per passage — against the oracle (fp32): loss, logits, every
+    gradient and the greedy tokens.  Valid lengths are ragged, so the unpadded path is the one exercised."""
+    dims = O.T5Dims(vocab_size=128, d_model=64, d_kv=32, d_ff=128, num_layers=2, num_decoder_layers=2, num_heads=2)
+    dims.dropout = 0.0
+    w = O.init_weights(dims, seed=21)
+    ids, mask, labels = O.synthetic_batch(B, N, L, T, dims.vocab_size, seed=31 + L)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+    loss, logits = O.fid_forward(leaves, dims, ids, mask, labels, training=False)
+    loss.backward()
+    model = FiDT5(cfg_of(dims), dtype=torch.float32)
+    model.load_t5(w)
+    model = model.cuda().train()
+    out = model(input_ids=ids.to(DEV), attention_mask=mask.to(DEV), labels=labels.to(DEV))
+    assert (model._engine.ctx.rag is not None) == bool((~mask).any())
+    assert abs(out[0].item() - loss.item()) < 1e-4
+    torch.testing.assert_close(out.logits.cpu(), logits.detach(), atol=1e-4, rtol=1e-4)
+    out[0].backward()
+    for n, p in model.named_parameters():
+        ref = leaves[plain_name(n)].grad
+        torch.testing.assert_close(p.grad.cpu(), ref, atol=1e-4 * max(1.0, ref.abs().max().item()), rtol=1e-3,
+                                   msg=lambda m, n=n: f"{n}: {m}")
+    toks = model.eval().generate(input_ids=ids.to(DEV), attention_mask=mask.to(DEV), max_length=6)
+    assert toks.cpu().tolist() == O.fid_generate(w, dims, ids, mask, 6).tolist()
