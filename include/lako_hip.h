@@ -204,6 +204,13 @@ int lako_shift_right(const int64_t* labels, int64_t* dec_ids, int B, int T, lako
 int lako_greedy_step(const float* logits, int64_t V, int B, int64_t* seq, int64_t seq_ld, int pos, int64_t* next_ids,
                      uint8_t* done, int32_t* n_done, int64_t eos_id, int64_t pad_id, lako_stream_t stream);
 
+/* ---- exact inner-product search (src/index.py:19-50 faiss.IndexFlatIP.search; the scores are one
+ * lako_gemm_nt of the queries against the stored embeddings) -----------------------------------------------------------
+ * out_vals / out_idx [rows, k]: the k largest entries of each row of scores [rows, n] (row stride ld), descending; equal
+ * scores in ascending index order.  1 <= k <= min(n, 1024). */
+int lako_topk(const float* scores, int64_t rows, int64_t n, int64_t ld, int k, float* out_vals, int64_t* out_idx,
+              lako_stream_t stream);
+
 /* Development knob for A/B measurements (tools/bench_ops.py); training never calls it.
  * "gemm_nt_variant": -1 auto (default), 0 = 128x128 tile / 4 waves, 1 = 256x128 / 8 waves, 2 = 256x256 / 8 waves,
  *                    3 = 256x256 4-slot ring;  "gemm_nt_persistent" 0/1;  "gemm_nt_stagger" 0/1;

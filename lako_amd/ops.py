@@ -282,6 +282,17 @@ class HipOps:
     def cast(self, src, dst):
         self._timed("cast", 0.0, lambda: check(self.lib.lako_cast(_p(src), _p(dst), src.numel(), _dt(dst), self._stream()), "lako_cast"))
 
+    # ---- exact inner-product search ---------------------------------------------------
+    def topk(self, scores, k, out_vals, out_idx):
+        """the k largest entries of every row of fp32 scores [rows, n], descending, ties in ascending index order"""
+        rows, n = scores.shape
+        if scores.dtype != torch.float32 or scores.stride(1) != 1 or out_idx.dtype != torch.int64 or out_vals.dtype != torch.float32:
+            raise LakoError("topk: scores fp32 row-major, out_vals fp32, out_idx int64")
+        if tuple(out_vals.shape) != (rows, k) or tuple(out_idx.shape) != (rows, k) or not out_vals.is_contiguous() or not out_idx.is_contiguous():
+            raise LakoError("topk: outputs must be contiguous [rows, k]")
+        self._timed("topk", 0.0, lambda: check(self.lib.lako_topk(_p(scores), rows, n, scores.stride(0), int(k), _p(out_vals), _p(out_idx),
+                                                                 self._stream()), "lako_topk"))
+
     # ---- integer helpers ------------------------------------------------------------------------
     def shift_right(self, labels, dec_ids):
         B, T = labels.shape

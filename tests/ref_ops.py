@@ -297,6 +297,12 @@ class RefOps:
     def cast(self, src, dst):
         dst.copy_(src.view(dst.shape))
 
+    def topk(self, scores, k, out_vals, out_idx):
+        # value descending, index ascending among equal values (a stable sort of the negated scores)
+        order = torch.sort(-scores, dim=1, stable=True).indices[:, :k]
+        out_idx.copy_(order)
+        out_vals.copy_(torch.gather(scores, 1, order))
+
     # ---- integer helpers ------------------------------------------------------------------------
     def shift_right(self, labels, dec_ids):
         dec_ids[:, 0] = 0

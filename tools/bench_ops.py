@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lako_amd.ops import HipOps  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--only", default="gemm,tn,attn,norm,misc")
+ap.add_argument("--only", default="gemm,tn,attn,norm,misc,index")
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--variants", default="-1", help="gemm_nt tile variants to time, e.g. 0,1,2")
@@ -225,3 +225,12 @@ if "misc" in only:
     timeit("zero grads 223M", lambda: g.zero_(), bytes_=4.0 * n)
     src, dst = torch.randn(3072, 768, device=dev), torch.empty(768, 3072, dtype=T, device=dev)
     timeit("transpose_cast 3072x768", lambda: ops.transpose_cast(src, dst), bytes_=3072 * 768 * (4 + ES))
+
+if "index" in only:
+    # exact inner-product search of 1024 queries over the reference's 300 600 facts × 256 dims, top-500
+    nq, nf, dim, k = 1024, 300600, 256, 500
+    q, e = torch.randn(nq, dim, device=dev), torch.randn(nf, dim, device=dev)
+    sc = torch.empty(nq, nf, device=dev)
+    vals, idx = torch.empty(nq, k, device=dev), torch.empty(nq, k, dtype=torch.int64, device=dev)
+    timeit("index scores [1024,256]x[300600,256] fp32", lambda: ops.gemm_nt(q, e, sc), flops=2.0 * nq * nf * dim)
+    timeit("index top-500 of [1024,300600]", lambda: ops.topk(sc, k, vals, idx), bytes_=5.0 * nq * nf * 4)
