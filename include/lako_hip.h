@@ -211,6 +211,26 @@ int lako_greedy_step(const float* logits, int64_t V, int B, int64_t* seq, int64_
 int lako_topk(const float* scores, int64_t rows, int64_t n, int64_t ld, int k, float* out_vals, int64_t* out_idx,
               lako_stream_t stream);
 
+/* ---- retriever bi-encoder, FORWARD only (src/model.py:375-483 over HF BertModel); the matrix products and
+ * the attention are lako_gemm_nt / lako_attn_fwd --------------------------------------------------------------------------
+ * y = LayerNorm(x + lin_bias + resid)·gamma + beta (torch.nn.LayerNorm); lin_bias (fp32 [d]) and resid may be NULL */
+int lako_layernorm_fwd(const void* x, const float* lin_bias, const void* resid, const float* gamma, const float* beta, void* y,
+                       int64_t rows, int d, float eps, int dtype, lako_stream_t stream);
+/* BertEmbeddings: out[t] = LayerNorm(word[ids[t]] + pos[t mod L] + type0) (token type 0, absolute positions); tables fp32 */
+int lako_bert_embed(const int64_t* ids, const float* word, const float* pos, const float* type0, const float* gamma,
+                    const float* beta, void* out, int64_t n_tok, int L, int d, int64_t vocab, float eps, int dtype,
+                    lako_stream_t stream);
+/* y = act(x + bias) over [rows, n]: act 0 identity, 1 exact (erf) GELU */
+int lako_bias_act(const void* x, const float* bias, void* y, int64_t rows, int n, int act, int dtype, lako_stream_t stream);
+/* out[b] (fp32 [d]) = mean of the L rows of x[b] ([B, L, d]); with mask ([B, L] uint8) only rows with mask != 0
+ * (src/model.py:471-478) */
+int lako_seq_mean(const void* x, const uint8_t* mask, float* out, int B, int L, int d, int dtype, lako_stream_t stream);
+/* score[b][i] = scale * <q[b], p[b][i]> (fp32; src/model.py:443-448 einsum('bd,bid->bi') / sqrt(d)) */
+int lako_bi_score(const float* q, const float* p, float* out, int B, int n, int d, float scale, lako_stream_t stream);
+
+/* loss[0] = torch.nn.KLDivLoss()(log_softmax(score, -1), gold) over fp32 [B, n] (src/model.py:480-483); value only */
+int lako_kldiv_fwd(const float* score, const float* gold, float* loss, int B, int n, lako_stream_t stream);
+
 /* Development knob for A/B measurements (tools/bench_ops.py); training never calls it.
  * "gemm_nt_variant": -1 auto (default), 0 = 128x128 tile / 4 waves, 1 = 256x128 / 8 waves, 2 = 256x256 / 8 waves,
  *                    3 = 256x256 4-slot ring;  "gemm_nt_persistent" 0/1;  "gemm_nt_stagger" 0/1;

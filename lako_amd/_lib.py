@@ -87,6 +87,12 @@ SIGNATURES = {
     "lako_shift_right": [vp, vp, i32, i32, vp],
     "lako_greedy_step": [vp, i64, i32, vp, i64, i32, vp, vp, vp, i64, i64, vp],
     "lako_topk": [vp, i64, i64, i64, i32, vp, vp, vp],
+    "lako_layernorm_fwd": [vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, vp],
+    "lako_bert_embed": [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i64, f32, i32, vp],
+    "lako_bias_act": [vp, vp, vp, i64, i32, i32, i32, vp],
+    "lako_seq_mean": [vp, vp, vp, i32, i32, i32, i32, vp],
+    "lako_bi_score": [vp, vp, vp, i32, i32, i32, f32, vp],
+    "lako_kldiv_fwd": [vp, vp, vp, i32, i32, vp],
     "lako_set_tuning": [C.c_char_p, i32],
 }
 

@@ -7,7 +7,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-pass-failed"
 objs=()
 pids=()
-for f in gemm rowops attn index; do
+for f in gemm rowops attn index bertops; do
   [ -f $f.hip ] || continue
   if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ common.h -nt $f.o ] || [ ../../include/lako_hip.h -nt $f.o ]; then
     extra=""

@@ -293,6 +293,46 @@ class HipOps:
         self._timed("topk", 0.0, lambda: check(self.lib.lako_topk(_p(scores), rows, n, scores.stride(0), int(k), _p(out_vals), _p(out_idx),
                                                                  self._stream()), "lako_topk"))
 
+    # ---- retriever bi-encoder forward ---------------------------------------------------
+    def layernorm_fwd(self, x, gamma, beta, y, *, lin_bias=None, resid=None, eps=1e-12):
+        """y = LayerNorm(x + lin_bias + resid)·gamma + beta over the rows of [rows, d]"""
+        rows, d = x.shape
+        if not x.is_contiguous() or not y.is_contiguous() or (resid is not None and (not resid.is_contiguous() or resid.dtype != x.dtype)):
+            raise LakoError("layernorm_fwd: contiguous [rows, d] tensors of one dtype")
+        self._timed("layernorm_fwd", 0.0, lambda: check(self.lib.lako_layernorm_fwd(_p(x), _p(lin_bias), _p(resid), _p(gamma), _p(beta), _p(y), rows, d,
+                                                                                float(eps), _dt(x), self._stream()), "lako_layernorm_fwd"))
+
+    def bert_embed(self, ids, word, pos, type0, gamma, beta, out, L, eps=1e-12):
+        n_tok, d = out.shape
+        if L > pos.shape[0]:
+            raise LakoError(f"bert_embed: sequence length {L} exceeds the {pos.shape[0]} learned positions")
+        self._timed("bert_embed", 0.0, lambda: check(self.lib.lako_bert_embed(_p(ids), _p(word), _p(pos), _p(type0), _p(gamma), _p(beta), _p(out), n_tok,
+                                                                             int(L), d, word.shape[0], float(eps), _dt(out), self._stream()), "lako_bert_embed"))
+
+    def bias_act(self, x, bias, y, gelu=False):
+        rows, n = x.shape
+        if not x.is_contiguous() or not y.is_contiguous():
+            raise LakoError("bias_act: contiguous [rows, n] tensors")
+        self._timed("bias_act", 0.0, lambda: check(self.lib.lako_bias_act(_p(x), _p(bias), _p(y), rows, n, 1 if gelu else 0, _dt(x), self._stream()), "lako_bias_act"))
+
+    def seq_mean(self, x, mask, out):
+        B, L, d = x.shape
+        if not x.is_contiguous() or out.dtype != torch.float32 or (mask is not None and mask.dtype not in (torch.uint8, torch.bool)):
+            raise LakoError("seq_mean: x contiguous [B, L, d], mask uint8/bool [B, L], out fp32 [B, d]")
+        self._timed("seq_mean", 0.0, lambda: check(self.lib.lako_seq_mean(_p(x), _p(mask), _p(out), B, L, d, _dt(x), self._stream()), "lako_seq_mean"))
+
+    def bi_score(self, q, p, out, scale):
+        B, n, d = p.shape
+        if q.dtype != torch.float32 or p.dtype != torch.float32 or not q.is_contiguous() or not p.is_contiguous():
+            raise LakoError("bi_score: fp32 contiguous q [B, d], p [B, n, d]")
+        self._timed("bi_score", 0.0, lambda: check(self.lib.lako_bi_score(_p(q), _p(p), _p(out), B, n, d, float(scale), self._stream()), "lako_bi_score"))
+
+    def kldiv_fwd(self, score, gold, loss):
+        B, n = score.shape
+        if score.dtype != torch.float32 or gold.dtype != torch.float32 or not score.is_contiguous() or not gold.is_contiguous() or gold.shape != score.shape:
+            raise LakoError("kldiv_fwd: fp32 contiguous [B, n] score and gold")
+        self._timed("kldiv_fwd", 0.0, lambda: check(self.lib.lako_kldiv_fwd(_p(score), _p(gold), _p(loss), B, n, self._stream()), "lako_kldiv_fwd"))
+
     # ---- integer helpers ------------------------------------------------------------------------
     def shift_right(self, labels, dec_ids):
         B, T = labels.shape

@@ -353,10 +353,49 @@ def make_evaluation():
     print("wrote evaluation.json", len(rows))
 
 
+RETRIEVER_CASES = {   # name → RetrieverConfig overrides; one tiny BERT shared by all
+    "proj_mean": dict(projection=True),
+    "proj_mask": dict(projection=True, apply_question_mask=True, apply_passage_mask=True),
+    "proj_cls": dict(projection=True, extract_cls=True, apply_passage_mask=True),
+    "raw_mean": dict(projection=False),
+    "asym_mask": dict(projection=False, asymmetric_retri="yes", apply_question_mask=True, apply_passage_mask=True),
+}
+RETRIEVER_TINY = dict(vocab_size=96, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                      max_position_embeddings=40, indexing_dimension=64)
+
+
+def make_retriever():
+    """Outputs of the reference's own Retriever (src/model.py:375-483 on transformers' BertModel, eval mode) for the
+    weights oracle/retriever_oracle.init_weights generates → tests/golden/retriever.npz (inputs are regenerated from seeds)."""
+    import src.model as rm
+    from lako_amd.retriever import RetrieverConfig
+    from oracle import retriever_oracle as RO
+    out = {}
+    for ci, (name, over) in enumerate(RETRIEVER_CASES.items()):
+        kw = dict(RETRIEVER_TINY, **over)
+        ref_cfg = rm.RetrieverConfig(**kw)
+        cfg = RetrieverConfig.from_hf(ref_cfg)
+        w = RO.init_weights(cfg, seed=40 + ci)
+        ref = rm.Retriever(ref_cfg)
+        sd = ref.state_dict()
+        assert set(w) <= set(sd), sorted(set(w) - set(sd))
+        missing, unexpected = ref.load_state_dict(w, strict=False)
+        assert not unexpected and all("position_ids" in k or "token_type_ids" in k for k in missing), (missing, unexpected)
+        ref.eval()
+        qi, qm, pi, pm, gold = RO.synthetic_batch(cfg, 3, 4, 9, 14, seed=70 + ci)
+        with torch.no_grad():
+            q, p, score, loss = ref(qi, qm, pi, pm, gold_score=gold)
+        for k, v in (("q", q), ("p", p), ("score", score), ("loss", loss)):
+            out[f"{name}.{k}"] = v.detach().double().numpy()
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "retriever.npz"), **out)
+    print("retriever.npz", {k: v.shape for k, v in out.items() if k.startswith("proj_mean")})
+
+
 if __name__ == "__main__":
     tiny = O.T5Dims.named("tiny")
     make_tables()
     make_collate()
+    make_retriever()
     make_evaluation()
     make_case("tiny_a", tiny, B=3, N=3, L=12, T=5, seed=1, full_pad=(1, 2))
     make_case("tiny_fact", tiny, B=3, N=2, L=24, T=4, seed=2, fact_case=True)

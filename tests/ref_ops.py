@@ -303,6 +303,40 @@ class RefOps:
         out_idx.copy_(order)
         out_vals.copy_(torch.gather(scores, 1, order))
 
+    # ---- retriever bi-encoder forward ------------------------------------------------------------------
+    def layernorm_fwd(self, x, gamma, beta, y, *, lin_bias=None, resid=None, eps=1e-12):
+        v = x.float()
+        if lin_bias is not None:
+            v = v + lin_bias.float()
+        if resid is not None:
+            v = v + resid.float()
+        y.copy_(torch.nn.functional.layer_norm(v, (v.shape[-1],), gamma.float(), beta.float(), eps))
+
+    def bert_embed(self, ids, word, pos, type0, gamma, beta, out, L, eps=1e-12):
+        n_tok, d = out.shape
+        ids = ids.reshape(-1)
+        ids = torch.where((ids < 0) | (ids >= word.shape[0]), torch.zeros_like(ids), ids)
+        v = word[ids].float() + pos[torch.arange(n_tok, device=ids.device) % L].float() + type0.float()
+        out.copy_(torch.nn.functional.layer_norm(v, (d,), gamma.float(), beta.float(), eps))
+
+    def bias_act(self, x, bias, y, gelu=False):
+        v = x.float() + bias.float()
+        y.copy_(torch.nn.functional.gelu(v) if gelu else v)
+
+    def seq_mean(self, x, mask, out):
+        v = x.float()
+        if mask is None:
+            out.copy_(v.mean(1))
+        else:
+            m = mask.bool()
+            out.copy_(v.masked_fill(~m[:, :, None], 0.0).sum(1) / m.sum(1, keepdim=True).float())
+
+    def bi_score(self, q, p, out, scale):
+        out.copy_(torch.einsum("bd,bid->bi", q, p) * scale)
+
+    def kldiv_fwd(self, score, gold, loss):
+        loss[0] = torch.nn.KLDivLoss()(torch.log_softmax(score, -1), gold)
+
     # ---- integer helpers ------------------------------------------------------------------------
     def shift_right(self, labels, dec_ids):
         dec_ids[:, 0] = 0

@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lako_amd.ops import HipOps  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--only", default="gemm,tn,attn,norm,misc,index")
+ap.add_argument("--only", default="gemm,tn,attn,norm,misc,index,retriever")
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--variants", default="-1", help="gemm_nt tile variants to time, e.g. 0,1,2")
@@ -234,3 +234,16 @@ if "index" in only:
     vals, idx = torch.empty(nq, k, device=dev), torch.empty(nq, k, dtype=torch.int64, device=dev)
     timeit("index scores [1024,256]x[300600,256] fp32", lambda: ops.gemm_nt(q, e, sc), flops=2.0 * nq * nf * dim)
     timeit("index top-500 of [1024,300600]", lambda: ops.topk(sc, k, vals, idx), bytes_=5.0 * nq * nf * 4)
+
+if "retriever" in only:
+    # BERT-base bi-encoder forward (src/model.py:451-478) at passage_maxlength 130 — embedding throughput
+    from lako_amd.retriever import Retriever, RetrieverConfig
+    cfg = RetrieverConfig(apply_passage_mask=True)
+    rt = Retriever(cfg, dtype=T).cuda()
+    nb, L = 512, 130
+    ids = torch.randint(1, cfg.vocab_size, (nb, L), device=dev)
+    lens = torch.randint(20, L + 1, (nb,), device=dev)
+    mask = torch.arange(L, device=dev)[None, :] < lens[:, None]
+    fl = nb * L * cfg.num_hidden_layers * (2.0 * 768 * 768 * 4 + 2.0 * 768 * 3072 * 2 + 4.0 * L * 768) + 2.0 * nb * L * 768 * 256
+    timeit(f"retriever embed_text {nb} x {L} BERT-base", lambda: rt.embed_text(ids, mask, "f", True, False), flops=fl)
+    ops.reset_timers() if hasattr(ops, "reset_timers") else None
