@@ -236,7 +236,9 @@ int lako_kldiv_fwd(const float* score, const float* gold, float* loss, int B, in
  *                    3 = 256x256 4-slot ring;  "gemm_nt_persistent" 0/1;  "gemm_nt_stagger" 0/1;
  * "gemm_nt_wide_epi" 0/1 (LDS-transposed epilogue for plain bf16 stores);  "gemm_nt_group_m": tile-rows per band of
  * the banded tile order (0 = row-major, >0 applied when the output is >= 16 tiles wide, <0 forces |value|);
- * "gemm_tn_big" 0/1 (256x256 weight-gradient kernel).  Unknown key: LAKO_E_BADARG. */
+ * "gemm_tn_big" 0/1 (256x256 weight-gradient kernel);  "gemm_nt_dephase": start offset between neighbouring workgroups of a
+ * multi-round persistent launch in 10-ns ticks (default 100, 0 = lockstep start), "gemm_nt_dephase_n": phases (default 2).
+ * Unknown key: LAKO_E_BADARG. */
 int lako_set_tuning(const char* key, int value);
 
 #ifdef __cplusplus

@@ -41,6 +41,7 @@ struct NtArgs {
   int split_k, k_chunk;   // ring kernel with LAKO_EPI_ATOMIC only: K split over split_k workgroups per tile, k_chunk BYTES each
   int64_t row0;   // rows [row0, row0 + M) of a larger problem (tail launch): only the dropout element index needs it
   int group_m;    // >0: tile ids walk bands of group_m tile-rows column-major (an XCD's 32 resident tiles form a ≈group_m × 32/group_m block)
+  int dephase;    // (phases << 16) | ticks: workgroup w of an XCD starts (w mod phases)·ticks·10 ns late (breaks the lockstep of main loops / epilogues)
   int wide_epi;   // 256² bf16 tile: LDS-transposed epilogue with 16-B row-major stores (needs N, ldc, ldr, ldaux % 8 == 0)
 };
 
@@ -237,6 +238,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
   tile_coords(tile, a.tiles_m, a.tiles_n, a.group_m, tm_, tn_);
   int m0 = tm_ * BM, n0 = tn_ * BN;
   int rows_a = min(BM, a.M - m0), rows_b = min(BN, a.N - n0);
+  if (a.dephase > 0) {
+    const int ph = (blockIdx.x >> 3) % (a.dephase >> 16);
+    if (ph) {
+      const uint64_t t0 = __builtin_amdgcn_s_memrealtime(), dt = (uint64_t)((a.dephase & 0xffff) * ph);   // 100 MHz
+      while (__builtin_amdgcn_s_memrealtime() - t0 < dt) __builtin_amdgcn_s_sleep(8);
+    }
+  }
   stage_rows<BM, NW>(smem, a.A + (int64_t)m0 * lda_b, rows_a, lda_b, kbytes, wave, lane);
   stage_rows<BN, NW>(smem + A_BYTES, a.B + (int64_t)n0 * ldb_b, rows_b, ldb_b, kbytes, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -957,6 +965,7 @@ int g_nt_group_m = 8;
 int g_nt_debug = 0;
 int g_nt_ring = 1;      // skinny problems go to gemm_nt_ring_kernel ("gemm_nt_ring" 0 disables; variant 4 forces it)
 int g_nt_stagger = 1;
+int g_nt_dephase = 100, g_nt_dephase_n = 2;   // 10-ns ticks (s_memrealtime), phases
 int g_nt_persistent = 1;
 int g_nt_variant = -1;   // -1 auto; 0: 128x128/4 waves; 1: 256x128/8 waves; 2: 256x256/8 waves (lako_set_tuning)
 
@@ -984,6 +993,10 @@ void launch_nt_cfg(NtArgs a, hipStream_t s) {
   int grid = a.tiles_m * a.tiles_n;
   if (g_nt_persistent && grid > 256 * per_cu) grid = 256 * per_cu;
   if ((g_nt_debug >> 8) > 0 && grid > (g_nt_debug >> 8)) grid = g_nt_debug >> 8;   // timing experiment: fewer resident workgroups
+  // DEPHASE: every other workgroup of an XCD starts 1 µs late when the workgroups walk several tiles.  Measured (tools/bench_ops.py
+  // --dephase 0,100,…): [64000,768]×[2304,768] 287 → 250 µs, o+res 140 → 134, wi 374 → 366, long launches unchanged; the size of
+  // the delay (1…16 µs) and the number of phases (2, 4, 8) do not matter — the lockstep start is what costs.
+  a.dephase = (g_nt_dephase > 0 && a.tiles_m * a.tiles_n > grid) ? ((g_nt_dephase_n << 16) | (g_nt_dephase & 0xffff)) : 0;
   hipLaunchKernelGGL((gemm_nt_kernel<T, TO, WM, WN, MT, NT>), dim3(grid), dim3(WM * WN * 64), LDS, s, a);
 }
 
@@ -1293,6 +1306,14 @@ extern "C" int lako_set_tuning(const char* key, int value) {
   }
   if (key && !strcmp(key, "gemm_nt_wide_epi")) {
     g_nt_wide_epi = value;
+    return LAKO_OK;
+  }
+  if (key && !strcmp(key, "gemm_nt_dephase_n")) {
+    g_nt_dephase_n = value < 2 ? 2 : value;
+    return LAKO_OK;
+  }
+  if (key && !strcmp(key, "gemm_nt_dephase")) {
+    g_nt_dephase = value;
     return LAKO_OK;
   }
   if (key && !strcmp(key, "gemm_nt_stagger")) {

@@ -16,6 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--only", default="gemm,tn,attn,norm,misc,index,retriever")
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--dephase", default="0", help="gemm_nt_dephase values (10-ns ticks) to time, e.g. 0,500,1000")
 ap.add_argument("--variants", default="-1", help="gemm_nt tile variants to time, e.g. 0,1,2")
 ap.add_argument("--vendor", action="store_true", help="also time torch.matmul (hipBLASLt / rocBLAS) on the GEMM shapes: a yardstick, "
                 "never part of the product path")
@@ -49,14 +50,17 @@ def timeit(name, fn, flops=0.0, bytes_=0.0):
 
 
 drop = (0.1, 1, 2)
-for variant in ([int(v) for v in args.variants.split(",")] if "gemm" in only else []):
-    ops.set_tuning("gemm_nt_variant", variant % 10)
+for variant, dephase in ([(int(v), int(dp)) for v in args.variants.split(",") for dp in args.dephase.split(",")] if "gemm" in only else []):
+    ops.set_tuning("gemm_nt_dephase", dephase % 100000)
+    ops.set_tuning("gemm_nt_dephase_n", max(2, dephase // 100000))
+    print(f"--- dephase {dephase}")
+    ops.set_tuning("gemm_nt_variant", variant if variant < 0 else variant % 10)
     ops.set_tuning("gemm_nt_persistent", 0 if 10 <= variant < 20 else 1)
     ops.set_tuning("gemm_nt_stagger", 0 if 20 <= variant < 30 else 1)
     ops.set_tuning("gemm_nt_wide_epi", 0 if 30 <= variant < 40 else 1)
     ops.set_tuning("gemm_nt_debug", {7: 1, 8: 2, 9: 4, 14: 8, 11: 128 << 8, 12: 64 << 8, 13: (128 << 8) | 1}.get(variant // 10, 0))   # 7x: no K-loop DMA; 8x: every DMA hits L2 (timing experiments, wrong results)
     ops.set_tuning("gemm_nt_group_m", {4: 0, 5: 4, 6: 16}.get(variant // 10, 8))
-    print(f"--- gemm_nt variant {variant % 10} (-1 auto, 0 128x128, 1 256x128, 2 256x256, 3 ring256, 4 ring128) "
+    print(f"--- gemm_nt variant {variant if variant < 0 else variant % 10} (-1 auto, 0 128x128, 1 256x128, 2 256x256, 3 ring256, 4 ring128) "
           f"persistent={not 10 <= variant < 20} stagger={not 20 <= variant < 30} wide_epi={not 30 <= variant < 40} "
           f"group_m={ {4: 0, 5: 4, 6: 16}.get(variant // 10, 8)}", flush=True)
     for nm, (M, Nn, K), kw in [
