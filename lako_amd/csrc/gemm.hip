@@ -105,7 +105,16 @@ __device__ __forceinline__ void stage_rows(char* lds_tile, const char* base, int
   }
 }
 
-// the same, one 1-KiB piece at a time (piece i of this wave), so that the K-loop can deal the pieces out between MFMAs
+// the same, one 1-KiB piece at a time (piece i of this wave), so that the K-loop can deal the pieces out between MFMAs.
+// piece_base / stage_piece_at (SIDE kernel): piece i of a wave is piece 0 moved down by i·NWAVES·8 rows (the chunk swizzle repeats
+// every 16 rows), so ONE per-lane offset serves all pieces, each with its own descriptor starting at its first row.  Rows past
+// the edge fall out of the descriptor's range by themselves (slice_rsrc: the range ends inside row rows_valid − 1 and a row
+// stride is at least a row long); chunks past the end of K start from an out-of-range offset.
+__device__ __forceinline__ uint32_t piece_base(int64_t ld_bytes, int kbytes_left, int wave, int lane) {
+  const int row = wave * 8 + (lane >> 3);
+  const int c = (lane & 7) ^ ((row >> 1) & 7);
+  return c * 16 < kbytes_left ? (uint32_t)(row * ld_bytes + c * 16) : 0x80000000u;
+}
 template <int NWAVES>
 __device__ __forceinline__ void stage_piece(char* lds_tile, __amdgpu_buffer_rsrc_t rsrc, int rows_valid, int64_t ld_bytes,
                                             int kbytes_left, int wave, int lane, int i) {
@@ -116,6 +125,11 @@ __device__ __forceinline__ void stage_piece(char* lds_tile, __amdgpu_buffer_rsrc
   bool ok = (row < rows_valid) && (c * 16 < kbytes_left);
   uint32_t voff = ok ? (uint32_t)(row * ld_bytes + c * 16) : 0xFFFFFFF0u;
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + inst * 1024), 16, (int)voff, 0, 0, 0);
+}
+// SIDE kernel: ONE per-lane offset (piece_base) serves all pieces of a wave, each piece with its own descriptor
+template <int NWAVES>
+__device__ __forceinline__ void stage_piece_at(char* lds_tile, __amdgpu_buffer_rsrc_t rsrc, uint32_t vbase, int wave, int i) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + (wave + i * NWAVES) * 1024), 16, (int)vbase, 0, 0, 0);
 }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t slice_rsrc(const char* base, int rows_valid, int64_t ld_bytes, int kbytes_left) {
   uint32_t nrec = (rows_valid > 0 && kbytes_left > 0)
@@ -215,7 +229,8 @@ __device__ __forceinline__ void nt_store_tile(const NtArgs& a, f32x4 (&acc)[NT][
 // Workgroup tile = (WM·MT·16) × (WN·NT·16); WM×WN waves, each owning MT×NT MFMA 16×16 tiles.
 //   <2,2,4,4> 128×128, 4 waves, 64 KiB LDS (2 workgroups / CU)      — small / skinny problems
 //   <2,4,8,4> 256×256, 8 waves, 128 KiB LDS (1 workgroup / CU)      — half the LDS+L2 bytes per FLOP
-template <typename T, typename TO, int WM, int WN, int MT, int NT>
+//   SIDE (256² bf16 only): the residual / aux operand of the epilogue is LDS-DMA'd in four 32-row passes (see the epilogue)
+template <typename T, typename TO, int WM, int WN, int MT, int NT, bool SIDE = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
   constexpr int NW = WM * WN, BM = WM * MT * 16, BN = WN * NT * 16;
   constexpr int A_BYTES = BM * TKB, B_BYTES = BN * TKB, BUF = A_BYTES + B_BYTES;
@@ -251,6 +266,27 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
   __syncthreads();
   int cur = 0;
 
+  // SIDE: pass p = rows [32p, 32p + 32) of this wave's 128×64 region of the residual / aux tile → 4 KiB of LDS, 16-B chunk c of
+  // row r at position c ^ (r & 7) (the accumulator-layout reads below are then conflict-free); 4 DMA instructions, always
+  // issued (rows / columns past the edge are out of the descriptor's range: they move nothing), so that the waits further
+  // down can be COUNTED.  The per-lane offset is rebuilt from an opaque lane id at every call: shared with the epilogue's
+  // calls it would stay live across the main loop (256 registers, spills).
+  auto side_issue = [&](int pass, char* slot, int tm0, int tn0) {
+    if constexpr (SIDE) {
+      const bool res = a.flags & LAKO_EPI_RESID;
+      const char* sp = res ? a.resid : a.aux;
+      const int ld_b = (int)(res ? a.ldr : a.ldaux) * 2;
+      const int rows_v = min(BM, a.M - tm0), cols_v = min(BN, a.N - tn0);
+      const auto rs = lds_dma_rsrc(sp + (int64_t)tm0 * ld_b + (int64_t)tn0 * 2, (uint32_t)((rows_v - 1) * ld_b + cols_v * 2));
+      int l = lane;
+      asm volatile("" : "+v"(l));
+      const int col_t = wc * 64 + (((l & 7) ^ ((l >> 3) & 7)) * 8);
+      const uint32_t vb = col_t < cols_v ? (uint32_t)((wr * 128 + (l >> 3)) * ld_b + col_t * 2) : 0x80000000u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) lds_dma16(slot + j * 1024, rs, vb + (uint32_t)((pass * 32 + j * 8) * ld_b));
+    }
+  };
+
   while (true) {
     const int next_tile = tile + gridDim.x;
     const bool has_next = next_tile < nwg;
@@ -277,13 +313,25 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
       const int pf_rows_a = more_k ? rows_a : min(BM, a.M - nm0), pf_rows_b = more_k ? rows_b : min(BN, a.N - nn0);
       const char* pf_a = more_k ? Abase + koff : a.A + (int64_t)nm0 * lda_b;
       const char* pf_b = more_k ? Bbase + koff : a.B + (int64_t)nn0 * ldb_b;
+      constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;    // 1-KiB DMA pieces per wave and K-step
       const auto rsrc_a = slice_rsrc(pf_a, pf_rows_a, lda_b, kbytes - koff);
       const auto rsrc_b = slice_rsrc(pf_b, pf_rows_b, ldb_b, kbytes - koff);
-      constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;    // 1-KiB DMA pieces per wave and K-step
       auto piece = [&](int j) {
         if (!pf) return;
-        if (j < PA) stage_piece<NW>(An, rsrc_a, pf_rows_a, lda_b, kbytes - koff, wave, lane, j);
-        else if (j < PA + PB) stage_piece<NW>(An + A_BYTES, rsrc_b, pf_rows_b, ldb_b, kbytes - koff, wave, lane, j - PA);
+        if constexpr (SIDE) {
+          // one per-lane offset, a descriptor per piece (scalar arithmetic): the eight per-lane offsets the plain kernel keeps
+          // in registers across the K-loop do not fit beside the SIDE epilogue's state (spills inside the K-loop); the plain
+          // kernel keeps them — the scalar variant measured 2 % slower there (SGPR pressure spills into VGPR lanes)
+          const uint32_t vb_a = piece_base(lda_b, kbytes - koff, wave, lane), vb_b = piece_base(ldb_b, kbytes - koff, wave, lane);
+          if (j < PA)
+            stage_piece_at<NW>(An, slice_rsrc(pf_a + (int64_t)j * NW * 8 * lda_b, pf_rows_a - j * NW * 8, lda_b, kbytes - koff), vb_a, wave, j);
+          else if (j < PA + PB)
+            stage_piece_at<NW>(An + A_BYTES, slice_rsrc(pf_b + (int64_t)(j - PA) * NW * 8 * ldb_b, pf_rows_b - (j - PA) * NW * 8, ldb_b, kbytes - koff),
+                               vb_b, wave, j - PA);
+        } else {
+          if (j < PA) stage_piece<NW>(An, rsrc_a, pf_rows_a, lda_b, kbytes - koff, wave, lane, j);
+          else if (j < PA + PB) stage_piece<NW>(An + A_BYTES, rsrc_b, pf_rows_b, ldb_b, kbytes - koff, wave, lane, j - PA);
+        }
       };
       auto prefetch = [&]() {
 #pragma unroll
@@ -319,6 +367,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
             prefetch();
             __builtin_amdgcn_sched_barrier(0);
           }
+          if (SIDE && t == 0) {   // pass 0 of the side operand → the spare 32 KiB, behind this step's K-slice DMA
+            __builtin_amdgcn_sched_barrier(0);
+            side_issue(0, smem + 2 * BUF + wave * 4096, m0, n0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
           mma_rows(Q, MT);
         } else {
           // the wait for the next K-slice and the barrier sit Q rows of MFMAs before the end of the step: late enough
@@ -326,7 +379,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
           // enough that the barrier round trip is covered by MFMAs already queued
           mma_rows(0, MT - Q);
           __builtin_amdgcn_sched_barrier(0);
-          if (!(a.debug & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (SIDE && t == 0 && nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // the side pass may land during the next K-step
+          else if (!(a.debug & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __syncthreads();
           __builtin_amdgcn_sched_barrier(0);
           mma_rows(MT - Q, MT);
@@ -342,6 +396,98 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
   const bool relu = a.flags & LAKO_EPI_RELU, has_res = a.flags & LAKO_EPI_RESID,
              auxm = a.flags & LAKO_EPI_AUXMASK, atomic = a.flags & LAKO_EPI_ATOMIC;
   const bool drop = a.drop_thresh != 0;
+  if constexpr (SIDE) {
+    // SIDE epilogue (256² bf16 tile with a residual OR an aux-mask operand).  The generic epilogue fetches the operand in the
+    // accumulator layout (32 dependent 8-B loads per lane, 32-B granules) and stores the same way: ≈24 µs per tile next to a
+    // 20 µs main loop at K = 768.  Here the operand arrives by LDS-DMA in four 32-row passes, two passes ahead of its use
+    // (slot A = the spare 32 KiB, slot B and the transposition scratch = the K-slice buffer this tile no longer reads; all
+    // wave-private, no barriers; retired by counted waits — stores and DMA share one in-order counter, so every store below
+    // is an always-issued buffer store); the arithmetic is the generic epilogue's, in the accumulator layout (identical
+    // results); the finished 16 rows then go through 4 KiB of scratch and leave as row-major 16-B stores.
+    // every lane-derived address below is rebuilt from an opaque copy of the lane id: as loop invariants of the persistent tile
+    // loop they would be hoisted to the kernel prologue and stay live across the main loop (spills)
+    int le = lane;
+    asm volatile("" : "+v"(le));
+    const int r16e = le & 15, ge = le >> 4;
+    char* slot_a = smem + 2 * BUF + wave * 4096;
+    char* fr = smem + (cur ^ 1) * BUF + wave * 8192;
+    char* slot_b = fr + 4096;
+    const int rows_v = min(BM, a.M - m0), cols_v = min(BN, a.N - n0), ldc_b = (int)a.ldc * 2;
+    // rows past the edge fall out of the descriptor's range by themselves; columns past it start from an out-of-range base
+    const auto crs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(C + (int64_t)m0 * a.ldc + n0), 0,
+                                                        (rows_v - 1) * ldc_b + cols_v * 2, 0x00020000);
+    const uint32_t cvb = (wc * 64 + (le & 7) * 8 < cols_v && !(a.debug & 8))
+                             ? (uint32_t)((wr * 128 + (le >> 3)) * ldc_b + (wc * 64 + (le & 7) * 8) * 2) : 0x80000000u;
+    side_issue(1, slot_b, m0, n0);
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      char* slot = (pass & 1) ? slot_b : slot_a;
+      // in flight behind the pass needed now — pass 1: side 2 + stores of pass 0; pass 2: stores 0, side 3, stores 1; pass 3: stores 1, 2
+      if (pass == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (pass == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else if (pass == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      bf16x4 sv[2][4];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const int row_l = mi * 16 + r16e;
+          sv[mi][nt] = *reinterpret_cast<const bf16x4*>(slot + row_l * 128 + (((nt * 2 + (ge >> 1)) ^ (row_l & 7)) * 16) + (ge & 1) * 8);
+        }
+      if (pass < 2) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot has been read: it may be overwritten
+        side_issue(pass + 2, slot, m0, n0);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const int mt = 2 * pass + mi;
+        const int m = m0 + (wr * MT + mt) * 16 + r16e;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const int n = n0 + (wc * NT + nt) * 16 + 4 * ge;
+          const bf16x4 q = sv[mi][nt];
+          const f32x4 x = {(float)q[0], (float)q[1], (float)q[2], (float)q[3]};
+          f32x4 v = acc[nt][mt] * a.alpha;
+          if (relu) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+          }
+          if (auxm) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = x[r] > 0.f ? v[r] * a.aux_scale : 0.f;
+          }
+          if (drop) {
+            const uint64_t idx = (uint64_t)(a.row0 + m) * (uint64_t)a.N + (uint64_t)n;
+            bool kp[4];
+            lako_keep4(a.drop_key, idx >> 2, a.drop_thresh, kp);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = kp[r] ? v[r] * a.drop_scale : 0.f;
+          }
+          if (has_res) v += x;
+          *reinterpret_cast<f32x4*>(fr + r16e * 256 + (((nt * 4 + ge) ^ r16e) * 16)) = v;
+        }
+        const int cj = le & 7;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int row_l = it * 8 + (le >> 3);
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(fr + row_l * 256 + (((2 * cj) ^ row_l) * 16));
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(fr + row_l * 256 + (((2 * cj + 1) ^ row_l) * 16));
+          bf16x8 o;
+          o[0] = (bf16_t)lo[0]; o[1] = (bf16_t)lo[1]; o[2] = (bf16_t)lo[2]; o[3] = (bf16_t)lo[3];
+          o[4] = (bf16_t)hi[0]; o[5] = (bf16_t)hi[1]; o[6] = (bf16_t)hi[2]; o[7] = (bf16_t)hi[3];
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), crs, (int)(cvb + (uint32_t)((mt * 16 + it * 8) * ldc_b)), 0, 0);
+        }
+      }
+    }
+    if (!has_next) break;
+    __syncthreads();   // the next tile's first prefetch DMA-writes the buffer the waves just used as scratch / slot B
+    tile = next_tile;
+    m0 = nm0;
+    n0 = nn0;
+    rows_a = min(BM, a.M - m0);
+    rows_b = min(BN, a.N - n0);
+    continue;
+  }
   if constexpr (sizeof(T) == 2 && sizeof(TO) == 2 && MT == 8 && NT == 4) {
     if (a.wide_epi) {
       // WIDE epilogue (256² bf16 tile).  In the accumulator layout a lane owns 4 consecutive columns of 32
@@ -969,12 +1115,12 @@ int g_nt_dephase = 100, g_nt_dephase_n = 2;   // 10-ns ticks (s_memrealtime), ph
 int g_nt_persistent = 1;
 int g_nt_variant = -1;   // -1 auto; 0: 128x128/4 waves; 1: 256x128/8 waves; 2: 256x256/8 waves (lako_set_tuning)
 
-template <typename T, typename TO, int WM, int WN, int MT, int NT>
+template <typename T, typename TO, int WM, int WN, int MT, int NT, bool SIDE = false>
 void launch_nt_cfg(NtArgs a, hipStream_t s) {
-  constexpr int BM = WM * MT * 16, BN = WN * NT * 16, LDS = 2 * (BM + BN) * TKB;
+  constexpr int BM = WM * MT * 16, BN = WN * NT * 16, LDS = 2 * (BM + BN) * TKB + (SIDE ? 32 * 1024 : 0);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, TO, WM, WN, MT, NT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, TO, WM, WN, MT, NT, SIDE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_done = true;
   }
@@ -997,10 +1143,28 @@ void launch_nt_cfg(NtArgs a, hipStream_t s) {
   // --dephase 0,100,…): [64000,768]×[2304,768] 287 → 250 µs, o+res 140 → 134, wi 374 → 366, long launches unchanged; the size of
   // the delay (1…16 µs) and the number of phases (2, 4, 8) do not matter — the lockstep start is what costs.
   a.dephase = (g_nt_dephase > 0 && a.tiles_m * a.tiles_n > grid) ? ((g_nt_dephase_n << 16) | (g_nt_dephase & 0xffff)) : 0;
-  hipLaunchKernelGGL((gemm_nt_kernel<T, TO, WM, WN, MT, NT>), dim3(grid), dim3(WM * WN * 64), LDS, s, a);
+  hipLaunchKernelGGL((gemm_nt_kernel<T, TO, WM, WN, MT, NT, SIDE>), dim3(grid), dim3(WM * WN * 64), LDS, s, a);
 }
 
 int g_nt_tail_split = 1;
+int g_nt_side_lds = 1;   // 256² bf16 tiles with ONE side operand (residual or aux mask): LDS-DMA'd operand + row-major stores
+
+// the 256² kernel, with the LDS-staged side operand where the epilogue has exactly one (bf16 in and out, 16-B aligned rows)
+template <typename T, typename TO>
+void launch_nt_256(const NtArgs& a, hipStream_t s) {
+  if constexpr (sizeof(T) == 2 && sizeof(TO) == 2) {
+    const int side = a.flags & (LAKO_EPI_RESID | LAKO_EPI_AUXMASK);
+    const char* sp = side == LAKO_EPI_RESID ? a.resid : a.aux;
+    const int64_t ld = side == LAKO_EPI_RESID ? a.ldr : a.ldaux;
+    if (g_nt_side_lds && (side == LAKO_EPI_RESID || side == LAKO_EPI_AUXMASK) && !(a.flags & LAKO_EPI_ATOMIC) && a.N % 8 == 0 &&
+        a.ldc % 8 == 0 && ld % 8 == 0 && reinterpret_cast<uintptr_t>(a.C) % 16 == 0 && reinterpret_cast<uintptr_t>(sp) % 16 == 0 &&
+        (int64_t)256 * a.ldc * 2 < (1ll << 31) && (int64_t)256 * ld * 2 < (1ll << 31)) {
+      launch_nt_cfg<T, TO, 2, 4, 8, 4, true>(a, s);
+      return;
+    }
+  }
+  launch_nt_cfg<T, TO, 2, 4, 8, 4>(a, s);
+}
 
 template <typename T, typename TO>
 int launch_nt(const NtArgs& a_in, hipStream_t s) {
@@ -1021,7 +1185,7 @@ int launch_nt(const NtArgs& a_in, hipStream_t s) {
       if (rest > 0 && rest < 128 && full_rows > 0) {
         NtArgs head = a;
         head.M = (int)(full_rows * 256);
-        launch_nt_cfg<T, TO, 2, 4, 8, 4>(head, s);
+        launch_nt_256<T, TO>(head, s);
         const int64_t r0 = full_rows * 256;
         a.M -= (int)r0;
         a.row0 += r0;
@@ -1074,7 +1238,7 @@ int launch_nt(const NtArgs& a_in, hipStream_t s) {
     hipLaunchKernelGGL((gemm_nt_ring_kernel<T, TO>), dim3(tiles * b.split_k), dim3(256), RING_NST * RING_STAGE, s, b);
     return 0;
   }
-  if (v == 2) launch_nt_cfg<T, TO, 2, 4, 8, 4>(a, s);
+  if (v == 2) launch_nt_256<T, TO>(a, s);
   else if (v == 1) launch_nt_cfg<T, TO, 4, 2, 4, 4>(a, s);
   else launch_nt_cfg<T, TO, 2, 2, 4, 4>(a, s);
   return 0;
@@ -1306,6 +1470,10 @@ extern "C" int lako_set_tuning(const char* key, int value) {
   }
   if (key && !strcmp(key, "gemm_nt_wide_epi")) {
     g_nt_wide_epi = value;
+    return LAKO_OK;
+  }
+  if (key && !strcmp(key, "gemm_nt_side_lds")) {
+    g_nt_side_lds = value;
     return LAKO_OK;
   }
   if (key && !strcmp(key, "gemm_nt_dephase_n")) {

@@ -91,6 +91,38 @@ def test_gemm_nt_tile_variants(ops, ref, variant, M, N, K):
         ops.set_tuning("gemm_nt_group_m", 8)
 
 
+@pytest.mark.parametrize("M,N,K", [(2048, 768, 768), (700, 520, 200), (515, 264, 72), (256, 524, 64)])
+def test_gemm_nt_side_operand_in_lds(ops, ref, M, N, K):
+    """256² bf16 tiles with a residual or an aux-mask operand: the LDS-staged operand + row-major stores epilogue must give
+    the generic epilogue's result BIT FOR BIT (same arithmetic, in the accumulator layout), on ragged edges, with row strides
+    wider than the row, and fall back when a row is not 16-byte granular (N = 524)."""
+    T = torch.bfloat16
+    A, B = rnd(M, K, dtype=T, seed=51), rnd(N, K, dtype=T, seed=52)
+    Rw, Xw = rnd(M, N + 24, dtype=T, seed=53), rnd(M, N + 8, dtype=T, seed=54)
+    R, X = Rw[:, :N], Xw[:, 8:]
+    Cw = torch.zeros(M, N + 16, dtype=T, device=dev())
+    cases = (dict(resid=R), dict(resid=R, drop=(0.1, 7, 8), alpha=0.5), dict(resid=R, relu=True), dict(aux=X, aux_scale=1.1),
+             dict(aux=X, aux_scale=1.0 / 0.9, drop=(0.1, 3, 4)))
+    try:
+        ops.set_tuning("gemm_nt_variant", 2)
+        for kw in cases:
+            got = {}
+            for side in (1, 0):
+                ops.set_tuning("gemm_nt_side_lds", side)
+                Cw.fill_(7.0)
+                C = Cw[:, 8:8 + N]
+                ops.gemm_nt(A, B, C, **kw)
+                assert torch.all(Cw[:, :8] == 7.0) and torch.all(Cw[:, 8 + N:] == 7.0), "stores outside the output columns"
+                got[side] = C.clone()
+            assert torch.equal(got[0], got[1]), f"side-in-LDS epilogue differs from the generic one {list(kw)} {M}x{N}x{K}"
+            Cr = torch.zeros(M, N, device=dev())
+            ref.gemm_nt(A, B, Cr, **kw)
+            close(got[1], Cr, T, f"gemm_nt side operand {list(kw)} {M}x{N}x{K}")
+    finally:
+        ops.set_tuning("gemm_nt_variant", -1)
+        ops.set_tuning("gemm_nt_side_lds", 1)
+
+
 def test_gemm_nt_tail_split(ops, ref):
     """270 tiles of 256² = one full round of the persistent grid + 15 tiles: the rows of the full round go to the 256²
     kernel, the rest to a second launch with small tiles; dropout draws must use the rows' GLOBAL index."""
