@@ -233,7 +233,8 @@ int lako_kldiv_fwd(const float* score, const float* gold, float* loss, int B, in
 
 /* Development knob for A/B measurements (tools/bench_ops.py); training never calls it.
  * "gemm_nt_variant": -1 auto (default), 0 = 128x128 tile / 4 waves, 1 = 256x128 / 8 waves, 2 = 256x256 / 8 waves,
- *                    3 = 256x256 4-slot ring;  "gemm_nt_persistent" 0/1;  "gemm_nt_stagger" 0/1;
+ *                    3 = 256x256 4-slot ring, 4 = 128x128 4-slot ring, 5 = 64x64 with K split over the four waves (M <= 256);
+ *                    "gemm_nt_skinny" 0/1, "gemm_nt_side_lds" 0/1 (LDS-staged residual / aux operand);  "gemm_nt_persistent" 0/1;  "gemm_nt_stagger" 0/1;
  * "gemm_nt_wide_epi" 0/1 (LDS-transposed epilogue for plain bf16 stores);  "gemm_nt_group_m": tile-rows per band of
  * the banded tile order (0 = row-major, >0 applied when the output is >= 16 tiles wide, <0 forces |value|);
  * "gemm_tn_big" 0/1 (256x256 weight-gradient kernel);  "gemm_nt_dephase": start offset between neighbouring workgroups of a

@@ -20,6 +20,7 @@
 // INIT, the causal mask is one select, and dropout draws two 16-bit keep decisions from one 32-bit hash.
 // bf16: v_mfma_f32_16x16x32_bf16; fp32 (parity mode): v_mfma_f32_16x16x4_f32.
 #include <float.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -55,6 +56,7 @@ struct AttnArgs {
   int chunk_rows;     // LDS-side rows per chunk (multiple of 32, <= CH_MAX)
   int blocks_per_wg;  // register-side 16-row blocks per workgroup
   int bn_per_wg;      // dQ pass: batch rows walked by one workgroup (bias-gradient register accumulation)
+  int grid_x, grid_z; // dQ pass, grid_x > 0: 1-D XCD-grouped grid standing for (grid_x, H, grid_z) — see attn_bwd_kernel
   uint32_t drop_t16, drop_key;   // attention dropout: keep iff 16-bit half >= drop_t16 (0 = off)
   float drop_scale;
 };
@@ -504,13 +506,25 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, l15 = lane & 15;
-  const int h = blockIdx.y;
+  // grid (register-side block groups, heads, batch-row groups) — or, dQ pass with several block groups per sequence
+  // (bias gradient), a 1-D grid dealt out so that the groups sharing the staged K / V of the same (head, batch rows) run on
+  // ONE XCD (workgroup id mod 8), i.e. behind one L2: id → (xcd, slot), slot → (block group, j), (j, xcd) → (head, rows)
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (MODE == 0 && a.grid_x > 0) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    bx = slot % a.grid_x;
+    const int grp = (slot / a.grid_x) * 8 + xcd;
+    if (grp >= a.H * a.grid_z) return;
+    by = grp % a.H;
+    bz = grp / a.H;
+  }
+  const int h = by;
   const int bn_per = MODE == 0 ? a.bn_per_wg : 1;
-  const int b_begin = blockIdx.z * bn_per, b_end = min(a.Bn, b_begin + bn_per);
+  const int b_begin = bz * bn_per, b_end = min(a.Bn, b_begin + bn_per);
   const int LXm = MODE == 0 ? a.Lk : a.Lq;  // LDS side length      } padded maxima: grid-uniform decisions
   const int LYm = MODE == 0 ? a.Lq : a.Lk;  // register side length }
   const int nyb = (LYm + 15) >> 4;
-  const int yb_begin = blockIdx.x * a.blocks_per_wg;
+  const int yb_begin = bx * a.blocks_per_wg;
   const int yb_end = min(nyb, yb_begin + a.blocks_per_wg);
   const int nchunks_m = (LXm + CH - 1) / CH;
   // ragged mode: row offset and length of sequence bb on the query / key side.  The offsets of the workgroup's batch rows
@@ -905,7 +919,8 @@ int run_bwd(AttnArgs& a, hipStream_t s) {
     const int nqb = (a.Lq + 15) / 16;
     q.blocks_per_wg = pick_blocks_per_wg(nqb, (int64_t)a.Bn * a.H);
     q.bn_per_wg = 1;
-    if (a.drel && a.Lk <= CH_MAX) {
+    static const int dbg = getenv("LAKO_ATTN_DEBUG") ? atoi(getenv("LAKO_ATTN_DEBUG")) : 0;
+    if ((a.drel || (dbg & 1)) && a.Lk <= CH_MAX) {
       // bias gradient: one query block per wave, several batch rows per workgroup (register accumulation of dS)
       q.blocks_per_wg = 4;
       const int64_t wgs = (int64_t)a.Bn * a.H * ((nqb + 3) / 4);
@@ -916,11 +931,19 @@ int run_bwd(AttnArgs& a, hipStream_t s) {
     static int cur0 = 0;
     set_lds_attr(&attn_bwd_kernel<T, DK, 0>, lds, cur0);
     dim3 grid((nqb + q.blocks_per_wg - 1) / q.blocks_per_wg, a.H, (a.Bn + q.bn_per_wg - 1) / q.bn_per_wg);
+    q.grid_x = 0;
+    if (grid.x > 1 && !(dbg & 2)) {
+      q.grid_x = (int)grid.x;
+      q.grid_z = (int)grid.z;
+      const int groups = (int)(grid.y * grid.z);
+      grid = dim3((unsigned)(((groups + 7) / 8) * 8 * q.grid_x), 1, 1);
+    }
     hipLaunchKernelGGL((attn_bwd_kernel<T, DK, 0>), grid, dim3(256), lds, s, q);
   }
   {  // dK/dV pass
     AttnArgs k = a;
     k.bn_per_wg = 1;
+    k.grid_x = 0;
     k.chunk_rows = pick_chunk(a.Lq);
     const int nkb = (a.Lk + 15) / 16;
     k.blocks_per_wg = pick_blocks_per_wg(nkb, (int64_t)a.Bn * a.H);

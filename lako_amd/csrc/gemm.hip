@@ -557,6 +557,129 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// NT, VERY SKINNY problems (M <= 256 rows: every GEMM of the decoder at the reader's batch sizes) — bf16.  One K-step of the
+// ring kernel below costs a global→LDS round trip however small the tile, and K is walked sequentially: 15 µs for
+// [128,768]×[2304,768], 36 µs at K = 3072, ≈150 such launches per training step.  Here a workgroup owns a 64×64 tile and its
+// WAVES SPLIT K (four, eight when K >= 2048): each wave streams its quarter of K straight from global memory into MFMA fragments (a lane's 16 bytes
+// are 8 consecutive k of one row — exactly the fragment layout; no LDS, no barriers, four K-steps in flight), accumulates
+// a full 64×64 partial tile, and the partials meet in LDS (swizzled 16-B chunks); each wave then finishes 16 rows in
+// row-major order: alpha, ReLU, aux mask, dropout, residual, 16-byte stores.  Needs K % 32 == 0 and 16-byte rows (host).
+// ---------------------------------------------------------------------------------------------
+template <typename TO, int NW>   // NW waves split K (4, or 8 for long K)
+__global__ __launch_bounds__(NW * 64) void gemm_nt_skinny_kernel(NtArgs a) {
+  constexpr int NS = 4;   // K-steps in flight per wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [NW waves][64 rows][256 B]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r16 = lane & 15, g = lane >> 4;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int nks = a.K / 32, per = (nks + NW - 1) / NW;
+  const int ks0 = wave * per, ks1 = min(nks, ks0 + per);
+  const char* ap[4];
+  const char* bp[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {   // rows past the edge are clamped: their products are never stored
+    ap[i] = a.A + ((int64_t)min(m0 + i * 16 + r16, a.M - 1) * a.lda + g * 8) * 2;
+    bp[i] = a.B + ((int64_t)min(n0 + i * 16 + r16, a.N - 1) * a.ldb + g * 8) * 2;
+  }
+  f32x4 acc[4][4];   // [nt][mt], element r of lane (r16, g): C[mt*16 + r16][nt*16 + 4g + r]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  u32x4 fa[NS][4], fb[NS][4];
+  auto load = [&](int st, int ks) {
+    if (ks < ks1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa[st][i] = *reinterpret_cast<const u32x4*>(ap[i] + (int64_t)ks * 64);
+        fb[st][i] = *reinterpret_cast<const u32x4*>(bp[i] + (int64_t)ks * 64);
+      }
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < NS - 1; ++u) load(u, ks0 + u);
+  for (int ks = ks0; ks < ks1; ks += NS) {
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      if (ks + u < ks1) {
+        load((u + NS - 1) % NS, ks + u + NS - 1);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) acc[nt][mt] = Mma<bf16_t>::run(fb[u][nt], fa[u][mt], acc[nt][mt]);
+      }
+    }
+  }
+  char* mine = smem + wave * 16384;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+      *reinterpret_cast<f32x4*>(mine + (mt * 16 + r16) * 256 + (((nt * 4 + g) ^ r16) * 16)) = acc[nt][mt];
+  __syncthreads();
+
+  TO* C = reinterpret_cast<TO*>(a.C);
+  const bf16_t* X = reinterpret_cast<const bf16_t*>(a.aux);
+  const TO* R = reinterpret_cast<const TO*>(a.resid);
+  const bool relu = a.flags & LAKO_EPI_RELU, has_res = a.flags & LAKO_EPI_RESID, auxm = a.flags & LAKO_EPI_AUXMASK;
+  const int cj = lane & 7, n = n0 + cj * 8;
+#pragma unroll
+  for (int it = 0; it < 8 / NW; ++it) {
+    const int row = wave * (64 / NW) + it * 8 + (lane >> 3), m = m0 + row;
+    f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {   // fixed summation order: deterministic
+      lo += *reinterpret_cast<const f32x4*>(smem + w * 16384 + row * 256 + (((2 * cj) ^ (row & 15)) * 16));
+      hi += *reinterpret_cast<const f32x4*>(smem + w * 16384 + row * 256 + (((2 * cj + 1) ^ (row & 15)) * 16));
+    }
+    if (m >= a.M || n >= a.N) continue;   // N % 8 == 0: a group of 8 columns is all in or all out
+    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      v[e] *= a.alpha;
+      if (relu) v[e] = fmaxf(v[e], 0.f);
+    }
+    if (auxm) {
+      const bf16x8 x = *reinterpret_cast<const bf16x8*>(X + (int64_t)m * a.ldaux + n);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (float)x[e] > 0.f ? v[e] * a.aux_scale : 0.f;
+    }
+    if (a.drop_thresh != 0) {
+      const uint64_t idx = (uint64_t)(a.row0 + m) * (uint64_t)a.N + (uint64_t)n;
+      bool kp[2][4];
+      lako_keep4(a.drop_key, idx >> 2, a.drop_thresh, kp[0]);
+      lako_keep4(a.drop_key, (idx >> 2) + 1, a.drop_thresh, kp[1]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = kp[e >> 2][e & 3] ? v[e] * a.drop_scale : 0.f;
+    }
+    if constexpr (sizeof(TO) == 2) {
+      if (has_res) {
+        const bf16x8 r = *reinterpret_cast<const bf16x8*>(R + (int64_t)m * a.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
+      }
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+      *reinterpret_cast<bf16x8*>(C + (int64_t)m * a.ldc + n) = o;
+    } else {
+      if (has_res) {
+        const f32x4 r0 = *reinterpret_cast<const f32x4*>(R + (int64_t)m * a.ldr + n);
+        const f32x4 r1 = *reinterpret_cast<const f32x4*>(R + (int64_t)m * a.ldr + n + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] += r0[e];
+          v[4 + e] += r1[e];
+        }
+      }
+      *reinterpret_cast<f32x4*>(C + (int64_t)m * a.ldc + n) = f32x4{v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4*>(C + (int64_t)m * a.ldc + n + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // NT, SKINNY problems (the decoder's 128-row GEMMs, the LM head): a handful of 128×128 tiles, so every workgroup
 // is alone on its CU and nothing hides the global→LDS latency of the 2-buffer kernel above — ≈2 µs per K-step,
 // 16–30 µs per GEMM of ≈0.5 GFLOP, 145 of them per training step.  Here the K-slices run through a 4-slot ring
@@ -1109,6 +1232,7 @@ int g_tn_split = 0;   // > 0: force the number of K-splits of the 256x256 TN ker
 int g_nt_wide_epi = 1;
 int g_nt_group_m = 8;
 int g_nt_debug = 0;
+int g_nt_skinny = 1;    // M <= 256 rows: gemm_nt_skinny_kernel ("gemm_nt_skinny" 0 disables; variant 5 forces it)
 int g_nt_ring = 1;      // skinny problems go to gemm_nt_ring_kernel ("gemm_nt_ring" 0 disables; variant 4 forces it)
 int g_nt_stagger = 1;
 int g_nt_dephase = 100, g_nt_dephase_n = 2;   // 10-ns ticks (s_memrealtime), phases
@@ -1214,6 +1338,28 @@ int launch_nt(const NtArgs& a_in, hipStream_t s) {
       return 0;
     }
     v = 2;
+  }
+  if (v == 5 && sizeof(T) != 2) v = 4;
+  if constexpr (sizeof(T) == 2) {
+    // very skinny (the decoder): 64×64 tiles, K split over the workgroup's four waves — see gemm_nt_skinny_kernel
+    const bool fits = a.K % 32 == 0 && a.K >= 128 && a.N % 8 == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0 && a.ldc % 8 == 0 &&
+                      !(a.flags & LAKO_EPI_ATOMIC) && (!(a.flags & LAKO_EPI_RESID) || (a.ldr % 8 == 0 && reinterpret_cast<uintptr_t>(a.resid) % 16 == 0)) &&
+                      (!(a.flags & LAKO_EPI_AUXMASK) || (a.ldaux % 8 == 0 && reinterpret_cast<uintptr_t>(a.aux) % 16 == 0)) &&
+                      reinterpret_cast<uintptr_t>(a.A) % 16 == 0 && reinterpret_cast<uintptr_t>(a.B) % 16 == 0 &&
+                      reinterpret_cast<uintptr_t>(a.C) % 16 == 0;
+    if (fits && (v == 5 || (g_nt_variant < 0 && g_nt_skinny && a.M <= 256 && a.N <= 4096))) {
+      static bool attr_done = false;
+      if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_skinny_kernel<TO, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16384);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_skinny_kernel<TO, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384);
+        attr_done = true;
+      }
+      const dim3 grid(cdiv(a.N, 64), cdiv(a.M, 64));
+      if (a.K >= 2048) hipLaunchKernelGGL((gemm_nt_skinny_kernel<TO, 8>), grid, dim3(512), 8 * 16384, s, a);
+      else hipLaunchKernelGGL((gemm_nt_skinny_kernel<TO, 4>), grid, dim3(256), 4 * 16384, s, a);
+      return 0;
+    }
+    if (v == 5) v = 4;
   }
   if (v == 4 || (g_nt_variant < 0 && g_nt_ring && (int64_t)cdiv(a.M, RING_BM) * cdiv(a.N, RING_BM) <= 256)) {
     // skinny: at most one 128² tile per CU → the 4-slot ring hides the global→LDS latency inside the workgroup
@@ -1470,6 +1616,10 @@ extern "C" int lako_set_tuning(const char* key, int value) {
   }
   if (key && !strcmp(key, "gemm_nt_wide_epi")) {
     g_nt_wide_epi = value;
+    return LAKO_OK;
+  }
+  if (key && !strcmp(key, "gemm_nt_skinny")) {
+    g_nt_skinny = value;
     return LAKO_OK;
   }
   if (key && !strcmp(key, "gemm_nt_side_lds")) {

@@ -62,11 +62,13 @@ def test_gemm_nt_plain(ops, ref, dt, M, N, K):
         close(C, Cr, T, f"gemm_nt {dt}->{out_t} {M}x{N}x{K}")
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
-@pytest.mark.parametrize("M,N,K", [(1024, 768, 768), (700, 520, 200), (256, 256, 32), (2048, 2304, 768), (300, 264, 3072), (128, 768, 72)])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("M,N,K", [(1024, 768, 768), (700, 520, 200), (256, 256, 32), (2048, 2304, 768), (300, 264, 3072), (128, 768, 72),
+                                   (128, 768, 768), (100, 200, 160), (16, 3072, 768), (130, 776, 3072)])
 def test_gemm_nt_tile_variants(ops, ref, variant, M, N, K):
     """every tile variant of the bf16 NT kernel (0: 128², 1: 256×128, 2: 256² 2-buffer, 3: 256² 4-slot ring, 4: the 128²
-    4-slot ring that skinny problems are dispatched to),
+    4-slot ring that skinny problems are dispatched to, 5: the 64² kernel whose four waves split K, for M <= 256 rows — it
+    falls back to the ring when K is not a multiple of 32),
     persistent and one-tile-per-workgroup grids, ragged edges, fused epilogues."""
     T = torch.bfloat16
     A, B = rnd(M, K, dtype=T, seed=41), rnd(N, K, dtype=T, seed=42)
@@ -78,7 +80,7 @@ def test_gemm_nt_tile_variants(ops, ref, variant, M, N, K):
             ops.set_tuning("gemm_nt_persistent", persistent)
             ops.set_tuning("gemm_nt_wide_epi", wide)
             ops.set_tuning("gemm_nt_group_m", group_m)
-            for kw in (dict(), dict(relu=True, drop=(0.1, 5, 6)), dict(resid=R, drop=(0.1, 7, 8), alpha=0.5)):
+            for kw in (dict(), dict(relu=True, drop=(0.1, 5, 6)), dict(resid=R, drop=(0.1, 7, 8), alpha=0.5), dict(aux=R, aux_scale=1.1)):
                 C = torch.empty(M, N, dtype=T, device=dev())
                 Cr = torch.zeros(M, N, device=dev())
                 ops.gemm_nt(A, B, C, **kw)
