@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblako_hip.so")
+LIB_PATH = os.environ.get("LAKO_LIB") or os.path.join(_HERE, "liblako_hip.so")   # LAKO_LIB: A/B measurements of two builds
 
 LAKO_F32, LAKO_BF16 = 0, 1
 EPI_RELU, EPI_RESID, EPI_AUXMASK, EPI_ATOMIC = 1, 2, 4, 8

@@ -560,78 +560,80 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
 // NT, VERY SKINNY problems (M <= 256 rows: every GEMM of the decoder at the reader's batch sizes) — bf16.  One K-step of the
 // ring kernel below costs a global→LDS round trip however small the tile, and K is walked sequentially: 15 µs for
 // [128,768]×[2304,768], 36 µs at K = 3072, ≈150 such launches per training step.  Here a workgroup owns a 64×64 tile and its
-// WAVES SPLIT K (four, eight when K >= 2048): each wave streams its quarter of K straight from global memory into MFMA fragments (a lane's 16 bytes
-// are 8 consecutive k of one row — exactly the fragment layout; no LDS, no barriers, four K-steps in flight), accumulates
+// EIGHT WAVES SPLIT K: each wave streams its quarter of K straight from global memory into MFMA fragments (a lane's 16 bytes
+// are 8 consecutive k of one row — exactly the fragment layout; no LDS, no barriers, three K-steps in flight), accumulates
 // a full 64×64 partial tile, and the partials meet in LDS (swizzled 16-B chunks); each wave then finishes 16 rows in
-// row-major order: alpha, ReLU, aux mask, dropout, residual, 16-byte stores.  Needs K % 32 == 0 and 16-byte rows (host).
+// row-major order: alpha, ReLU, aux mask, dropout, residual, 16-byte stores.  Needs K % 32 == 0, K <= 4096 and 16-byte rows (host).
 // ---------------------------------------------------------------------------------------------
-template <typename TO, int NW>   // NW waves split K (4, or 8 for long K)
+template <typename TO, int NW, int MAXS, int TB>   // NW waves split K; at most MAXS K-steps of 32 per wave (fully unrolled); tile = (16·TB)²
 __global__ __launch_bounds__(NW * 64) void gemm_nt_skinny_kernel(NtArgs a) {
-  constexpr int NS = 4;   // K-steps in flight per wave
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [NW waves][64 rows][256 B]
+  constexpr int NS = 4;   // register stages: NS - 1 K-steps in flight per wave
+  constexpr int TS = TB * 16, CPR = TS / 4, PART = TS * TS * 4;   // tile side, 16-B chunks per fp32 row, bytes of a partial tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [NW waves][TS rows][TS fp32]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r16 = lane & 15, g = lane >> 4;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int m0 = blockIdx.y * TS, n0 = blockIdx.x * TS;
   const int nks = a.K / 32, per = (nks + NW - 1) / NW;
   const int ks0 = wave * per, ks1 = min(nks, ks0 + per);
-  const char* ap[4];
-  const char* bp[4];
+  // Branch-free K loop: every load is a bounds-checked buffer load whose offset is pushed out of range once the wave's K
+  // range is exhausted (zeros: the MFMAs of a padding step add nothing), so the trip count is uniform, the loop body is
+  // straight-line code and the compiler's load counter stays exact (conditional loads made it wait for the newest request).
+  const auto ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.A), 0, (int)((int64_t)(a.M - 1) * a.lda * 2 + a.K * 2), 0x00020000);
+  const auto rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.B), 0, (int)((int64_t)(a.N - 1) * a.ldb * 2 + a.K * 2), 0x00020000);
+  uint32_t ao[TB], bo[TB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {   // rows past the edge are clamped: their products are never stored
-    ap[i] = a.A + ((int64_t)min(m0 + i * 16 + r16, a.M - 1) * a.lda + g * 8) * 2;
-    bp[i] = a.B + ((int64_t)min(n0 + i * 16 + r16, a.N - 1) * a.ldb + g * 8) * 2;
+  for (int i = 0; i < TB; ++i) {   // rows past the edge are clamped: their products are never stored
+    ao[i] = (uint32_t)((min(m0 + i * 16 + r16, a.M - 1) * a.lda + g * 8) * 2);
+    bo[i] = (uint32_t)((min(n0 + i * 16 + r16, a.N - 1) * a.ldb + g * 8) * 2);
   }
-  f32x4 acc[4][4];   // [nt][mt], element r of lane (r16, g): C[mt*16 + r16][nt*16 + 4g + r]
+  f32x4 acc[TB][TB];   // [nt][mt], element r of lane (r16, g): C[mt*16 + r16][nt*16 + 4g + r]
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TB; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  u32x4 fa[NS][4], fb[NS][4];
+    for (int j = 0; j < TB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  u32x4 fa[NS][TB], fb[NS][TB];
   auto load = [&](int st, int ks) {
-    if (ks < ks1) {
+    const uint32_t ko = ks < ks1 ? (uint32_t)ks * 64u : 0x80000000u;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        fa[st][i] = *reinterpret_cast<const u32x4*>(ap[i] + (int64_t)ks * 64);
-        fb[st][i] = *reinterpret_cast<const u32x4*>(bp[i] + (int64_t)ks * 64);
-      }
+    for (int i = 0; i < TB; ++i) {
+      fa[st][i] = __builtin_amdgcn_raw_buffer_load_b128(ra, (int)(ao[i] + ko), 0, 0);
+      fb[st][i] = __builtin_amdgcn_raw_buffer_load_b128(rb, (int)(bo[i] + ko), 0, 0);
     }
   };
+  // fully unrolled over the MAXS K-steps a wave can have (steps past its range load zeros): straight-line code, so the
+  // compiler's load counter is exact — as a rolled loop with requests in flight across the back edge it drained the queue
+  // (s_waitcnt vmcnt(0)) at every loop header
 #pragma unroll
   for (int u = 0; u < NS - 1; ++u) load(u, ks0 + u);
-  for (int ks = ks0; ks < ks1; ks += NS) {
 #pragma unroll
-    for (int u = 0; u < NS; ++u) {
-      if (ks + u < ks1) {
-        load((u + NS - 1) % NS, ks + u + NS - 1);
+  for (int st = 0; st < MAXS; ++st) {
+    if (st + NS - 1 < MAXS) load((st + NS - 1) % NS, ks0 + st + NS - 1);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < TB; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < 4; ++nt) acc[nt][mt] = Mma<bf16_t>::run(fb[u][nt], fa[u][mt], acc[nt][mt]);
-      }
-    }
+      for (int nt = 0; nt < TB; ++nt) acc[nt][mt] = Mma<bf16_t>::run(fb[st % NS][nt], fa[st % NS][mt], acc[nt][mt]);
+    __builtin_amdgcn_sched_barrier(0);
   }
-  char* mine = smem + wave * 16384;
+  char* mine = smem + wave * PART;
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
+  for (int mt = 0; mt < TB; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-      *reinterpret_cast<f32x4*>(mine + (mt * 16 + r16) * 256 + (((nt * 4 + g) ^ r16) * 16)) = acc[nt][mt];
+    for (int nt = 0; nt < TB; ++nt)
+      *reinterpret_cast<f32x4*>(mine + (mt * 16 + r16) * (TS * 4) + (((nt * 4 + g) ^ (r16 & (CPR - 1))) * 16)) = acc[nt][mt];
   __syncthreads();
 
   TO* C = reinterpret_cast<TO*>(a.C);
   const bf16_t* X = reinterpret_cast<const bf16_t*>(a.aux);
   const TO* R = reinterpret_cast<const TO*>(a.resid);
   const bool relu = a.flags & LAKO_EPI_RELU, has_res = a.flags & LAKO_EPI_RESID, auxm = a.flags & LAKO_EPI_AUXMASK;
-  const int cj = lane & 7, n = n0 + cj * 8;
-#pragma unroll
-  for (int it = 0; it < 8 / NW; ++it) {
-    const int row = wave * (64 / NW) + it * 8 + (lane >> 3), m = m0 + row;
+  for (int idx = threadIdx.x; idx < TS * TS / 8; idx += NW * 64) {   // 8 consecutive columns of one row per thread
+    const int row = idx / (TS / 8), cj = idx % (TS / 8), m = m0 + row, n = n0 + cj * 8;
     f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int w = 0; w < NW; ++w) {   // fixed summation order: deterministic
-      lo += *reinterpret_cast<const f32x4*>(smem + w * 16384 + row * 256 + (((2 * cj) ^ (row & 15)) * 16));
-      hi += *reinterpret_cast<const f32x4*>(smem + w * 16384 + row * 256 + (((2 * cj + 1) ^ (row & 15)) * 16));
+      lo += *reinterpret_cast<const f32x4*>(smem + w * PART + row * (TS * 4) + (((2 * cj) ^ (row & (CPR - 1))) * 16));
+      hi += *reinterpret_cast<const f32x4*>(smem + w * PART + row * (TS * 4) + (((2 * cj + 1) ^ (row & (CPR - 1))) * 16));
     }
     if (m >= a.M || n >= a.N) continue;   // N % 8 == 0: a group of 8 columns is all in or all out
     float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -1232,7 +1234,7 @@ int g_tn_split = 0;   // > 0: force the number of K-splits of the 256x256 TN ker
 int g_nt_wide_epi = 1;
 int g_nt_group_m = 8;
 int g_nt_debug = 0;
-int g_nt_skinny = 1;    // M <= 256 rows: gemm_nt_skinny_kernel ("gemm_nt_skinny" 0 disables; variant 5 forces it)
+int g_nt_skinny = 1;    // M <= 256 rows: gemm_nt_skinny_kernel ("gemm_nt_skinny" 0 disables, 2 / 3 force 64² / 32² tiles; variant 5 forces the kernel)
 int g_nt_ring = 1;      // skinny problems go to gemm_nt_ring_kernel ("gemm_nt_ring" 0 disables; variant 4 forces it)
 int g_nt_stagger = 1;
 int g_nt_dephase = 100, g_nt_dephase_n = 2;   // 10-ns ticks (s_memrealtime), phases
@@ -1342,7 +1344,7 @@ int launch_nt(const NtArgs& a_in, hipStream_t s) {
   if (v == 5 && sizeof(T) != 2) v = 4;
   if constexpr (sizeof(T) == 2) {
     // very skinny (the decoder): 64×64 tiles, K split over the workgroup's four waves — see gemm_nt_skinny_kernel
-    const bool fits = a.K % 32 == 0 && a.K >= 128 && a.N % 8 == 0 && a.lda % 8 == 0 && a.ldb % 8 == 0 && a.ldc % 8 == 0 &&
+    const bool fits = a.K % 32 == 0 && a.K >= 128 && a.K <= 4096 && a.N % 8 == 0 && (int64_t)a.M * a.lda * 2 < (1ll << 31) && (int64_t)a.N * a.ldb * 2 < (1ll << 31) && a.lda % 8 == 0 && a.ldb % 8 == 0 && a.ldc % 8 == 0 &&
                       !(a.flags & LAKO_EPI_ATOMIC) && (!(a.flags & LAKO_EPI_RESID) || (a.ldr % 8 == 0 && reinterpret_cast<uintptr_t>(a.resid) % 16 == 0)) &&
                       (!(a.flags & LAKO_EPI_AUXMASK) || (a.ldaux % 8 == 0 && reinterpret_cast<uintptr_t>(a.aux) % 16 == 0)) &&
                       reinterpret_cast<uintptr_t>(a.A) % 16 == 0 && reinterpret_cast<uintptr_t>(a.B) % 16 == 0 &&
@@ -1350,13 +1352,32 @@ int launch_nt(const NtArgs& a_in, hipStream_t s) {
     if (fits && (v == 5 || (g_nt_variant < 0 && g_nt_skinny && a.M <= 256 && a.N <= 4096))) {
       static bool attr_done = false;
       if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_skinny_kernel<TO, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16384);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_skinny_kernel<TO, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_skinny_kernel<TO, 8, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_skinny_kernel<TO, 8, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_skinny_kernel<TO, 8, 16, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384);
         attr_done = true;
       }
-      const dim3 grid(cdiv(a.N, 64), cdiv(a.M, 64));
-      if (a.K >= 2048) hipLaunchKernelGGL((gemm_nt_skinny_kernel<TO, 8>), grid, dim3(512), 8 * 16384, s, a);
-      else hipLaunchKernelGGL((gemm_nt_skinny_kernel<TO, 4>), grid, dim3(256), 4 * 16384, s, a);
+      // a CU pulls ≈45 GB/s through its L1 whatever the other CUs do, so the bytes have to be spread over many CUs: 32² tiles
+      // (4 × the workgroups of 64² tiles, half the operand bytes each) — measured on the whole training step: 64² 50.4 ms,
+      // 32² 49.4 ms, 16² 49.3 ms ("gemm_nt_skinny" 2 / 3 / 4 force them)
+      const bool small = g_nt_skinny != 2;
+      const int ts = small ? 32 : 64;
+      const dim3 grid(cdiv(a.N, ts), cdiv(a.M, ts));
+      const int per = cdiv(a.K / 32, 8);
+      if (g_nt_skinny == 4) {
+        const dim3 g16(cdiv(a.N, 16), cdiv(a.M, 16));
+        if (per <= 4) hipLaunchKernelGGL((gemm_nt_skinny_kernel<TO, 8, 4, 1>), g16, dim3(512), 8 * 1024, s, a);
+        else if (per <= 8) hipLaunchKernelGGL((gemm_nt_skinny_kernel<TO, 8, 8, 1>), g16, dim3(512), 8 * 1024, s, a);
+        else hipLaunchKernelGGL((gemm_nt_skinny_kernel<TO, 8, 16, 1>), g16, dim3(512), 8 * 1024, s, a);
+      } else if (small) {
+        if (per <= 4) hipLaunchKernelGGL((gemm_nt_skinny_kernel<TO, 8, 4, 2>), grid, dim3(512), 8 * 4096, s, a);
+        else if (per <= 8) hipLaunchKernelGGL((gemm_nt_skinny_kernel<TO, 8, 8, 2>), grid, dim3(512), 8 * 4096, s, a);
+        else hipLaunchKernelGGL((gemm_nt_skinny_kernel<TO, 8, 16, 2>), grid, dim3(512), 8 * 4096, s, a);
+      } else {
+        if (per <= 4) hipLaunchKernelGGL((gemm_nt_skinny_kernel<TO, 8, 4, 4>), grid, dim3(512), 8 * 16384, s, a);
+        else if (per <= 8) hipLaunchKernelGGL((gemm_nt_skinny_kernel<TO, 8, 8, 4>), grid, dim3(512), 8 * 16384, s, a);
+        else hipLaunchKernelGGL((gemm_nt_skinny_kernel<TO, 8, 16, 4>), grid, dim3(512), 8 * 16384, s, a);
+      }
       return 0;
     }
     if (v == 5) v = 4;

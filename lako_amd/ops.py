@@ -62,6 +62,10 @@ class HipOps:
         self.lib = _lib.load()
         assert self.lib.lako_version() == 1
         self.probe = None   # list → every op records (name, algorithmic flops, start event, end event)
+        import os
+        for kv in filter(None, os.environ.get("LAKO_TUNING", "").split(",")):   # A/B measurements: "key=value,key=value"
+            k, v = kv.split("=")
+            self.set_tuning(k.strip(), int(v))
 
     @staticmethod
     def _stream():

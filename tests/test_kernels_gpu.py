@@ -125,6 +125,34 @@ def test_gemm_nt_side_operand_in_lds(ops, ref, M, N, K):
         ops.set_tuning("gemm_nt_side_lds", 1)
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 768, 768), (128, 768, 3072), (100, 200, 160), (256, 2304, 2304), (16, 3072, 4096), (130, 776, 1056)])
+def test_gemm_nt_skinny_tiles(ops, ref, M, N, K):
+    """the decoder's GEMM kernel (K split over the workgroup's waves) with both tile sizes and every fused epilogue, bf16 and
+    fp32 output"""
+    T = torch.bfloat16
+    A, B = rnd(M, K, dtype=T, seed=61), rnd(N, K, dtype=T, seed=62)
+    R, Rf = rnd(M, N, dtype=T, seed=63), rnd(M, N, seed=64)
+    try:
+        ops.set_tuning("gemm_nt_variant", 5)
+        for tiles in (2, 3):
+            ops.set_tuning("gemm_nt_skinny", tiles)
+            for kw in (dict(), dict(relu=True, drop=(0.1, 5, 6)), dict(resid=R, drop=(0.1, 7, 8), alpha=0.5), dict(aux=R, aux_scale=1.1)):
+                C = torch.empty(M, N, dtype=T, device=dev())
+                Cr = torch.zeros(M, N, device=dev())
+                ops.gemm_nt(A, B, C, **kw)
+                ref.gemm_nt(A, B, Cr, **kw)
+                close(C, Cr, T, f"gemm_nt skinny tiles {tiles} {list(kw)} {M}x{N}x{K}")
+            for kw in (dict(alpha=0.25), dict(resid=Rf)):
+                C = torch.empty(M, N, device=dev())
+                Cr = torch.zeros(M, N, device=dev())
+                ops.gemm_nt(A, B, C, **kw)
+                ref.gemm_nt(A, B, Cr, **kw)
+                close(C, Cr, T, f"gemm_nt skinny f32 out tiles {tiles} {list(kw)} {M}x{N}x{K}")
+    finally:
+        ops.set_tuning("gemm_nt_variant", -1)
+        ops.set_tuning("gemm_nt_skinny", 1)
+
+
 def test_gemm_nt_tail_split(ops, ref):
     """270 tiles of 256² = one full round of the persistent grid + 15 tiles: the rows of the full round go to the 256²
     kernel, the rest to a second launch with small tiles; dropout draws must use the rows' GLOBAL index."""
