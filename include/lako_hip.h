@@ -94,10 +94,12 @@ int lako_gemm_tn_grouped(const lako_gemm_tn_item_t* items, int n_items, int64_t 
  * rstd [rows] fp32 is written for the backward.  w is fp32 [d]. */
 int lako_rmsnorm_fwd(const void* x, const float* w, void* y, float* rstd, int64_t rows, int d, float eps,
                      int dtype, lako_dropout_t drop, lako_stream_t stream);
-/* dx = (dres ? dres : 0) + rmsnorm_bwd(dropout_bwd(dy)); dw (fp32 [d]) += Σ_rows dy·x·rstd (atomics) */
+/* dx = (dres ? dres : 0) + rmsnorm_bwd(dropout_bwd(dy)); dw (fp32 [d]) += Σ_rows dy·x·rstd (atomics).
+ * dx_drop (may be NULL): also written, = lako_dropout_apply(dx, drop_out) — the gradient entering the next residual branch
+ * through ITS output dropout, produced in the same pass instead of a second read of dx */
 int lako_rmsnorm_bwd(const void* dy, const void* x, const float* w, const float* rstd, const void* dres,
-                     void* dx, float* dw, int64_t rows, int d, int dtype, lako_dropout_t drop,
-                     lako_stream_t stream);
+                     void* dx, float* dw, int64_t rows, int d, int dtype, lako_dropout_t drop, void* dx_drop,
+                     lako_dropout_t drop_out, lako_stream_t stream);
 
 /* ---- embedding (HF5:678 embed_tokens + HF5:725 dropout) --------------------------------------------
  * out[t] = dropout(table[ids[t]]);  bwd: dtable (fp32 [vocab, d]) += scatter of dropout_bwd(dout) */

@@ -70,7 +70,7 @@ SIGNATURES = {
     "lako_gemm_tn": [vp, vp, vp, i64, i64, i64, i64, i64, i64, i32, f32, i32, vp],
     "lako_gemm_tn_grouped": [C.POINTER(GemmTNItem), i32, i64, i32, vp],
     "lako_rmsnorm_fwd": [vp, vp, vp, vp, i64, i32, f32, i32, Dropout, vp],
-    "lako_rmsnorm_bwd": [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, Dropout, vp],
+    "lako_rmsnorm_bwd": [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, Dropout, vp, Dropout, vp],
     "lako_embed_fwd": [vp, vp, vp, i64, i32, i64, i32, Dropout, vp],
     "lako_embed_bwd": [vp, vp, vp, i64, i32, i64, i32, Dropout, vp],
     "lako_relpos_expand": [vp, vp, vp, i32, i32, i32, vp],

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* __restrict__ 
                                                           const float* __restrict__ w,
                                                           const float* __restrict__ rstd, const T* __restrict__ dres,
                                                           T* __restrict__ dx, float* __restrict__ dw, int64_t rows,
-                                                          int d, DropDev dr) {
+                                                          int d, DropDev dr, T* __restrict__ dx_drop, DropDev dr_out) {
   const int lane = threadIdx.x & 63;
   const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t nw = (int64_t)gridDim.x * 4;
@@ -166,6 +166,13 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* __restrict__ 
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] += rs * wv[it][i] * g[it][i] - xv[it][i] * k;
         store8(dx + row * d + c, o);
+        if (dx_drop) {   // the consumer's dropout_bwd(dx) in the same pass: exactly lako_dropout_apply of the ROUNDED dx
+          bool kp[8];
+          keep8(dr_out.key, (uint64_t)row * d + c, dr_out.thresh, kp);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] = kp[i] ? (float)(T)o[i] * dr_out.scale : 0.f;
+          store8(dx_drop + row * d + c, o);
+        }
       }
     }
   }
@@ -558,8 +565,8 @@ extern "C" int lako_rmsnorm_fwd(const void* x, const float* w, void* y, float* r
 }
 
 extern "C" int lako_rmsnorm_bwd(const void* dy, const void* x, const float* w, const float* rstd, const void* dres,
-                                void* dx, float* dw, int64_t rows, int d, int dtype, lako_dropout_t drop,
-                                lako_stream_t stream) {
+                                void* dx, float* dw, int64_t rows, int d, int dtype, lako_dropout_t drop, void* dx_drop,
+                                lako_dropout_t drop_out, lako_stream_t stream) {
   CHECK_DTYPE("lako_rmsnorm_bwd", dtype);
   LAKO_CHECK_ARG(rows > 0 && d > 0 && d % 8 == 0 && d <= 1024, "lako_rmsnorm_bwd: rows=%lld d=%d (d %% 8 == 0, d <= 1024)",
                  (long long)rows, d);
@@ -567,12 +574,15 @@ extern "C" int lako_rmsnorm_bwd(const void* dy, const void* x, const float* w, c
   LAKO_CHECK_ALIGN(x, 16);
   LAKO_CHECK_ALIGN(dx, 16);
   LAKO_CHECK_ALIGN(w, 16);
-  DropDev dr = make_drop(drop);
+  LAKO_CHECK_ARG(!dx_drop || drop_out.p > 0.f, "lako_rmsnorm_bwd: dx_drop without a dropout");
+  LAKO_CHECK_ALIGN(dx_drop, 16);
+  DropDev dr = make_drop(drop), dr_out = make_drop(drop_out);
   int grid = rows_grid(rows);
   if (grid > 1024) grid = 1024;   // 4 blocks per CU: enough waves to stream (measured: 512 → 4.0, 1024 → 5.1, 2048 → 4.6 TB/s at
                                   // 64 k rows), still few adders per dw address
   DISPATCH_T(dtype, hipLaunchKernelGGL((rmsnorm_bwd_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                                       (const T*)dy, (const T*)x, w, rstd, (const T*)dres, (T*)dx, dw, rows, d, dr));
+                                       (const T*)dy, (const T*)x, w, rstd, (const T*)dres, (T*)dx, dw, rows, d, dr, (T*)dx_drop,
+                                       dr_out));
   LAKO_LAUNCH_CHECK();
   return LAKO_OK;
 }

@@ -459,15 +459,19 @@ class Engine:
             a, b = self.by_name[first_block], self.by_name[last_block]
             self.grad_hook(a.off, b.off + -(-b.numel // ALIGN) * ALIGN)
 
-    def _ffn_bwd(self, lw, dh, a1, xn, h_in, rs, ln, p, drop_out, tmp, dw=None):
+    def _ffn_bwd(self, lw, dh, a1, xn, h_in, rs, ln, p, drop_out, tmp, dw=None, dy_pre=None, nxt=None):
         """residual FFN sublayer backward; dh is updated in place to the gradient wrt the sublayer input.
         `dw`: list collecting the weight-gradient problems for one grouped launch (encoder layers with dropout: their
-        operands live in per-layer scratch that stays untouched until the layer's backward is complete)."""
+        operands live in per-layer scratch that stays untouched until the layer's backward is complete).
+        `dy_pre`: dropout_bwd(dh) already written by the RMSNorm backward that produced dh; `nxt` = (buffer, dropout) asks
+        this sublayer's RMSNorm backward to do the same for the next consumer (saves a pass over the residual gradient)."""
         ops = self.ops
         M, d = dh.shape
         f = a1.shape[1]
         dy = dh
-        if p > 0:
+        if p > 0 and dy_pre is not None:
+            dy = dy_pre
+        elif p > 0:
             dy = self._buf(tmp, f"dy.ffn.{M}" if dw is not None else f"dy.{M}", (M, d))
             ops.dropout_apply(dh, dy, drop_out)
         if dw is not None and p > 0:
@@ -482,7 +486,11 @@ class Engine:
             ops.gemm_tn(dpre, xn, lw["wi"].g)
         dxn = self._buf(tmp, f"dxn.{M}", (M, d))
         ops.gemm_nt(dpre, lw["wi"].wt, dxn)
-        ops.rmsnorm_bwd(dxn, h_in, ln.p, rs, dh, dh, ln.g)
+        ops.rmsnorm_bwd(dxn, h_in, ln.p, rs, dh, dh, ln.g, **self._nxt(nxt))
+
+    @staticmethod
+    def _nxt(nxt):
+        return {} if nxt is None else dict(dx_drop=nxt[0], drop_out=nxt[1])
 
     def backward(self, upstream=None):
         """Accumulate d(loss)/d(params) into G.  `upstream`: optional device scalar tensor multiplying the loss."""
@@ -515,7 +523,13 @@ class Engine:
         if dout32 is not dout:
             ops.cast(dout32.view(-1), dout.view(-1))
         ops.gemm_tn(dlog, ws["d.out"], self.shared.g, alpha=alpha)
-        ops.rmsnorm_bwd(dout, ws[f"d.h{Ld}"], self.dec_final.p, ws["d.rsf"], None, dh, self.dec_final.g, dr(S_DEC_FINAL))
+        # every RMSNorm backward also writes dropout_bwd(dx) for the residual branch that consumes dx next (fused=True)
+        fused = p > 0 and os.environ.get("LAKO_FUSE_DROP", "1") != "0"   # 0: separate dropout_apply launches (A/B)
+        dy_f = self._buf(tmp, f"dy.ffn.{Md}", (Md, d)) if fused else None
+        dy_c = self._buf(tmp, f"dy.c.{Md}", (Md, d)) if fused else None
+        dy_s = self._buf(tmp, f"dy.{Md}", (Md, d)) if fused else None
+        ops.rmsnorm_bwd(dout, ws[f"d.h{Ld}"], self.dec_final.p, ws["d.rsf"], None, dh, self.dec_final.g, dr(S_DEC_FINAL),
+                        **self._nxt((dy_f, dr(_dec_site(Ld - 1, 5))) if fused else None))
         dkv = self._buf(tmp, "dkv", (Me, self.kv_all.w.shape[0]))
         drel = self._buf(tmp, "d.drel", (H, 2 * T - 1), torch.float32)
         ops.zero_(drel)
@@ -525,12 +539,13 @@ class Engine:
             # the layer's six weight gradients (K = B·T rows: two K-steps each) as one grouped launch at the end of the layer
             dw = []
             self._ffn_bwd(lw, dh, ws[f"d.a1.{i}"], ws[f"d.xn3.{i}"], ws[f"d.h2.{i}"], ws[f"d.rs3.{i}"], lw["ln3"], p,
-                          dr(_dec_site(i, 5)), tmp, dw)
+                          dr(_dec_site(i, 5)), tmp, dw, dy_pre=dy_f, nxt=(dy_c, dr(_dec_site(i, 3))) if fused else None)
             # cross-attention
             dy = dh
             if p > 0:
-                dy = self._buf(tmp, f"dy.c.{Md}", (Md, d))
-                ops.dropout_apply(dh, dy, dr(_dec_site(i, 3)))
+                dy = dy_c if fused else self._buf(tmp, f"dy.c.{Md}", (Md, d))
+                if not fused:
+                    ops.dropout_apply(dh, dy, dr(_dec_site(i, 3)))
                 dw.append((dy, ws[f"d.cctx.{i}"], lw["co"].g, 1.0))
             else:
                 ops.gemm_tn(dy, ws[f"d.cctx.{i}"], lw["co"].g)
@@ -545,11 +560,14 @@ class Engine:
             dw.append((dqc, ws[f"d.xn2.{i}"], lw["cq"].g, 1.0))
             dxn = self._buf(tmp, f"dxn.{Md}", (Md, d))
             ops.gemm_nt(dqc, lw["cq"].wt, dxn)
-            ops.rmsnorm_bwd(dxn, ws[f"d.h1.{i}"], lw["ln2"].p, ws[f"d.rs2.{i}"], dh, dh, lw["ln2"].g)
+            ops.rmsnorm_bwd(dxn, ws[f"d.h1.{i}"], lw["ln2"].p, ws[f"d.rs2.{i}"], dh, dh, lw["ln2"].g,
+                            **self._nxt((dy_s, dr(_dec_site(i, 1))) if fused else None))
             # causal self-attention
             dy = dh
             if p > 0:
-                ops.dropout_apply(dh, dy := self._buf(tmp, f"dy.{Md}", (Md, d)), dr(_dec_site(i, 1)))
+                dy = dy_s if fused else self._buf(tmp, f"dy.{Md}", (Md, d))
+                if not fused:
+                    ops.dropout_apply(dh, dy, dr(_dec_site(i, 1)))
                 dw.append((dy, ws[f"d.ctx.{i}"], lw["o"].g, 1.0))
             else:
                 ops.gemm_tn(dy, ws[f"d.ctx.{i}"], lw["o"].g)
@@ -562,8 +580,9 @@ class Engine:
                          rel_bias=ws["d.rel"], drel=drel, rel_off=T - 1, causal=True, drop=dr(_dec_site(i, 0)))
             dw.append((dqkv, ws[f"d.xn1.{i}"], lw["qkv"].g, 1.0))
             ops.gemm_nt(dqkv, lw["qkv"].wt, dxn)
-            ops.rmsnorm_bwd(dxn, ws[f"d.h{i}"], lw["ln1"].p, ws[f"d.rs1.{i}"], dh, dh, lw["ln1"].g)
-            ops.gemm_tn_grouped(dw)
+            ops.gemm_tn_grouped(dw)      # before the norm backward below overwrites dy_f for the next layer
+            ops.rmsnorm_bwd(dxn, ws[f"d.h{i}"], lw["ln1"].p, ws[f"d.rs1.{i}"], dh, dh, lw["ln1"].g,
+                            **self._nxt((dy_f, dr(_dec_site(i - 1, 5))) if fused and i > 0 else None))
         ops.embed_bwd(ctx.dec_ids.view(-1), dh, self.shared.g, dr(S_DEC_EMBED))
         ops.relpos_reduce(drel, self._lut(T, T, False), self.dec_rel.g)
         # ---- cross K/V projection of all decoder layers -----------------------------------------
@@ -571,7 +590,10 @@ class Engine:
         deh = self._buf(tmp, "e.dh", (Me, d))
         dxe = self._buf(tmp, f"dxn.{Me}", (Me, d))
         ops.gemm_nt(dkv, self.kv_all.wt, dxe)
-        ops.rmsnorm_bwd(dxe, ws[f"e.h{Le}"], self.enc_final.p, ws["e.rsf"], None, deh, self.enc_final.g, dr(S_ENC_FINAL))
+        dy_f = self._buf(tmp, f"dy.ffn.{Me}", (Me, d)) if fused else None
+        dy_s = self._buf(tmp, f"dy.{Me}", (Me, d)) if fused else None
+        ops.rmsnorm_bwd(dxe, ws[f"e.h{Le}"], self.enc_final.p, ws["e.rsf"], None, deh, self.enc_final.g, dr(S_ENC_FINAL),
+                        **self._nxt((dy_f, dr(_enc_site(Le - 1, 3))) if fused else None))
         self._ready("dec.final_ln", "enc.final_ln")
         # ---- encoder ---------------------------------------------------------------------------
         BN = B * N
@@ -588,10 +610,12 @@ class Engine:
             # pay one fp32 atomic pass over the output per split
             dw = []
             self._ffn_bwd(lw, deh, ws[f"e.a1.{j}"], ws[f"e.xn2.{j}"], ws[f"e.h1.{j}"], ws[f"e.rs2.{j}"], lw["ln2"], p,
-                          dr(_enc_site(i, 3)), tmp, dw)
+                          dr(_enc_site(i, 3)), tmp, dw, dy_pre=dy_f, nxt=(dy_s, dr(_enc_site(i, 1))) if fused else None)
             dy = deh
             if p > 0:
-                ops.dropout_apply(deh, dy := self._buf(tmp, f"dy.{Me}", (Me, d)), dr(_enc_site(i, 1)))
+                dy = dy_s if fused else self._buf(tmp, f"dy.{Me}", (Me, d))
+                if not fused:
+                    ops.dropout_apply(deh, dy, dr(_enc_site(i, 1)))
                 dw.append((dy, ws[f"e.ctx.{j}"], lw["o"].g, 1.0))
             else:
                 ops.gemm_tn(dy, ws[f"e.ctx.{j}"], lw["o"].g)     # dy aliases deh, which the next ops rewrite
@@ -607,8 +631,9 @@ class Engine:
                          drop=dr(_enc_site(i, 0)), **akw)
             dw.append((dqkv, ws[f"e.xn1.{j}"], lw["qkv"].g, 1.0))
             ops.gemm_nt(dqkv, lw["qkv"].wt, dxe)
-            ops.rmsnorm_bwd(dxe, ws[f"e.h{i}"], lw["ln1"].p, ws[f"e.rs1.{j}"], deh, deh, lw["ln1"].g)
-            ops.gemm_tn_grouped(dw)
+            ops.gemm_tn_grouped(dw)      # before the norm backward below overwrites dy_f for the next layer
+            ops.rmsnorm_bwd(dxe, ws[f"e.h{i}"], lw["ln1"].p, ws[f"e.rs1.{j}"], deh, deh, lw["ln1"].g,
+                            **self._nxt((dy_f, dr(_enc_site(i - 1, 3))) if fused and i > 0 else None))
             self._ready(f"enc.{i}.qkv", f"enc.{i}.ln2")
         ops.embed_bwd(ctx.enc_ids, deh, self.shared.g, dr(S_ENC_EMBED))
         ops.relpos_reduce(drel_e, self._lut(L, L, True), self.enc_rel.g)

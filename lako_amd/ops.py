@@ -163,10 +163,13 @@ class HipOps:
         self._timed("rmsnorm_fwd", 0.0, lambda: check(self.lib.lako_rmsnorm_fwd(_p(x), _p(w), _p(y), _p(rstd), rows, d, float(eps), _dt(x), _drop(drop),
                                         self._stream()), "lako_rmsnorm_fwd"))
 
-    def rmsnorm_bwd(self, dy, x, w, rstd, dres, dx, dw, drop=None):
+    def rmsnorm_bwd(self, dy, x, w, rstd, dres, dx, dw, drop=None, dx_drop=None, drop_out=None):
+        """dx_drop (optional): also receives dropout_apply(dx, drop_out) — the next residual branch's incoming gradient"""
         rows, d = x.shape
+        if dx_drop is not None and (not dx_drop.is_contiguous() or dx_drop.shape != dx.shape or dx_drop.dtype != dx.dtype):
+            raise LakoError("rmsnorm_bwd: dx_drop must match dx")
         self._timed("rmsnorm_bwd", 0.0, lambda: check(self.lib.lako_rmsnorm_bwd(_p(dy), _p(x), _p(w), _p(rstd), _p(dres), _p(dx), _p(dw), rows, d, _dt(x),
-                                        _drop(drop), self._stream()), "lako_rmsnorm_bwd"))
+                                        _drop(drop), _p(dx_drop), _drop(drop_out), self._stream()), "lako_rmsnorm_bwd"))
 
     def embed_fwd(self, ids, table, out, drop=None):
         self._timed("embed_fwd", 0.0, lambda: check(self.lib.lako_embed_fwd(_p(ids), _p(table), _p(out), ids.numel(), table.shape[1], table.shape[0],

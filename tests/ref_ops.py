@@ -112,7 +112,7 @@ class RefOps:
         rstd.copy_(rs)
         y.copy_(_apply_drop(w * (xf * rs[:, None]), drop))
 
-    def rmsnorm_bwd(self, dy, x, w, rstd, dres, dx, dw, drop=None):
+    def rmsnorm_bwd(self, dy, x, w, rstd, dres, dx, dw, drop=None, dx_drop=None, drop_out=None):
         g = _apply_drop(f(dy), drop)
         xf, rs = f(x), rstd[:, None]
         d = xf.shape[1]
@@ -122,6 +122,8 @@ class RefOps:
             out = out + f(dres)
         dx.copy_(out)
         dw += (g * xf * rs).sum(0)
+        if dx_drop is not None:
+            self.dropout_apply(dx, dx_drop, drop_out)
 
     def embed_fwd(self, ids, table, out, drop=None):
         out.copy_(_apply_drop(f(table)[ids.reshape(-1)], drop).view(out.shape))

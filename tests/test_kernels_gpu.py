@@ -277,6 +277,12 @@ def test_rmsnorm(ops, ref, dt, rows, d):
             ref.rmsnorm_bwd(dy, x, w, rsr, dr, dxr, dwr, drop)
             close(dx, dxr, T, f"rmsnorm_bwd dx {dt}")
             close(dw, dwr, torch.float32, f"rmsnorm_bwd dw {dt}", k=20)
+            # second output: dropout_bwd(dx) for the next residual branch — bit-identical to a separate lako_dropout_apply
+            dx2, dd, dw2 = torch.empty_like(x), torch.empty_like(x), torch.ones(d, device=dev())
+            ops.rmsnorm_bwd(dy, x, w, rsr, dr, dx2, dw2, drop, dx_drop=dd, drop_out=(0.2, 11, 12))
+            want = torch.empty_like(x)
+            ops.dropout_apply(dx, want, (0.2, 11, 12))
+            assert torch.equal(dx2, dx) and torch.equal(dd, want)
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
