@@ -56,6 +56,7 @@ struct AttnArgs {
   int chunk_rows;     // LDS-side rows per chunk (multiple of 32, <= CH_MAX)
   int blocks_per_wg;  // register-side 16-row blocks per workgroup
   int bn_per_wg;      // dQ pass: batch rows walked by one workgroup (bias-gradient register accumulation)
+  int dbg_flags;      // timing experiments (LAKO_ATTN_DEBUG): bit 2 = skip the global bias-gradient flush, bit 3 = skip the LDS flush too
   int grid_x, grid_z; // dQ pass, grid_x > 0: 1-D XCD-grouped grid standing for (grid_x, H, grid_z) — see attn_bwd_kernel
   uint32_t drop_t16, drop_key;   // attention dropout: keep iff 16-bit half >= drop_t16 (0 = off)
   float drop_scale;
@@ -838,18 +839,48 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
     }
   }
   }  // batch rows of this workgroup
-  if (MODE == 0 && fast_drel) {
-    // this wave's query block is the same for every batch row: yi = (yb_begin + wave)*16 + l15
-    const int yq = (yb_begin + wave) * 16 + l15;
-    if (yb_begin + wave < yb_end) {
+  if (MODE == 0 && fast_drel && !(a.dbg_flags & 8)) {
+    // Reduce the register-accumulated dS tiles over diagonals (key − query).  One LDS float atomic per element (64 per lane)
+    // cost ≈95 µs per layer; instead each wave lays its 16-query × CH-key stripe out in LDS — the K / V images are dead by
+    // now: 64·CH bytes per wave of the 288·CH they occupy — row q rotated by 4q floats so that both the 16-B tile writes and
+    // the reads ALONG a diagonal (consecutive lanes = consecutive diagonals = consecutive addresses) are conflict-free, sums
+    // each diagonal with 16 plain reads and issues ONE atomic per diagonal.
+    __syncthreads();   // every wave is done with the images
+    if constexpr (2 * C::ROWB < 256) {   // bf16 with d_head 32: the images are smaller than four stripes — per-element atomics
+      const int yq = (yb_begin + wave) * 16 + l15;
+      if (yb_begin + wave < yb_end) {
 #pragma unroll
-      for (int t = 0; t < 16; ++t)
+        for (int t = 0; t < 16; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          atomicAdd(&drel_l[clampi(t * 16 + 4 * g + r - yq + a.rel_off, 0, a.R - 1)], dsacc[t][r]);
+          for (int r = 0; r < 4; ++r)
+            atomicAdd(&drel_l[clampi(t * 16 + 4 * g + r - yq + a.rel_off, 0, a.R - 1)], dsacc[t][r]);
+      }
+    } else if (yb_begin + wave < yb_end) {
+      float* reg = reinterpret_cast<float*>(smem) + wave * 16 * CH;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        if (t * 16 < CH) {
+          int pos = t * 16 + 4 * g + 4 * l15;
+          pos = pos >= CH ? pos - CH : pos;     // 4·l15 <= 60 < CH + 1 only when CH >= 64; CH = 32: second wrap below
+          pos = pos >= CH ? pos - CH : pos;
+          *reinterpret_cast<f32x4*>(reg + l15 * CH + pos) = dsacc[t];     // 4-float groups never straddle the wrap (CH % 4 == 0)
+        }
+      }
+      const int yq0 = (yb_begin + wave) * 16;
+      for (int dd = lane; dd < CH + 15; dd += 64) {
+        float sum = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int key = q + dd - 15;
+          int pos = key + (4 * q) % CH;
+          pos = pos >= CH ? pos - CH : pos;
+          if (key >= 0 && key < CH) sum += reg[q * CH + pos];
+        }
+        if (sum != 0.f) atomicAdd(&drel_l[clampi(dd - 15 - yq0 + a.rel_off, 0, a.R - 1)], sum);
+      }
     }
   }
-  if (want_drel) {
+  if (want_drel && !(a.dbg_flags & 4)) {
     __syncthreads();
     for (int i = threadIdx.x; i < a.R; i += 256) {
       float v = drel_l[i];
@@ -924,7 +955,8 @@ int run_bwd(AttnArgs& a, hipStream_t s) {
       // bias gradient: one query block per wave, several batch rows per workgroup (register accumulation of dS)
       q.blocks_per_wg = 4;
       const int64_t wgs = (int64_t)a.Bn * a.H * ((nqb + 3) / 4);
-      q.bn_per_wg = (int)(wgs / 1024 > 1 ? wgs / 1024 : 1);
+      static const int wg_target = getenv("LAKO_ATTN_WGS") ? atoi(getenv("LAKO_ATTN_WGS")) : 1024;
+      q.bn_per_wg = (int)(wgs / wg_target > 1 ? wgs / wg_target : 1);
       if (q.bn_per_wg > OFFS_MAX - 1) q.bn_per_wg = OFFS_MAX - 1;   // the kernel stages bn_per_wg + 1 row offsets in LDS
     }
     const int lds = lds_bytes_bwd<T, DK>(q.chunk_rows, a.R, nqb == 1);
@@ -932,6 +964,7 @@ int run_bwd(AttnArgs& a, hipStream_t s) {
     set_lds_attr(&attn_bwd_kernel<T, DK, 0>, lds, cur0);
     dim3 grid((nqb + q.blocks_per_wg - 1) / q.blocks_per_wg, a.H, (a.Bn + q.bn_per_wg - 1) / q.bn_per_wg);
     q.grid_x = 0;
+    q.dbg_flags = dbg;
     if (grid.x > 1 && !(dbg & 2)) {
       q.grid_x = (int)grid.x;
       q.grid_z = (int)grid.z;
