@@ -254,8 +254,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    host_ms = None
     for i in range(args.warmup):
-        step(i)
+        if i == args.warmup - 1 and i > 0:
+            # host cost of ENQUEUEING one step: the last warm-up step starts on an idle GPU and is not synchronised inside, so
+            # the wall time of its Python calls is the launch path alone (if it approaches ms_per_step the run is host-bound)
+            fence()
+            th = time.perf_counter()
+            step(i)
+            host_ms = (time.perf_counter() - th) * 1e3
+        else:
+            step(i)
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -292,6 +301,7 @@ def main():
                                    f"synthetic OKVQA-shaped batches resident in HBM",
                        "per_gpu_batch": B, "global_batch": B * world, "n_passages": N, "text_maxlength": L,
                        "answer_len": T, "dropout": args.dropout, "parallelism": f"dp{world}",
+                       "host_enqueue_ms_per_step": None if host_ms is None else round(host_ms, 2),
                        "master_weights": "fp32", "final_mean_loss": round(final_loss, 4),
                        "passage_lengths": "all text_maxlength" if args.all_valid else "U{L/2..L} (SURVEY.md §8d)",
                        "valid_token_frac": round(float(lens_all.double().mean()) / L, 4),
