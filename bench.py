@@ -309,7 +309,9 @@ def main():
                                   else "computed like the reference (LAKO_UNPAD=0)"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": gemm_traffic_bytes(args),
-                         "kernel": "gemm_nt_kernel<bf16,bf16>" if args.dtype == "bf16" else "gemm_nt_kernel<f32,f32>",
+                         "kernel": ("gemm_nt_kernel<bf16,bf16,2,4,8,4> (256x256 tile, both epilogue instantiations; calls with M > 256"
+                                    " rows: encoder + cross-K/V GEMMs incl. their small-tile row tails)") if args.dtype == "bf16"
+                                   else "gemm_nt_kernel<f32,f32>",
                          "launches_per_step": n_l, "avg_launch_us": round(t_ms * 1e3 / max(n_l, 1), 2),
                          "step_mfma_frac": round(world * B / (elapsed / args.steps) * fl_exec / 1e12 / (peak * world), 4),
                          "train_gflop_per_sample": round(fl / 1e9, 1),

@@ -122,7 +122,8 @@ class HipOps:
             p.aux, p.ldaux = aux.data_ptr(), aux.stride(0)
         p.aux_scale = float(aux_scale)
         p.drop = _drop(drop)
-        self._timed(f"gemm_nt.{p.in_dtype}{p.out_dtype}", 2.0 * M * N * K, lambda: check(self.lib.lako_gemm_nt(C.byref(p), self._stream()), "lako_gemm_nt"))
+        # probe classes follow the kernel the library picks: M <= 256 rows (the decoder) runs on the split-K / ring kernels
+        self._timed(f"gemm_nt{'_skinny' if M <= 256 else ''}.{p.in_dtype}{p.out_dtype}", 2.0 * M * N * K, lambda: check(self.lib.lako_gemm_nt(C.byref(p), self._stream()), "lako_gemm_nt"))
 
     def gemm_tn(self, A, B, Cm, *, alpha=1.0, split_k=0):
         K, M, lda = _rowmajor2d(A, "gemm_tn A")
