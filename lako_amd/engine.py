@@ -666,7 +666,14 @@ class Engine:
         seq = self._buf(ws, "g.seq", (B, ML), torch.int64)
         nxt = self._buf(ws, "g.next", (B,), torch.int64)
         done = self._buf(ws, "g.done", (B,), torch.uint8)
-        ndone = self._buf(ws, "g.ndone", (1,), torch.int32)
+        # finished-row count after every step, mirrored to pinned host memory: the host looks at the count of step t − LAG
+        # (an event wait on that step only), so it keeps enqueueing LAG steps ahead of the GPU instead of draining the queue
+        # after every token; the LAG extra steps a finished batch may run emit pad for every row and are cut off below
+        ndone = self._buf(ws, "g.ndone", (ML,), torch.int32)
+        if "g.ndone_host" not in ws or ws["g.ndone_host"].numel() < ML:
+            ws["g.ndone_host"] = torch.zeros(ML, dtype=torch.int32).pin_memory() if torch.cuda.is_available() else \
+                torch.zeros(ML, dtype=torch.int32)
+        ndone_host, LAG, events = ws["g.ndone_host"], 2, []
         for t_ in (seq, nxt, done, ndone):
             ops.zero_(t_)                                  # decoder_start_token_id = pad = 0
         rel = self._buf(ws, "g.rel", (H, 2 * ML - 1), torch.float32)
@@ -702,10 +709,20 @@ class Engine:
                 ops.gemm_nt(a1, lw["wo"].w, h, resid=h2)
             ops.rmsnorm_fwd(h, self.dec_final.p, xn, rs, eps)
             ops.gemm_nt(xn, self.shared.w, logits, alpha=d ** -0.5)
-            ops.greedy_step(logits, seq, t + 1, nxt, done, ndone, cfg.eos_token_id, cfg.pad_token_id)
+            ops.greedy_step(logits, seq, t + 1, nxt, done, ndone[t:t + 1], cfg.eos_token_id, cfg.pad_token_id)
             n_out = t + 2
-            if int(ndone.item()) == B:       # HF stops right after the step in which the last row emitted EOS
-                break
+            ndone_host[t:t + 1].copy_(ndone[t:t + 1], non_blocking=True)
+            if ndone.is_cuda:
+                events.append(torch.cuda.Event())
+                events[-1].record()
+            look = t - LAG if (ndone.is_cuda and t < ML - 2) else t     # the last step is checked at once
+            if look >= 0:
+                if ndone.is_cuda:
+                    events[look].synchronize()
+                first = next((u for u in range(max(look - LAG, 0), look + 1) if int(ndone_host[u]) == B), None)
+                if first is not None:        # HF stops right after the step in which the last row emitted EOS
+                    n_out = first + 2
+                    break
         out = seq[:, :n_out].clone()
         if capture_scores:
             # [B, H, n_layers, S] — the layout get_crossattention_scores builds with torch.cat(dim=2), src/model.py:152-160
