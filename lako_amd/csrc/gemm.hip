@@ -41,6 +41,7 @@ struct NtArgs {
   int split_k, k_chunk;   // ring kernel with LAKO_EPI_ATOMIC only: K split over split_k workgroups per tile, k_chunk BYTES each
   int64_t row0;   // rows [row0, row0 + M) of a larger problem (tail launch): only the dropout element index needs it
   int group_m;    // >0: tile ids walk bands of group_m tile-rows column-major (an XCD's 32 resident tiles form a ≈group_m × 32/group_m block)
+  int store_aux;  // cache-policy bits for the 256² kernel's 16-byte output stores (store_b128_policy)
   int dephase;    // (phases << 16) | ticks: workgroup w of an XCD starts (w mod phases)·ticks·10 ns late (breaks the lockstep of main loops / epilogues)
   int wide_epi;   // 256² bf16 tile: LDS-transposed epilogue with 16-B row-major stores (needs N, ldc, ldr, ldaux % 8 == 0)
 };
@@ -141,6 +142,25 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t slice_rsrc(const char* base, i
 __device__ __forceinline__ u32x4 read_frag_rows(const char* lds_tile, int row, int chunk) {
   int cp = chunk ^ ((row >> 1) & 7);
   return *reinterpret_cast<const u32x4*>(lds_tile + row * TKB + cp * 16);
+}
+
+// 16-byte buffer store with run-time selectable cache-policy bits (gfx940 encoding of the builtin's aux operand: 1 = sc0, 2 = nt,
+// 16 = sc1).  EXPERIMENT, off by default ("gemm_nt_store_aux"): a round of the 256² kernel leaves 4 MB of output per XCD dirty in
+// the 4 MB L2 — the same stores aimed at one L2-resident tile (debug bit 4) run the K = 768 shapes 30 % faster, so the cost of
+// the epilogue is the write-back traffic, not the store instructions.  Non-temporal / sc1 stores helped on one box
+// ([.,768]×[2304,768] 248 → 221 µs, ×[3072,768] 333 → 292 µs) and hurt on another (×[18432,768] 1 754 → 1 855 µs); the whole
+// training step moved by 0.2 ms.  tools/store_policy_probe.py repeats the measurement.
+__device__ __forceinline__ void store_b128_policy(u32x4 v, __amdgpu_buffer_rsrc_t rs, int voff, int aux) {
+  switch (aux) {
+    case 0: __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, 0, 0); break;
+    case 1: __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, 0, 1); break;
+    case 2: __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, 0, 2); break;
+    case 3: __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, 0, 3); break;
+    case 16: __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, 0, 16); break;
+    case 17: __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, 0, 17); break;
+    case 18: __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, 0, 18); break;
+    default: __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, 0, 19); break;
+  }
 }
 
 // Generic epilogue in the accumulator layout (element r of lane (l&15, g) of sub-tile (mt, nt) is
@@ -475,7 +495,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
           bf16x8 o;
           o[0] = (bf16_t)lo[0]; o[1] = (bf16_t)lo[1]; o[2] = (bf16_t)lo[2]; o[3] = (bf16_t)lo[3];
           o[4] = (bf16_t)hi[0]; o[5] = (bf16_t)hi[1]; o[6] = (bf16_t)hi[2]; o[7] = (bf16_t)hi[3];
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), crs, (int)(cvb + (uint32_t)((mt * 16 + it * 8) * ldc_b)), 0, 0);
+          store_b128_policy(__builtin_bit_cast(u32x4, o), crs, (int)(cvb + (uint32_t)((mt * 16 + it * 8) * ldc_b)), a.store_aux);
         }
       }
     }
@@ -532,7 +552,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
             bf16x8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-            if (!(a.debug & 8)) *reinterpret_cast<bf16x8*>(C + (int64_t)m * a.ldc + n) = o;
+            if (a.debug & 16) *reinterpret_cast<bf16x8*>(C + (int64_t)(m - m0) * a.ldc + (n - n0)) = o;   // timing experiment: every tile stores to tile (0, 0)
+            else if (a.store_aux) {   // streaming cache policy (see store_b128_policy)
+              const auto crs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(C + (int64_t)m0 * a.ldc + n0), 0, 0x7fffffff, 0x00020000);
+              if (!(a.debug & 8))
+                store_b128_policy(__builtin_bit_cast(u32x4, o), crs, (int)(((int64_t)(m - m0) * a.ldc + (n - n0)) * 2), a.store_aux);
+            } else if (!(a.debug & 8)) *reinterpret_cast<bf16x8*>(C + (int64_t)m * a.ldc + n) = o;
           }
         }
       }
@@ -1237,6 +1262,7 @@ int g_nt_debug = 0;
 int g_nt_skinny = 1;    // M <= 256 rows: gemm_nt_skinny_kernel ("gemm_nt_skinny" 0 disables, 2 / 3 force 64² / 32² tiles; variant 5 forces the kernel)
 int g_nt_ring = 1;      // skinny problems go to gemm_nt_ring_kernel ("gemm_nt_ring" 0 disables; variant 4 forces it)
 int g_nt_stagger = 1;
+int g_nt_store_aux = 0;    // cache-policy bits of the 256² kernel's output stores ("gemm_nt_store_aux"; 0 = default write-back — see store_b128_policy)
 int g_nt_dephase = 100, g_nt_dephase_n = 2;   // 10-ns ticks (s_memrealtime), phases
 int g_nt_persistent = 1;
 int g_nt_variant = -1;   // -1 auto; 0: 128x128/4 waves; 1: 256x128/8 waves; 2: 256x256/8 waves (lako_set_tuning)
@@ -1253,6 +1279,7 @@ void launch_nt_cfg(NtArgs a, hipStream_t s) {
   a.tiles_m = cdiv(a.M, BM);
   a.tiles_n = cdiv(a.N, BN);
   a.stagger = g_nt_stagger;
+  a.store_aux = (int64_t)256 * a.ldc * 2 < (1ll << 31) ? g_nt_store_aux : 0;   // tile-relative 32-bit store offsets
   a.debug = g_nt_debug;
   // narrow outputs already give an XCD a compact block; a negative knob forces |value| on every shape (tests)
   a.group_m = g_nt_group_m < 0 ? -g_nt_group_m : (a.tiles_n >= 16 ? g_nt_group_m : 0);
@@ -1637,6 +1664,10 @@ extern "C" int lako_set_tuning(const char* key, int value) {
   }
   if (key && !strcmp(key, "gemm_nt_wide_epi")) {
     g_nt_wide_epi = value;
+    return LAKO_OK;
+  }
+  if (key && !strcmp(key, "gemm_nt_store_aux")) {
+    g_nt_store_aux = value;
     return LAKO_OK;
   }
   if (key && !strcmp(key, "gemm_nt_skinny")) {
