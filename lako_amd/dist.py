@@ -6,7 +6,7 @@ The engine lays gradients out in ONE flat fp32 buffer, in the order they complet
 reports finished ranges through `Engine.grad_hook`.  Two modes:
 
   "deferred" (default)  one SUM all-reduce of the whole flat buffer after backward.  892 MB at T5-base:
-                        ≈5 ms on an 8-GPU xGMI ring against a ≈73 ms step.  Chosen as the default because the
+                        ≈4.5 ms on 8 GPUs (≈14 ms on 2: one xGMI link per pair) against a ≈48 ms step.  Chosen as the default because the
                         big GEMM kernels fill the chip with exactly one workgroup per CU (128 KiB LDS, ≈240
                         VGPRs): RCCL kernels running concurrently on their own stream would take CUs away and
                         stretch every such kernel by a whole scheduling round.
