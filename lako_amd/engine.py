@@ -678,11 +678,13 @@ class Engine:
             ops.zero_(t_)                                  # decoder_start_token_id = pad = 0
         rel = self._buf(ws, "g.rel", (H, 2 * ML - 1), torch.float32)
         ops.relpos_expand(self.dec_rel.p, self._lut(ML, ML, False), rel)
-        cache = [self._buf(ws, f"g.cache.{i}", (B, ML, 2 * inner)) for i in range(Ld)]
+        # per layer [B, max_length, (q | k | v)]: ONE projection GEMM per step writes the step's q, k and v into row t; q is read
+        # back from there, k and v stay as the cache
+        cache = [self._buf(ws, f"g.cache.{i}", (B, ML, 3 * inner)) for i in range(Ld)]
         scores = self._buf(ws, "g.scores", (Ld, B, H, 1, S), torch.float32) if capture_scores else None
         h, h1, h2, xn = (self._buf(ws, f"g.{n}", (B, d)) for n in ("h", "h1", "h2", "xn"))
         rs = self._buf(ws, "g.rs", (B,), torch.float32)
-        q, c1, qc, c2 = (self._buf(ws, f"g.{n}", (B, inner)) for n in ("q", "c1", "qc", "c2"))
+        c1, qc, c2 = (self._buf(ws, f"g.{n}", (B, inner)) for n in ("c1", "qc", "c2"))
         st = self._buf(ws, "g.st", (B, H, 1, 4), torch.float32)
         a1 = self._buf(ws, "g.a1", (B, f))
         logits = self._buf(ws, "g.logits", (B, V), torch.float32)
@@ -692,11 +694,11 @@ class Engine:
             for i in range(Ld):
                 lw = self.dec[i]
                 ops.rmsnorm_fwd(h, lw["ln1"].p, xn, rs, eps)
-                ops.gemm_nt(xn, lw["qkv"].w[:inner], q)
-                ops.gemm_nt(xn, lw["qkv"].w[inner:], cache[i].view(B, ML * 2 * inner)[:, t * 2 * inner:(t + 1) * 2 * inner])
-                kc = cache[i][:, :t + 1, :inner].unflatten(2, (H, dk))
-                vc = cache[i][:, :t + 1, inner:].unflatten(2, (H, dk))
-                ops.attn_fwd(q.view(B, 1, H, dk), kc, vc, c1.view(B, 1, H, dk), st, rel_bias=rel, rel_off=ML - 1 - t)
+                ops.gemm_nt(xn, lw["qkv"].w, cache[i].view(B, ML * 3 * inner)[:, t * 3 * inner:(t + 1) * 3 * inner])
+                qs = cache[i][:, t:t + 1, :inner].unflatten(2, (H, dk))
+                kc = cache[i][:, :t + 1, inner:2 * inner].unflatten(2, (H, dk))
+                vc = cache[i][:, :t + 1, 2 * inner:].unflatten(2, (H, dk))
+                ops.attn_fwd(qs, kc, vc, c1.view(B, 1, H, dk), st, rel_bias=rel, rel_off=ML - 1 - t)
                 ops.gemm_nt(c1, lw["o"].w, h1, resid=h)
                 ops.rmsnorm_fwd(h1, lw["ln2"].p, xn, rs, eps)
                 ops.gemm_nt(xn, lw["cq"].w, qc)
