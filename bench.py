@@ -12,10 +12,17 @@ the step, overlapped with backward.  Workload = BASELINE config 2: T5-base, per-
 (run_okvqa_train.sh:25-27), n_passages 20, text_maxlength 200, answer length 8, bf16 compute with fp32
 master weights / optimizer.  Weak scaling: per-GPU batch fixed, one sample = question + 20 passages.
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the bf16 MFMA GEMM): algorithmic
-FLOPs of its launches ÷ their HIP-event time measured live on the last timed step; `step_mfma_frac` is
-the whole step against the same peak.  `cpu_baseline` times the CPU oracle (same algorithm, torch fp32 on
-the host cores) on a bounded sample of the same workload — a reported baseline, not the target.
+Every timed step is a NEW batch (8 distinct resident batches, cycled) handed over as the data loader would: device
+tensors plus the collator's host-side passage lengths; the unpadded encoder's input preparation (row offsets, packed-row
+index) is part of the timed step — nothing about a batch is cached across steps.
+
+Rank 0 prints ONE JSON line.  `value` = samples of all ranks ÷ the wall time of the K timed steps (barrier +
+synchronize on both sides, max over ranks); `median_step_ms` is the median of the per-step HIP-event times.  `roofline` is
+for the dominant kernel (the bf16 MFMA GEMM): algorithmic FLOPs of its launches ÷ their HIP-event time measured live on
+one extra step after the timed region; `step_mfma_frac` is the whole step against the same peak.  `all_valid` is a second,
+shorter measurement of the same step with every passage at full length (nothing to skip: the pure-roofline variant).
+`cpu_baseline` times the CPU oracle (same algorithm, torch fp32 on the host cores) on a bounded sample of the same workload —
+a reported baseline, not the target.
 """
 from __future__ import annotations
 
@@ -37,13 +44,17 @@ def gemm_traffic_bytes(args):
     skipped, profiles/r01b_* = 64 k rows on the padded path / --all-valid).  null for any other workload or when the file is absent —
     counters cannot be collected from inside a timed run."""
     if (args.model, args.batch, args.n_passages, args.seq_len, args.dtype) != ("base", 16, 20, 200, "bf16"):
-        return None
-    try:
-        padded = os.environ.get("LAKO_UNPAD", "1") == "0" or args.all_valid
-        with open(os.path.join(ROOT, "profiles", "r01b_gemm_traffic.json" if padded else "r01c_gemm_traffic.json")) as f:
-            return json.load(f)["nt_mean_traffic_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        return None
+        return None, None
+    padded = os.environ.get("LAKO_UNPAD", "1") == "0" or args.all_valid
+    for name in (("r02_gemm_traffic_padded.json", "r01b_gemm_traffic.json") if padded else
+                 ("r02_gemm_traffic.json", "r01c_gemm_traffic.json")):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return json.load(f)["nt_mean_traffic_bytes_per_launch"], \
+                    f"static: profiles/{name} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/gemm_probe.py, not this run)"
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
 PEAK_BF16_TFLOPS = 2500.0      # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (no 2:1 sparsity)
@@ -73,7 +84,7 @@ def executed_train_flops(cfg, lens, T):
     return 3.0 * fwd
 
 
-def synthetic_batch(B, N, L, T, vocab, seed, device, all_valid=False):
+def synthetic_batch(B, N, L, T, vocab, seed, device, all_valid=False, with_lengths=False):
     """ids ~ U{2..32099}, per-passage valid length ~ U{ceil(L/2)..L} (or all L: the pure-roofline variant),
     labels end in EOS, -100 pad."""
     g = torch.Generator().manual_seed(seed)
@@ -89,7 +100,14 @@ def synthetic_batch(B, N, L, T, vocab, seed, device, all_valid=False):
     pos = torch.arange(T)[None]
     labels = torch.where(pos == (tl - 1)[:, None], torch.ones_like(labels), labels)
     labels = labels.masked_fill(pos >= tl[:, None], -100)
-    return ids.to(device), mask.to(device), labels.to(device)
+    out = (ids.to(device), mask.to(device), labels.to(device))
+    return out + (lens.to(torch.int32),) if with_lengths else out     # lens stays on the host (the collator's knowledge)
+
+
+def workload_tag(args) -> str:
+    """BASELINE.json config this run corresponds to (SURVEY.md §8 shorthand), or 'custom'."""
+    key = (args.model, args.n_passages, args.seq_len)
+    return {("small", 5, 64): "C1", ("base", 20, 200): "C2", ("large", 40, 200): "C4", ("large", 100, 200): "C5"}.get(key, "custom")
 
 
 def effective_cpus() -> int:
@@ -127,7 +145,7 @@ def cpu_worker(args):
     w = O.init_weights(dims, seed=0, shared_std=0.05)
     state = {}
     print(f"CPUINFO {cores}", flush=True)
-    for k in range(1 + args.cpu_steps):
+    for k in range(args.cpu_warmup + args.cpu_steps):
         ids, mask, labels = O.synthetic_batch(args.cpu_batch, args.n_passages, args.seq_len, args.target_len,
                                               dims.vocab_size, seed=1000 + k)
         t0 = time.time()
@@ -139,7 +157,8 @@ def cpu_baseline(args):
     """Run cpu_worker in a subprocess with a hard deadline (bench.py must finish within minutes)."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", "--model", args.model, "--cpu-batch",
-           str(args.cpu_batch), "--cpu-steps", str(args.cpu_steps), "--n-passages", str(args.n_passages),
+           str(args.cpu_batch), "--cpu-steps", str(args.cpu_steps), "--cpu-warmup", str(args.cpu_warmup), "--n-passages",
+           str(args.n_passages),
            "--seq-len", str(args.seq_len), "--target-len", str(args.target_len), "--dropout", str(args.dropout)]
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env)
@@ -154,7 +173,8 @@ def cpu_baseline(args):
             cores = int(line.split()[1])
         elif line.startswith("CPUSTEP"):
             times.append(float(line.split()[1]))
-    timed = times[1:] if len(times) > 1 else times
+    nw = min(args.cpu_warmup, max(len(times) - 1, 0))
+    timed = times[nw:]
     B = args.cpu_batch
     if not timed:
         return {"value": None, "unit": "samples/s", "cores": cores, "kind": "port",
@@ -162,15 +182,15 @@ def cpu_baseline(args):
     med = sorted(timed)[len(timed) // 2]
     return {"value": round(B / med, 4), "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": f"oracle train step (torch CPU fp32, dropout on), same model/N/L/T, batch {B} instead of "
-                      f"{args.batch}; median of {len(timed)} step(s) after {1 if len(times) > 1 else 0} warm-up, "
-                      f"{cores} threads"}
+                      f"{args.batch}; median of {len(timed)} step(s) after {nw} warm-up(s) (SURVEY §8d asks for >= 10 after 2; "
+                      f"the leg is cut off after {args.cpu_seconds:.0f} s), {cores} threads"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--model", default="base")
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (run_okvqa_train.sh:25-27: 16 for base)")
     ap.add_argument("--n-passages", type=int, default=20)
@@ -181,7 +201,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--all-valid", action="store_true", help="every passage has the full text_maxlength tokens (no padding to skip)")
     ap.add_argument("--cpu-batch", type=int, default=1)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=10)
+    ap.add_argument("--cpu-warmup", type=int, default=2)
+    ap.add_argument("--all-valid-steps", type=int, default=10, help="timed steps of the second, all-passages-full measurement (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=150.0, help="hard deadline for the CPU baseline leg")
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--breakdown", action="store_true", help="print the per-op HIP-event breakdown to stderr")
@@ -230,99 +252,131 @@ def main():
     ops = model._get_engine().ops
 
     B, N, L, T = args.batch, args.n_passages, args.seq_len, args.target_len
-    batches = [synthetic_batch(B, N, L, T, cfg.vocab_size, seed=rank * 7919 + i, device=device, all_valid=args.all_valid)
-               for i in range(4)]
-    lens_all = torch.stack([b[1].sum(-1).cpu() for b in batches])            # [4, B, N] valid lengths
+    NB = 8                                                   # distinct resident batches, cycled
     unpadded = os.environ.get("LAKO_UNPAD", "1") != "0"
-    if unpadded:     # input preparation, like building the batches: passage offsets of the resident batches (cached by mask)
-        for _, m_, _ in batches:
-            model._get_engine()._ragged_batch(m_, B, N, L)
     loss_acc = torch.zeros((), device=device)
-
-    def step(i):
-        ids, mask, labels = batches[i % len(batches)]
-        loss = model(input_ids=ids, attention_mask=mask, labels=labels)[0]
-        loss.backward()
-        U.clip_grad_norm_(model, 1.0)
-        optimizer.step()
-        scheduler.step()
-        model.zero_grad()
-        loss_acc.add_(loss.detach())
+    peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+    dom = "gemm_nt.11" if args.dtype == "bf16" else "gemm_nt.00"
+    fl = train_flops_per_sample(cfg, N, L, T)                # nominal: every position of [B, N, L]
 
     def fence():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    host_ms = None
-    for i in range(args.warmup):
-        if i == args.warmup - 1 and i > 0:
-            # host cost of ENQUEUEING one step: the last warm-up step starts on an idle GPU and is not synchronised inside, so
-            # the wall time of its Python calls is the launch path alone (if it approaches ms_per_step the run is host-bound)
-            fence()
-            th = time.perf_counter()
-            step(i)
-            host_ms = (time.perf_counter() - th) * 1e3
-        else:
-            step(i)
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if i == args.steps - 1:
-            ops.probe = []                                  # HIP events around every launch of the LAST timed step
-        step(args.warmup + i)
-    fence()
-    elapsed = time.perf_counter() - t0
-    probe = ops.probe_summary()
-    ops.probe = None
-    if use_dist:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def measure(all_valid, warmup, steps):
+        """warm-up, then EXACTLY `steps` timed steps between two fences; one more step afterwards carries the per-launch
+        HIP-event probe (its event records would perturb the step they sit in)."""
+        batches = [synthetic_batch(B, N, L, T, cfg.vocab_size, seed=rank * 7919 + i, device=device, all_valid=all_valid,
+                                   with_lengths=True) for i in range(NB)]
+
+        def step(i):
+            ids, mask, labels, lens = batches[i % NB]
+            # the batch arrives as from the data loader: device tensors + the collator's host-side lengths; offsets and the
+            # packed-row index of the unpadded encoder are rebuilt from them inside the step (no per-batch cache)
+            loss = model(input_ids=ids, attention_mask=mask, labels=labels, passage_lengths=lens)[0]
+            loss.backward()
+            U.clip_grad_norm_(model, 1.0)
+            optimizer.step()
+            scheduler.step()
+            model.zero_grad()
+            loss_acc.add_(loss.detach())
+
+        host_ms = None
+        for i in range(warmup):
+            if i == warmup - 1 and i > 0:
+                # host cost of ENQUEUEING one step: the last warm-up step starts on an idle GPU and is not synchronised inside,
+                # so the wall time of its Python calls is the launch path alone (if it approaches ms_per_step the run is host-bound)
+                fence()
+                th = time.perf_counter()
+                step(i)
+                host_ms = (time.perf_counter() - th) * 1e3
+            else:
+                step(i)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        fence()
+        t0 = time.perf_counter()
+        marks[0].record()
+        for i in range(steps):
+            step(warmup + i)
+            marks[i + 1].record()
+        fence()
+        elapsed = time.perf_counter() - t0
+        per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+        ops.probe = []
+        step(warmup + steps)
+        torch.cuda.synchronize()
+        probe = ops.probe_summary()
+        ops.probe = None
+        if use_dist:
+            t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        lens_all = torch.stack([b[3] for b in batches])                       # [NB, B, N]
+        # what this implementation executes: padded positions are skipped on the unpadded path (exact: DESIGN.md §4)
+        fl_exec = (sum(executed_train_flops(cfg, lens_all[i % NB], T) for i in range(warmup, warmup + steps))
+                   / (steps * B)) if unpadded else fl
+        n_l, t_ms, f_tot = probe.get(dom, (0, 0.0, 0.0))
+        achieved = f_tot / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0
+        return dict(elapsed=elapsed, ms=elapsed / steps * 1e3, median_ms=per_step[len(per_step) // 2], host_ms=host_ms,
+                    probe=probe, fl_exec=fl_exec, valid_frac=float(lens_all.double().mean()) / L, n_l=n_l, t_ms=t_ms,
+                    achieved=achieved, value=world * B * steps / elapsed,
+                    step_frac=world * B / (elapsed / steps) * fl_exec / 1e12 / (peak * world))
+
+    main_run = measure(args.all_valid, args.warmup, args.steps)
+    av_run = None
+    if not args.all_valid and args.all_valid_steps > 0:
+        av_run = measure(True, 3, args.all_valid_steps)
+    total = args.warmup + args.steps + 1 + (3 + args.all_valid_steps + 1 if av_run else 0)
     final_loss = float(loss_acc.item()) / total
 
     if rank == 0:
-        ms = elapsed / args.steps * 1e3
-        value = world * B * args.steps / elapsed
-        fl = train_flops_per_sample(cfg, N, L, T)                                 # nominal: every position of [B, N, L]
-        # what this implementation executes: padded positions are skipped on the unpadded path (exact: DESIGN.md §4)
-        fl_exec = (sum(executed_train_flops(cfg, lens_all[i % 4], T) for i in range(args.warmup, args.warmup + args.steps))
-                   / (args.steps * B)) if unpadded else fl
-        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
-        dom = "gemm_nt.11" if args.dtype == "bf16" else "gemm_nt.00"
-        n_l, t_ms, f_tot = probe.get(dom, (0, 0.0, 0.0))
-        achieved = f_tot / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0
+        r = main_run
+        traffic, traffic_src = gemm_traffic_bytes(args)
         out = {
             "metric": "train samples/sec (question+n_passages) T5-base OKVQA, 1/2/4/8 GPU",
-            "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+            "value": round(r["value"], 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(r["ms"], 3), "median_step_ms": round(r["median_ms"], 3),
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"C2: FiD reader train step (fwd+bwd+clip+AdamW), T5-{args.model} random-init, "
-                                   f"synthetic OKVQA-shaped batches resident in HBM",
+            "config": {"workload": f"{workload_tag(args)}: FiD reader train step "
+                                   f"(fwd+bwd+clip+AdamW), T5-{args.model} random-init, synthetic OKVQA-shaped batches resident in HBM",
                        "per_gpu_batch": B, "global_batch": B * world, "n_passages": N, "text_maxlength": L,
                        "answer_len": T, "dropout": args.dropout, "parallelism": f"dp{world}",
-                       "host_enqueue_ms_per_step": None if host_ms is None else round(host_ms, 2),
+                       "rccl_world_size": dist.get_world_size() if use_dist else None,
+                       "dp_mode": os.environ.get("LAKO_DP_MODE", "flat") if use_dist else None,
+                       "host_enqueue_ms_per_step": None if r["host_ms"] is None else round(r["host_ms"], 2),
                        "master_weights": "fp32", "final_mean_loss": round(final_loss, 4),
                        "passage_lengths": "all text_maxlength" if args.all_valid else "U{L/2..L} (SURVEY.md §8d)",
-                       "valid_token_frac": round(float(lens_all.double().mean()) / L, 4),
+                       "valid_token_frac": round(r["valid_frac"], 4),
+                       "distinct_batches": NB,
+                       "ragged_prep": "in timed region (offsets + packed-row index rebuilt every step from the collator's host-side "
+                                      "lengths; no mask read-back, no per-batch cache)" if unpadded else "n/a (padded path)",
                        "padding": "skipped: encoder runs on valid tokens only (results identical)" if unpadded
                                   else "computed like the reference (LAKO_UNPAD=0)"},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": gemm_traffic_bytes(args),
+            "roofline": {"bound": "mfma", "achieved": round(r["achieved"], 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(r["achieved"] / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": ("gemm_nt_kernel<bf16,bf16,2,4,8,4> (256x256 tile, both epilogue instantiations; calls with M > 256"
                                     " rows: encoder + cross-K/V GEMMs incl. their small-tile row tails)") if args.dtype == "bf16"
                                    else "gemm_nt_kernel<f32,f32>",
-                         "launches_per_step": n_l, "avg_launch_us": round(t_ms * 1e3 / max(n_l, 1), 2),
-                         "step_mfma_frac": round(world * B / (elapsed / args.steps) * fl_exec / 1e12 / (peak * world), 4),
+                         "launches_per_step": r["n_l"], "avg_launch_us": round(r["t_ms"] * 1e3 / max(r["n_l"], 1), 2),
+                         "step_mfma_frac": round(r["step_frac"], 4),
                          "train_gflop_per_sample": round(fl / 1e9, 1),
-                         "executed_gflop_per_sample": round(fl_exec / 1e9, 1)},
+                         "executed_gflop_per_sample": round(r["fl_exec"] / 1e9, 1)},
         }
+        if av_run is not None:
+            out["all_valid"] = {"value": round(av_run["value"], 3), "unit": "samples/s", "steps": args.all_valid_steps, "warmup": 3,
+                                "ms_per_step": round(av_run["ms"], 3), "median_step_ms": round(av_run["median_ms"], 3),
+                                "passage_lengths": "all text_maxlength (no padding to skip)",
+                                "roofline_frac": round(av_run["achieved"] / peak, 4),
+                                "step_mfma_frac": round(av_run["step_frac"], 4)}
         if args.breakdown:
+            probe = r["probe"]
             tot = sum(v[1] for v in probe.values())
             for k, (n, t, f) in sorted(probe.items(), key=lambda kv: -kv[1][1]):
                 tf = f / (t * 1e-3) / 1e12 if t > 0 and f > 0 else 0.0
                 print(f"  {k:16s} launches {n:4d}  {t:8.3f} ms  {100 * t / tot:5.1f}%  {tf:8.1f} TFLOP/s", file=sys.stderr)
-            print(f"  sum of kernels {tot:.3f} ms vs step {ms:.3f} ms", file=sys.stderr)
+            print(f"  sum of kernels {tot:.3f} ms vs step {r['ms']:.3f} ms", file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
     if use_dist:

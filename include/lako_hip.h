@@ -206,6 +206,16 @@ int lako_shift_right(const int64_t* labels, int64_t* dec_ids, int B, int T, lako
 int lako_greedy_step(const float* logits, int64_t V, int B, int64_t* seq, int64_t seq_ld, int pos, int64_t* next_ids,
                      uint8_t* done, int32_t* n_done, int64_t eos_id, int64_t pad_id, lako_stream_t stream);
 
+/* ---- per-fact aggregation of the captured step-0 cross-attention scores (src/model.py:100-115,143-204,
+ * FiDT5.get_crossattention_scores; replaces its per-sample Python loops) ----------------------------------------------------
+ * scores fp32 [B, H, n_layers, N·L] (raw pre-softmax scores as lako_attn_fwd's scores_out lays them out per layer),
+ * mask uint8 [B, N, L], ids int64 [B, N, L], out fp64 [B, n_context].  Per sample: vals[l] = Σ over heads and the layers
+ * [layer0, layer0 + layers_used) of the scores of passage `passage` (masked positions 0); the passage is cut into spans that end
+ * at token id 5, starting at index 2; span j -> style 0 mean | 1 max | 2 "21mean" (mean of the larger half); an unterminated
+ * last span counts when the passage's last token is not pad(0); missing spans are -5; all divided by layers_used * H. */
+int lako_fact_scores(const float* scores, const uint8_t* mask, const int64_t* ids, double* out, int B, int H, int n_layers,
+                     int layer0, int layers_used, int N, int L, int passage, int n_context, int style, lako_stream_t stream);
+
 /* ---- exact inner-product search (src/index.py:19-50 faiss.IndexFlatIP.search; the scores are one
  * lako_gemm_nt of the queries against the stored embeddings) -----------------------------------------------------------
  * out_vals / out_idx [rows, k]: the k largest entries of each row of scores [rows, n] (row stride ld), descending; equal

@@ -26,6 +26,12 @@
 
 #include "common.h"
 
+#ifdef LAKO_EXPERIMENTS
+#define ATTN_DBG(a, bits) ((a).dbg_flags & (bits))
+#else
+#define ATTN_DBG(a, bits) 0
+#endif
+
 namespace {
 
 constexpr int CH_MAX = 256;  // LDS-side rows per chunk
@@ -839,7 +845,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
     }
   }
   }  // batch rows of this workgroup
-  if (MODE == 0 && fast_drel && !(a.dbg_flags & 8)) {
+  if (MODE == 0 && fast_drel && !ATTN_DBG(a, 8)) {
     // Reduce the register-accumulated dS tiles over diagonals (key − query).  One LDS float atomic per element (64 per lane)
     // cost ≈95 µs per layer; instead each wave lays its 16-query × CH-key stripe out in LDS — the K / V images are dead by
     // now: 64·CH bytes per wave of the 288·CH they occupy — row q rotated by 4q floats so that both the 16-B tile writes and
@@ -880,7 +886,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
       }
     }
   }
-  if (want_drel && !(a.dbg_flags & 4)) {
+  if (want_drel && !ATTN_DBG(a, 4)) {
     __syncthreads();
     for (int i = threadIdx.x; i < a.R; i += 256) {
       float v = drel_l[i];
@@ -950,7 +956,11 @@ int run_bwd(AttnArgs& a, hipStream_t s) {
     const int nqb = (a.Lq + 15) / 16;
     q.blocks_per_wg = pick_blocks_per_wg(nqb, (int64_t)a.Bn * a.H);
     q.bn_per_wg = 1;
+#ifdef LAKO_EXPERIMENTS   // timing experiments (bits 4 / 8 drop the bias-gradient flushes: wrong results) — never in the release library
     static const int dbg = getenv("LAKO_ATTN_DEBUG") ? atoi(getenv("LAKO_ATTN_DEBUG")) : 0;
+#else
+    constexpr int dbg = 0;
+#endif
     if ((a.drel || (dbg & 1)) && a.Lk <= CH_MAX) {
       // bias gradient: one query block per wave, several batch rows per workgroup (register accumulation of dS)
       q.blocks_per_wg = 4;

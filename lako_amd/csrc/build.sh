@@ -1,24 +1,36 @@
 #!/usr/bin/env bash
 # Build liblako_hip.so for gfx950 in-tree (the .so is git-ignored but travels to the GPU box).
+#   build.sh            incremental: recompiles the sources newer than their objects
+#   build.sh --force    recompiles everything (what __graft_entry__.build() runs)
+#   LAKO_EXPERIMENTS=1 build.sh   → liblako_hip_exp.so with the timing experiments compiled in (tools/ only; objects *.exp.o)
 set -euo pipefail
 cd "$(dirname "$0")"
-OUT=../liblako_hip.so
+FORCE=0
+[ "${1:-}" = "--force" ] && FORCE=1
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-pass-failed"
+OUT=../liblako_hip.so
+SFX=o
+if [ "${LAKO_EXPERIMENTS:-0}" = "1" ]; then
+  FLAGS="$FLAGS -DLAKO_EXPERIMENTS"
+  OUT=../liblako_hip_exp.so
+  SFX=exp.o
+fi
 objs=()
 pids=()
 for f in gemm rowops attn index bertops; do
   [ -f $f.hip ] || continue
-  if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ common.h -nt $f.o ] || [ ../../include/lako_hip.h -nt $f.o ]; then
+  o=$f.$SFX
+  if [ $FORCE = 1 ] || [ ! -f $o ] || [ $f.hip -nt $o ] || [ common.h -nt $o ] || [ ../../include/lako_hip.h -nt $o ] || [ build.sh -nt $o ]; then
     extra=""
     # attention is VALU-bound on the score tiles: keep MFMA results in VGPRs (no v_accvgpr_read/write round trips)
     [ $f = attn ] && extra="-mllvm -amdgpu-mfma-vgpr-form=1"
-    $HIPCC $FLAGS $extra -c $f.hip -o $f.o &
+    $HIPCC $FLAGS $extra -c $f.hip -o $o &
     pids+=($!)
   fi
-  objs+=($f.o)
+  objs+=($o)
 done
 for p in "${pids[@]:-}"; do if [ -n "$p" ]; then wait $p || { echo "COMPILE FAILED"; exit 1; }; fi; done
 # link WITHOUT an rpath to /opt/rocm: the library must bind to the HIP runtime torch already loaded
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT "${objs[@]}"
-echo "built $(realpath $OUT)"
+echo "built $(realpath $OUT) (${#pids[@]} source(s) compiled)"

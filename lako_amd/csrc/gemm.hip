@@ -18,6 +18,16 @@
 
 #include "common.h"
 
+// Timing experiments (bench_ops / tools/*_probe.py) that produce WRONG results — K-loop DMA switched off, stores dropped or
+// redirected, cache-policy bits on the stores, atomics skipped — exist only in a build with -DLAKO_EXPERIMENTS
+// (csrc/build.sh LAKO_EXPERIMENTS=1 → liblako_hip_exp.so, never loaded by the product).  In the release library the
+// tests below are compile-time zero and lako_set_tuning rejects the keys that would set them.
+#ifdef LAKO_EXPERIMENTS
+#define NT_DBG(a, bits) ((a).debug & (bits))
+#else
+#define NT_DBG(a, bits) 0
+#endif
+
 namespace {
 
 constexpr int TM = 128, TN_ = 128, TKB = 128;  // TN-kernel tile rows / cols; K bytes per step (both kernels)
@@ -144,6 +154,7 @@ __device__ __forceinline__ u32x4 read_frag_rows(const char* lds_tile, int row, i
   return *reinterpret_cast<const u32x4*>(lds_tile + row * TKB + cp * 16);
 }
 
+#ifdef LAKO_EXPERIMENTS
 // 16-byte buffer store with run-time selectable cache-policy bits (gfx940 encoding of the builtin's aux operand: 1 = sc0, 2 = nt,
 // 16 = sc1).  EXPERIMENT, off by default ("gemm_nt_store_aux"): a round of the 256² kernel leaves 4 MB of output per XCD dirty in
 // the 4 MB L2 — the same stores aimed at one L2-resident tile (debug bit 4) run the K = 768 shapes 30 % faster, so the cost of
@@ -162,6 +173,7 @@ __device__ __forceinline__ void store_b128_policy(u32x4 v, __amdgpu_buffer_rsrc_
     default: __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, 0, 19); break;
   }
 }
+#endif
 
 // Generic epilogue in the accumulator layout (element r of lane (l&15, g) of sub-tile (mt, nt) is
 // C[m0 + (wr·MT + mt)·16 + (l&15)][n0 + (wc·NT + nt)·16 + 4g + r]): alpha, ReLU, aux mask, dropout, residual, store / atomic.
@@ -241,7 +253,7 @@ __device__ __forceinline__ void nt_store_tile(const NtArgs& a, f32x4 (&acc)[NT][
           continue;
         }
       }
-      if (!(a.debug & 8)) store4(cp, v);
+      if (!NT_DBG(a, 8)) store4(cp, v);
     }
   }
 }
@@ -313,8 +325,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
     tile_coords(has_next ? next_tile : 0, a.tiles_m, a.tiles_n, a.group_m, tm_, tn_);
     const int nm0 = tm_ * BM, nn0 = tn_ * BN;
     // debug bit 1: every workgroup streams tile (0, 0)'s operands — all requests hit L2 (timing experiment)
-    const char* Abase = a.A + ((a.debug & 2) ? 0 : (int64_t)m0 * lda_b);
-    const char* Bbase = a.B + ((a.debug & 2) ? 0 : (int64_t)n0 * ldb_b);
+    const char* Abase = a.A + (NT_DBG(a, 2) ? 0 : (int64_t)m0 * lda_b);
+    const char* Bbase = a.B + (NT_DBG(a, 2) ? 0 : (int64_t)n0 * ldb_b);
 
     f32x4 acc[NT][MT];  // element r of lane (l&15, g): C[m = mt*16 + (l&15)][n = nt*16 + 4g + r]
 #pragma unroll
@@ -328,7 +340,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
       char* An = smem + (cur ^ 1) * BUF;
       // source of the NEXT K-slice: this tile's slice t+1, or the first slice of the workgroup's next tile
       const bool more_k = t + 1 < nk;
-      const bool pf = !(a.debug & 1) && (more_k || has_next);
+      const bool pf = !NT_DBG(a, 1) && (more_k || has_next);
       const int koff = more_k ? (t + 1) * TKB : 0;
       const int pf_rows_a = more_k ? rows_a : min(BM, a.M - nm0), pf_rows_b = more_k ? rows_b : min(BN, a.N - nn0);
       const char* pf_a = more_k ? Abase + koff : a.A + (int64_t)nm0 * lda_b;
@@ -400,7 +412,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
           mma_rows(0, MT - Q);
           __builtin_amdgcn_sched_barrier(0);
           if (SIDE && t == 0 && nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // the side pass may land during the next K-step
-          else if (!(a.debug & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          else if (!NT_DBG(a, 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __syncthreads();
           __builtin_amdgcn_sched_barrier(0);
           mma_rows(MT - Q, MT);
@@ -436,7 +448,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
     // rows past the edge fall out of the descriptor's range by themselves; columns past it start from an out-of-range base
     const auto crs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(C + (int64_t)m0 * a.ldc + n0), 0,
                                                         (rows_v - 1) * ldc_b + cols_v * 2, 0x00020000);
-    const uint32_t cvb = (wc * 64 + (le & 7) * 8 < cols_v && !(a.debug & 8))
+    const uint32_t cvb = (wc * 64 + (le & 7) * 8 < cols_v && !NT_DBG(a, 8))
                              ? (uint32_t)((wr * 128 + (le >> 3)) * ldc_b + (wc * 64 + (le & 7) * 8) * 2) : 0x80000000u;
     side_issue(1, slot_b, m0, n0);
 #pragma unroll
@@ -495,7 +507,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
           bf16x8 o;
           o[0] = (bf16_t)lo[0]; o[1] = (bf16_t)lo[1]; o[2] = (bf16_t)lo[2]; o[3] = (bf16_t)lo[3];
           o[4] = (bf16_t)hi[0]; o[5] = (bf16_t)hi[1]; o[6] = (bf16_t)hi[2]; o[7] = (bf16_t)hi[3];
+#ifdef LAKO_EXPERIMENTS
           store_b128_policy(__builtin_bit_cast(u32x4, o), crs, (int)(cvb + (uint32_t)((mt * 16 + it * 8) * ldc_b)), a.store_aux);
+#else
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), crs, (int)(cvb + (uint32_t)((mt * 16 + it * 8) * ldc_b)), 0, 0);
+#endif
         }
       }
     }
@@ -552,12 +568,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
             bf16x8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+#ifdef LAKO_EXPERIMENTS
             if (a.debug & 16) *reinterpret_cast<bf16x8*>(C + (int64_t)(m - m0) * a.ldc + (n - n0)) = o;   // timing experiment: every tile stores to tile (0, 0)
             else if (a.store_aux) {   // streaming cache policy (see store_b128_policy)
               const auto crs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(C + (int64_t)m0 * a.ldc + n0), 0, 0x7fffffff, 0x00020000);
               if (!(a.debug & 8))
                 store_b128_policy(__builtin_bit_cast(u32x4, o), crs, (int)(((int64_t)(m - m0) * a.ldc + (n - n0)) * 2), a.store_aux);
-            } else if (!(a.debug & 8)) *reinterpret_cast<bf16x8*>(C + (int64_t)m * a.ldc + n) = o;
+            } else if (!(a.debug & 8))
+#endif
+            *reinterpret_cast<bf16x8*>(C + (int64_t)m * a.ldc + n) = o;
           }
         }
       }
@@ -774,153 +793,6 @@ __global__ __launch_bounds__(256) void gemm_nt_ring_kernel(NtArgs a) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the (empty) slices issued past K
   nt_store_tile<T, TO, WM, WN, MT, NT>(a, acc, m0, n0, wr, wc, lane);
-}
-
-// ---------------------------------------------------------------------------------------------
-// NT, bf16, 256×256 tile / 8 waves, DEEP pipeline.  PMC counters of the 2-buffer kernel above show the
-// MFMA pipe 35 % busy and the waves parked 42 % of the time in s_waitcnt/s_barrier: with two 64 KiB
-// buffers the LDS-DMA prefetch distance is ONE K-step (≈1 µs), too short for the ≈20 % of requests that
-// miss L2.  Here K advances in 64-BYTE slices (one 16×16×32 MFMA deep) through a 4-slot LDS ring of
-// 32 KiB stages: three slices are in flight while one is consumed, retired by a COUNTED s_waitcnt vmcnt
-// and a raw s_barrier (never vmcnt(0) in steady state).  The stream of stages is continuous across the
-// persistent workgroup's tiles, so a tile's epilogue overlaps the next tile's first three slices.
-// LDS image of a stage: [256 rows][64 B]; 16-B chunk c of row r sits at c ^ (((r >> 2) & 1) << 1)
-// (conflict-free for the ds_read_b128 lane groups); applied on the DMA source address and on the read.
-// ---------------------------------------------------------------------------------------------
-constexpr int PSB = 64, PA_BYTES = 256 * PSB, PSTAGE = 2 * PA_BYTES, PNST = 4;
-
-__device__ __forceinline__ void stage_rows64(char* lds, const char* base, int rows_valid, int64_t ld_bytes,
-                                             int kbytes_left, int wave, int lane) {
-  uint32_t nrec = (rows_valid > 0 && kbytes_left > 0)
-                      ? (uint32_t)((int64_t)(rows_valid - 1) * ld_bytes + (kbytes_left < PSB ? kbytes_left : PSB))
-                      : 0u;
-  auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)nrec, 0x00020000);
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int inst = wave + i * 8;                  // 16 wave-instructions of 16 rows each
-    const int row = inst * 16 + (lane >> 2);
-    const int c = (lane & 3) ^ (((row >> 2) & 1) << 1);
-    const bool ok = (row < rows_valid) && (c * 16 < kbytes_left);
-    const uint32_t voff = ok ? (uint32_t)(row * ld_bytes + c * 16) : 0xFFFFFFF0u;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds + inst * 1024), 16, (int)voff, 0, 0, 0);
-  }
-}
-
-__device__ __forceinline__ u32x4 read_frag64(const char* lds, int row, int g) {
-  return *reinterpret_cast<const u32x4*>(lds + row * PSB + ((g ^ (((row >> 2) & 1) << 1)) * 16));
-}
-
-template <typename TO>
-__global__ __launch_bounds__(512) void gemm_nt_pipe_kernel(NtArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
-  const int nwg = a.tiles_m * a.tiles_n;
-  const int64_t lda_b = a.lda * 2, ldb_b = a.ldb * 2;
-  const int kbytes = a.K * 2;
-  const int nk = (kbytes + PSB - 1) / PSB;
-  const int r16 = lane & 15, g = lane >> 4;
-  const int G = gridDim.x;
-  const int v = xcd_remap(blockIdx.x, G);
-  const int my_tiles = (nwg - v + G - 1) / G;
-  const int total = my_tiles * nk;          // stages this workgroup streams
-
-  // issue cursor
-  int i_tile = v, i_k = 0;
-  auto issue = [&](int s) {
-    if (s >= total) return;
-    const int m0 = (i_tile / a.tiles_n) * 256, n0 = (i_tile % a.tiles_n) * 256;
-    char* buf = smem + (s & (PNST - 1)) * PSTAGE;
-    const int koff = i_k * PSB;
-    stage_rows64(buf, a.A + (int64_t)m0 * lda_b + koff, min(256, a.M - m0), lda_b, kbytes - koff, wave, lane);
-    stage_rows64(buf + PA_BYTES, a.B + (int64_t)n0 * ldb_b + koff, min(256, a.N - n0), ldb_b, kbytes - koff, wave, lane);
-    if (++i_k == nk) {
-      i_k = 0;
-      i_tile += G;
-    }
-  };
-  issue(0);
-  issue(1);
-  issue(2);
-
-  f32x4 acc[4][8];  // [nt][mt]
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  int c_tile = v, c_k = 0;
-
-  for (int t = 0; t < total; ++t) {
-    // retire stage t: this wave's 4 DMA ops of it are the oldest outstanding; younger stages stay in flight
-    const int younger = min(total - 1 - t, 2);
-    if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();            // every wave's part of stage t has landed; stage t-1 is fully consumed
-    asm volatile("" ::: "memory");
-    issue(t + 3);                            // refill the slot stage t-1 occupied
-    const char* As = smem + (t & (PNST - 1)) * PSTAGE;
-    const char* Bs = As + PA_BYTES;
-    u32x4 af[8], bf[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) bf[nt] = read_frag64(Bs, (wc * 4 + nt) * 16 + r16, g);
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt) af[mt] = read_frag64(As, (wr * 8 + mt) * 16 + r16, g);
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) acc[nt][mt] = Mma<bf16_t>::run(bf[nt], af[mt], acc[nt][mt]);
-
-    if (++c_k < nk) continue;
-    // ---- tile finished: epilogue (registers only; the ring keeps streaming the next tile) -------------
-    c_k = 0;
-    const int m0 = (c_tile / a.tiles_n) * 256, n0 = (c_tile % a.tiles_n) * 256;
-    c_tile += G;
-    TO* C = reinterpret_cast<TO*>(a.C);
-    const TO* R = reinterpret_cast<const TO*>(a.resid);
-    const bf16_t* X = reinterpret_cast<const bf16_t*>(a.aux);
-    const bool relu = a.flags & LAKO_EPI_RELU, has_res = a.flags & LAKO_EPI_RESID,
-               auxm = a.flags & LAKO_EPI_AUXMASK, atomic = a.flags & LAKO_EPI_ATOMIC;
-    const bool drop = a.drop_thresh != 0;
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
-      const int m = m0 + (wr * 8 + mt) * 16 + r16;
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const int n = n0 + (wc * 4 + nt) * 16 + 4 * g;
-        f32x4 vv = acc[nt][mt] * a.alpha;
-        acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (m >= a.M || n >= a.N) continue;
-        if (relu) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) vv[r] = fmaxf(vv[r], 0.f);
-        }
-        if (auxm) {
-          f32x4 x = load4(X + (int64_t)m * a.ldaux + n);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) vv[r] = x[r] > 0.f ? vv[r] * a.aux_scale : 0.f;
-        }
-        if (drop) {
-          uint64_t idx = (uint64_t)(a.row0 + m) * (uint64_t)a.N + (uint64_t)n;
-          bool kp[4];
-          lako_keep4(a.drop_key, idx >> 2, a.drop_thresh, kp);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) vv[r] = kp[r] ? vv[r] * a.drop_scale : 0.f;
-        }
-        if (has_res) vv += load4(R + (int64_t)m * a.ldr + n);
-        TO* cp = C + (int64_t)m * a.ldc + n;
-        if constexpr (sizeof(TO) == 4) {
-          if (atomic) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(reinterpret_cast<float*>(cp) + r, vv[r]);
-            continue;
-          }
-        }
-        store4(cp, vv);
-      }
-    }
-  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1248,7 +1120,10 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(TnArgs a) {
     for (int row = 0; row < 16; ++row) {
       const float v = slab[row * 64 + lane];
       const int m = m0 + wr * 128 + mt * 16 + row;
-      if (m < it.M && n < it.N && !a.no_atomics) atomicAdd(it.C + (int64_t)m * it.ldc + n, v);
+      #ifdef LAKO_EXPERIMENTS
+      if (a.no_atomics) continue;
+#endif
+      if (m < it.M && n < it.N) atomicAdd(it.C + (int64_t)m * it.ldc + n, v);
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -1291,7 +1166,9 @@ void launch_nt_cfg(NtArgs a, hipStream_t s) {
   const int per_cu = (160 * 1024) / LDS > 0 ? (160 * 1024) / LDS : 1;
   int grid = a.tiles_m * a.tiles_n;
   if (g_nt_persistent && grid > 256 * per_cu) grid = 256 * per_cu;
+#ifdef LAKO_EXPERIMENTS
   if ((g_nt_debug >> 8) > 0 && grid > (g_nt_debug >> 8)) grid = g_nt_debug >> 8;   // timing experiment: fewer resident workgroups
+#endif
   // DEPHASE: every other workgroup of an XCD starts 1 µs late when the workgroups walk several tiles.  Measured (tools/bench_ops.py
   // --dephase 0,100,…): [64000,768]×[2304,768] 287 → 250 µs, o+res 140 → 134, wi 374 → 366, long launches unchanged; the size of
   // the delay (1…16 µs) and the number of phases (2, 4, 8) do not matter — the lockstep start is what costs.
@@ -1350,24 +1227,7 @@ int launch_nt(const NtArgs& a_in, hipStream_t s) {
       }
     }
   }
-  if (v == 3) {
-    if constexpr (sizeof(T) == 2) {
-      static bool attr_done = false;
-      if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_pipe_kernel<TO>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, PNST * PSTAGE);
-        attr_done = true;
-      }
-      NtArgs b = a;
-      b.tiles_m = cdiv(a.M, 256);
-      b.tiles_n = cdiv(a.N, 256);
-      int grid = b.tiles_m * b.tiles_n;
-      if (grid > 256) grid = 256;
-      hipLaunchKernelGGL((gemm_nt_pipe_kernel<TO>), dim3(grid), dim3(512), PNST * PSTAGE, s, b);
-      return 0;
-    }
-    v = 2;
-  }
+  if (v == 3) v = 2;   // (the 4-slot 256² ring kernel of round 1 measured slower and was removed)
   if (v == 5 && sizeof(T) != 2) v = 4;
   if constexpr (sizeof(T) == 2) {
     // very skinny (the decoder): 64×64 tiles, K split over the workgroup's four waves — see gemm_nt_skinny_kernel
@@ -1583,7 +1443,6 @@ extern "C" int lako_gemm_tn(const void* A, const void* B, float* C, int64_t M, i
   return LAKO_OK;
 }
 
-// Development knob (not part of the training path): select kernel variants for A/B measurements.
 extern "C" int lako_gemm_tn_grouped(const lako_gemm_tn_item_t* items, int n_items, int64_t K, int in_dtype,
                                     lako_stream_t stream) {
   LAKO_CHECK_ARG(items && n_items >= 1 && n_items <= LAKO_TN_GROUP_MAX, "lako_gemm_tn_grouped: 1..%d items", LAKO_TN_GROUP_MAX);
@@ -1641,6 +1500,8 @@ extern "C" int lako_gemm_tn_grouped(const lako_gemm_tn_item_t* items, int n_item
   return LAKO_OK;
 }
 
+// Kernel-selection knobs for A/B measurements and tests.  Every key the release build accepts selects between kernels / tilings
+// that compute the SAME result; the process-global values are meant to be set once at start-up (LAKO_TUNING), not per call.
 extern "C" int lako_set_tuning(const char* key, int value) {
   if (key && !strcmp(key, "gemm_nt_variant")) {
     g_nt_variant = value;
@@ -1654,20 +1515,27 @@ extern "C" int lako_set_tuning(const char* key, int value) {
     g_nt_ring = value;
     return 0;
   }
+#ifdef LAKO_EXPERIMENTS
   if (key && !strcmp(key, "gemm_nt_debug")) {
     g_nt_debug = value;
     return 0;
   }
+  if (key && !strcmp(key, "gemm_nt_store_aux")) {
+    g_nt_store_aux = value;
+    return LAKO_OK;
+  }
+#else
+  if (key && (!strcmp(key, "gemm_nt_debug") || !strcmp(key, "gemm_nt_store_aux") || (!strcmp(key, "gemm_tn_big") && value == 2))) {
+    lako_set_error("lako_set_tuning: '%s' is a timing experiment with wrong results / non-default cache policy; it exists only in the -DLAKO_EXPERIMENTS build", key);
+    return LAKO_E_UNSUPPORTED;
+  }
+#endif
   if (key && !strcmp(key, "gemm_nt_group_m")) {
     g_nt_group_m = value;
     return 0;
   }
   if (key && !strcmp(key, "gemm_nt_wide_epi")) {
     g_nt_wide_epi = value;
-    return LAKO_OK;
-  }
-  if (key && !strcmp(key, "gemm_nt_store_aux")) {
-    g_nt_store_aux = value;
     return LAKO_OK;
   }
   if (key && !strcmp(key, "gemm_nt_skinny")) {

@@ -508,6 +508,7 @@ __global__ __launch_bounds__(256) void greedy_step_kernel(const float* __restric
   if (threadIdx.x == 0) {
     for (int w = 1; w < 4; ++w)
       if (bv[w] > best || (bv[w] == best && bi[w] < besti)) { best = bv[w]; besti = bi[w]; }
+    if (besti >= V) besti = 0;   // a row of NaNs compares false everywhere: emit id 0 (what torch.argmax gives is unspecified), never an out-of-range id
     int64_t nxt = done[b] ? pad : besti;
     seq[(int64_t)b * seq_ld + pos] = nxt;
     next_ids[b] = nxt;
@@ -523,6 +524,83 @@ __global__ void count_done_kernel(const uint8_t* done, int B, int32_t* n_done) {
   atomicAdd(&cnt, c);
   __syncthreads();
   if (threadIdx.x == 0) n_done[0] = cnt;
+}
+
+// ---- per-fact aggregation of captured cross-attention scores (src/model.py:100-115,143-204) ----------------
+// One workgroup per sample.  vals[l] = Σ_{head, layer} scores[b, h, layer, p0·L + l] over the layers [ly0, ly0 + nly), masked
+// positions 0 (the reference's masked_fill + sum(dim=[1,2]), rounded to fp32 like its tensor).  The fact passage p0 is then cut
+// into spans ending at token id 5 ('.'), starting at index 2 (after '▁fact', ':'); an unterminated last span counts when the
+// passage is not padded; each of the first n_ctx spans is reduced by mean | max | mean of the larger half ("21mean": the
+// reference's heapq.nlargest(max(int((len+1)/2), 1))), in double and in the reference's summation order; missing facts get −5;
+// everything is divided by (layers · heads).
+__global__ __launch_bounds__(256) void fact_scores_kernel(const float* __restrict__ scores, const uint8_t* __restrict__ mask,
+                                                          const int64_t* __restrict__ ids, double* __restrict__ out, int H, int nl,
+                                                          int ly0, int nly, int N, int L, int p0, int n_ctx, int style) {
+  extern __shared__ __attribute__((aligned(16))) char fs_smem[];
+  float* vals = reinterpret_cast<float*>(fs_smem);        // [L]
+  int* tok = reinterpret_cast<int*>(vals + L);             // [L]  (only == 5 / != 0 matter)
+  int* sp = tok + L;                                       // [2·n_ctx] (start, end) + [1] count
+  const int b = blockIdx.x;
+  const int64_t S = (int64_t)N * L;
+  for (int l = threadIdx.x; l < L; l += 256) {
+    double acc = 0.0;
+    if (mask[((int64_t)b * N + p0) * L + l]) {
+      for (int h = 0; h < H; ++h)
+        for (int ly = ly0; ly < ly0 + nly; ++ly) acc += (double)scores[(((int64_t)b * H + h) * nl + ly) * S + (int64_t)p0 * L + l];
+    }
+    vals[l] = (float)acc;
+    const int64_t t = ids[((int64_t)b * N + p0) * L + l];
+    tok[l] = t == 5 ? 5 : (t == 0 ? 0 : 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int n = 0, start = 2;
+    while (n < n_ctx) {
+      int e = start;
+      while (e < L && tok[e] != 5) ++e;
+      if (e >= L) break;
+      sp[2 * n] = start;
+      sp[2 * n + 1] = e + 1;
+      ++n;
+      start = e + 1;
+    }
+    if (n < n_ctx && tok[L - 1] != 0 && L > start) {
+      sp[2 * n] = start;
+      sp[2 * n + 1] = L;
+      ++n;
+    }
+    sp[2 * n_ctx] = n;
+  }
+  __syncthreads();
+  const int nspan = sp[2 * n_ctx];
+  const double denom = (double)nly * (double)H;
+  for (int j = threadIdx.x; j < n_ctx; j += 256) {
+    double r = -5.0;
+    if (j < nspan) {
+      const int s0 = sp[2 * j], e0 = sp[2 * j + 1], len = e0 - s0;
+      if (style == 0) {           // mean
+        double a = 0.0;
+        for (int i = s0; i < e0; ++i) a += (double)vals[i];
+        r = a / (double)len;
+      } else if (style == 1) {    // max
+        double m = (double)vals[s0];
+        for (int i = s0 + 1; i < e0; ++i) m = fmax(m, (double)vals[i]);
+        r = m;
+      } else {                    // 21mean: the num largest, summed from the largest down
+        const int num = max((len + 1) / 2, 1);
+        double a = 0.0;
+        for (int rk = 0; rk < num; ++rk) {
+          for (int i = s0; i < e0; ++i) {
+            int rank = 0;
+            for (int k = s0; k < e0; ++k) rank += (vals[k] > vals[i]) || (vals[k] == vals[i] && k < i);
+            if (rank == rk) { a += (double)vals[i]; break; }
+          }
+        }
+        r = a / (double)num;
+      }
+    }
+    out[(int64_t)b * n_ctx + j] = r / denom;
+  }
 }
 
 inline int rows_grid(int64_t rows) {
@@ -731,6 +809,22 @@ extern "C" int lako_greedy_step(const float* logits, int64_t V, int B, int64_t* 
   hipLaunchKernelGGL(greedy_step_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, V, seq, seq_ld, pos,
                      next_ids, done, eos_id, pad_id);
   hipLaunchKernelGGL(count_done_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, done, B, n_done);
+  LAKO_LAUNCH_CHECK();
+  return LAKO_OK;
+}
+
+extern "C" int lako_fact_scores(const float* scores, const uint8_t* mask, const int64_t* ids, double* out, int B, int H, int n_layers,
+                                int layer0, int layers_used, int N, int L, int passage, int n_context, int style,
+                                lako_stream_t stream) {
+  LAKO_CHECK_ARG(scores && mask && ids && out, "lako_fact_scores: null tensor");
+  LAKO_CHECK_ARG(B > 0 && H > 0 && n_layers > 0 && N > 0 && L >= 3 && n_context > 0, "lako_fact_scores: bad dims");
+  LAKO_CHECK_ARG(layer0 >= 0 && layers_used > 0 && layer0 + layers_used <= n_layers, "lako_fact_scores: bad layer range");
+  LAKO_CHECK_ARG(passage >= 0 && passage < N, "lako_fact_scores: bad passage index");
+  LAKO_CHECK_ARG(style >= 0 && style <= 2, "lako_fact_scores: style 0 mean | 1 max | 2 21mean");
+  const size_t lds = (size_t)L * 8 + (size_t)(2 * n_context + 1) * 4;
+  LAKO_CHECK_ARG(lds <= 60 * 1024, "lako_fact_scores: L / n_context too large for one workgroup's LDS");
+  hipLaunchKernelGGL(fact_scores_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, scores, mask, ids, out, H, n_layers, layer0,
+                     layers_used, N, L, passage, n_context, style);
   LAKO_LAUNCH_CHECK();
   return LAKO_OK;
 }

@@ -347,15 +347,39 @@ class Engine:
         ops.gemm_nt(enc_out, self.kv_all.w, kv)
         return enc_out, kv
 
-    def _ragged_batch(self, attention_mask, B, N, L):
+    def _ragged_batch(self, attention_mask, B, N, L, lengths=None):
         """Padded positions never influence the loss, the gradients or the decoded tokens: they are masked as keys in the
         encoder's self-attention and in the decoder's cross-attention, and nothing else reads them.  When the mask has the
         tokenizer's form (valid tokens first, then padding) the encoder therefore runs on the valid tokens only — a quarter
         fewer rows in every GEMM / norm / attention at the OKVQA-like lengths of the benchmark.  Returns None (padded path)
         for LAKO_UNPAD=0, masks with holes, a sample without any valid token, or when nothing is padded.
-        One host sync per new mask tensor (lengths → host); repeated batches hit the cache."""
+
+        `lengths` (host int tensor [B, N] or [B·N]): the number of valid tokens of every passage as the collator that
+        built the mask knows it (the mask is born on the host: src/data.py:88-104 pads to text_maxlength) — asserts the
+        prefix form, so no device→host sync is needed: offsets are built on the host, uploaded from pinned memory, and the
+        packed-row index is expanded on the device.  Without it the lengths are read back from the mask (one host sync per
+        new mask tensor; repeated batches hit a cache keyed by the tensor's identity and version)."""
         if os.environ.get("LAKO_UNPAD", "1") == "0":
             return None
+        dev = attention_mask.device
+        if lengths is not None:
+            lens_h = torch.as_tensor(lengths, dtype=torch.int32, device="cpu").reshape(-1)
+            if lens_h.numel() != B * N:
+                raise ValueError(f"passage_lengths has {lens_h.numel()} entries for {B * N} passages")
+            if int(lens_h.min()) < 0 or int(lens_h.max()) > L:
+                raise ValueError("passage_lengths out of range [0, L]")
+            M = int(lens_h.sum())
+            if int(lens_h.view(B, N).sum(1).min()) <= 0 or M >= B * N * L:
+                return None
+            off = torch.zeros(B * N + 1, dtype=torch.int32)
+            torch.cumsum(lens_h, 0, out=off[1:])
+            pin = (lambda t: t.pin_memory()) if dev.type == "cuda" else (lambda t: t)
+            off_d = pin(off).to(dev, non_blocking=True)
+            # packed row r of passage j is input position j·L + (r − off[j])
+            base = torch.arange(B * N, device=dev, dtype=torch.int64) * L - off_d[:-1].long()
+            idx = torch.repeat_interleave(base, off_d[1:].long() - off_d[:-1].long(), output_size=M) + \
+                torch.arange(M, device=dev, dtype=torch.int64)
+            return _Ragged(M=M, off=off_d, soff=off_d[::N].contiguous(), idx=idx)
         key = (attention_mask.data_ptr(), attention_mask._version, B, N, L)
         hit = self._rag_cache.get(key)
         if hit is not None:
@@ -370,7 +394,6 @@ class Engine:
         if ok and int(per_sample.min()) > 0 and int(lens_h.sum()) < B * N * L:
             off = torch.zeros(B * N + 1, dtype=torch.int32)
             off[1:] = torch.cumsum(lens_h, 0)
-            dev = attention_mask.device
             rag = _Ragged(M=int(off[-1]), off=off.to(dev), soff=off[::N].contiguous().to(dev),
                           idx=m.reshape(-1).nonzero().reshape(-1))
         if len(self._rag_cache) >= 16:
@@ -378,8 +401,9 @@ class Engine:
         self._rag_cache[key] = (rag, attention_mask)      # holding the tensor keeps (data_ptr, version) unambiguous
         return rag
 
-    def forward_loss(self, input_ids, attention_mask, labels, training: bool):
-        """input_ids/attention_mask [B,N,L], labels [B,T] (−100 = ignore) → (loss 0-d fp32, logits [B,T,V] fp32)."""
+    def forward_loss(self, input_ids, attention_mask, labels, training: bool, lengths=None):
+        """input_ids/attention_mask [B,N,L], labels [B,T] (−100 = ignore) → (loss 0-d fp32, logits [B,T,V] fp32).
+        `lengths`: optional host-side valid lengths per passage (see _ragged_batch)."""
         if self.shadows_stale:
             self.refresh_shadows()
         cfg, ops = self.cfg, self.ops
@@ -396,7 +420,7 @@ class Engine:
         dr = (lambda site: (p, seed, site)) if p > 0 else (lambda site: None)
         eps = cfg.layer_norm_epsilon
         ctx.ckpt = bool(self.use_checkpoint and training)
-        rag = ctx.rag = self._ragged_batch(attention_mask, B, N, L)
+        rag = ctx.rag = self._ragged_batch(attention_mask, B, N, L, lengths)
         self._row_cap = {rag.M: B * N * L} if rag is not None else {}
         enc_ids = ctx.ids if rag is None else ctx.ids[rag.idx]
         ctx.enc_ids = enc_ids
@@ -459,12 +483,14 @@ class Engine:
             a, b = self.by_name[first_block], self.by_name[last_block]
             self.grad_hook(a.off, b.off + -(-b.numel // ALIGN) * ALIGN)
 
-    def _ffn_bwd(self, lw, dh, a1, xn, h_in, rs, ln, p, drop_out, tmp, dw=None, dy_pre=None, nxt=None):
+    def _ffn_bwd(self, lw, dh, a1, xn, h_in, rs, ln, p, drop_out, tmp, dw=None, dy_pre=None, nxt=None, role="d"):
         """residual FFN sublayer backward; dh is updated in place to the gradient wrt the sublayer input.
         `dw`: list collecting the weight-gradient problems for one grouped launch (encoder layers with dropout: their
         operands live in per-layer scratch that stays untouched until the layer's backward is complete).
         `dy_pre`: dropout_bwd(dh) already written by the RMSNorm backward that produced dh; `nxt` = (buffer, dropout) asks
-        this sublayer's RMSNorm backward to do the same for the next consumer (saves a pass over the residual gradient)."""
+        this sublayer's RMSNorm backward to do the same for the next consumer (saves a pass over the residual gradient).
+        `role` ("d" decoder / "e" encoder) names the scratch: by ROLE, never by row count — the unpadded encoder has a
+        different row count for almost every batch, and a size in the name would leave one dead buffer set per batch."""
         ops = self.ops
         M, d = dh.shape
         f = a1.shape[1]
@@ -472,19 +498,19 @@ class Engine:
         if p > 0 and dy_pre is not None:
             dy = dy_pre
         elif p > 0:
-            dy = self._buf(tmp, f"dy.ffn.{M}" if dw is not None else f"dy.{M}", (M, d))
+            dy = self._buf(tmp, f"{role}.dy.ffn" if dw is not None else f"{role}.dy", (M, d))
             ops.dropout_apply(dh, dy, drop_out)
         if dw is not None and p > 0:
             dw.append((dy, a1, lw["wo"].g, 1.0))
         else:
             ops.gemm_tn(dy, a1, lw["wo"].g)
-        dpre = self._buf(tmp, f"dpre.{M}", (M, f))
+        dpre = self._buf(tmp, f"{role}.dpre", (M, f))
         ops.gemm_nt(dy, lw["wo"].wt, dpre, aux=a1, aux_scale=1.0 / (1.0 - p))   # ∘ [relu'>0] ∘ dropout
         if dw is not None:
             dw.append((dpre, xn, lw["wi"].g, 1.0))
         else:
             ops.gemm_tn(dpre, xn, lw["wi"].g)
-        dxn = self._buf(tmp, f"dxn.{M}", (M, d))
+        dxn = self._buf(tmp, f"{role}.dxn", (M, d))
         ops.gemm_nt(dpre, lw["wi"].wt, dxn)
         ops.rmsnorm_bwd(dxn, h_in, ln.p, rs, dh, dh, ln.g, **self._nxt(nxt))
 
@@ -514,7 +540,7 @@ class Engine:
         ops.ce_fwd_bwd(ws["d.logits"], ctx.labels, self._buf(tmp, "loss2", (2,), torch.float32), dlog, upstream)
         alpha = d ** -0.5
         dh = self._buf(tmp, "d.dh", (Md, d))
-        dout = self._buf(tmp, f"dxn.{Md}", (Md, d))
+        dout = self._buf(tmp, "d.dxn", (Md, d))
         # K = vocabulary (32128) for an [Md, d] output of a handful of tiles: accumulate in fp32 with atomics so that the
         # library may split K over the idle CUs (gemm_nt_ring_kernel), then round once to the compute dtype
         dout32 = dout if dout.dtype == torch.float32 else self._buf(tmp, "d.dout32", (Md, d), torch.float32)
@@ -525,9 +551,9 @@ class Engine:
         ops.gemm_tn(dlog, ws["d.out"], self.shared.g, alpha=alpha)
         # every RMSNorm backward also writes dropout_bwd(dx) for the residual branch that consumes dx next (fused=True)
         fused = p > 0 and os.environ.get("LAKO_FUSE_DROP", "1") != "0"   # 0: separate dropout_apply launches (A/B)
-        dy_f = self._buf(tmp, f"dy.ffn.{Md}", (Md, d)) if fused else None
-        dy_c = self._buf(tmp, f"dy.c.{Md}", (Md, d)) if fused else None
-        dy_s = self._buf(tmp, f"dy.{Md}", (Md, d)) if fused else None
+        dy_f = self._buf(tmp, "d.dy.ffn", (Md, d)) if fused else None
+        dy_c = self._buf(tmp, "d.dy.c", (Md, d)) if fused else None
+        dy_s = self._buf(tmp, "d.dy", (Md, d)) if fused else None
         ops.rmsnorm_bwd(dout, ws[f"d.h{Ld}"], self.dec_final.p, ws["d.rsf"], None, dh, self.dec_final.g, dr(S_DEC_FINAL),
                         **self._nxt((dy_f, dr(_dec_site(Ld - 1, 5))) if fused else None))
         dkv = self._buf(tmp, "dkv", (Me, self.kv_all.w.shape[0]))
@@ -543,13 +569,13 @@ class Engine:
             # cross-attention
             dy = dh
             if p > 0:
-                dy = dy_c if fused else self._buf(tmp, f"dy.c.{Md}", (Md, d))
+                dy = dy_c if fused else self._buf(tmp, "d.dy.c", (Md, d))
                 if not fused:
                     ops.dropout_apply(dh, dy, dr(_dec_site(i, 3)))
                 dw.append((dy, ws[f"d.cctx.{i}"], lw["co"].g, 1.0))
             else:
                 ops.gemm_tn(dy, ws[f"d.cctx.{i}"], lw["co"].g)
-            dctx = self._buf(tmp, f"dctx.{Md}", (Md, inner))
+            dctx = self._buf(tmp, "d.dctx", (Md, inner))
             ops.gemm_nt(dy, lw["co"].wt, dctx)
             dqc = self._buf(tmp, "d.dqc", (Md, inner))
             ops.attn_bwd(self._heads(ws[f"d.qc.{i}"], B, T, 0), self._heads(kv, kb, kt, 2 * i * inner),
@@ -558,14 +584,14 @@ class Engine:
                          self._heads(dkv, kb, kt, 2 * i * inner), self._heads(dkv, kb, kt, (2 * i + 1) * inner),
                          drop=dr(_dec_site(i, 2)), **ckw)
             dw.append((dqc, ws[f"d.xn2.{i}"], lw["cq"].g, 1.0))
-            dxn = self._buf(tmp, f"dxn.{Md}", (Md, d))
+            dxn = self._buf(tmp, "d.dxn", (Md, d))
             ops.gemm_nt(dqc, lw["cq"].wt, dxn)
             ops.rmsnorm_bwd(dxn, ws[f"d.h1.{i}"], lw["ln2"].p, ws[f"d.rs2.{i}"], dh, dh, lw["ln2"].g,
                             **self._nxt((dy_s, dr(_dec_site(i, 1))) if fused else None))
             # causal self-attention
             dy = dh
             if p > 0:
-                dy = dy_s if fused else self._buf(tmp, f"dy.{Md}", (Md, d))
+                dy = dy_s if fused else self._buf(tmp, "d.dy", (Md, d))
                 if not fused:
                     ops.dropout_apply(dh, dy, dr(_dec_site(i, 1)))
                 dw.append((dy, ws[f"d.ctx.{i}"], lw["o"].g, 1.0))
@@ -573,7 +599,7 @@ class Engine:
                 ops.gemm_tn(dy, ws[f"d.ctx.{i}"], lw["o"].g)
             ops.gemm_nt(dy, lw["o"].wt, dctx)
             qkv = ws[f"d.qkv.{i}"]
-            dqkv = self._buf(tmp, f"dqkv.{Md}", (Md, 3 * inner))
+            dqkv = self._buf(tmp, "d.dqkv", (Md, 3 * inner))
             ops.attn_bwd(self._heads(qkv, B, T, 0), self._heads(qkv, B, T, inner), self._heads(qkv, B, T, 2 * inner),
                          self._heads(ws[f"d.ctx.{i}"], B, T, 0), self._heads(dctx, B, T, 0), ws[f"d.st.{i}"],
                          self._heads(dqkv, B, T, 0), self._heads(dqkv, B, T, inner), self._heads(dqkv, B, T, 2 * inner),
@@ -588,10 +614,10 @@ class Engine:
         # ---- cross K/V projection of all decoder layers -----------------------------------------
         ops.gemm_tn(dkv, ws["e.out"], self.kv_all.g)
         deh = self._buf(tmp, "e.dh", (Me, d))
-        dxe = self._buf(tmp, f"dxn.{Me}", (Me, d))
+        dxe = self._buf(tmp, "e.dxn", (Me, d))
         ops.gemm_nt(dkv, self.kv_all.wt, dxe)
-        dy_f = self._buf(tmp, f"dy.ffn.{Me}", (Me, d)) if fused else None
-        dy_s = self._buf(tmp, f"dy.{Me}", (Me, d)) if fused else None
+        dy_f = self._buf(tmp, "e.dy.ffn", (Me, d)) if fused else None
+        dy_s = self._buf(tmp, "e.dy", (Me, d)) if fused else None
         ops.rmsnorm_bwd(dxe, ws[f"e.h{Le}"], self.enc_final.p, ws["e.rsf"], None, deh, self.enc_final.g, dr(S_ENC_FINAL),
                         **self._nxt((dy_f, dr(_enc_site(Le - 1, 3))) if fused else None))
         self._ready("dec.final_ln", "enc.final_ln")
@@ -610,19 +636,19 @@ class Engine:
             # pay one fp32 atomic pass over the output per split
             dw = []
             self._ffn_bwd(lw, deh, ws[f"e.a1.{j}"], ws[f"e.xn2.{j}"], ws[f"e.h1.{j}"], ws[f"e.rs2.{j}"], lw["ln2"], p,
-                          dr(_enc_site(i, 3)), tmp, dw, dy_pre=dy_f, nxt=(dy_s, dr(_enc_site(i, 1))) if fused else None)
+                          dr(_enc_site(i, 3)), tmp, dw, dy_pre=dy_f, nxt=(dy_s, dr(_enc_site(i, 1))) if fused else None, role="e")
             dy = deh
             if p > 0:
-                dy = dy_s if fused else self._buf(tmp, f"dy.{Me}", (Me, d))
+                dy = dy_s if fused else self._buf(tmp, "e.dy", (Me, d))
                 if not fused:
                     ops.dropout_apply(deh, dy, dr(_enc_site(i, 1)))
                 dw.append((dy, ws[f"e.ctx.{j}"], lw["o"].g, 1.0))
             else:
                 ops.gemm_tn(dy, ws[f"e.ctx.{j}"], lw["o"].g)     # dy aliases deh, which the next ops rewrite
-            dctx = self._buf(tmp, f"dctx.{Me}", (Me, inner))
+            dctx = self._buf(tmp, "e.dctx", (Me, inner))
             ops.gemm_nt(dy, lw["o"].wt, dctx)
             qkv = ws[f"e.qkv.{j}"]
-            dqkv = self._buf(tmp, f"dqkv.{Me}", (Me, 3 * inner))
+            dqkv = self._buf(tmp, "e.dqkv", (Me, 3 * inner))
             hb, ht, akw = self._enc_attn_layout(rag, BN, L, ctx.mask_u8)
             ops.attn_bwd(self._heads(qkv, hb, ht, 0), self._heads(qkv, hb, ht, inner), self._heads(qkv, hb, ht, 2 * inner),
                          self._heads(ws[f"e.ctx.{j}"], hb, ht, 0), self._heads(dctx, hb, ht, 0), ws[f"e.st.{j}"],
@@ -644,7 +670,7 @@ class Engine:
     # ------------------------------------------------------------------------------------------
     # greedy decode  (HF generate: num_beams=1, do_sample=False, use_cache=True)
     # ------------------------------------------------------------------------------------------
-    def generate(self, input_ids, attention_mask, max_length: int, capture_scores: bool = False):
+    def generate(self, input_ids, attention_mask, max_length: int, capture_scores: bool = False, lengths=None):
         if self.shadows_stale:
             self.refresh_shadows()
         cfg, ops = self.cfg, self.ops
@@ -655,7 +681,7 @@ class Engine:
         ids = input_ids.reshape(-1).contiguous()
         mask_u8 = attention_mask.reshape(B * N, L).to(torch.uint8).contiguous()
         # valid tokens only (as in forward_loss) unless the raw scores are captured: those are laid out per padded position
-        rag = None if capture_scores else self._ragged_batch(attention_mask, B, N, L)
+        rag = None if capture_scores else self._ragged_batch(attention_mask, B, N, L, lengths)
         self._row_cap = {rag.M: B * N * L} if rag is not None else {}
         if rag is None:
             kb, kt, ckw = B, S, dict(key_mask=mask_u8.view(B, S))

@@ -8,13 +8,19 @@ are not on the throughput path; restated here so that `evaluate()` reports the r
   ems / includ_ems(p, golds)     max over the gold dict {answer: soft score}  (OKVQA: score = min(1, #annotators/3))
   stem_ems(p, golds, tok, stem)  first gold (by descending score) that shares a stemmed token with the prediction
 
-`normalize_answer(..., dele_sw=True)` needs the reference's ad-hoc stop-word table; pass it as `stop_words=` (the
-reference only uses that mode inside stem_ems, which train_reader.py keeps commented out).
+`normalize_answer(..., dele_sw=True)` deletes, as SUBSTRINGS, every word of the text that is in the reference's stop-word table
+(src/evaluation.py:21-28 — the values ship as data in stop_words.json, written by oracle/make_fixtures.py; `stop_words=`
+overrides it).  test_reader.py uses that mode for the stem metric and the answer-aware fact prior (test_reader.py:84-117).
 """
 from __future__ import annotations
 
+import json
+import os
 import re
 import string
+
+with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "stop_words.json"), encoding="utf-8") as _f:
+    STOP_WORDS = frozenset(json.load(_f))
 
 _ARTICLES = re.compile(r"\b(a|an|the)\b")
 _PUNCT = set(string.punctuation)
@@ -25,8 +31,7 @@ def normalize_answer(s: str, dele_sw: bool = False, stop_words=None) -> str:
     text = "".join(ch for ch in text if ch not in _PUNCT)
     text = _ARTICLES.sub(" ", text)
     if dele_sw:
-        if stop_words is None:
-            raise ValueError("dele_sw=True needs the stop-word table (stop_words=...)")
+        stop_words = STOP_WORDS if stop_words is None else stop_words
         for word in text.split():        # the reference deletes every occurrence of a stop word as a SUBSTRING
             if word in stop_words:
                 text = text.replace(word, "")

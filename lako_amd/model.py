@@ -13,12 +13,10 @@ inject a CPU test double through the private `_ops` argument — never the produ
 """
 from __future__ import annotations
 
-import heapq
 import json
 import os
 import weakref
 
-import numpy as np
 import torch
 from torch import nn
 
@@ -58,8 +56,8 @@ class FiDOutput(tuple):
 
 class _LossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, anchor, model, ids, mask, labels):
-        loss, logits = model._engine.forward_loss(ids, mask, labels, training=model.training)
+    def forward(ctx, anchor, model, ids, mask, labels, lengths):
+        loss, logits = model._engine.forward_loss(ids, mask, labels, training=model.training, lengths=lengths)
         ctx.model = model
         ctx.mark_non_differentiable(logits)
         return loss.clone(), logits
@@ -67,7 +65,7 @@ class _LossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gloss, _glogits):
         ctx.model._engine.backward(upstream=gloss.detach().float().reshape(1).contiguous())
-        return None, None, None, None, None
+        return None, None, None, None, None, None
 
 
 class FiDT5(nn.Module):
@@ -127,6 +125,13 @@ class FiDT5(nn.Module):
 
     def _apply(self, fn, recurse=True):
         new = fn(self._master)
+        if self._engine is not None and new.device == self._master.device:
+            # .cuda() / .to(same device) / .float() on a model that already has its engine: nothing moves.  The engine
+            # holds the AdamW moments of a resumed run and the data-parallel gradient hook — rebuilding it would drop both.
+            if new.data_ptr() != self._master.data_ptr():
+                self._master.copy_(new)          # fn produced a copy (e.g. a dtype round trip): keep P as the storage
+                self._mark_stale()
+            return self
         self._master = new if new.dtype == torch.float32 else new.float()
         self._engine = None
         self._rebind()
@@ -182,8 +187,10 @@ class FiDT5(nn.Module):
     # ------------------------------------------------------------------------------------------
     # reference API
     # ------------------------------------------------------------------------------------------
-    def forward(self, input_ids=None, attention_mask=None, labels=None, **kwargs):
-        """src/model.py:39-51: accepts [B,N,L] or already-flattened [B,N·L] (n_passages remembered)."""
+    def forward(self, input_ids=None, attention_mask=None, labels=None, passage_lengths=None, **kwargs):
+        """src/model.py:39-51: accepts [B,N,L] or already-flattened [B,N·L] (n_passages remembered).
+        `passage_lengths` (extension, optional): HOST int tensor [B, N] of valid tokens per passage, for masks of the
+        collator's form (valid tokens first) — lets the unpadded encoder skip the device→host read-back of the mask."""
         if input_ids is None or labels is None:
             raise ValueError("FiDT5.forward needs input_ids and labels (train_reader.py:67-71)")
         if input_ids.dim() == 3:
@@ -196,11 +203,11 @@ class FiDT5(nn.Module):
             attention_mask = torch.ones_like(ids, dtype=torch.bool)
         mask = attention_mask.reshape(B, self.n_passages, -1)
         self._get_engine()
-        loss, logits = _LossFn.apply(self._params_by_plain["shared.weight"], self, ids, mask, labels)
+        loss, logits = _LossFn.apply(self._params_by_plain["shared.weight"], self, ids, mask, labels, passage_lengths)
         return FiDOutput(loss, logits)
 
     @torch.no_grad()
-    def generate(self, input_ids, attention_mask, max_length):
+    def generate(self, input_ids, attention_mask, max_length, passage_lengths=None):
         """src/model.py:54-60 → greedy decode, int64 [B, ≤max_length] with the leading start token."""
         self.n_passages = input_ids.size(1)
         eng = self._get_engine()
@@ -208,7 +215,7 @@ class FiDT5(nn.Module):
             out, scores = eng.generate(input_ids, attention_mask, max_length, capture_scores=True)
             self._score_storage = scores
             return out
-        return eng.generate(input_ids, attention_mask, max_length)
+        return eng.generate(input_ids, attention_mask, max_length, lengths=passage_lengths)
 
     def set_checkpoint(self, use_checkpoint):
         """src/model.py:84-90: recompute each encoder block in backward from its saved input instead of keeping its
@@ -299,49 +306,26 @@ class FiDT5(nn.Module):
     def reset_score_storage(self):
         self._score_storage = None
 
-    @staticmethod
-    def _span_score(vals, start, end, style):
-        if style == "mean":
-            return sum(vals[start:end]) / (end - start)
-        if style == "max":
-            return max(vals[start:end])
-        if style == "21mean":
-            num = max(int((end - start + 1) / 2), 1)
-            return sum(heapq.nlargest(num, vals[start:end])) / num
-        raise ValueError(style)
-
     def get_crossattention_scores(self, opt, context_ids, tokenizer, context_mask):
-        """src/model.py:143-204 (stream == 2): per-fact aggregation of the stored step-0 scores → float64
-        [B, n_context].  Facts are the spans of passage 1 separated by token id 5 ('.'), starting at index 2."""
+        """src/model.py:143-204 (stream == 2): per-fact aggregation of the stored step-0 scores → float64 [B, n_context].
+        Facts are the spans of the fact passage separated by token id 5 ('.'), starting at index 2.  One launch of
+        `lako_fact_scores` (a workgroup per sample: masked head/layer sum, span cut, mean | max | 21mean) replaces the
+        reference's per-sample Python loops; the result comes back as a CPU tensor like the reference's."""
         assert opt.stream == 2
         scores = self._score_storage
         if scores is None:
             raise RuntimeError("no scores stored: call overwrite_forward_crossattention() and generate() first")
-        n_context = opt.n_context
-        if opt.use_last_half_layer_attention == "yes":
-            scores = torch.chunk(scores, 2, dim=2)[1]
-        B, H, nl, _ = scores.shape
-        N = context_mask.size(1)
-        s = scores.view(B, H, nl, N, -1).masked_fill(~context_mask[:, None, None].bool().to(scores.device), 0.0)
-        fact = torch.chunk(s, 2, dim=3)[1].sum(dim=[1, 2]).double().cpu()
-        out = []
-        for b in range(B):
-            ids = context_ids[b][1].cpu().numpy().tolist()
-            vals = fact[b][0].numpy().tolist()
-            res, start = [], 2
-            for _ in range(n_context):
-                try:
-                    end = ids.index(5, start) + 1
-                except ValueError:
-                    break
-                res.append(self._span_score(vals, start, end, opt.attention_score_style))
-                start = end
-            if len(res) < n_context and ids[-1] != 0:
-                end = len(ids)
-                if end > start:
-                    res.append(self._span_score(vals, start, end, opt.attention_score_style))
-            while len(res) < n_context:
-                res.append(-5)
-            assert len(res) == n_context
-            out.append(np.array(res))
-        return torch.from_numpy(np.array(out)) / (nl * H)
+        eng = self._get_engine()
+        B, H, nl, S = scores.shape
+        N, L = context_mask.size(1), context_mask.size(2)
+        if S != N * L:
+            raise ValueError(f"stored scores cover {S} keys, the batch has {N}x{L}")
+        # torch.chunk(·, 2): the second chunk starts at ceil(n / 2) — the later half of the layers, the fact passage(s)
+        layer0 = -(-nl // 2) if opt.use_last_half_layer_attention == "yes" else 0
+        passage = -(-N // 2)
+        dev = scores.device
+        out = torch.empty(B, opt.n_context, dtype=torch.float64, device=dev)
+        eng.ops.fact_scores(scores.contiguous(), context_mask.to(dev).to(torch.uint8).contiguous(),
+                            context_ids.to(dev).contiguous(), out, layer0=layer0, layers_used=nl - layer0, passage=passage,
+                            style=opt.attention_score_style)
+        return out.cpu()

@@ -290,6 +290,24 @@ class HipOps:
     def cast(self, src, dst):
         self._timed("cast", 0.0, lambda: check(self.lib.lako_cast(_p(src), _p(dst), src.numel(), _dt(dst), self._stream()), "lako_cast"))
 
+    # ---- per-fact aggregation of captured cross-attention scores ---------------------------
+    FACT_STYLES = {"mean": 0, "max": 1, "21mean": 2}
+
+    def fact_scores(self, scores, mask, ids, out, *, layer0, layers_used, passage, style):
+        """scores fp32 [B, H, nl, N·L], mask uint8/bool [B, N, L], ids int64 [B, N, L] → out fp64 [B, n_context]
+        (see lako_fact_scores in include/lako_hip.h; src/model.py:143-204)"""
+        B, H, nl, S = scores.shape
+        _, N, L = ids.shape
+        if scores.dtype != torch.float32 or not scores.is_contiguous() or S != N * L or out.dtype != torch.float64 or \
+                ids.dtype != torch.int64 or not ids.is_contiguous() or not mask.is_contiguous() or \
+                mask.dtype not in (torch.uint8, torch.bool) or tuple(mask.shape) != (B, N, L) or not out.is_contiguous():
+            raise LakoError("fact_scores: scores fp32 [B,H,nl,N·L], mask uint8 [B,N,L], ids int64 [B,N,L], out fp64 [B,n_context]")
+        if style not in self.FACT_STYLES:
+            raise LakoError(f"fact_scores: attention_score_style {style!r} (mean | max | 21mean)")
+        self._timed("fact_scores", 0.0, lambda: check(self.lib.lako_fact_scores(
+            _p(scores), _p(mask), _p(ids), _p(out), B, H, nl, int(layer0), int(layers_used), N, L, int(passage), out.shape[1],
+            self.FACT_STYLES[style], self._stream()), "lako_fact_scores"))
+
     # ---- exact inner-product search (SURVEY.md §8 f4) ---------------------------------------------------
     def topk(self, scores, k, out_vals, out_idx):
         """the k largest entries of every row of fp32 scores [rows, n], descending, ties in ascending index order"""

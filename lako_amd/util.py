@@ -34,18 +34,23 @@ def _model_of(params):
 
 class AdamW(torch.optim.Optimizer):
     """HF<=4 AdamW semantics (SURVEY.md A.6): m ← β1 m + (1−β1) g; v ← β2 v + (1−β2) g²;
-    p ← p − lr·m/(√v+eps); p ← p − lr·wd·p.  `correct_bias=True` is not implemented (the reference passes
-    False, src/util.py:225).  All parameter groups must share lr / weight_decay (they do: src/util.py:189-194)."""
+    p ← p − lr·m/(√v+eps); p ← p − lr·wd·p — one fused launch over the flat parameter buffer.
+    `correct_bias=True` (HF: step size lr·√(1−β2ᵗ)/(1−β1ᵗ), decay with the plain lr) and `torch_adam=True`
+    (torch.optim.Adam as the reference's `--optim adam` builds it, src/util.py:231-232: bias-corrected, eps inside the
+    corrected denominator, no decay) run on the same kernel through an equivalent (lr, eps, wd) per step:
+        torch Adam:  p −= lr/bc1 · m / (√v/√bc2 + eps)  =  lr·√bc2/bc1 · m / (√v + eps·√bc2).
+    All parameter groups must share lr / weight_decay (they do: src/util.py:189-194)."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=False,
-                 model=None):
-        if correct_bias:
-            raise NotImplementedError("correct_bias=True: the reference trains with correct_bias=False")
+                 model=None, torch_adam=False):
         params = list(params)
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, correct_bias=False))
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
+                                      correct_bias=bool(correct_bias)))
         if model is None:
             model = _model_of(p for g in self.param_groups for p in g["params"])
         self._model = model
+        self._torch_adam = bool(torch_adam)
+        self._t = 0
 
     def _find_model(self):
         return self._model
@@ -68,8 +73,18 @@ class AdamW(torch.optim.Optimizer):
             eng.opt_v = torch.zeros_like(eng.P)
         clip = getattr(model, "_pending_clip", None)
         b1, b2 = g0["betas"]
+        self._t += 1
+        lr, eps, wd = g0["lr"], g0["eps"], g0["weight_decay"]
+        if self._torch_adam or g0["correct_bias"]:
+            bc1, bc2 = 1.0 - b1 ** self._t, 1.0 - b2 ** self._t
+            step_lr = lr * (bc2 ** 0.5) / bc1
+            if self._torch_adam:
+                eps, wd = eps * (bc2 ** 0.5), 0.0
+            elif step_lr > 0:
+                wd = wd * lr / step_lr          # the kernel decays by (step size)·wd: keep HF's lr·wd
+            lr = step_lr
         eng.ops.adamw_step(eng.P, eng.G, eng.opt_m, eng.opt_v, None if eng.W is eng.P else eng.W,
-                           lr=g0["lr"], beta1=b1, beta2=b2, eps=g0["eps"], weight_decay=g0["weight_decay"],
+                           lr=lr, beta1=b1, beta2=b2, eps=eps, weight_decay=wd,
                            gnorm_sq=eng.gnorm_sq if clip is not None else None,
                            max_norm=clip if clip is not None else 0.0, grad_scale=scale)
         model._pending_clip = None
@@ -78,6 +93,7 @@ class AdamW(torch.optim.Optimizer):
 
     def state_dict(self):
         sd = super().state_dict()
+        sd["lako_step"] = self._t
         eng = self._find_model()._engine
         if eng is not None and eng.opt_m is not None:
             sd["lako_exp_avg"], sd["lako_exp_avg_sq"] = eng.opt_m.detach().cpu(), eng.opt_v.detach().cpu()
@@ -86,6 +102,7 @@ class AdamW(torch.optim.Optimizer):
     def load_state_dict(self, sd):
         sd = dict(sd)
         m, v = sd.pop("lako_exp_avg", None), sd.pop("lako_exp_avg_sq", None)
+        self._t = int(sd.pop("lako_step", 0))
         super().load_state_dict(sd)
         if m is not None:
             eng = self._find_model()._get_engine()
@@ -143,8 +160,10 @@ def set_optim(opt, model):
             {"params": [p for n, p in named if any(nd in n for nd in no_decay)], "weight_decay": opt.weight_decay},
         ]
         optimizer = AdamW(groups, lr=opt.lr, correct_bias=False, model=model)
+    elif opt.optim == "adam":        # src/util.py:231-232: torch.optim.Adam(model.parameters(), lr=opt.lr)
+        optimizer = AdamW(model.parameters(), lr=opt.lr, eps=1e-8, weight_decay=0.0, model=model, torch_adam=True)
     else:
-        raise NotImplementedError(f"--optim {opt.optim}: only adamw is fused (the reference's scripts use adamw)")
+        raise ValueError(f"--optim {opt.optim}: adam or adamw (src/options.py)")
     if opt.scheduler == "fixed":
         scheduler = FixedScheduler(optimizer)
     elif opt.scheduler == "linear":

@@ -337,9 +337,28 @@ EVAL_STRINGS = [
 ]
 
 
+from tests.util_golden import FixStem as _FixStem, FixTok as _FixTok  # noqa: E402
+
+
+STEM_STRINGS = [
+    ("what is the dog doing", {"dogs": 1.0, "running": 0.6}),
+    ("he is skiing on the snow", {"ski": 1.0, "snowboard": 0.6}),
+    ("the man rides a wave", {"surfing": 1.0, "waves": 0.3}),
+    ("yes", {"yes": 1.0, "no": 0.3}),
+    ("which and this", {"which": 1.0}),
+    ("a frisbee and the dogs", {"frisbees": 0.6, "dog": 1.0}),
+    ("bananas with apples", {"apple": 0.6, "banana": 0.6, "pear": 1.0}),
+    ("washing machine", {"wash": 0.3, "machines": 1.0}),
+    ("north america", {"america": 1.0}),
+    ("", {"nothing": 1.0}),
+]
+
+
 def make_evaluation():
-    """Golden values of the reference's answer metrics (src/evaluation.py: normalize_answer, ems, includ_ems) on
-    fixed strings; the predictions / golds are data of this repository."""
+    """Golden values of the reference's answer metrics (src/evaluation.py: normalize_answer, ems, includ_ems, stem_ems incl.
+    the stop-word mode) on fixed strings; the predictions / golds are data of this repository.  Also writes
+    lako_amd/stop_words.json: the VALUES of the reference's module-level `stop_words` table (src/evaluation.py:21-28), which
+    `normalize_answer(dele_sw=True)` deletes as substrings — a data table of the metric, de-duplicated and sorted."""
     import json
     import src.evaluation as rev
     rows = []
@@ -348,9 +367,16 @@ def make_evaluation():
                      "normalized": rev.normalize_answer(pred),
                      "golds_normalized": {k: rev.normalize_answer(k) for k in golds},
                      "ems": float(rev.ems(pred, golds)), "includ_ems": float(rev.includ_ems(pred, golds))})
+    for pred, golds in STEM_STRINGS + EVAL_STRINGS:
+        rows.append({"prediction": pred, "golds": golds, "stem": True,
+                     "normalized_sw": rev.normalize_answer(pred, True),
+                     "stem_ems": float(rev.stem_ems(pred, golds, _FixTok(), _FixStem())),
+                     "stem_ems_sw": float(rev.stem_ems(pred, golds, _FixTok(), _FixStem(), dele_sw=True))})
     with open(os.path.join(ROOT, "tests", "golden", "evaluation.json"), "w") as f:
         json.dump(rows, f, indent=1, ensure_ascii=False)
-    print("wrote evaluation.json", len(rows))
+    with open(os.path.join(ROOT, "lako_amd", "stop_words.json"), "w") as f:
+        json.dump(sorted(set(rev.stop_words)), f, ensure_ascii=False)
+    print("wrote evaluation.json", len(rows), "stop words", len(set(rev.stop_words)))
 
 
 RETRIEVER_CASES = {   # name → RetrieverConfig overrides; one tiny BERT shared by all

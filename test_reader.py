@@ -73,7 +73,7 @@ def evaluate(model, dataset, dataloader, tokenizer, opt, dir_path, stop_words=No
     exactmatch, stem_exactmatch, include_exactmatch = [], [], []
     result_json = []
     tk_tokenizer, stemmer = stem_tools()
-    sw = stop_words if stop_words is not None else ()
+    sw = stop_words          # None → the reference's table (lako_amd.evaluation.STOP_WORDS)
     device = next(model.parameters()).device
     with torch.no_grad():
         for batch in dataloader:

@@ -352,3 +352,34 @@ class RefOps:
         next_ids.copy_(nxt)
         done |= (nxt == eos_id).to(done.dtype)
         n_done[0] = int(done.sum())
+
+    # ---- per-fact aggregation (test double of lako_fact_scores: the reference's own loops, src/model.py:100-115,170-199) ----
+    def fact_scores(self, scores, mask, ids, out, *, layer0, layers_used, passage, style):
+        import heapq
+        B, H, nl, S = scores.shape
+        _, N, L = ids.shape
+        s = scores.view(B, H, nl, N, L)[:, :, layer0:layer0 + layers_used].masked_fill(~mask.bool()[:, None, None], 0.0)
+        fact = s[:, :, :, passage].sum(dim=[1, 2])
+
+        def span(vals, a, b):
+            if style == "mean":
+                return sum(vals[a:b]) / (b - a)
+            if style == "max":
+                return max(vals[a:b])
+            num = max(int((b - a + 1) / 2), 1)
+            return sum(heapq.nlargest(num, vals[a:b])) / num
+        n_ctx = out.shape[1]
+        for b in range(B):
+            toks, vals = ids[b][passage].tolist(), fact[b].tolist()
+            res, start = [], 2
+            for _ in range(n_ctx):
+                try:
+                    end = toks.index(5, start) + 1
+                except ValueError:
+                    break
+                res.append(span(vals, start, end))
+                start = end
+            if len(res) < n_ctx and toks[-1] != 0 and len(toks) > start:
+                res.append(span(vals, start, len(toks)))
+            res += [-5] * (n_ctx - len(res))
+            out[b] = torch.tensor(res, dtype=torch.float64) / (layers_used * H)

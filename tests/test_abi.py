@@ -90,3 +90,38 @@ def test_product_fails_loudly_without_library(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "_lib", None)
     with pytest.raises(_lib.LakoError, match="no CPU fallback"):
         _lib.load(str(tmp_path / "missing.so"))
+
+
+def test_release_library_rejects_timing_experiments(lib):
+    """The knobs that switch off DMA / stores / atomics (wrong results) or change the stores' cache policy exist only in
+    the -DLAKO_EXPERIMENTS build: the shipped library refuses them, so a stray LAKO_TUNING cannot corrupt training."""
+    from lako_amd import _lib
+    _lib._lib = None
+    L = _lib.load()
+    for key, val in ((b"gemm_nt_debug", 1), (b"gemm_nt_debug", 16), (b"gemm_nt_store_aux", 2), (b"gemm_tn_big", 2)):
+        assert L.lako_set_tuning(key, val) == -4, key
+        buf = ctypes.create_string_buffer(256)
+        L.lako_last_error(buf, 256)
+        assert b"LAKO_EXPERIMENTS" in buf.value
+    for key, val in ((b"gemm_nt_variant", -1), (b"gemm_nt_group_m", 8), (b"gemm_tn_big", 1), (b"gemm_nt_tail_split", 1)):
+        assert L.lako_set_tuning(key, val) == 0, key       # result-preserving kernel selection stays available
+    src = open(os.path.join(ROOT, "lako_amd", "csrc", "gemm.hip")).read() + open(os.path.join(ROOT, "lako_amd", "csrc", "attn.hip")).read()
+    assert "gemm_nt_pipe_kernel" not in src
+    # no un-gated use of the experiment bits is left in the sources
+    depth = 0
+    for line in src.splitlines():
+        t = line.strip()
+        if t.startswith("#ifdef LAKO_EXPERIMENTS"):
+            depth += 1
+        elif t.startswith("#else") or t.startswith("#endif"):
+            depth = max(depth - 1, 0) if t.startswith("#endif") or depth else depth
+        if depth == 0 and re.search(r"\ba\.debug\s*&|dbg_flags\s*&|g_nt_debug\s*>>", line):
+            assert False, f"ungated experiment test: {t}"
+
+
+def test_build_force_recompiles_every_source():
+    """__graft_entry__.build() must exercise the compiler, not just relink stale objects (build.sh --force)."""
+    script = open(os.path.join(ROOT, "lako_amd", "csrc", "build.sh")).read()
+    assert "--force" in script and "FORCE = 1" in script.replace("$FORCE", "FORCE")
+    entry = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    assert '"--force"' in entry

@@ -46,6 +46,8 @@ def test_synthetic_batch_recipe():
         assert 2 <= len(valid) <= 8 and valid[-1] == 1 and (row[len(valid):] == -100).all()
     _, m2, _ = bench.synthetic_batch(3, 5, 64, 8, 32128, seed=1, device="cpu", all_valid=True)
     assert m2.all()
+    i4, m4, l4, lens4 = bench.synthetic_batch(3, 5, 64, 8, 32128, seed=1, device="cpu", with_lengths=True)
+    assert torch.equal(i4, ids) and torch.equal(m4, mask) and torch.equal(lens4.long(), mask.sum(-1)) and not lens4.is_cuda
 
 
 @pytest.mark.gpu
@@ -66,3 +68,8 @@ def test_bench_prints_one_json_line_last(tmp_path):
     rf = out["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert {"value", "unit", "cores", "kind", "sample"} <= set(out["cpu_baseline"]) and out["cpu_baseline"]["kind"] == "port"
+    # round 2: the unpadded encoder's input preparation is inside the timed step, per-step median and the all-valid variant are on record
+    assert "in timed region" in out["config"]["ragged_prep"] and out["config"]["distinct_batches"] >= 4
+    assert out["median_step_ms"] > 0 and "traffic_source" in rf
+    av = out["all_valid"]
+    assert av["value"] > 0 and av["steps"] >= 1 and "no padding" in av["passage_lengths"]

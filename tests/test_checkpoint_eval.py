@@ -21,11 +21,29 @@ def test_answer_metrics_match_reference():
         rows = json.load(f)
     assert len(rows) >= 10
     for r in rows:
+        if r.get("stem"):
+            continue
         assert E.normalize_answer(r["prediction"]) == r["normalized"]
         for k, v in r["golds_normalized"].items():
             assert E.normalize_answer(k) == v
         assert float(E.ems(r["prediction"], r["golds"])) == r["ems"]
         assert float(E.includ_ems(r["prediction"], r["golds"])) == r["includ_ems"]
+
+
+def test_stem_ems_and_stopword_table_match_reference():
+    """stem_ems with and without the stop-word mode, and normalize_answer(dele_sw=True) on the shipped table, against
+    values the reference's own functions produced (oracle/make_fixtures.py::make_evaluation, same stand-in stemmer)."""
+    from tests.util_golden import FixStem as _FixStem, FixTok as _FixTok
+    with open(os.path.join(os.path.dirname(__file__), "golden", "evaluation.json")) as f:
+        rows = [r for r in json.load(f) if r.get("stem")]
+    assert len(rows) >= 20 and len(E.STOP_WORDS) > 300
+    hit = 0
+    for r in rows:
+        assert E.normalize_answer(r["prediction"], dele_sw=True) == r["normalized_sw"]
+        assert float(E.stem_ems(r["prediction"], r["golds"], _FixTok(), _FixStem())) == r["stem_ems"]
+        assert float(E.stem_ems(r["prediction"], r["golds"], _FixTok(), _FixStem(), dele_sw=True)) == r["stem_ems_sw"]
+        hit += r["stem_ems"] != r["stem_ems_sw"] or r["normalized_sw"] != E.normalize_answer(r["prediction"])
+    assert hit >= 3          # the stop-word mode changes something on these strings
 
 
 def test_stem_ems_and_stopword_mode():

@@ -255,3 +255,113 @@ def test_unpadded_path_equals_padded_path(name, monkeypatch):
     model(input_ids=ids, attention_mask=more, labels=labels)
     assert eng.ctx.rag is not None and eng.ctx.rag.M > int(mask.sum())
     assert eng._workspace(("train",) + tuple(ids.shape) + (labels.shape[1],))["^e.xn1.0"] is base
+
+
+def _ws_footprint(eng):
+    n, nbytes = 0, 0
+    for ws in eng._ws_cache.values():
+        for k, t in ws.items():
+            if k.startswith("^") and isinstance(t, torch.Tensor):
+                n += 1
+                nbytes += t.numel() * t.element_size()
+    return n, nbytes
+
+
+def test_workspace_constant_over_batches_with_different_token_counts():
+    """Scratch buffers are named by role, not by row count: on the unpadded path the number of valid tokens differs for
+    almost every batch, and the workspace (forward AND backward) must not grow with the number of batches seen."""
+    z, dims, w, model = build("mid_a", dropout=0.1)
+    ids, mask, labels = (torch.from_numpy(z[k]) for k in ("input_ids", "attention_mask", "labels"))
+    B, N, L = ids.shape
+    model.train()
+    g = torch.Generator().manual_seed(0)
+    seen, foot = set(), None
+    for step in range(7):
+        lens = torch.randint(1, L + 1, (B, N), generator=g)
+        m = torch.arange(L)[None, None, :] < lens[..., None]
+        model.zero_grad()
+        out = model(input_ids=ids.masked_fill(~m, 0), attention_mask=m, labels=labels)
+        out[0].backward()
+        seen.add(int(m.sum()))
+        if step == 1:
+            foot = _ws_footprint(model._engine)
+        elif step > 1:
+            assert _ws_footprint(model._engine) == foot, "workspace grew with a new valid-token count"
+    assert len(seen) >= 5
+
+
+@pytest.mark.parametrize("name", ["tiny_a", "mid_a"])
+def test_host_passage_lengths_equal_mask_readback(name):
+    """`passage_lengths` (the collator's host-side lengths) must select exactly the packing the mask read-back builds,
+    for forward/backward and for generate; degenerate inputs fall back to the padded path the same way."""
+    z, dims, w, model = build(name)
+    ids, mask, labels = (torch.from_numpy(z[k]) for k in ("input_ids", "attention_mask", "labels"))
+    lens = mask.sum(-1).to(torch.int32)
+    model.train()
+    l0, lg0, g0, eng = _run_fb(model, ids, mask, labels)
+    model.zero_grad()
+    out = model(input_ids=ids, attention_mask=mask, labels=labels, passage_lengths=lens)
+    rag = eng.ctx.rag
+    ref = eng._ragged_batch(mask, *ids.shape)
+    assert rag is not None and rag.M == ref.M
+    assert torch.equal(rag.off, ref.off) and torch.equal(rag.soff, ref.soff) and torch.equal(rag.idx, ref.idx)
+    out[0].backward()
+    assert abs(out[0].item() - l0) < 1e-7
+    torch.testing.assert_close(eng.G, g0, atol=1e-7, rtol=1e-6)
+    model.eval()
+    assert torch.equal(model.generate(input_ids=ids, attention_mask=mask, max_length=8),
+                       model.generate(input_ids=ids, attention_mask=mask, max_length=8, passage_lengths=lens))
+    assert eng._ragged_batch(torch.ones_like(mask), *ids.shape, lengths=torch.full_like(lens, ids.shape[2])) is None
+    with pytest.raises(ValueError):
+        eng._ragged_batch(mask, *ids.shape, lengths=lens[:1])
+
+
+def test_noop_move_keeps_engine_state():
+    """model.cuda()/.to(same device) after the engine exists must not drop it (AdamW moments of a resumed run and the
+    data-parallel gradient hook live there)."""
+    z, dims, w, model = build("tiny_a")
+    eng = model._get_engine()
+    eng.grad_hook = lambda lo, hi: None
+    eng.opt_m = torch.ones(4)
+    p0 = model._params_by_plain["shared.weight"].data_ptr()
+    model.to("cpu")
+    model.float()
+    assert model._engine is eng and eng.grad_hook is not None and eng.opt_m is not None
+    assert model._params_by_plain["shared.weight"].data_ptr() == p0
+
+
+@pytest.mark.parametrize("mode", ["adam", "adamw_bc"])
+def test_adam_and_bias_corrected_adamw_match_torch(mode):
+    """`--optim adam` is torch.optim.Adam(params, lr) in the reference (src/util.py:231-232); HF AdamW's correct_bias=True is
+    the bias-corrected step with the plain-lr decay.  Both run on the fused no-bias-correction kernel through an equivalent
+    (lr, eps, wd) per step — checked here against torch's own optimizers on the same gradients."""
+    z, dims, w, model = build("tiny_a")
+    eng = model._get_engine()
+    g = torch.Generator().manual_seed(0)
+    p_ref = eng.P.clone().requires_grad_(True)
+    if mode == "adam":
+        opt = types.SimpleNamespace(optim="adam", lr=3e-3, weight_decay=0.0, scheduler="fixed", fixed_lr=True)
+        ours, _ = U.set_optim(opt, model)
+        ref = torch.optim.Adam([p_ref], lr=3e-3)
+    else:
+        ours = U.AdamW(model.parameters(), lr=3e-3, eps=1e-6, weight_decay=0.05, correct_bias=True, model=model)
+        ref = None
+    m = torch.zeros_like(eng.P)
+    v = torch.zeros_like(eng.P)
+    for t in range(1, 5):
+        grad = torch.randn(eng.P.shape, generator=g) * 0.1
+        eng.G.copy_(grad)
+        ours.step()
+        if ref is not None:
+            p_ref.grad = grad.clone()
+            ref.step()
+        else:     # HF<=4 AdamW.step with correct_bias=True, written out
+            with torch.no_grad():
+                m.mul_(0.9).add_(grad, alpha=0.1)
+                v.mul_(0.999).addcmul_(grad, grad, value=0.001)
+                step_size = 3e-3 * (1 - 0.999 ** t) ** 0.5 / (1 - 0.9 ** t)
+                p_ref.addcdiv_(m, v.sqrt().add_(1e-6), value=-step_size)
+                p_ref.add_(p_ref, alpha=-3e-3 * 0.05)
+        torch.testing.assert_close(eng.P, p_ref.detach(), atol=2e-7, rtol=2e-5)
+    sd = ours.state_dict()
+    assert sd["lako_step"] == 4

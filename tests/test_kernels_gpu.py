@@ -581,3 +581,33 @@ def test_int_helpers(ops, ref):
     exp[4] = 0
     assert nxt.tolist() == exp.tolist() and nxt[2].item() == 100 and nxt[3].item() == 1
     assert seq[:, 2].tolist() == exp.tolist() and done.tolist() == [0, 0, 0, 1, 1] and nd.item() == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("style", ["mean", "max", "21mean"])
+@pytest.mark.parametrize("half", [False, True])
+def test_fact_scores_segmented_reduce(ops, ref, style, half):
+    """lako_fact_scores (per-fact aggregation of captured cross-attention scores, src/model.py:100-115,143-204) against the
+    reference's own loops (test double): terminated and unterminated last spans, a passage without any '.', padded tails,
+    more spans than n_context, ties inside a span (21mean picks by rank)."""
+    B, H, nl, N, L, n_ctx = 6, 4, 6, 2, 48, 5
+    g = torch.Generator().manual_seed(11)
+    scores = torch.randn(B, H, nl, N * L, generator=g) * 3
+    scores[2, :, :, L + 4:L + 9] = 0.25                                   # ties
+    ids = torch.randint(11, 60, (B, N, L), generator=g)
+    mask = torch.ones(B, N, L, dtype=torch.bool)
+    for b, (dots, valid) in enumerate([((7, 15, 22, 40), 41), ((9, 20), 30), ((), 48), ((5, 6, 7, 12, 19, 25, 33), 48),
+                                       ((10, 47), 48), ((3,), 4)]):
+        ids[b, 1, list(dots)] = 5
+        ids[b, 1, valid:] = 0
+        mask[b, 1, valid:] = False
+    layer0 = nl - nl // 2 if half else 0
+    want = torch.zeros(B, n_ctx, dtype=torch.float64)
+    ref.fact_scores(scores, mask, ids, want, layer0=layer0, layers_used=nl - layer0, passage=1, style=style)
+    got = torch.zeros(B, n_ctx, dtype=torch.float64, device=dev())
+    ops.fact_scores(scores.to(dev()), mask.to(dev()).to(torch.uint8), ids.to(dev()), got, layer0=layer0, layers_used=nl - layer0,
+                    passage=1, style=style)
+    # the per-position head/layer sums are rounded to fp32 in a different order (torch.sum vs an fp64 accumulation)
+    torch.testing.assert_close(got.cpu(), want, atol=2e-6, rtol=2e-6)
+    assert (got.cpu()[2] == -5.0 / ((nl - layer0) * H))[1:].all()          # no '.', not padded → ONE span, then the −5 filler
+    assert (got.cpu()[5] == -5.0 / ((nl - layer0) * H))[1:].all()

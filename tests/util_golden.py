@@ -20,3 +20,20 @@ def load_case(name):
 
 def group(z, prefix):
     return {k[len(prefix):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(prefix)}
+
+
+class FixTok:
+    """deterministic stand-ins for nltk's WordPunctTokenizer / PorterStemmer (nltk is absent here and on the GPU box): the
+    reference's stem_ems takes both as arguments, so its own code runs unchanged on them"""
+
+    def tokenize(self, s):
+        import re
+        return re.findall(r"\w+|[^\w\s]+", s)
+
+
+class FixStem:
+    def stem(self, w):
+        for suf in ("ing", "es", "s"):
+            if w.endswith(suf) and len(w) - len(suf) >= 3:
+                return w[:-len(suf)]
+        return w

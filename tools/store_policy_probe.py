@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Timing experiment: cache-policy bits on the output stores of the 256x256 NT kernel (lako_set_tuning "gemm_nt_store_aux")."""
+"""Timing experiment: cache-policy bits on the output stores of the 256x256 NT kernel (lako_set_tuning "gemm_nt_store_aux").
+Needs the experiments build: LAKO_EXPERIMENTS=1 bash lako_amd/csrc/build.sh; LAKO_LIB=lako_amd/liblako_hip_exp.so python tools/store_policy_probe.py"""
 import os
 import sys
 

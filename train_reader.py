@@ -35,7 +35,9 @@ def synthetic_loader(opt, cfg, device, n_batches):
     B, N, L, T = (int(x) for x in opt.synthetic.split(","))
     assert B == opt.per_gpu_batch_size, "--synthetic B must equal --per_gpu_batch_size"
     for i in range(n_batches):
-        yield synthetic_batch(B, N, L, T, cfg.vocab_size, seed=opt.seed + opt.global_rank * 7919 + i, device=device)
+        ids, mask, labels, lens = synthetic_batch(B, N, L, T, cfg.vocab_size, seed=opt.seed + opt.global_rank * 7919 + i,
+                                                  device=device, with_lengths=True)
+        yield dict(idx=None, ids=ids, mask=mask, labels=labels, lens=lens)
 
 
 def json_dataset(opt, path):
@@ -55,8 +57,13 @@ def json_loader(opt, ds, tokenizer, device, shuffle, with_index=False):
     dl = DataLoader(ds, sampler=RandomSampler(ds) if shuffle else SequentialSampler(ds),
                     batch_size=opt.per_gpu_batch_size, drop_last=shuffle, num_workers=2, collate_fn=col)
     for idx, labels, _, ids, mask in dl:
-        batch = (ids.to(device, non_blocking=True), mask.to(device, non_blocking=True), labels.to(device, non_blocking=True))
-        yield (idx,) + batch if with_index else batch
+        # the mask is born on the host (src/data.py:88-104: pad to text_maxlength): its per-passage lengths go along, so the
+        # unpadded encoder needs no device→host read-back; a mask that is not "valid tokens first" gets no lengths
+        lens = mask.sum(-1).to(torch.int32)
+        prefix = bool((mask == (torch.arange(mask.shape[-1])[None, None, :] < lens[..., None])).all())
+        yield dict(idx=idx if with_index else None, ids=ids.to(device, non_blocking=True),
+                   mask=mask.to(device, non_blocking=True), labels=labels.to(device, non_blocking=True),
+                   lens=lens if prefix else None)
 
 
 def evaluate(model, batches, opt, tokenizer=None, dataset=None):
@@ -68,8 +75,8 @@ def evaluate(model, batches, opt, tokenizer=None, dataset=None):
     scores = []
     with torch.no_grad():
         for batch in batches:
-            idx, (ids, mask, labels) = (batch[0], batch[1:]) if len(batch) == 4 else (None, batch)
-            out = model.generate(input_ids=ids, attention_mask=mask, max_length=50)
+            idx, ids, mask, labels = batch["idx"], batch["ids"], batch["mask"], batch["labels"]
+            out = model.generate(input_ids=ids, attention_mask=mask, max_length=50, passage_lengths=batch["lens"])
             if tokenizer is not None and dataset is not None:
                 for k, ans in enumerate(tokenizer.batch_decode(out, skip_special_tokens=True)):
                     scores.append(float(E.ems(ans, dataset.get_example(int(idx[k]))["answer"])))
@@ -139,7 +146,8 @@ def main():
         model, optimizer, scheduler, _, step, best = U.load(FiDT5, opt.model_path, opt, reset_params=True, dtype=dtype,
                                                             seed=opt.seed + opt.global_rank)
         model = model.cuda(local_rank)
-        logger.info(f"model loaded from {opt.model_path} (step {step}, best {best})")
+        logger.info(f"model loaded from {opt.model_path} (was at step {step}, best {best})")
+        step, best = 0, 0.0       # train_reader.py:266: a warm start, not a resume — counters restart like the reference's
     else:
         model = FiDT5.from_pretrained(opt.model_path, dtype=dtype, seed=opt.seed + opt.global_rank).cuda(local_rank)
         optimizer, scheduler = U.set_optim(opt, model)
@@ -151,13 +159,16 @@ def main():
 
     torch.manual_seed(opt.global_rank + opt.seed)
     model.train()
+    patience, epoch = 0, 0
     for epoch in range(1, opt.epochs + 1):
         curr_loss = torch.zeros((), device=opt.device)
         t0 = time.time()
         n = 0
-        for ids, mask, labels in train_batches(steps_per_epoch):
+        for batch in train_batches(steps_per_epoch):
             step += 1
-            train_loss = model(input_ids=ids, attention_mask=mask, labels=labels)[0]
+            ids = batch["ids"]
+            train_loss = model(input_ids=ids, attention_mask=batch["mask"], labels=batch["labels"],
+                               passage_lengths=batch["lens"])[0]
             train_loss.backward()
             U.clip_grad_norm_(model, opt.clip)
             optimizer.step()
@@ -170,16 +181,28 @@ def main():
                 break
         torch.cuda.synchronize()
         dt = time.time() - t0
+        patience += 1                       # train_reader.py:86: epochs since the dev metric last improved
         dev_em = evaluate(model, eval_batches(), opt, tokenizer, eval_ds)
+        stop = False
         if opt.is_main:
             logger.info(f"epoch {epoch} |step {step} |train loss: {curr_loss.item() / max(n, 1):.3f} |"
                         f"evaluation: {100 * dev_em:.2f}EM |lr: {scheduler.get_last_lr()[0]:.5f} |"
                         f"{n * ids.shape[0] * opt.world_size / dt:.1f} samples/s")
-            if dev_em > best:      # train_reader.py:104-107
+            if dev_em > best:      # train_reader.py:99-108
+                patience = 0
                 best = dev_em
                 U.save(model, optimizer, scheduler, step, best, opt, os.path.join(opt.checkpoint_dir, opt.name), "best_dev")
-        if opt.steps and step >= opt.steps:
+            if patience > opt.early_stop:       # train_reader.py:112-114
+                logger.info(f"early stop in epoch {epoch}")
+                stop = True
+        if opt.is_distributed:                  # rank 0 decides (only it knows `best`); everyone leaves together
+            flag = torch.tensor([int(stop)], device=opt.device)
+            dist.broadcast(flag, 0)
+            stop = bool(flag.item())
+        if stop or (opt.steps and step >= opt.steps):
             break
+    if opt.is_main:
+        logger.info(f"stop epoch {epoch} |evaluation: {100 * best:.2f}EM |")
     if opt.is_distributed:
         dist.destroy_process_group()
 
