@@ -19,101 +19,9 @@
 // mask (0 / −FLT_MAX / −inf, exactly HF's "scores + finfo.min") are folded into the MFMA accumulator
 // INIT, the causal mask is one select, and dropout draws two 16-bit keep decisions from one 32-bit hash.
 // bf16: v_mfma_f32_16x16x32_bf16; fp32 (parity mode): v_mfma_f32_16x16x4_f32.
-#include <float.h>
-#include <stdlib.h>
-
-#include <type_traits>
-
-#include "common.h"
-
-#ifdef LAKO_EXPERIMENTS
-#define ATTN_DBG(a, bits) ((a).dbg_flags & (bits))
-#else
-#define ATTN_DBG(a, bits) 0
-#endif
+#include "attn_shared.h"
 
 namespace {
-
-constexpr int CH_MAX = 256;  // LDS-side rows per chunk
-constexpr int OFFS_MAX = 64; // batch rows per workgroup (+1) whose ragged offsets are staged in LDS
-
-template <typename T, int DK> struct AC {
-  static constexpr int ES = sizeof(T);
-  static constexpr int ROWB = DK * ES + 16;   // padded LDS row
-  static constexpr int CPR = DK * ES / 16;    // 16-B chunks per row
-  static constexpr int NF = DK * ES / 64;     // fragment steps along d (4 lane groups × 16 B)
-  static constexpr int NDB = DK / 16;         // 16-wide output blocks along d
-};
-
-struct AttnArgs {
-  const char *q, *k, *v, *o, *dout;
-  char *out, *dq, *dk, *dv;
-  float* stats;        // [Bn, H, Lq, 4] = (row max, 1 / row sum, delta = rowsum(dO∘O) [written by the dQ pass], -)
-  const float* rel_bias;
-  float* drel;
-  const uint8_t* key_mask;
-  float* scores_out;
-  // ragged (unpadded) sequences: rows of sequence b are rows [off[b], off[b+1]) of ONE packed [rows, H·dk] buffer (the batch
-  // stride is ignored); Lq / Lk are then the maxima (grid sizing, statistics and dropout indexing stay in padded coordinates)
-  const int32_t *q_off, *k_off;
-  int64_t qsb, qst, ksb, kst, vsb, vst, osb, ost;  // strides in elements
-  int R, rel_off, causal, causal_off;
-  int Bn, H, Lq, Lk;
-  int chunk_rows;     // LDS-side rows per chunk (multiple of 32, <= CH_MAX)
-  int blocks_per_wg;  // register-side 16-row blocks per workgroup
-  int bn_per_wg;      // dQ pass: batch rows walked by one workgroup (bias-gradient register accumulation)
-  int dbg_flags;      // timing experiments (LAKO_ATTN_DEBUG): bit 2 = skip the global bias-gradient flush, bit 3 = skip the LDS flush too
-  int grid_x, grid_z; // dQ pass, grid_x > 0: 1-D XCD-grouped grid standing for (grid_x, H, grid_z) — see attn_bwd_kernel
-  uint32_t drop_t16, drop_key;   // attention dropout: keep iff 16-bit half >= drop_t16 (0 = off)
-  float drop_scale;
-};
-
-// f(integral_constant<int, 0>) … f(integral_constant<int, N-1>): a compile-time-indexed unrolled loop
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (N > 0) {
-    static_for<N - 1>(f);
-    f(std::integral_constant<int, N - 1>{});
-  }
-}
-
-template <int N> using FragArr = u32x4[N];
-template <int N> using AccArr = f32x4[N];
-
-template <typename T> struct Mma16;
-template <> struct Mma16<bf16_t> {
-  static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
-                                                   0, 0);
-  }
-};
-template <> struct Mma16<float> {
-  static __device__ __forceinline__ f32x4 run(u32x4 a, u32x4 b, f32x4 c) {
-    f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[e], c, 0, 0, 0);
-    return c;
-  }
-};
-
-// Attention-probability dropout: the four elements (row, 4c … 4c+3) of a score row share ONE hash,
-//   h = hash32(key ^ (row·⌈Lk/4⌉ + c)),  w = h · 0x9E3779B1 (low 32 bits);
-// their 16-bit draws are h>>16, h&0xffff, w>>16, w&0xffff; keep iff draw >= round(p·65536).  Compared without
-// extracting the fields: x>>16 >= t  ⟺  x >= t<<16,  x&0xffff >= t  ⟺  x<<16 >= t<<16.
-// (tests/ref_ops.py carries the same integer recipe; measured keep rate / neighbour correlations: DESIGN.md §4.)
-struct QuadDraw { uint32_t h, w; };
-__device__ __forceinline__ QuadDraw quad_hash(uint32_t key, uint32_t quad_idx) {
-  QuadDraw d;
-  d.h = lako_hash32(quad_idx ^ key);
-  d.w = d.h * 0x9E3779B1u;
-  return d;
-}
-__device__ __forceinline__ void quad_keep(QuadDraw d, uint32_t t_hi, bool (&k)[4]) {
-  k[0] = d.h >= t_hi;
-  k[1] = (d.h << 16) >= t_hi;
-  k[2] = d.w >= t_hi;
-  k[3] = (d.w << 16) >= t_hi;
-}
 
 // Stage rows [r0, r0 + nrows) of a strided [L, ·] tensor into a padded LDS image; rows >= L are
 // zero-filled (so padded keys/queries contribute exact zeros).  8 independent loads in flight per thread.
@@ -262,6 +170,7 @@ __device__ __forceinline__ void fwd_chunk(const AttnArgs& a, const char* Kimg, c
   using C = AC<T, DK>;
   const int g = lane >> 4;
   const bool has_bias = bias_l != nullptr;
+  const DropRow drc = drop_row_consts(qi);
   f32x4 s[2 * NP];
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
@@ -319,7 +228,7 @@ __device__ __forceinline__ void fwd_chunk(const AttnArgs& a, const char* Kimg, c
     if (a.drop_t16) {
       const int row0 = (tp0 + (t >> 1) * tstride) * 32 + (t & 1) * 16;
       bool kp[4];
-      quad_keep(quad_hash(a.drop_key, prow + (uint32_t)((kc0 + row0 + 4 * g) >> 2)), t_hi, kp);
+      drop_keep_row(drop_base(prow + (uint32_t)((kc0 + row0 + 4 * g) >> 2), a.drop_key), drc, t_hi, kp);
 #pragma unroll
       for (int r = 0; r < 4; ++r) pr[r] = kp[r] ? pr[r] * a.drop_scale : 0.f;
     }
@@ -369,7 +278,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   const bool has_bias = a.rel_bias != nullptr;
   if (has_bias)
     for (int i = threadIdx.x; i < a.R; i += 256) bias_l[i] = a.rel_bias[(int64_t)h * a.R + i];
-  const int hq = (a.Lk + 3) >> 2;   // dropout quads per score row
+  const int hq = (a.Lk + 3) >> 2, hqq = (a.Lq + 3) >> 2;   // dropout blocks per score row / per score column (padded coordinates)
   const uint32_t t_hi = a.drop_t16 << 16;
 
   // Key-split mode: a workgroup that owns a single 16-query block (cross-attention, decode steps) lets its
@@ -401,7 +310,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
     for (int db = 0; db < C::NDB; ++db) oacc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int jmax = a.causal ? qi + a.causal_off : 0x7fffffff;       // keys j > jmax are causally masked
-    const uint32_t prow = (uint32_t)((b * a.H + h) * a.Lq + qi) * (uint32_t)hq;  // dropout quad index of (qi, key 0)
+    const uint32_t prow = (uint32_t)((b * a.H + h) * hqq + (qi >> 2)) * (uint32_t)hq;  // dropout block index of (qi, key 0)
 
     for (int ch = 0; ch < nchunks; ++ch) {
       const int kc0 = ch * CH;
@@ -564,7 +473,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
     for (int i = threadIdx.x; i < a.R; i += 256) bias_l[i] = a.rel_bias[(int64_t)h * a.R + i];
   if (want_drel)
     for (int i = threadIdx.x; i < a.R; i += 256) drel_l[i] = 0.f;
-  const int hq = (a.Lk + 3) >> 2;
+  const int hq = (a.Lk + 3) >> 2, hqq = (a.Lq + 3) >> 2;
   const uint32_t t_hi = a.drop_t16 << 16;
 
   // key-split (dQ pass only): a workgroup owning one query block shares it between its 4 waves, which split the
@@ -773,18 +682,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
           f32x4 pd = p, dpd = dp;
           if (a.drop_t16) {
             bool kp[4];
-            if constexpr (MODE == 0) {   // 4 consecutive keys of one query: one quad
-              quad_keep(quad_hash(a.drop_key, (uint32_t)((b * a.H + h) * a.Lq + yi) * (uint32_t)hq + (uint32_t)(x_first >> 2)),
-                        t_hi, kp);
-            } else {                      // one key, 4 consecutive queries: this lane's draw of four different quads
-              const bool use_w = (yi & 2) != 0;
-              const uint32_t sh = (uint32_t)(yi & 1) * 16u;
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const QuadDraw d = quad_hash(a.drop_key, (uint32_t)((b * a.H + h) * a.Lq + x_first + r) * (uint32_t)hq +
-                                                             (uint32_t)(yi >> 2));
-                kp[r] = ((use_w ? d.w : d.h) << sh) >= t_hi;
-              }
+            if constexpr (MODE == 0) {   // 4 consecutive keys of one query: one block row (2 words)
+              drop_keep_row(drop_base((uint32_t)((b * a.H + h) * hqq + (yi >> 2)) * (uint32_t)hq + (uint32_t)(x_first >> 2), a.drop_key),
+                            drop_row_consts(yi), t_hi, kp);
+            } else {                      // one key, 4 consecutive queries: one block column (4 words)
+              drop_keep_col(drop_base((uint32_t)((b * a.H + h) * hqq + (x_first >> 2)) * (uint32_t)hq + (uint32_t)(yi >> 2), a.drop_key),
+                            drop_col_consts(yi), t_hi, kp);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -1015,8 +918,8 @@ int check_common(const char* fn, int Bn, int H, int Lq, int Lk, int d_head, int 
   }
   if (rel_bias && !(R > 0 && R <= 4096)) { lako_set_error("%s: bad R=%d", fn, R); return LAKO_E_BADARG; }
   if (!(p >= 0.f && p < 1.f)) { lako_set_error("%s: dropout p out of range", fn); return LAKO_E_BADARG; }
-  if (p > 0.f && (int64_t)Bn * H * Lq * ((Lk + 1) / 2) >= (1ll << 32)) {
-    lako_set_error("%s: dropout pair index exceeds 32 bits", fn);
+  if (p > 0.f && (int64_t)Bn * H * ((Lq + 3) / 4) * ((Lk + 3) / 4) >= (1ll << 32)) {
+    lako_set_error("%s: dropout block index exceeds 32 bits", fn);
     return LAKO_E_UNSUPPORTED;
   }
   return LAKO_OK;
@@ -1074,7 +977,8 @@ extern "C" int lako_attn_fwd(const lako_attn_fwd_t* p, lako_stream_t stream) {
   LAKO_CHECK_ARG(!(p->scores_out && (p->q_off || p->k_off)), "lako_attn_fwd: score capture needs the padded layout");
   LAKO_CHECK_ARG(!(p->key_mask && p->k_off), "lako_attn_fwd: ragged keys carry no padding — pass key_mask = NULL");
   set_drop(a, p->drop);
-  ATTN_DISPATCH(p->dtype, p->d_head, run_fwd, a, (hipStream_t)stream);
+  if (lako_attn_enc_supported(a, p->dtype, p->d_head)) lako_attn_enc_fwd(a, (hipStream_t)stream);
+  else ATTN_DISPATCH(p->dtype, p->d_head, run_fwd, a, (hipStream_t)stream);
   LAKO_LAUNCH_CHECK();
   return LAKO_OK;
 }
@@ -1110,7 +1014,8 @@ extern "C" int lako_attn_bwd(const lako_attn_bwd_t* p, lako_stream_t stream) {
   a.k_off = p->k_off;
   LAKO_CHECK_ARG(!(p->key_mask && p->k_off), "lako_attn_bwd: ragged keys carry no padding — pass key_mask = NULL");
   set_drop(a, p->drop);
-  ATTN_DISPATCH(p->dtype, p->d_head, run_bwd, a, (hipStream_t)stream);
+  if (lako_attn_enc_supported(a, p->dtype, p->d_head)) lako_attn_enc_bwd(a, (hipStream_t)stream);
+  else ATTN_DISPATCH(p->dtype, p->d_head, run_bwd, a, (hipStream_t)stream);
   LAKO_LAUNCH_CHECK();
   return LAKO_OK;
 }

@@ -1,0 +1,661 @@
+// Fast path of the T5 attention (HF5:144-173,281-369; src/model.py:286-349): bf16, d_head 64, at most 256 keys per sequence,
+// no causal mask, no score capture — the ENCODER self-attention of the FiD reader, which is 96 % of the attention work of a
+// training step (B·N passages × H heads of ≤ text_maxlength tokens).  Same math, same launch contract and the same dropout
+// recipe as the generic kernels of attn.hip (which keep every other case: fp32 parity mode, d_head 32, causal decoder
+// self-attention, key-split cross-attention over N·L keys, score capture).
+//
+// Why a second implementation: the generic kernels issue ≈27 vector instructions per score element in the forward and
+// ≈36 / 40 in the two backward passes (rocprofv3 SQ_INSTS_VALU ÷ MFMA count, profiles/r02a_attn_pmc.txt) against 4–8 MFMAs
+// per 16×16 tile: they are bound by vector issue, and a third of their LDS cycles are bank conflicts.  Here
+//   * the K / V / Q / dO images in LDS are unpadded 128-byte rows whose 32-byte slots are XOR-swizzled by (row >> 1) & 3:
+//     conflict-free for BOTH access patterns an image sees — ds_read_b128 row fragments (score products) and
+//     ds_read_b64_tr_b16 transposed fragments (P·V, dSᵀ·K, Pᵀ·dO, dSᵀ·Q) — with per-lane offsets that are loop constants;
+//   * the relative-position bias is the MFMA accumulator's initial value, read as ONE aligned 16-byte LDS vector per tile
+//     from four copies of the [2L−1] table shifted by 0..3 floats (key − query changes by 16 per tile, so the copy a lane
+//     needs and its base address are constants of the 16-row block; no index clamps, no per-element gathers);
+//   * exp(s − m) is v_fma + v_exp (base-2 domain), the normaliser and the dropout scale are folded into per-row factors;
+//   * dropout draws come from the full-rate block hash of attn_shared.h (no 32-bit multiplies);
+//   * no key mask: sequences are ragged (packed rows + offsets, the training path) or exactly Lk long, so only the LAST tile
+//     pair of a sequence can hold keys past its end — a −inf vector built in registers; launches with a key mask (the padded
+//     path: LAKO_UNPAD=0, masks with holes) stay on the generic kernels.
+// Occupancy is what these kernels are bound by (rocprofv3: with 8 waves per CU every wave waits half of its cycles and the
+// vector pipes are a third busy; the work does not get faster by issuing fewer instructions, it gets faster with more waves):
+// the forward and the dK/dV pass run 8 waves per workgroup on one staged image pair — 16 waves per CU, ≤ 128 registers —
+// and the dQ pass stages K / V ONCE per (sequence, head) for all its query blocks (attn.hip: once per 4 blocks).
+// Structure as in attn.hip: one workgroup (4 waves) per (sequence, head[, block group]); one operand side staged in LDS, the
+// other held per wave as MFMA fragments loaded straight from HBM; the score tile leaves the MFMA with the LDS-side index in
+// the accumulator registers, so it is directly the B operand of the product that contracts over that index.
+#include "attn_shared.h"
+
+namespace {
+
+constexpr int EROW = 128;                 // bytes per image row: 64 bf16, unpadded
+constexpr int EB_PADLO = 16;              // bias table: entries in front of index 0 (queries past Lq in the last block)
+constexpr int EB_ST = 592;                // floats per shifted copy: ≥ 511 + 16 + 36, ≡ 16 (mod 64) → the 4 copies sit 16 banks apart
+constexpr float LOG2E = 1.4426950408889634f;
+
+// 16-byte chunk c (0..7) of image row r lives at chunk position ((c >> 1) ^ ((r >> 1) & 3)) << 1 | (c & 1)
+__device__ __forceinline__ int eswz(int c, int r) { return ((((c >> 1) ^ ((r >> 1) & 3)) << 1) | (c & 1)); }
+
+// Stage rows [0, nrows) of a strided [L, 64] bf16 tensor into a swizzled image; rows >= L are zero-filled.
+template <int NT = 256>
+__device__ __forceinline__ void estage(char* img, const char* base, int64_t stride_b, int nrows, int L) {
+  const int total = nrows * 8;
+  for (int idx0 = threadIdx.x; idx0 < total; idx0 += NT * 8) {
+    u32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = idx0 + u * NT;
+      const int row = idx >> 3, c = idx & 7;
+      v[u] = u32x4{0u, 0u, 0u, 0u};
+      if (idx < total && row < L) v[u] = *reinterpret_cast<const u32x4*>(base + (int64_t)row * stride_b + c * 16);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = idx0 + u * NT;
+      const int row = idx >> 3, c = idx & 7;
+      if (idx < total) *reinterpret_cast<u32x4*>(img + row * EROW + eswz(c, row) * 16) = v[u];
+    }
+  }
+}
+
+// The four shifted copies of the (optionally reversed) bias table of head h:  copy c, float j  =  T'[j + c],
+// T'[t] = rel_bias[h][t − PADLO] inside [0, R) and 0 outside (only masked keys / discarded queries ever read the padding);
+// REV: T' is read backwards, T'rev[t] = T'[last − t] (the dK/dV pass walks key − query downwards along the registers).
+template <int NT = 256>
+__device__ __forceinline__ void estage_bias(float* b4, const float* rel_bias, int h, int R, bool rev) {
+  const int last = R - 1 + EB_PADLO + 36;
+  for (int i = threadIdx.x; i < 4 * EB_ST; i += NT) {
+    const int c = i / EB_ST, j = i - c * EB_ST;
+    int t = j + c;
+    if (rev) t = last - t;
+    t -= EB_PADLO;
+    b4[i] = (rel_bias != nullptr && t >= 0 && t < R) ? rel_bias[(int64_t)h * R + t] : 0.f;
+  }
+}
+
+__device__ __forceinline__ float egroup_max(float v) {  // across the 4 lane groups (same lane & 15)
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float egroup_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+__device__ __forceinline__ void eload_frags(u32x4 (&f)[2], const char* base, int64_t stride_b, int row, int L, int g) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (row < L) v = *reinterpret_cast<const u32x4*>(base + (int64_t)row * stride_b + (i * 4 + g) * 16);
+    f[i] = v;
+  }
+}
+
+__device__ __forceinline__ f32x4 emma(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// tile[image row row0 + 4g + r][register side = lane & 15] = init + Σ_d X[row0 + ·][d]·Y[·][d];  roff[i]: the lane's byte
+// offset of fragment step i inside the 16-row block (a constant of the lane: the swizzle key repeats every 8 rows)
+__device__ __forceinline__ f32x4 escore(const char* img, int row0, const u32x4 (&yf)[2], const uint32_t (&roff)[2], f32x4 acc) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) acc = emma(*reinterpret_cast<const u32x4*>(img + row0 * EROW + roff[i]), yf[i], acc);
+  return acc;
+}
+
+// acc[db][r] (d = 16·db + 4g + r, register side = lane & 15) += Σ_{32 rows from row0} X[row][d]·w[row][lane & 15]: w0 / w1 are
+// the two 16-row tiles at row0 and row0 + 16; toff[db]: the lane's byte offset of its transposed 8-byte read in the block
+__device__ __forceinline__ void epv(f32x4 (&acc)[4], f32x4 w0, f32x4 w1, const char* img, int row0, const uint32_t (&toff)[4]) {
+  bf16x8 bfrag;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    bfrag[e] = (bf16_t)w0[e];
+    bfrag[4 + e] = (bf16_t)w1[e];
+  }
+#pragma unroll
+  for (int db = 0; db < 4; ++db) {
+    const char* ap = img + row0 * EROW + toff[db];
+    s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ap));
+    s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ap + 16 * EROW));
+    u32x2 u0 = __builtin_bit_cast(u32x2, t0), u1 = __builtin_bit_cast(u32x2, t1);
+    u32x4 afrag = {u0[0], u0[1], u1[0], u1[1]};
+    acc[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, afrag), bfrag, acc[db], 0, 0, 0);
+  }
+}
+
+struct ELane {          // loop-invariant per-lane addressing
+  uint32_t roff[2];     // row-fragment reads (ds_read_b128)
+  uint32_t toff[4];     // transposed reads (ds_read_b64_tr_b16)
+};
+__device__ __forceinline__ ELane elane(int lane) {
+  ELane e;
+  const int l15 = lane & 15, g = lane >> 4, qq = l15 >> 2, pp = l15 & 3;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) e.roff[i] = (uint32_t)(l15 * EROW + eswz(i * 4 + g, l15) * 16);
+  const int tr = 4 * g + qq;                      // row inside the 16-row block
+#pragma unroll
+  for (int db = 0; db < 4; ++db) e.toff[db] = (uint32_t)(tr * EROW + ((db ^ ((tr >> 1) & 3)) << 5) + pp * 8);
+  return e;
+}
+
+// DPP move of a float inside 16-lane rows (CTRL: 0x100 + n row_shl:n — lane j reads lane j + n; 0x110 + n row_shr:n — lane j
+// reads lane j − n); lanes whose source lies outside the row read 0
+template <int CTRL>
+__device__ __forceinline__ float edpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// −inf for keys past the sequence's end in tile `t` (rows t·16 + 4g + r), 0 elsewhere
+__device__ __forceinline__ f32x4 etail(int t, int g, int Lk) {
+  f32x4 v;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = (t * 16 + 4 * g + r < Lk) ? 0.f : -INFINITY;
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward: 16 queries of one wave against the staged K / V, keys in chunks of at most 4 tile pairs (online softmax across the
+// two chunks a sequence of <= 256 keys can have: the score tiles of a chunk are 32 registers, the kernel fits 128)
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool DROP, int NPC>
+__device__ __forceinline__ void efwd_chunk(const char* Kimg, const char* Vimg, int pair0, bool last, const f32x4 (&tail)[2],
+                                           const float* bptr, const u32x4 (&qf)[2], const ELane& el, uint32_t pblk, uint32_t dkey,
+                                           const DropRow& drc, uint32_t t_hi, float& m_run, float& l_run, f32x4 (&oacc)[4]) {
+  f32x4 s[2 * NPC];
+#pragma unroll
+  for (int t = 0; t < 2 * NPC; ++t) {
+    const int row0 = (pair0 * 2 + t) * 16;
+    f32x4 init = *reinterpret_cast<const f32x4*>(bptr + row0);
+    if (t >= 2 * NPC - 2) {
+      if (last) init += tail[t - (2 * NPC - 2)];
+    }
+    s[t] = escore(Kimg, row0, qf, el.roff, init);
+  }
+  float m = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < 2 * NPC; ++t) m = fmaxf(fmaxf(m, fmaxf(s[t][0], s[t][1])), fmaxf(s[t][2], s[t][3]));
+  m = fmaxf(egroup_max(m), m_run);
+  const float alpha = __builtin_amdgcn_exp2f((m_run - m) * LOG2E);       // first chunk: exp2(−inf) = 0
+  const float mneg = -m * LOG2E;
+  float psum = 0.f;
+#pragma unroll
+  for (int t = 0; t < 2 * NPC; ++t) {
+    f32x4 pr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      pr[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], LOG2E, mneg));
+      psum += pr[r];
+    }
+    if (DROP) {
+      bool kp[4];
+      drop_keep_row(drop_base(pblk + (uint32_t)((pair0 * 2 + t) * 4), dkey), drc, t_hi, kp);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pr[r] = kp[r] ? pr[r] : 0.f;
+    }
+    s[t] = pr;
+  }
+  l_run = l_run * alpha + psum;           // per-lane partial (its 4 key columns); summed over the lane groups at the end
+  m_run = m;
+  if (pair0 > 0) {
+#pragma unroll
+    for (int db = 0; db < 4; ++db) oacc[db] *= alpha;
+  }
+#pragma unroll
+  for (int p = 0; p < NPC; ++p) epv(oacc, s[2 * p], s[2 * p + 1], Vimg, (pair0 + p) * 32, el.toff);
+}
+
+constexpr int FWD_NW = 8;     // waves per forward workgroup: 2 workgroups (133 KB of LDS) = 16 waves per CU, 4 per SIMD
+// LDS: K image | V image | 4 bias copies
+__host__ __device__ constexpr int efwd_lds(int rows) { return 2 * rows * EROW + 4 * EB_ST * 4; }
+
+template <bool DROP>
+__global__ __launch_bounds__(FWD_NW * 64, FWD_NW / 2) void enc_fwd_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int R = a.chunk_rows;
+  char* Kimg = smem;
+  char* Vimg = smem + R * EROW;
+  float* b4 = reinterpret_cast<float*>(smem + 2 * R * EROW);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, l15 = lane & 15;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = a.q_off ? __builtin_amdgcn_readfirstlane(a.q_off[b]) : 0;
+  const int k0 = a.k_off ? __builtin_amdgcn_readfirstlane(a.k_off[b]) : 0;
+  const int Lq = a.q_off ? __builtin_amdgcn_readfirstlane(a.q_off[b + 1]) - q0 : a.Lq;
+  const int Lk = a.k_off ? __builtin_amdgcn_readfirstlane(a.k_off[b + 1]) - k0 : a.Lk;
+  const int qb_begin = blockIdx.x * a.blocks_per_wg;
+  const int qb_end = min((Lq + 15) >> 4, qb_begin + a.blocks_per_wg);
+  if (qb_begin >= qb_end || Lk <= 0) return;            // nothing to write (ragged: a short or empty sequence)
+  const int64_t hoff = (int64_t)h * 64;
+  const char* qbase = a.q + ((a.q_off ? (int64_t)q0 * a.qst : (int64_t)b * a.qsb) + hoff) * 2;
+  const char* kbase = a.k + ((a.k_off ? (int64_t)k0 * a.kst : (int64_t)b * a.ksb) + hoff) * 2;
+  const char* vbase = a.v + ((a.k_off ? (int64_t)k0 * a.vst : (int64_t)b * a.vsb) + hoff) * 2;
+  char* obase = a.out + ((a.q_off ? (int64_t)q0 * a.ost : (int64_t)b * a.osb) + hoff) * 2;
+  const int np = (Lk + 31) >> 5;                        // tile pairs; only the last can hold keys past the end
+  const int nk = np << 5;
+  estage<FWD_NW * 64>(Kimg, kbase, a.kst * 2, nk, Lk);
+  estage<FWD_NW * 64>(Vimg, vbase, a.vst * 2, nk, Lk);
+  estage_bias<FWD_NW * 64>(b4, a.rel_bias, h, a.R, false);
+  __syncthreads();
+  const ELane el = elane(lane);
+  const uint32_t t_hi = a.drop_t16 << 16;
+  const int KB = (a.Lk + 3) >> 2, QB = (a.Lq + 3) >> 2;
+  const float oscale = DROP ? a.drop_scale : 1.0f;
+  const f32x4 tail[2] = {etail(2 * np - 2, g, Lk), etail(2 * np - 1, g, Lk)};
+  const int npa = min(np, 4), npb = np - npa;           // chunk A: pairs [0, npa), chunk B: [4, 4 + npb)
+
+  u32x4 qf_next[2];
+  auto request_q = [&](int qbn) { eload_frags(qf_next, qbase, a.qst * 2, qbn < qb_end ? qbn * 16 + l15 : Lq, Lq, g); };
+  request_q(qb_begin + wave);
+  for (int qb = qb_begin + wave; qb < qb_end; qb += FWD_NW) {
+    const int qi = qb * 16 + l15;
+    u32x4 qf[2] = {qf_next[0], qf_next[1]};
+    request_q(qb + FWD_NW);
+    // bias: tile row0, lane (query qi, group g), register r reads T[row0 + 4g + r − qi + rel_off]; the copy and the aligned
+    // base are constants of the block (row0 is a multiple of 16)
+    const int i0 = 4 * g - qi + a.rel_off + EB_PADLO;
+    const float* bptr = b4 + (i0 & 3) * EB_ST + (i0 & ~3);
+    const uint32_t pblk = (uint32_t)((b * a.H + h) * QB + (qi >> 2)) * (uint32_t)KB + (uint32_t)g;
+    const DropRow drc = drop_row_consts(qi);
+    float m = -INFINITY, l = 0.f;
+    f32x4 oacc[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) oacc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define ECH(N, P0, LAST) case N: efwd_chunk<DROP, N>(Kimg, Vimg, P0, LAST, tail, bptr, qf, el, pblk, a.drop_key, drc, t_hi, m, l, oacc); break;
+    switch (npa) { ECH(1, 0, npb == 0) ECH(2, 0, npb == 0) ECH(3, 0, npb == 0) ECH(4, 0, npb == 0) default: break; }
+    switch (npb) { ECH(1, 4, true) ECH(2, 4, true) ECH(3, 4, true) ECH(4, 4, true) default: break; }
+#undef ECH
+    l = egroup_sum(l);
+    if (qi < Lq) {
+      const float inv = 1.0f / l;
+      const float f = inv * oscale;
+      bf16_t* op = reinterpret_cast<bf16_t*>(obase + (int64_t)qi * a.ost * 2);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) store4(op + db * 16 + 4 * g, oacc[db] * f);
+      if (g == 0 && a.stats) {
+        float* st = a.stats + (((int64_t)b * a.H + h) * a.Lq + qi) * 4;
+        st[0] = m;
+        st[1] = inv;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward, dQ pass: K / V in LDS — staged ONCE per (sequence, head) —, a wave owns the query blocks wave, wave + 4, wave + 8,
+// wave + 12 of the sequence (static slots); Sᵀ[key][query] and dPᵀ tiles → dSᵀ → dQᵀ += Kᵀ·dSᵀ.
+// The bias gradient (Σ dS over batch rows and score diagonals) is accumulated in registers over the workgroup's batch rows:
+// tile (slot s, key tile t) of wave w lies on tile diagonal t − (w + 4s), so the accumulators are indexed by t − 4s + 12
+// (28 of them — every index static).  Inside a tile the element of lane (query l15, group g), register r sits on diagonal
+// key − query = 16·Δ + 4g + (r − l15): a DPP row shift by r brings the four registers of a 16-lane row onto a common
+// r − l15, so a tile costs TWO accumulator registers (lo: r − l15 = −j ≤ 0 at lane j; hi: r − l15 = 16 − j > 0 at lanes
+// 13..15) instead of four — 56 registers for the 28 tile diagonals, which leaves room to request the next block's
+// operands (Q, dO, O fragments, statistics) while the current one is computed.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int DQ_NACC = 28;
+// LDS: K | V | 4 bias copies | drel_l[512] | offsets
+__host__ __device__ constexpr int ebwd0_lds(int rows) { return 2 * rows * EROW + 4 * EB_ST * 4 + 512 * 4 + (4 + 2 * OFFS_MAX) * 4; }
+
+template <bool DROP>
+__global__ __launch_bounds__(256, 2) void enc_bwd_dq_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int R = a.chunk_rows;
+  char* Kimg = smem;
+  char* Vimg = smem + R * EROW;
+  float* b4 = reinterpret_cast<float*>(smem + 2 * R * EROW);
+  float* drel_l = b4 + 4 * EB_ST;
+  int* offs_l = reinterpret_cast<int*>(drel_l + 512) + 4;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, l15 = lane & 15;
+  const int h = blockIdx.y;
+  const int b_begin = blockIdx.z * a.bn_per_wg, b_end = min(a.Bn, b_begin + a.bn_per_wg);
+  if (threadIdx.x <= b_end - b_begin) {
+    if (a.q_off) offs_l[threadIdx.x] = a.q_off[b_begin + threadIdx.x];
+    if (a.k_off) offs_l[OFFS_MAX + threadIdx.x] = a.k_off[b_begin + threadIdx.x];
+  }
+  const bool want_drel = a.drel != nullptr;
+  for (int i = threadIdx.x; i < 512; i += 256) drel_l[i] = 0.f;
+  estage_bias(b4, a.rel_bias, h, a.R, false);
+  __syncthreads();
+  const ELane el = elane(lane);
+  const uint32_t t_hi = a.drop_t16 << 16;
+  const int KB = (a.Lk + 3) >> 2, QB = (a.Lq + 3) >> 2;
+  const float dscale = DROP ? a.drop_scale : 1.0f, inv_dscale = 1.0f / dscale;
+  float acc_lo[DQ_NACC], acc_hi[DQ_NACC];
+#pragma unroll
+  for (int t = 0; t < DQ_NACC; ++t) acc_lo[t] = acc_hi[t] = 0.f;
+
+  for (int b = b_begin; b < b_end; ++b) {
+    const int q0 = a.q_off ? __builtin_amdgcn_readfirstlane(offs_l[b - b_begin]) : 0;
+    const int k0 = a.k_off ? __builtin_amdgcn_readfirstlane(offs_l[OFFS_MAX + b - b_begin]) : 0;
+    const int Lq = a.q_off ? __builtin_amdgcn_readfirstlane(offs_l[b - b_begin + 1]) - q0 : a.Lq;
+    const int Lk = a.k_off ? __builtin_amdgcn_readfirstlane(offs_l[OFFS_MAX + b - b_begin + 1]) - k0 : a.Lk;
+    if (Lq <= 0 || Lk <= 0) continue;                      // (workgroup-uniform) an empty sequence
+    const int64_t hoff = (int64_t)h * 64;
+    const char* qbase = a.q + ((a.q_off ? (int64_t)q0 * a.qst : (int64_t)b * a.qsb) + hoff) * 2;
+    const char* kbase = a.k + ((a.k_off ? (int64_t)k0 * a.kst : (int64_t)b * a.ksb) + hoff) * 2;
+    const char* vbase = a.v + ((a.k_off ? (int64_t)k0 * a.vst : (int64_t)b * a.vsb) + hoff) * 2;
+    const char* obase = a.o + ((a.q_off ? (int64_t)q0 * a.ost : (int64_t)b * a.osb) + hoff) * 2;
+    const char* dobase = a.dout + ((a.q_off ? (int64_t)q0 * a.ost : (int64_t)b * a.osb) + hoff) * 2;
+    char* dqbase = a.dq + ((a.q_off ? (int64_t)q0 * a.qst : (int64_t)b * a.qsb) + hoff) * 2;
+    float* stats = a.stats + ((int64_t)b * a.H + h) * a.Lq * 4;
+    const int np = (Lk + 31) >> 5, nk = np << 5;
+    const int nqb = (Lq + 15) >> 4;
+    // operands of the wave's next query block: requested one block ahead (the first before the staging barrier)
+    u32x4 qf_n[2], dof_n[2], of_n[2];
+    float m_n = 0.f, il_n = 0.f;
+    auto request = [&](int qbn) {
+      const int qn = qbn < nqb ? qbn * 16 + l15 : Lq;
+      eload_frags(qf_n, qbase, a.qst * 2, qn, Lq, g);
+      eload_frags(dof_n, dobase, a.ost * 2, qn, Lq, g);
+      eload_frags(of_n, obase, a.ost * 2, qn, Lq, g);
+      m_n = il_n = 0.f;
+      if (qn < Lq) {
+        m_n = stats[qn * 4];
+        il_n = stats[qn * 4 + 1];
+      }
+    };
+    request(wave);
+    __syncthreads();                                        // every wave is done with the previous row's images
+    if (!ATTN_DBG(a, 16)) {
+      estage(Kimg, kbase, a.kst * 2, nk, Lk);
+      estage(Vimg, vbase, a.vst * 2, nk, Lk);
+    }
+    __syncthreads();
+    const f32x4 tail[2] = {etail(2 * np - 2, g, Lk), etail(2 * np - 1, g, Lk)};
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+      const int qb = wave + 4 * sl;
+      if (qb < nqb) {                                       // (wave-uniform; a guard, not a break: see the pair loop)
+      const int qi = qb * 16 + l15;
+      u32x4 qf[2] = {qf_n[0], qf_n[1]}, dof[2] = {dof_n[0], dof_n[1]};
+      const float st_m = m_n, st_il = il_n;
+      // δ = rowsum(dO ∘ O), handed to the dK/dV pass through the statistics
+      float part = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        bf16x8 dv = __builtin_bit_cast(bf16x8, dof_n[i]), ov = __builtin_bit_cast(bf16x8, of_n[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part += (float)dv[e] * (float)ov[e];
+      }
+      if (sl < 3) request(qb + 4);
+      const float delta = egroup_sum(part);
+      if (qi < Lq && g == 0) stats[qi * 4 + 2] = delta;
+      // p̃ = scale·p = exp2(s·log2e − lse2) with lse2 = m·log2e + log2(l) − log2(scale);  p = 0 for rows past Lq (1/l = 0)
+      const float lse2 = st_il > 0.f ? st_m * LOG2E - __builtin_amdgcn_logf(st_il * dscale) : INFINITY;
+      const float ndel = -delta * inv_dscale;               // dP′ = dP − δ/scale straight out of the MFMA
+      const int i0 = 4 * g - qi + a.rel_off + EB_PADLO;
+      int boff = (i0 & 3) * EB_ST + (i0 & ~3);
+      asm volatile("" : "+v"(boff));                        // keeps the bias reads at their use (hoisted they cost 64 registers)
+      const float* bptr = b4 + boff;
+      const uint32_t pblk = (uint32_t)((b * a.H + h) * QB + (qi >> 2)) * (uint32_t)KB + (uint32_t)g;
+      const DropRow drc = drop_row_consts(qi);
+      f32x4 dq[4];
+#pragma unroll
+      for (int db = 0; db < 4; ++db) dq[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // every pair is a guarded block that finishes its own accumulations: with `break`s in the unrolled loop the compiler sinks
+      // the bias-gradient adds of ALL pairs into the exit paths and keeps their operands live until then (500 bytes of spills)
+#pragma unroll
+      for (int tp = 0; tp < 8; ++tp) {
+        if (tp < np && !ATTN_DBG(a, 32)) {
+        f32x4 ds[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int t = 2 * tp + u, row0 = t * 16;
+          f32x4 init = *reinterpret_cast<const f32x4*>(bptr + row0);
+          if (tp == np - 1) init += tail[u];
+          const f32x4 sv = escore(Kimg, row0, qf, el.roff, init);
+          f32x4 dp = escore(Vimg, row0, dof, el.roff, f32x4{ndel, ndel, ndel, ndel});
+          f32x4 p;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[r], LOG2E, -lse2));
+          if (DROP) {
+            bool kp[4];
+            drop_keep_row(drop_base(pblk + (uint32_t)(t * 4), a.drop_key), drc, t_hi, kp);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dp[r] = kp[r] ? dp[r] : ndel;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ds[u][r] = p[r] * dp[r];      // dS = P ∘ (dropped dP − δ)
+          // bias gradient: shift register r left by r lanes inside its 16-lane row (lanes shifted in from outside the row: 0)
+          const int ai = t - 4 * sl + 12;
+          acc_lo[ai] += ds[u][0] + edpp<0x101>(ds[u][1]) + edpp<0x102>(ds[u][2]) + edpp<0x103>(ds[u][3]);     // row_shl:1..3
+          acc_hi[ai] += edpp<0x11F>(ds[u][1]) + edpp<0x11E>(ds[u][2]) + edpp<0x11D>(ds[u][3]);               // row_shr:15..13
+        }
+        epv(dq, ds[0], ds[1], Kimg, tp * 32, el.toff);              // dQᵀ += Kᵀ·dSᵀ
+        __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (qi < Lq) {
+        bf16_t* op = reinterpret_cast<bf16_t*>(dqbase + (int64_t)qi * a.qst * 2);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) store4(op + db * 16 + 4 * g, dq[db]);
+      }
+      }
+    }
+  }
+  if (want_drel) {
+    // accumulator i of wave w, lane (j = lane & 15, g): lo is the sum over key − query = 16·(i − 12 − w) + 4g − j, hi (lanes 13..15)
+    // over 16·(i − 12 − w) + 4g + 16 − j.  Once per workgroup: LDS atomics into the head's table, then one global atomic per entry.
+#pragma unroll
+    for (int i = 0; i < DQ_NACC; ++i) {
+      const int d0 = 16 * (i - 12 - wave) + 4 * g - l15 + a.rel_off;
+      if (acc_lo[i] != 0.f && d0 >= 0 && d0 < a.R) atomicAdd(&drel_l[d0], acc_lo[i]);
+      if (acc_hi[i] != 0.f && d0 + 16 >= 0 && d0 + 16 < a.R) atomicAdd(&drel_l[d0 + 16], acc_hi[i]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.R; i += 256) {
+      const float v = drel_l[i];
+      if (v != 0.f) atomicAdd(a.drel + (int64_t)h * a.R + i, v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward, dK/dV pass: Q / dO in LDS, a wave owns 16 keys; S[query][key] and dP tiles → P̃, dS → dKᵀ += Qᵀ·dS, dVᵀ += dOᵀ·P̃
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int DKV_NW = 4;     // (8 waves on <= 128 registers measured 10 % slower: no room to request the next key block ahead)
+// LDS: Q | dO | 4 reversed bias copies | lse2[R] | −δ/scale[R]
+__host__ __device__ constexpr int ebwd1_lds(int rows) { return 2 * rows * EROW + 4 * EB_ST * 4 + 2 * rows * 4; }
+
+template <bool DROP>
+__global__ __launch_bounds__(DKV_NW * 64, 2) void enc_bwd_dkv_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int R = a.chunk_rows;
+  char* Qimg = smem;
+  char* dOimg = smem + R * EROW;
+  float* b4 = reinterpret_cast<float*>(smem + 2 * R * EROW);
+  float* lse_l = b4 + 4 * EB_ST;
+  float* ndel_l = lse_l + R;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, l15 = lane & 15;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = a.q_off ? __builtin_amdgcn_readfirstlane(a.q_off[b]) : 0;
+  const int k0 = a.k_off ? __builtin_amdgcn_readfirstlane(a.k_off[b]) : 0;
+  const int Lq = a.q_off ? __builtin_amdgcn_readfirstlane(a.q_off[b + 1]) - q0 : a.Lq;
+  const int Lk = a.k_off ? __builtin_amdgcn_readfirstlane(a.k_off[b + 1]) - k0 : a.Lk;
+  const int kb_begin = blockIdx.x * a.blocks_per_wg;
+  const int kb_end = min((Lk + 15) >> 4, kb_begin + a.blocks_per_wg);
+  if (kb_begin >= kb_end) return;
+  const int64_t hoff = (int64_t)h * 64;
+  const char* qbase = a.q + ((a.q_off ? (int64_t)q0 * a.qst : (int64_t)b * a.qsb) + hoff) * 2;
+  const char* dobase = a.dout + ((a.q_off ? (int64_t)q0 * a.ost : (int64_t)b * a.osb) + hoff) * 2;
+  const char* kbase = a.k + ((a.k_off ? (int64_t)k0 * a.kst : (int64_t)b * a.ksb) + hoff) * 2;
+  const char* vbase = a.v + ((a.k_off ? (int64_t)k0 * a.vst : (int64_t)b * a.vsb) + hoff) * 2;
+  char* dkbase = a.dk + ((a.k_off ? (int64_t)k0 * a.kst : (int64_t)b * a.ksb) + hoff) * 2;
+  char* dvbase = a.dv + ((a.k_off ? (int64_t)k0 * a.vst : (int64_t)b * a.vsb) + hoff) * 2;
+  const float* stats = a.stats + ((int64_t)b * a.H + h) * a.Lq * 4;
+  const float dscale = DROP ? a.drop_scale : 1.0f, inv_dscale = 1.0f / dscale;
+  const int npq = (max(Lq, 1) + 31) >> 5, nq = npq << 5;    // query tile pairs, staged query rows
+  estage<DKV_NW * 64>(Qimg, qbase, a.qst * 2, nq, Lq);
+  estage<DKV_NW * 64>(dOimg, dobase, a.ost * 2, nq, Lq);
+  estage_bias<DKV_NW * 64>(b4, a.rel_bias, h, a.R, true);
+  for (int i = threadIdx.x; i < nq; i += DKV_NW * 64) {
+    float l2 = INFINITY, nd = 0.f;                          // rows past Lq: p = exp2(−inf) = 0
+    if (i < Lq) {
+      const f32x4 st4 = *reinterpret_cast<const f32x4*>(stats + i * 4);
+      l2 = st4[0] * LOG2E - __builtin_amdgcn_logf(st4[1] * dscale);
+      nd = -st4[2] * inv_dscale;
+    }
+    lse_l[i] = l2;
+    ndel_l[i] = nd;
+  }
+  __syncthreads();
+  const ELane el = elane(lane);
+  const uint32_t t_hi = a.drop_t16 << 16;
+  const int KB = (a.Lk + 3) >> 2, QB = (a.Lq + 3) >> 2;
+  const int last = a.R - 1 + EB_PADLO + 36;
+
+  u32x4 kf_next[2], vf_next[2];
+  auto request = [&](int kbn) {
+    const int kn = kbn < kb_end ? kbn * 16 + l15 : Lk;
+    eload_frags(kf_next, kbase, a.kst * 2, kn, Lk, g);
+    eload_frags(vf_next, vbase, a.vst * 2, kn, Lk, g);
+  };
+  request(kb_begin + wave);
+  for (int kb = kb_begin + wave; kb < kb_end; kb += DKV_NW) {
+    const int ki = kb * 16 + l15;                           // this lane's key
+    u32x4 kf[2] = {kf_next[0], kf_next[1]}, vf[2] = {vf_next[0], vf_next[1]};
+    request(kb + DKV_NW);
+    const float kadd_lane = ki < Lk ? 0.f : -INFINITY;
+    f32x4 dkacc[4], dvacc[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      dkacc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dvacc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // bias: tile rows are queries row0 + 4g + r, the lane's key is ki: T[ki − (row0 + 4g + r) + rel_off] = Trev[j0 + row0 + r],
+    // j0 = last − (ki − 4g + rel_off + PADLO)
+    const int j0 = last - (ki - 4 * g + a.rel_off + EB_PADLO);
+    const float* bptr = b4 + (j0 & 3) * EB_ST + (j0 & ~3);
+    const DropCol dcc = drop_col_consts(ki);
+    const uint32_t cblk = (uint32_t)((b * a.H + h) * QB + g) * (uint32_t)KB + (uint32_t)(ki >> 2);
+    const f32x4 kaddv = {kadd_lane, kadd_lane, kadd_lane, kadd_lane};
+    for (int tp = 0; tp < npq; ++tp) {
+      f32x4 pt[2], ds[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int row0 = tp * 32 + u * 16;
+        const f32x4 init = *reinterpret_cast<const f32x4*>(bptr + row0) + kaddv;
+        const f32x4 nd = *reinterpret_cast<const f32x4*>(ndel_l + row0 + 4 * g);
+        const f32x4 l2 = *reinterpret_cast<const f32x4*>(lse_l + row0 + 4 * g);
+        const f32x4 sv = escore(Qimg, row0, kf, el.roff, init);
+        f32x4 dp = escore(dOimg, row0, vf, el.roff, nd);
+        f32x4 p;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[r], LOG2E, -l2[r]));
+        pt[u] = p;
+        if (DROP) {
+          bool kp[4];
+          drop_keep_col(drop_base(cblk + (uint32_t)((row0 >> 2) * KB), a.drop_key), dcc, t_hi, kp);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            pt[u][r] = kp[r] ? p[r] : 0.f;
+            dp[r] = kp[r] ? dp[r] : nd[r];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ds[u][r] = p[r] * dp[r];
+      }
+      epv(dkacc, ds[0], ds[1], Qimg, tp * 32, el.toff);       // dKᵀ += Qᵀ·dS
+      epv(dvacc, pt[0], pt[1], dOimg, tp * 32, el.toff);      // dVᵀ += dOᵀ·P̃
+    }
+    if (ki < Lk) {
+      bf16_t* kp_ = reinterpret_cast<bf16_t*>(dkbase + (int64_t)ki * a.kst * 2);
+      bf16_t* vp_ = reinterpret_cast<bf16_t*>(dvbase + (int64_t)ki * a.vst * 2);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        store4(kp_ + db * 16 + 4 * g, dkacc[db]);
+        store4(vp_ + db * 16 + 4 * g, dvacc[db]);
+      }
+    }
+  }
+}
+
+template <typename K>
+void eset_lds(K kern, int bytes, int& cur) {
+  if (bytes <= cur) return;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  cur = bytes;
+}
+
+// query / key blocks per workgroup: all of them when there are already plenty of workgroups, otherwise split so that the grid
+// reaches ~1024 workgroups (multiples of the workgroup's wave count)
+inline int eblocks_per_wg(int nblocks, int64_t bh, int nw) {
+  const int64_t want = 1024;
+  if (bh >= want || nblocks <= nw) return ((nblocks + nw - 1) / nw) * nw;
+  const int groups = (int)((want + bh - 1) / bh);
+  int per = (nblocks + groups - 1) / groups;
+  per = ((per + nw - 1) / nw) * nw;
+  return per < nw ? nw : per;
+}
+
+#define EDISPATCH(KERN, NTHR, drop, grid, lds, s, args)                                                                          \
+  do {                                                                                                                           \
+    if (drop) { static int c = 0; eset_lds(&KERN<true>, lds, c); hipLaunchKernelGGL((KERN<true>), grid, dim3(NTHR), lds, s, args); }    \
+    else { static int c = 0; eset_lds(&KERN<false>, lds, c); hipLaunchKernelGGL((KERN<false>), grid, dim3(NTHR), lds, s, args); }       \
+  } while (0)
+
+}  // namespace
+
+// Shapes the fast path takes (attn.hip asks before falling back to its generic kernels).
+bool lako_attn_enc_supported(const AttnArgs& a, int dtype, int d_head) {
+  static const bool off = getenv("LAKO_ATTN_FAST") && atoi(getenv("LAKO_ATTN_FAST")) == 0;   // A/B against the generic kernels
+  if (off) return false;
+  if (dtype != LAKO_BF16 || d_head != 64 || a.causal || a.scores_out || a.key_mask) return false;
+  if (a.Lk > 256 || a.Lq > 256 || a.Lk < 1) return false;
+  if (a.rel_bias && !(a.R == a.Lq + a.Lk - 1 && a.rel_off == a.Lq - 1)) return false;   // the encoder's table: no index clamping
+  if (a.Lq <= 16 && a.Lk > 64) return false;        // one query block over many keys: the generic key-split mode is the better fit
+  if ((int64_t)a.Bn * a.H >= 65536) return false;
+  return true;
+}
+
+int lako_attn_enc_fwd(AttnArgs& a, hipStream_t s) {
+#ifdef LAKO_EXPERIMENTS
+  static const int dbg = getenv("LAKO_ATTN_DEBUG") ? atoi(getenv("LAKO_ATTN_DEBUG")) : 0;
+  a.dbg_flags = dbg;
+#endif
+  a.chunk_rows = ((a.Lk + 31) / 32) * 32;
+  const int nqb = (a.Lq + 15) / 16;
+  a.blocks_per_wg = eblocks_per_wg(nqb, (int64_t)a.Bn * a.H, FWD_NW);
+  const int lds = efwd_lds(a.chunk_rows);
+  const dim3 grid((nqb + a.blocks_per_wg - 1) / a.blocks_per_wg, a.H, a.Bn);
+  EDISPATCH(enc_fwd_kernel, FWD_NW * 64, a.drop_t16 != 0, grid, lds, s, a);
+  return 0;
+}
+
+int lako_attn_enc_bwd(AttnArgs& a, hipStream_t s) {
+#ifdef LAKO_EXPERIMENTS
+  static const int dbg = getenv("LAKO_ATTN_DEBUG") ? atoi(getenv("LAKO_ATTN_DEBUG")) : 0;
+  a.dbg_flags = dbg;
+  if (dbg & 256) goto dkv_pass;      // time the passes separately
+#endif
+  {  // dQ pass: every query block of a sequence in one workgroup, several batch rows per workgroup (bias gradient in registers)
+    AttnArgs q = a;
+    q.chunk_rows = ((a.Lk + 31) / 32) * 32;
+    const int64_t wgs = (int64_t)a.Bn * a.H;
+    static const int wg_target = getenv("LAKO_ATTN_WGS") ? atoi(getenv("LAKO_ATTN_WGS")) : 1024;
+    q.bn_per_wg = (int)(wgs / wg_target > 1 ? wgs / wg_target : 1);
+    if (q.bn_per_wg > OFFS_MAX - 1) q.bn_per_wg = OFFS_MAX - 1;
+    const int lds = ebwd0_lds(q.chunk_rows);
+    const dim3 grid(1, a.H, (a.Bn + q.bn_per_wg - 1) / q.bn_per_wg);
+    EDISPATCH(enc_bwd_dq_kernel, 256, a.drop_t16 != 0, grid, lds, s, q);
+  }
+#ifdef LAKO_EXPERIMENTS
+  if (a.dbg_flags & 512) return 0;
+dkv_pass:
+#endif
+  {  // dK/dV pass
+    AttnArgs k = a;
+    k.chunk_rows = ((a.Lq + 31) / 32) * 32;
+    const int nkb = (a.Lk + 15) / 16;
+    k.blocks_per_wg = eblocks_per_wg(nkb, (int64_t)a.Bn * a.H, DKV_NW);
+    const int lds = ebwd1_lds(k.chunk_rows);
+    const dim3 grid((nkb + k.blocks_per_wg - 1) / k.blocks_per_wg, a.H, a.Bn);
+    EDISPATCH(enc_bwd_dkv_kernel, DKV_NW * 64, a.drop_t16 != 0, grid, lds, s, k);
+  }
+  return 0;
+}

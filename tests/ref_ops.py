@@ -59,6 +59,32 @@ def keep_mask(drop, idx: torch.Tensor):
     return draw >= t16, scale
 
 
+DROP_C0 = 0x5BD1E9
+DROP_MUL = [0x6C8E95, 0x1B873B, 0x4F1BBD, 0x7A3C6F, 0x35D2A7, 0x59E4C1, 0x2545F5, 0x63D9AB]      # [i·2 + j]
+
+
+def _drop_mix(a, c, s):
+    t = ((a & 0xFFFFFF) * c + (a >> s)) & M32
+    return t ^ (t >> 16)
+
+
+def attn_keep_mask(BH, Lq, Lk, key, p, dev="cpu"):
+    """keep[bh, q, k] of the attention-probability dropout — the integer recipe of csrc/attn_shared.h (drop_base / drop_mix)."""
+    QB, KB = (Lq + 3) // 4, (Lk + 3) // 4
+    bh = torch.arange(BH, device=dev, dtype=torch.int64).view(BH, 1, 1)
+    q = torch.arange(Lq, device=dev, dtype=torch.int64).view(1, Lq, 1)
+    k = torch.arange(Lk, device=dev, dtype=torch.int64).view(1, 1, Lk)
+    blk = ((bh * QB + (q >> 2)) * KB + (k >> 2)) & M32
+    h = _drop_mix(blk ^ key, DROP_C0, 13)
+    i, j = (q & 3).expand(BH, Lq, Lk), ((k & 3) >> 1).expand(BH, Lq, Lk)
+    mul = torch.tensor(DROP_MUL, device=dev, dtype=torch.int64)[i * 2 + j]
+    w = ((h & 0xFFFFFF) * mul + (h >> (6 + 2 * i + 5 * j))) & M32
+    w = w ^ (w >> 16)
+    draw = torch.where((k & 1).bool(), w & 0xFFFF, w >> 16)
+    t16 = min(max(int(float(np.float32(p)) * 65536.0 + 0.5), 1), 65535)
+    return draw >= t16
+
+
 def _on(d):
     return d is not None and d[0] > 0.0
 
@@ -172,19 +198,13 @@ class RefOps:
         l = p.sum(-1)
         pn = p / l[..., None]
         if _on(drop):
-            # attention-probability dropout (csrc/attn.hip quad_hash): keys 4c … 4c+3 of a score row share one hash h;
-            # draws: h>>16, h&0xffff, w>>16, w&0xffff with w = h·0x9E3779B1 mod 2^32
+            # attention-probability dropout (csrc/attn_shared.h): the 4×4 block (queries 4a…, keys 4c…) of head-row bh shares
+            # h = mix(((bh·QB + a)·KB + c) ^ key, C0, 13); element (q, k) draws 16 bits of W = mix(h, M[q&3][(k&3)>>1], S[…]):
+            # high half for even k, low half for odd k; mix(a, c, s) = t ^ (t >> 16), t = (a mod 2^24)·c + (a >> s) mod 2^32
             pr, seed, site = drop
-            hq = (Lk + 3) // 4
-            rows = torch.arange(B * H * Lq, device=dev, dtype=torch.int64).view(B, H, Lq, 1)
-            qi = (rows * hq + (j >> 2)) & M32
-            hsh = hash32(qi ^ drop_key(int(seed) & M32, int(site) & M32))
-            wsh = _mul32(hsh, 0x9E3779B1)
-            word = torch.where((j & 2).bool(), wsh, hsh)
-            half = torch.where((j & 1).bool(), word & 0xFFFF, word >> 16)
-            t16 = min(max(int(float(np.float32(pr)) * 65536.0 + 0.5), 1), 65535)
+            keep = attn_keep_mask(B * H, Lq, Lk, drop_key(int(seed) & M32, int(site) & M32), pr, dev).view(B, H, Lq, Lk)
             scale = float(np.float32(1.0) / (np.float32(1.0) - np.float32(pr)))
-            pn = torch.where(half >= t16, pn * scale, torch.zeros_like(pn))
+            pn = torch.where(keep, pn * scale, torch.zeros_like(pn))
         out = torch.einsum("bhqk,bkhd->bqhd", pn, v)
         return out, m, 1.0 / l, raw
 

@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEV = "cuda"
 
 
-@pytest.mark.parametrize("mode", ["flat", "overlap"])
+@pytest.mark.parametrize("mode", ["deferred", "overlap"])
 def test_rccl_gradient_path_in_child_process(mode):
     """bench.py with LAKO_FORCE_DIST=1: init_process_group('nccl') = RCCL, parameter broadcast, the gradient all-reduce on the
     flat device buffer (or per finished gradient range, LAKO_DP_MODE=overlap), the 1/world factor inside the fused AdamW.
