@@ -59,6 +59,7 @@ def gemm_traffic_bytes(args):
 
 PEAK_BF16_TFLOPS = 2500.0      # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (no 2:1 sparsity)
 PEAK_F32_TFLOPS = 157.3
+PEAK_FP8_TFLOPS = 5000.0       # dense block-scaled fp8 (v_mfma_scale_f32_16x16x128_f8f6f4), same guide
 
 
 def train_flops_per_sample(cfg, N, L, T):
@@ -206,6 +207,8 @@ def main():
     ap.add_argument("--all-valid-steps", type=int, default=10, help="timed steps of the second, all-passages-full measurement (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=150.0, help="hard deadline for the CPU baseline leg")
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--fp8", action="store_true", help="MX block-scaled fp8 (e4m3 + E8M0 scales) forward GEMMs for the encoder's QKV / FFN-in "
+                    "projections and the cross-K/V projection (BASELINE config 5); roofline then describes that kernel against the fp8 peak")
     ap.add_argument("--breakdown", action="store_true", help="print the per-op HIP-event breakdown to stderr")
     args = ap.parse_args()
     if args.cpu_worker:
@@ -234,7 +237,7 @@ def main():
     cfg = FiDConfig.named(args.model, dropout_rate=args.dropout)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(0)                                   # identical initial weights on every rank
-    model = FiDT5(cfg, dtype=dtype, seed=rank)
+    model = FiDT5(cfg, dtype=dtype, seed=rank, fp8=True if args.fp8 else None)
     with torch.no_grad():
         model._params_by_plain["shared.weight"].mul_(0.05)  # random-init stand-in for the t5-* checkpoint
     model = model.cuda(local_rank)
@@ -257,6 +260,8 @@ def main():
     loss_acc = torch.zeros((), device=device)
     peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
     dom = "gemm_nt.11" if args.dtype == "bf16" else "gemm_nt.00"
+    if args.fp8:       # the line describes the fp8 kernel (the bf16 GEMMs of the same run are in `bf16_gemm`)
+        peak, dom = PEAK_FP8_TFLOPS, "gemm_nt_mx"
     fl = train_flops_per_sample(cfg, N, L, T)                # nominal: every position of [B, N, L]
 
     def fence():
@@ -318,10 +323,14 @@ def main():
                    / (steps * B)) if unpadded else fl
         n_l, t_ms, f_tot = probe.get(dom, (0, 0.0, 0.0))
         achieved = f_tot / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0
-        return dict(elapsed=elapsed, ms=elapsed / steps * 1e3, median_ms=per_step[len(per_step) // 2], host_ms=host_ms,
+        nb, tb, fb = probe.get("gemm_nt.11", (0, 0.0, 0.0))
+        bf16_gemm = {"launches_per_step": nb, "achieved_tflops": round(fb / (tb * 1e-3) / 1e12, 1) if tb > 0 else 0.0,
+                     "ms_per_step": round(tb, 3)}
+        mxq = probe.get("mx_quantize", (0, 0.0, 0.0))
+        return dict(bf16_gemm=bf16_gemm, mxq_ms=mxq[1], elapsed=elapsed, ms=elapsed / steps * 1e3, median_ms=per_step[len(per_step) // 2], host_ms=host_ms,
                     probe=probe, fl_exec=fl_exec, valid_frac=float(lens_all.double().mean()) / L, n_l=n_l, t_ms=t_ms,
                     achieved=achieved, value=world * B * steps / elapsed,
-                    step_frac=world * B / (elapsed / steps) * fl_exec / 1e12 / (peak * world))
+                    step_frac=world * B / (elapsed / steps) * fl_exec / 1e12 / (PEAK_BF16_TFLOPS * world if args.fp8 else peak * world))
 
     main_run = measure(args.all_valid, args.warmup, args.steps)
     av_run = None
@@ -338,7 +347,8 @@ def main():
             "value": round(r["value"], 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(r["ms"], 3), "median_step_ms": round(r["median_ms"], 3),
             "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "vs_baseline": None, "dtype": "fp8-mx (e4m3 operands + E8M0 block scales in the fwd QKV / FFN-in / cross-K/V GEMMs; bf16 elsewhere)"
+            if args.fp8 else args.dtype, "data": "synthetic",
             "config": {"workload": f"{workload_tag(args)}: FiD reader train step "
                                    f"(fwd+bwd+clip+AdamW), T5-{args.model} random-init, synthetic OKVQA-shaped batches resident in HBM",
                        "per_gpu_batch": B, "global_batch": B * world, "n_passages": N, "text_maxlength": L,
@@ -356,7 +366,9 @@ def main():
                                   else "computed like the reference (LAKO_UNPAD=0)"},
             "roofline": {"bound": "mfma", "achieved": round(r["achieved"], 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(r["achieved"] / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": ("gemm_nt_kernel<bf16,bf16,2,4,8,4> (256x256 tile, both epilogue instantiations; calls with M > 256"
+                         "kernel": ("gemm_nt_mx_kernel (256x256 tile, v_mfma_scale_f32_16x16x128_f8f6f4, e4m3 x e4m3 with E8M0 block scales: "
+                                    "forward QKV / FFN-in / cross-K/V projections)") if args.fp8 else
+                                   ("gemm_nt_kernel<bf16,bf16,2,4,8,4> (256x256 tile, both epilogue instantiations; calls with M > 256"
                                     " rows: encoder + cross-K/V GEMMs incl. their small-tile row tails)") if args.dtype == "bf16"
                                    else "gemm_nt_kernel<f32,f32>",
                          "launches_per_step": r["n_l"], "avg_launch_us": round(r["t_ms"] * 1e3 / max(r["n_l"], 1), 2),
@@ -364,6 +376,10 @@ def main():
                          "train_gflop_per_sample": round(fl / 1e9, 1),
                          "executed_gflop_per_sample": round(r["fl_exec"] / 1e9, 1)},
         }
+        if args.fp8:
+            out["roofline"]["bf16_gemm"] = r["bf16_gemm"]          # the GEMMs that stay bf16 in the same run (backward, o / wo projections)
+            out["roofline"]["mx_quantize_ms_per_step"] = round(r["mxq_ms"], 3)
+            out["roofline"]["step_mfma_frac_note"] = "whole step priced against the bf16 peak (most FLOPs of the step still run in bf16)"
         if av_run is not None:
             out["all_valid"] = {"value": round(av_run["value"], 3), "unit": "samples/s", "steps": args.all_valid_steps, "warmup": 3,
                                 "ms_per_step": round(av_run["ms"], 3), "median_step_ms": round(av_run["median_ms"], 3),

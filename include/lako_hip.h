@@ -27,7 +27,7 @@ extern "C" {
 
 #define LAKO_ABI_VERSION 1
 
-enum { LAKO_F32 = 0, LAKO_BF16 = 1 };
+enum { LAKO_F32 = 0, LAKO_BF16 = 1, LAKO_FP8_E4M3 = 2 /* MX block-scaled operands of lako_gemm_nt_mx only */ };
 enum { LAKO_OK = 0, LAKO_E_BADARG = -1, LAKO_E_ALIGN = -2, LAKO_E_LAUNCH = -3, LAKO_E_UNSUPPORTED = -4 };
 
 typedef void* lako_stream_t; /* hipStream_t */
@@ -70,6 +70,18 @@ typedef struct {
   lako_dropout_t drop; /* applied after relu / before the residual add; idx = m*N + n */
 } lako_gemm_nt_t;
 int lako_gemm_nt(const lako_gemm_nt_t* p, lako_stream_t stream);
+
+/* ---- MX block-scaled fp8 GEMM (BASELINE config 5 "fp8 MFMA GEMMs"; the same nn.Linear products as lako_gemm_nt) -----------
+ * OCP microscaling: operands are e4m3 bytes, every 32 consecutive k of a row share one E8M0 scale byte s (element = q * 2^(s-127));
+ * gfx950's v_mfma_scale_f32_16x16x128_f8f6f4 applies the scales inside the matrix core at twice the bf16 rate.
+ * lako_mx_quantize: x bf16 [rows, K] (row stride ld) -> q [rows, K] e4m3 (contiguous) and scales [rows, 4, KSP] bytes with
+ *   KSP = ceil(K/128) rounded up to a multiple of 4: the scale of block j (k = 32j .. 32j+31) of a row sits at [row][j % 4][j / 4]
+ *   (the four K-steps a matrix-core lane needs next are one aligned dword).  s - 127 = floor(log2(max|x| of the block)) - 8,
+ *   q = saturate_e4m3(x * 2^(127-s)).  K % 128 == 0.
+ * lako_gemm_nt_mx: C [M,N] bf16 = epilogue(alpha * A.B^T), p->A / p->B the e4m3 matrices (in_dtype LAKO_FP8_E4M3, lda / ldb in
+ *   bytes), a_scales / b_scales as written by lako_mx_quantize; epilogue flags RELU, RESID, AUXMASK and dropout as lako_gemm_nt. */
+int lako_mx_quantize(const void* x, int64_t rows, int64_t K, int64_t ld, void* q, uint8_t* scales, lako_stream_t stream);
+int lako_gemm_nt_mx(const lako_gemm_nt_t* p, const uint8_t* a_scales, const uint8_t* b_scales, lako_stream_t stream);
 
 /* C[M,N] (fp32) += alpha * Aᵀ·B with A [K, M], B [K, N] row-major (weight gradients dW = dYᵀ·X —
  * the autograd of every nn.Linear above).  Split-K over `split_k` workgroups, fp32 atomics. */

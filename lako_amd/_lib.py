@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LAKO_LIB") or os.path.join(_HERE, "liblako_hip.so")   # LAKO_LIB: A/B measurements of two builds
 
-LAKO_F32, LAKO_BF16 = 0, 1
+LAKO_F32, LAKO_BF16, LAKO_FP8_E4M3 = 0, 1, 2
 EPI_RELU, EPI_RESID, EPI_AUXMASK, EPI_ATOMIC = 1, 2, 4, 8
 
 i64, i32, u32, f32, vp = C.c_int64, C.c_int, C.c_uint32, C.c_float, C.c_void_p
@@ -67,6 +67,8 @@ SIGNATURES = {
     "lako_version": [],
     "lako_last_error": [C.c_char_p, C.c_size_t],
     "lako_gemm_nt": [C.POINTER(GemmNT), vp],
+    "lako_mx_quantize": [vp, i64, i64, i64, vp, vp, vp],
+    "lako_gemm_nt_mx": [C.POINTER(GemmNT), vp, vp, vp],
     "lako_gemm_tn": [vp, vp, vp, i64, i64, i64, i64, i64, i64, i32, f32, i32, vp],
     "lako_gemm_tn_grouped": [C.POINTER(GemmTNItem), i32, i64, i32, vp],
     "lako_rmsnorm_fwd": [vp, vp, vp, vp, i64, i32, f32, i32, Dropout, vp],

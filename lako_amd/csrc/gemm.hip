@@ -1129,6 +1129,260 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(TnArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// NT with MX-scaled fp8 operands (BASELINE config 5: "fp8 MFMA GEMMs"): C = epilogue(alpha · A·Bᵀ), A [M,K] and B [N,K] in
+// OCP e4m3 bytes, every 32 consecutive k of a row sharing one E8M0 scale (OCP microscaling: element = q · 2^(s − 127)).
+// v_mfma_scale_f32_16x16x128_f8f6f4 applies both operands' block scales inside the matrix core and runs at twice the bf16
+// rate per clock; the non-scaled fp8 MFMA runs at the bf16 rate (MI355X_MICROARCH.md § Matrix cores), so this is the only
+// fp8 form worth having.  Same 256×256 persistent structure as gemm_nt_kernel<bf16, …, 2, 4, 8, 4>: one 128-BYTE K-slice
+// per step is now 128 k — exactly one MFMA deep — so a step moves the same bytes through LDS and does twice the FLOPs.
+// Operand layout (measured with exact integer data and per-block scales, tools/probe/mx_probe.hip): lane (row = lane & 15,
+// g = lane >> 4) holds, in its 32 operand bytes, k = 16g … 16g + 15 and k = 64 + 16g … 64 + 16g + 15 of its row — the two
+// 16-byte LDS chunks g and 4 + g, exactly the two K-halves of the bf16 kernel — while its SCALE byte is the one of block g,
+// k = 32g … 32g + 31.  Scales are stored [rows][4 (kb)][KSP] bytes, KSP = ⌈K/128⌉ rounded up to 4:
+// the scales of (row, kb) for 4 consecutive K-steps are ONE aligned dword, fetched a group ahead.
+// Epilogues: the wide LDS-transposed store (plain / ReLU / dropout) and the accumulator-layout generic one (residual, aux mask).
+// ---------------------------------------------------------------------------------------------
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+struct MxArgs {
+  NtArgs nt;
+  const uint8_t* sa;   // [M][4][ksp]
+  const uint8_t* sb;   // [N][4][ksp]
+  int ksp;
+};
+
+__global__ __launch_bounds__(512) void gemm_nt_mx_kernel(MxArgs ma) {
+  const NtArgs& a = ma.nt;
+  constexpr int WM = 2, WN = 4, MT = 8, NT = 4, NW = 8, BM = 256, BN = 256;
+  constexpr int A_BYTES = BM * TKB, B_BYTES = BN * TKB, BUF = A_BYTES + B_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave / WN, wc = wave % WN;
+  const int nwg = a.tiles_m * a.tiles_n;
+  const int64_t lda_b = a.lda, ldb_b = a.ldb;          // bytes = elements
+  const int kbytes = a.K;
+  const int nk = (kbytes + TKB - 1) / TKB;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int srow = 4 * ma.ksp;                          // scale bytes per operand row
+
+  int tile = xcd_remap(blockIdx.x, gridDim.x);
+  int tm_, tn_;
+  tile_coords(tile, a.tiles_m, a.tiles_n, a.group_m, tm_, tn_);
+  int m0 = tm_ * BM, n0 = tn_ * BN;
+  int rows_a = min(BM, a.M - m0), rows_b = min(BN, a.N - n0);
+  if (a.dephase > 0) {
+    const int ph = (blockIdx.x >> 3) % (a.dephase >> 16);
+    if (ph) {
+      const uint64_t t0 = __builtin_amdgcn_s_memrealtime(), dt = (uint64_t)((a.dephase & 0xffff) * ph);
+      while (__builtin_amdgcn_s_memrealtime() - t0 < dt) __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  stage_rows<BM, NW>(smem, a.A + (int64_t)m0 * lda_b, rows_a, lda_b, kbytes, wave, lane);
+  stage_rows<BN, NW>(smem + A_BYTES, a.B + (int64_t)n0 * ldb_b, rows_b, ldb_b, kbytes, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+
+  while (true) {
+    const int next_tile = tile + gridDim.x;
+    const bool has_next = next_tile < nwg;
+    tile_coords(has_next ? next_tile : 0, a.tiles_m, a.tiles_n, a.group_m, tm_, tn_);
+    const int nm0 = tm_ * BM, nn0 = tn_ * BN;
+    const char* Abase = a.A + (int64_t)m0 * lda_b;
+    const char* Bbase = a.B + (int64_t)n0 * ldb_b;
+    // the lane's scale rows as 32-bit byte offsets (clamped at the edge: those operand rows are zero-filled, their scale is irrelevant)
+    uint32_t sao[MT], sbo[NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) sao[mt] = (uint32_t)(min(m0 + (wr * MT + mt) * 16 + r16, a.M - 1) * srow + g * ma.ksp);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) sbo[nt] = (uint32_t)(min(n0 + (wc * NT + nt) * 16 + r16, a.N - 1) * srow + g * ma.ksp);
+    uint32_t sca[MT], scb[NT], sca_n[MT], scb_n[NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) sca_n[mt] = *reinterpret_cast<const uint32_t*>(ma.sa + sao[mt]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) scb_n[nt] = *reinterpret_cast<const uint32_t*>(ma.sb + sbo[nt]);
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int t = 0; t < nk; ++t) {
+      const char* As = smem + cur * BUF;
+      const char* Bs = As + A_BYTES;
+      char* An = smem + (cur ^ 1) * BUF;
+      const bool more_k = t + 1 < nk;
+      const bool pf = more_k || has_next;
+      const int koff = more_k ? (t + 1) * TKB : 0;
+      const int pf_rows_a = more_k ? rows_a : min(BM, a.M - nm0), pf_rows_b = more_k ? rows_b : min(BN, a.N - nn0);
+      const char* pf_a = more_k ? Abase + koff : a.A + (int64_t)nm0 * lda_b;
+      const char* pf_b = more_k ? Bbase + koff : a.B + (int64_t)nn0 * ldb_b;
+      constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;
+      const auto rsrc_a = slice_rsrc(pf_a, pf_rows_a, lda_b, kbytes - koff);
+      const auto rsrc_b = slice_rsrc(pf_b, pf_rows_b, ldb_b, kbytes - koff);
+      auto prefetch = [&]() {
+        if (!pf) return;
+#pragma unroll
+        for (int j = 0; j < PA; ++j) stage_piece<NW>(An, rsrc_a, pf_rows_a, lda_b, kbytes - koff, wave, lane, j);
+#pragma unroll
+        for (int j = 0; j < PB; ++j) stage_piece<NW>(An + A_BYTES, rsrc_b, pf_rows_b, ldb_b, kbytes - koff, wave, lane, j);
+      };
+      if ((t & 3) == 0) {       // a new group of 4 K-steps: its scale dwords were requested a group ago; request the next group's
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) sca[mt] = sca_n[mt];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) scb[nt] = scb_n[nt];
+        if (t + 4 < nk) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) sca_n[mt] = *reinterpret_cast<const uint32_t*>(ma.sa + sao[mt] + (uint32_t)(t + 4));
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) scb_n[nt] = *reinterpret_cast<const uint32_t*>(ma.sb + sbo[nt] + (uint32_t)(t + 4));
+        }
+      }
+      const int sh = (t & 3) * 8;
+      const bool late = wave >= NW / 2;
+      if (!late) prefetch();
+      v8i_t bfr[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const u32x4 lo = read_frag_rows(Bs, (wc * NT + nt) * 16 + r16, g), hi = read_frag_rows(Bs, (wc * NT + nt) * 16 + r16, 4 + g);
+        bfr[nt] = v8i_t{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+      }
+      // A fragments two m-tiles at a time (16 registers; all eight at once would be 64 beside the 128 of the accumulators)
+#pragma unroll
+      for (int qd = 0; qd < MT / 2; ++qd) {
+        v8i_t afr[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int row = (wr * MT + 2 * qd + i) * 16 + r16;
+          const u32x4 lo = read_frag_rows(As, row, g), hi = read_frag_rows(As, row, 4 + g);
+          afr[i] = v8i_t{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+        }
+        if (qd == MT / 2 - 1) {     // the wait for the next K-slice and the barrier sit before the last quarter of the step's MFMAs
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int mt = 2 * qd + i;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[nt][mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bfr[nt], afr[i], acc[nt][mt], 0, 0, 0, (int)(scb[nt] >> sh), 0,
+                                                                           (int)(sca[mt] >> sh));
+        }
+        if (qd == 0 && late) {
+          __builtin_amdgcn_sched_barrier(0);
+          prefetch();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      cur ^= 1;
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------
+    bf16_t* C = reinterpret_cast<bf16_t*>(a.C);
+    const bool relu = a.flags & LAKO_EPI_RELU;
+    const bool drop = a.drop_thresh != 0;
+    if (a.wide_epi) {       // as gemm_nt_kernel's WIDE epilogue: 32 rows at a time through the wave's 8 KiB of the free buffer
+      char* ep = smem + (cur ^ 1) * BUF + wave * 8192;
+      const int cj = lane & 7, n = n0 + wc * 64 + cj * 8;
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const int mt = 2 * pass + mi, row_l = mi * 16 + r16;
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            f32x4 v = acc[nt][mt] * a.alpha;
+            if (relu) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            *reinterpret_cast<f32x4*>(ep + row_l * 256 + (((nt * 4 + g) ^ (row_l & 15)) * 16)) = v;
+          }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int row_l = it * 8 + (lane >> 3);
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(ep + row_l * 256 + (((2 * cj) ^ (row_l & 15)) * 16));
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(ep + row_l * 256 + (((2 * cj + 1) ^ (row_l & 15)) * 16));
+          const int m = m0 + wr * 128 + pass * 32 + row_l;
+          if (m < a.M && n < a.N) {
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            if (drop) {
+              const uint64_t idx = (uint64_t)(a.row0 + m) * (uint64_t)a.N + (uint64_t)n;
+              bool kp[2][4];
+              lako_keep4(a.drop_key, idx >> 2, a.drop_thresh, kp[0]);
+              lako_keep4(a.drop_key, (idx >> 2) + 1, a.drop_thresh, kp[1]);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = kp[e >> 2][e & 3] ? v[e] * a.drop_scale : 0.f;
+            }
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+            *reinterpret_cast<bf16x8*>(C + (int64_t)m * a.ldc + n) = o;
+          }
+        }
+      }
+      if (!has_next) break;
+      __syncthreads();
+    } else {
+      nt_store_tile<bf16_t, bf16_t, WM, WN, MT, NT>(a, acc, m0, n0, wr, wc, lane);
+      if (!has_next) break;
+    }
+    tile = next_tile;
+    m0 = nm0;
+    n0 = nn0;
+    rows_a = min(BM, a.M - m0);
+    rows_b = min(BN, a.N - n0);
+  }
+}
+
+// MX quantisation of a bf16 matrix: per row and per 32 consecutive k one E8M0 scale 2^(e − 127), e − 127 = floor(log2(amax)) − 8
+// (8 = the exponent of e4m3's largest normal, 448 = 1.75·2^8: the OCP microscaling rule), elements q = sat_e4m3(x · 2^−(e−127)).
+// One lane = 8 consecutive k (a 16-byte load, an 8-byte store); the 4 lanes of a block agree on amax by two shuffles.
+__global__ __launch_bounds__(256) void mx_quantize_kernel(const bf16_t* __restrict__ x, int64_t rows, int K, int64_t ld,
+                                                          uint8_t* __restrict__ q, uint8_t* __restrict__ sc, int ksp) {
+  const int per_row = K >> 3;
+  const int64_t total = rows * per_row;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / per_row;
+    const int c = (int)(i - row * per_row);                 // 8-element chunk of the row
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + row * ld + c * 8);
+    float f[8], amax = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      f[e] = (float)v[e];
+      amax = fmaxf(amax, fabsf(f[e]));
+    }
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+    // exponent of amax from its bits (0 and subnormals: the smallest scale); non-finite inputs saturate
+    int ex = (int)((__builtin_bit_cast(uint32_t, amax) >> 23) & 0xff) - 8;
+    ex = min(max(ex, 0), 254);
+    const float inv = __builtin_bit_cast(float, (uint32_t)(254 - ex) << 23);        // 2^(127 − ex): exact
+    uint32_t w[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float t[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] = fminf(fmaxf(f[4 * h + e] * inv, -448.f), 448.f);
+      int p = __builtin_amdgcn_cvt_pk_fp8_f32(t[0], t[1], 0, false);
+      p = __builtin_amdgcn_cvt_pk_fp8_f32(t[2], t[3], p, true);
+      w[h] = (uint32_t)p;
+    }
+    *reinterpret_cast<u32x2*>(q + row * K + c * 8) = u32x2{w[0], w[1]};
+    if ((c & 3) == 0) {
+      const int blk = c >> 2;                               // 32-element block of the row
+      sc[row * 4 * ksp + (blk & 3) * ksp + (blk >> 2)] = (uint8_t)ex;
+    }
+  }
+}
+
 int g_tn_big = 1;
 int g_tn_split = 0;   // > 0: force the number of K-splits of the 256x256 TN kernel (A/B measurements)
 int g_nt_wide_epi = 1;
@@ -1496,6 +1750,79 @@ extern "C" int lako_gemm_tn_grouped(const lako_gemm_tn_item_t* items, int n_item
     attr_done = true;
   }
   hipLaunchKernelGGL(gemm_tn256_kernel, dim3(tiles * a.split_k), dim3(512), 4 * TN2_IMG, (hipStream_t)stream, a);
+  LAKO_LAUNCH_CHECK();
+  return LAKO_OK;
+}
+
+extern "C" int lako_mx_quantize(const void* x, int64_t rows, int64_t K, int64_t ld, void* q, uint8_t* scales, lako_stream_t stream) {
+  LAKO_CHECK_ARG(x && q && scales, "lako_mx_quantize: null tensor");
+  LAKO_CHECK_ARG(rows > 0 && K > 0 && K % 128 == 0 && K < (1 << 24) && ld % 8 == 0 && ld >= K, "lako_mx_quantize: K must be a positive multiple of 128, ld %% 8 == 0");
+  LAKO_CHECK_ALIGN(x, 16);
+  LAKO_CHECK_ALIGN(q, 8);
+  const int ksp = (int)(((K / 128) + 3) / 4 * 4);
+  const int64_t total = rows * (K / 8);
+  int64_t grid = (total + 255) / 256;
+  if (grid > 256 * 16) grid = 256 * 16;
+  hipLaunchKernelGGL(mx_quantize_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, rows, (int)K, ld,
+                     (uint8_t*)q, scales, ksp);
+  LAKO_LAUNCH_CHECK();
+  return LAKO_OK;
+}
+
+extern "C" int lako_gemm_nt_mx(const lako_gemm_nt_t* p, const uint8_t* a_scales, const uint8_t* b_scales, lako_stream_t stream) {
+  LAKO_CHECK_ARG(p != nullptr && a_scales && b_scales, "lako_gemm_nt_mx: null params");
+  LAKO_CHECK_ARG(p->M > 0 && p->N > 0 && p->K > 0, "lako_gemm_nt_mx: bad dims");
+  LAKO_CHECK_ARG(p->in_dtype == LAKO_FP8_E4M3 && p->out_dtype == LAKO_BF16, "lako_gemm_nt_mx: e4m3 operands, bf16 output");
+  LAKO_CHECK_ARG(p->K % 128 == 0 && p->lda % 16 == 0 && p->ldb % 16 == 0, "lako_gemm_nt_mx: K %% 128 == 0, 16-byte rows");
+  LAKO_CHECK_ARG(p->N % 8 == 0 && p->ldc % 8 == 0, "lako_gemm_nt_mx: N and ldc must be multiples of 8");
+  LAKO_CHECK_ARG(p->M < (1 << 30) && p->N < (1 << 30) && p->K < (1 << 24), "lako_gemm_nt_mx: dims too large");
+  LAKO_CHECK_ARG(!(p->flags & LAKO_EPI_ATOMIC), "lako_gemm_nt_mx: no atomic epilogue");
+  LAKO_CHECK_ALIGN(p->A, 16);
+  LAKO_CHECK_ALIGN(p->B, 16);
+  LAKO_CHECK_ALIGN(p->C, 16);
+  LAKO_CHECK_ALIGN(a_scales, 4);
+  LAKO_CHECK_ALIGN(b_scales, 4);
+  if (p->flags & LAKO_EPI_RESID) LAKO_CHECK_ARG(p->resid != nullptr && p->ldr % 4 == 0, "lako_gemm_nt_mx: RESID needs resid, ldr %% 4 == 0");
+  if (p->flags & LAKO_EPI_AUXMASK) LAKO_CHECK_ARG(p->aux != nullptr && p->ldaux % 4 == 0, "lako_gemm_nt_mx: AUXMASK needs aux (bf16), ldaux %% 4 == 0");
+  MxArgs m;
+  NtArgs& a = m.nt;
+  a = NtArgs{};
+  a.A = (const char*)p->A;
+  a.B = (const char*)p->B;
+  a.C = (char*)p->C;
+  a.resid = (const char*)p->resid;
+  a.aux = (const char*)p->aux;
+  a.M = (int)p->M;
+  a.N = (int)p->N;
+  a.K = (int)p->K;
+  a.lda = p->lda;
+  a.ldb = p->ldb;
+  a.ldc = p->ldc;
+  a.ldr = p->ldr;
+  a.ldaux = p->ldaux;
+  a.alpha = p->alpha;
+  a.aux_scale = p->aux_scale;
+  a.flags = p->flags;
+  a.drop_thresh = p->drop.p > 0.f ? lako_drop_thresh(p->drop.p) : 0u;
+  a.drop_scale = p->drop.p > 0.f ? 1.0f / (1.0f - p->drop.p) : 1.0f;
+  a.drop_key = lako_drop_key(p->drop.seed, p->drop.site);
+  a.tiles_m = cdiv(a.M, 256);
+  a.tiles_n = cdiv(a.N, 256);
+  a.group_m = a.tiles_n >= 16 ? (g_nt_group_m < 0 ? -g_nt_group_m : g_nt_group_m) : (g_nt_group_m < 0 ? -g_nt_group_m : 0);
+  a.wide_epi = !(a.flags & (LAKO_EPI_RESID | LAKO_EPI_AUXMASK));
+  m.sa = a_scales;
+  m.sb = b_scales;
+  m.ksp = (int)(((p->K / 128) + 3) / 4 * 4);
+  int grid = a.tiles_m * a.tiles_n;
+  if (grid > 256) grid = 256;
+  a.dephase = (g_nt_dephase > 0 && a.tiles_m * a.tiles_n > grid) ? ((g_nt_dephase_n << 16) | (g_nt_dephase & 0xffff)) : 0;
+  constexpr int LDS = 2 * (256 + 256) * TKB;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_mx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(gemm_nt_mx_kernel, dim3(grid), dim3(512), LDS, (hipStream_t)stream, m);
   LAKO_LAUNCH_CHECK();
   return LAKO_OK;
 }

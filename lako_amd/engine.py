@@ -152,7 +152,7 @@ class _Ctx:
 
 
 class Engine:
-    def __init__(self, cfg: FiDConfig, ops, device, dtype=torch.bfloat16, seed: int = 0):
+    def __init__(self, cfg: FiDConfig, ops, device, dtype=torch.bfloat16, seed: int = 0, fp8: bool | None = None):
         if cfg.d_kv not in (32, 64):
             raise ValueError(f"d_kv={cfg.d_kv} unsupported by the attention kernels (32 or 64)")
         if cfg.d_model % 8 or cfg.d_ff % 8 or cfg.vocab_size % 8:
@@ -181,6 +181,13 @@ class Engine:
         self.ctx: _Ctx | None = None
         self.grad_hook = None    # callable(lo, hi): gradients G[lo:hi] are final (data-parallel overlap)
         self.shadows_stale = True
+        # MX block-scaled fp8 forward GEMMs (BASELINE config 5): the encoder's QKV and FFN-in projections and the cross-K/V
+        # projection — the GEMMs whose A operand is a norm output — multiply e4m3 operands with E8M0 block scales on
+        # v_mfma_scale_f32_16x16x128_f8f6f4; everything else (attention, norms, the other GEMMs, the whole backward) stays bf16
+        self.fp8 = bool(int(os.environ.get("LAKO_FP8", "0"))) if fp8 is None else bool(fp8)
+        if self.fp8 and (dtype != torch.bfloat16 or not hasattr(ops, "gemm_nt_mx")):
+            raise ValueError("fp8 GEMMs need the bf16 engine on the HIP op set")
+        self._w8: dict = {}      # block name → (e4m3 bytes [N, K], scales) of the weight shadow
 
     # ------------------------------------------------------------------------------------------
     # parameter views
@@ -246,7 +253,35 @@ class Engine:
         if self.W is not self.P:
             self.ops.cast(self.P, self.W)
         self.refresh_transposed()
+        if self.fp8:
+            self.refresh_fp8()
         self.shadows_stale = False
+
+    def _fp8_blocks(self):
+        names = [f"enc.{i}.{m}" for i in range(self.cfg.num_layers) for m in ("qkv", "wi")] + ["dec.kv_all"]
+        return [self.by_name[n] for n in names if self.by_name[n].shape[1] % 128 == 0]
+
+    def refresh_fp8(self):
+        """e4m3 + block-scale shadows of the weights that take part in fp8 GEMMs, from the bf16 shadow W"""
+        for b in self._fp8_blocks():
+            if b.name not in self._w8:
+                n, k = b.shape
+                self._w8[b.name] = (torch.empty(n, k, dtype=torch.uint8, device=self.device),
+                                    torch.empty(n, self.ops.mx_scale_cols(k), dtype=torch.uint8, device=self.device))
+            q, sc = self._w8[b.name]
+            self.ops.mx_quantize(self._view(self.W, b), q, sc)
+
+    def _gemm_w(self, ws, x, name, w, out, **epi):
+        """out = epilogue(x · wᵀ): on the block-scaled fp8 matrix cores when this weight has an fp8 shadow (x is quantised into
+        workspace scratch first), else the bf16 GEMM"""
+        w8 = self._w8.get(name) if self.fp8 else None
+        if w8 is None:
+            return self.ops.gemm_nt(x, w, out, **epi)
+        M, K = x.shape
+        xq = self._buf(ws, f"q8.{K}", (M, K), torch.uint8)
+        xs = self._buf(ws, f"s8.{K}", (M, self.ops.mx_scale_cols(K)), torch.uint8)
+        self.ops.mx_quantize(x, xq, xs)
+        self.ops.gemm_nt_mx(xq, xs, w8[0], w8[1], out, **epi)
 
     def zero_grad(self):
         self.ops.zero_(self.G)
@@ -299,7 +334,7 @@ class Engine:
         xn1 = self._buf(ws, f"e.xn1.{j}", (Me, d))
         ops.rmsnorm_fwd(h, lw["ln1"].p, xn1, self._buf(ws, f"e.rs1.{j}", (Me,), torch.float32), eps)
         qkv = self._buf(ws, f"e.qkv.{j}", (Me, 3 * inner))
-        ops.gemm_nt(xn1, lw["qkv"].w, qkv)
+        self._gemm_w(ws, xn1, f"enc.{i}.qkv", lw["qkv"].w, qkv)
         ctx = self._buf(ws, f"e.ctx.{j}", (Me, inner))
         hb, ht, akw = self._enc_attn_layout(rag, BN, L, mask_u8)
         ops.attn_fwd(self._heads(qkv, hb, ht, 0), self._heads(qkv, hb, ht, inner), self._heads(qkv, hb, ht, 2 * inner),
@@ -310,7 +345,7 @@ class Engine:
         xn2 = self._buf(ws, f"e.xn2.{j}", (Me, d))
         ops.rmsnorm_fwd(h1, lw["ln2"].p, xn2, self._buf(ws, f"e.rs2.{j}", (Me,), torch.float32), eps)
         a1 = self._buf(ws, f"e.a1.{j}", (Me, f))
-        ops.gemm_nt(xn2, lw["wi"].w, a1, relu=True, drop=dr(_enc_site(i, 2)))
+        self._gemm_w(ws, xn2, f"enc.{i}.wi", lw["wi"].w, a1, relu=True, drop=dr(_enc_site(i, 2)))
         if h_out is not None:
             ops.gemm_nt(a1, lw["wo"].w, h_out, resid=h1, drop=dr(_enc_site(i, 3)))
 
@@ -344,7 +379,7 @@ class Engine:
                         eps, dr(S_ENC_FINAL))
         # K/V projections of every decoder layer's cross-attention in ONE GEMM (reads enc_out once)
         kv = self._buf(ws, "e.kv", (Me, self.kv_all.w.shape[0]))
-        ops.gemm_nt(enc_out, self.kv_all.w, kv)
+        self._gemm_w(ws, enc_out, "dec.kv_all", self.kv_all.w, kv)
         return enc_out, kv
 
     def _ragged_batch(self, attention_mask, B, N, L, lengths=None):

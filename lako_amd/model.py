@@ -69,13 +69,13 @@ class _LossFn(torch.autograd.Function):
 
 
 class FiDT5(nn.Module):
-    def __init__(self, config, dtype: torch.dtype | None = None, seed: int = 0, _ops=None):
+    def __init__(self, config, dtype: torch.dtype | None = None, seed: int = 0, _ops=None, fp8: bool | None = None):
         super().__init__()
         self.config = config if isinstance(config, FiDConfig) else FiDConfig.from_hf(config)
         env = os.environ.get("LAKO_DTYPE", "bf16").lower()
         self.compute_dtype = dtype or {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "f32": torch.float32,
                                        "fp32": torch.float32, "float32": torch.float32}[env]
-        self._ops, self._seed = _ops, seed
+        self._ops, self._seed, self._fp8 = _ops, seed, fp8
         self._blocks = build_layout(self.config)
         n, _ = layout_sizes(self._blocks)
         self._master = torch.zeros(n, dtype=torch.float32)
@@ -176,7 +176,7 @@ class FiDT5(nn.Module):
                 from .ops import HipOps
                 ops = HipOps()
             eng = Engine.__new__(Engine)
-            Engine.__init__(eng, self.config, ops, dev, self.compute_dtype, seed=self._seed)
+            Engine.__init__(eng, self.config, ops, dev, self.compute_dtype, seed=self._seed, fp8=self._fp8)
             eng.P.copy_(self._master)
             self._master = eng.P
             eng.use_checkpoint = self._use_checkpoint

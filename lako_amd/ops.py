@@ -15,7 +15,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (EPI_ATOMIC, EPI_AUXMASK, EPI_RELU, EPI_RESID, LAKO_BF16, LAKO_F32, AttnBwd, AttnFwd, Dropout,
+from ._lib import (EPI_ATOMIC, EPI_AUXMASK, EPI_RELU, EPI_RESID, LAKO_BF16, LAKO_F32, LAKO_FP8_E4M3, AttnBwd, AttnFwd, Dropout,
                    GemmNT, LakoError, NO_DROP, check)
 
 
@@ -96,6 +96,48 @@ class HipOps:
 
     def set_tuning(self, key: str, value: int):
         check(self.lib.lako_set_tuning(key.encode(), int(value)), "lako_set_tuning")
+
+    # ---- MX block-scaled fp8 GEMM (BASELINE config 5) -------------------------------------------------------------
+    @staticmethod
+    def mx_scale_cols(K):
+        """bytes of scales per operand row: 4 (k-blocks of a K-step) × KSP, KSP = ⌈K/128⌉ rounded up to 4"""
+        return 4 * (((K // 128) + 3) // 4 * 4)
+
+    def mx_quantize(self, x, q, scales):
+        """x bf16 [rows, K] (unit inner stride) → q uint8 [rows, K] (e4m3 bytes), scales uint8 [rows, mx_scale_cols(K)]"""
+        rows, K, ld = _rowmajor2d(x, "mx_quantize x")
+        if x.dtype != torch.bfloat16 or q.dtype != torch.uint8 or scales.dtype != torch.uint8 or tuple(q.shape) != (rows, K) or \
+                not q.is_contiguous() or not scales.is_contiguous() or tuple(scales.shape) != (rows, self.mx_scale_cols(K)):
+            raise LakoError("mx_quantize: x bf16 [rows, K], q uint8 [rows, K], scales uint8 [rows, mx_scale_cols(K)], all contiguous rows")
+        self._timed("mx_quantize", 0.0, lambda: check(self.lib.lako_mx_quantize(_p(x), rows, K, ld, _p(q), _p(scales), self._stream()), "lako_mx_quantize"))
+
+    def gemm_nt_mx(self, Aq, As, Bq, Bs, Cm, *, alpha=1.0, relu=False, resid=None, aux=None, aux_scale=1.0, drop=None):
+        """C bf16 [M, N] = epilogue(alpha · dequant(Aq, As) · dequant(Bq, Bs)ᵀ) on the block-scaled fp8 matrix cores"""
+        M, K, lda = _rowmajor2d(Aq, "gemm_nt_mx A")
+        N, K2, ldb = _rowmajor2d(Bq, "gemm_nt_mx B")
+        M2, N2, ldc = _rowmajor2d(Cm, "gemm_nt_mx C")
+        if K != K2 or M != M2 or N != N2 or Aq.dtype != torch.uint8 or Bq.dtype != torch.uint8 or Cm.dtype != torch.bfloat16:
+            raise LakoError(f"gemm_nt_mx: shape/dtype mismatch A{tuple(Aq.shape)} B{tuple(Bq.shape)} C{tuple(Cm.shape)}")
+        sc = self.mx_scale_cols(K)
+        if tuple(As.shape) != (M, sc) or tuple(Bs.shape) != (N, sc) or not As.is_contiguous() or not Bs.is_contiguous():
+            raise LakoError("gemm_nt_mx: scales must be contiguous [rows, mx_scale_cols(K)] uint8")
+        p = GemmNT()
+        p.A, p.B, p.C = Aq.data_ptr(), Bq.data_ptr(), Cm.data_ptr()
+        p.M, p.N, p.K, p.lda, p.ldb, p.ldc = M, N, K, lda, ldb, ldc
+        p.in_dtype, p.out_dtype = LAKO_FP8_E4M3, LAKO_BF16
+        p.alpha = float(alpha)
+        p.flags = (EPI_RELU if relu else 0) | (EPI_RESID if resid is not None else 0) | (EPI_AUXMASK if aux is not None else 0)
+        if resid is not None:
+            if resid.dtype != Cm.dtype or resid.shape != Cm.shape:
+                raise LakoError("gemm_nt_mx: resid must match C")
+            p.resid, p.ldr = resid.data_ptr(), resid.stride(0)
+        if aux is not None:
+            if aux.dtype != torch.bfloat16 or aux.shape != Cm.shape:
+                raise LakoError("gemm_nt_mx: aux must be bf16 [M, N]")
+            p.aux, p.ldaux = aux.data_ptr(), aux.stride(0)
+        p.aux_scale = float(aux_scale)
+        p.drop = _drop(drop)
+        self._timed("gemm_nt_mx", 2.0 * M * N * K, lambda: check(self.lib.lako_gemm_nt_mx(C.byref(p), _p(As), _p(Bs), self._stream()), "lako_gemm_nt_mx"))
 
     # ---- GEMMs -----------------------------------------------------------------------------
     def gemm_nt(self, A, B, Cm, *, alpha=1.0, relu=False, resid=None, aux=None, aux_scale=1.0, drop=None,

@@ -403,3 +403,33 @@ class RefOps:
                 res.append(span(vals, start, len(toks)))
             res += [-5] * (n_ctx - len(res))
             out[b] = torch.tensor(res, dtype=torch.float64) / (layers_used * H)
+
+
+# ---- MX (OCP microscaling) e4m3: the integer recipe of csrc/gemm.hip::mx_quantize_kernel, for the kernel tests ---------------
+def mx_quantize_ref(x: torch.Tensor):
+    """x float [rows, K] → (q float [rows, K] = the e4m3-rounded scaled elements, e int [rows, K/32] = E8M0 scale bytes)."""
+    rows, K = x.shape
+    xb = x.float().view(rows, K // 32, 32)
+    amax = xb.abs().amax(-1)
+    ex = ((amax.view(torch.int32) >> 23) & 0xFF) - 8
+    ex = ex.clamp(0, 254)
+    inv = ((254 - ex) << 23).to(torch.int32).view(torch.float32)
+    t = (xb * inv[..., None]).clamp(-448.0, 448.0)
+    q = t.to(torch.float8_e4m3fn).float()                 # OCP e4m3, round to nearest even
+    return q.view(rows, K), ex
+
+
+def mx_dequant_ref(q: torch.Tensor, ex: torch.Tensor):
+    rows, K = q.shape
+    scale = torch.ldexp(torch.ones_like(ex, dtype=torch.float32), ex - 127)
+    return (q.view(rows, K // 32, 32) * scale[..., None]).view(rows, K)
+
+
+def mx_scales_layout(ex: torch.Tensor, K: int):
+    """[rows, K/32] block exponents → the library's [rows, 4, KSP] byte layout"""
+    rows = ex.shape[0]
+    ksp = ((K // 128) + 3) // 4 * 4
+    out = torch.zeros(rows, 4, ksp, dtype=torch.uint8)
+    blk = torch.arange(K // 32)
+    out[:, blk % 4, blk // 4] = ex.to(torch.uint8)
+    return out.view(rows, 4 * ksp)

@@ -681,3 +681,71 @@ def test_attention_dropout_recipe_statistics():
                        (k[:, :-4], k[:, 4:]), (k[:, :, :-4], k[:, :, 4:]), (k[:-1], k[1:]), (k[:, :-1, :-1], k[:, 1:, 1:])):
             assert abs(c(a_, b_)) < 2.5e-3
         assert abs(float(k.mean(2).std()) - (0.09 / 200) ** 0.5) < 1.5e-3          # per-row keep fractions: binomial spread
+
+
+# ------------------------------------------------------------------------------------------------
+# MX block-scaled fp8 GEMM (BASELINE config 5)
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,K", [(300, 768), (64, 3072), (1000, 128), (33, 1024)])
+def test_mx_quantize(ops, rows, K):
+    """lako_mx_quantize against the recipe in tests/ref_ops.py: e4m3 bytes and E8M0 block scales bit for bit (incl. an all-zero
+    block, a block with one huge value, tiny values) and the [rows, 4, KSP] scale layout."""
+    from tests.ref_ops import mx_quantize_ref, mx_scales_layout
+    x = rnd(rows, K, seed=5, scale=2.0)
+    x[3, 32:64] = 0.0
+    x[5, 7] = 3.0e4
+    x[7, 96:128] *= 1e-6
+    xb = x.to(torch.bfloat16)
+    q = torch.zeros(rows, K, dtype=torch.uint8, device=dev())
+    sc = torch.zeros(rows, ops.mx_scale_cols(K), dtype=torch.uint8, device=dev())
+    ops.mx_quantize(xb, q, sc)
+    qr, ex = mx_quantize_ref(xb.float().cpu())
+    assert torch.equal(q.cpu().view(torch.float8_e4m3fn).float(), qr)
+    assert torch.equal(sc.cpu(), mx_scales_layout(ex, K))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 264, 768), (1024, 768, 3072), (3000, 2304, 768), (70000, 768, 768)])
+def test_gemm_nt_mx(ops, M, N, K):
+    """lako_gemm_nt_mx: quantise both operands with lako_mx_quantize, multiply on the block-scaled matrix cores, compare with the
+    fp32 product of the DEQUANTISED operands (the kernel's only rounding is fp32 accumulation + the bf16 store) — edge tiles,
+    several K-step groups (scale dword reloads), more tiles than workgroups (persistent loop)."""
+    from tests.ref_ops import mx_dequant_ref, mx_quantize_ref
+    A = rnd(M, K, seed=31, scale=1.5).to(torch.bfloat16)
+    B = rnd(N, K, seed=32, scale=0.7).to(torch.bfloat16)
+    Aq, Bq = (torch.zeros(t.shape, dtype=torch.uint8, device=dev()) for t in (A, B))
+    As, Bs = (torch.zeros(t.shape[0], ops.mx_scale_cols(K), dtype=torch.uint8, device=dev()) for t in (A, B))
+    ops.mx_quantize(A, Aq, As)
+    ops.mx_quantize(B, Bq, Bs)
+    Cm = torch.zeros(M, N, dtype=torch.bfloat16, device=dev())
+    ops.gemm_nt_mx(Aq, As, Bq, Bs, Cm, alpha=0.5)
+    Ad = mx_dequant_ref(*mx_quantize_ref(A.float().cpu())).to(dev())
+    Bd = mx_dequant_ref(*mx_quantize_ref(B.float().cpu())).to(dev())
+    want = 0.5 * (Ad @ Bd.t())
+    close(Cm, want, torch.bfloat16, f"gemm_nt_mx {M}x{N}x{K}", k=0.5)
+    # and it is a usable approximation of the bf16 product: block-scaled e4m3 carries ≈ 2^-4 relative error per element
+    exact = 0.5 * (A.float() @ B.float().t())
+    rel = float((Cm.float() - exact).norm() / exact.norm())
+    assert rel < 0.06, rel
+
+
+@pytest.mark.gpu
+def test_gemm_nt_mx_epilogues(ops, ref):
+    from tests.ref_ops import mx_dequant_ref, mx_quantize_ref
+    M, N, K = 520, 768, 768
+    A = rnd(M, K, seed=41).to(torch.bfloat16)
+    B = rnd(N, K, seed=42, scale=0.5).to(torch.bfloat16)
+    res = rnd(M, N, seed=43).to(torch.bfloat16)
+    aux = rnd(M, N, seed=44).to(torch.bfloat16)
+    Aq, Bq = (torch.zeros(t.shape, dtype=torch.uint8, device=dev()) for t in (A, B))
+    As, Bs = (torch.zeros(t.shape[0], ops.mx_scale_cols(K), dtype=torch.uint8, device=dev()) for t in (A, B))
+    ops.mx_quantize(A, Aq, As)
+    ops.mx_quantize(B, Bq, Bs)
+    Ad = mx_dequant_ref(*mx_quantize_ref(A.float().cpu())).to(dev()).to(torch.bfloat16)
+    Bd = mx_dequant_ref(*mx_quantize_ref(B.float().cpu())).to(dev()).to(torch.bfloat16)
+    for kw in (dict(relu=True, drop=(0.1, 3, 4)), dict(resid=res, drop=(0.1, 5, 6)), dict(aux=aux, aux_scale=1.0 / 0.9), dict()):
+        got = torch.zeros(M, N, dtype=torch.bfloat16, device=dev())
+        want = torch.zeros(M, N, device=dev())
+        ops.gemm_nt_mx(Aq, As, Bq, Bs, got, **kw)
+        ref.gemm_nt(Ad, Bd, want, **kw)                    # same epilogue recipe on the dequantised (bf16-exact) operands
+        close(got, want, torch.bfloat16, f"gemm_nt_mx epilogue {sorted(kw)}", k=0.5)

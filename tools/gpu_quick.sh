@@ -1,6 +1,3 @@
-python -m pytest tests/test_kernels_gpu.py -q -x -k "attention" 2>&1 | tail -3
-python tools/attn_time.py
-export LAKO_LIB=$PWD/lako_amd/liblako_hip_exp.so
-LAKO_ATTN_DEBUG=512 TAG=dq-only python tools/attn_time.py
-LAKO_ATTN_DEBUG=560 TAG=dq-only-no-staging-no-compute python tools/attn_time.py
-LAKO_ATTN_DEBUG=256 TAG=dkv-only python tools/attn_time.py
+python -m pytest tests/test_real_size_gpu.py -q -k "fp8 or batch16 or c4" 2>&1 | grep -E "^E|passed|failed" | head
+python bench.py --fp8 --steps 15 --warmup 5 --no-cpu-baseline --all-valid-steps 0 --breakdown 2> gpurun_out/fp8_breakdown.txt | cut -c1-300; head -8 gpurun_out/fp8_breakdown.txt
+python bench.py --steps 15 --warmup 5 --no-cpu-baseline --all-valid-steps 0 | cut -c1-200
