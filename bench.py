@@ -355,6 +355,7 @@ def main():
                        "answer_len": T, "dropout": args.dropout, "parallelism": f"dp{world}",
                        "rccl_world_size": dist.get_world_size() if use_dist else None,
                        "dp_mode": os.environ.get("LAKO_DP_MODE", "deferred") if use_dist else None,
+                       "dp_grad_dtype": os.environ.get("LAKO_DP_GRAD_DTYPE", "fp32") if use_dist else None,
                        "host_enqueue_ms_per_step": None if r["host_ms"] is None else round(r["host_ms"], 2),
                        "master_weights": "fp32", "final_mean_loss": round(final_loss, 4),
                        "passage_lengths": "all text_maxlength" if args.all_valid else "U{L/2..L} (SURVEY.md §8d)",

@@ -155,8 +155,8 @@ __device__ __forceinline__ f32x4 etail(int t, int g, int Lk) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// forward: 16 queries of one wave against the staged K / V, keys in chunks of at most 4 tile pairs (online softmax across the
-// two chunks a sequence of <= 256 keys can have: the score tiles of a chunk are 32 registers, the kernel fits 128)
+// forward: 16 queries of one wave against the staged K / V, keys in chunks of at most 3 tile pairs (online softmax across the
+// up to three chunks of a sequence of <= 256 keys: the score tiles of a chunk are 24 registers, the kernel fits 128)
 // ---------------------------------------------------------------------------------------------------------------------
 template <bool DROP, int NPC>
 __device__ __forceinline__ void efwd_chunk(const char* Kimg, const char* Vimg, int pair0, bool last, const f32x4 (&tail)[2],
@@ -243,7 +243,11 @@ __global__ __launch_bounds__(FWD_NW * 64, FWD_NW / 2) void enc_fwd_kernel(AttnAr
   const int KB = (a.Lk + 3) >> 2, QB = (a.Lq + 3) >> 2;
   const float oscale = DROP ? a.drop_scale : 1.0f;
   const f32x4 tail[2] = {etail(2 * np - 2, g, Lk), etail(2 * np - 1, g, Lk)};
-  const int npa = min(np, 4), npb = np - npa;           // chunk A: pairs [0, npa), chunk B: [4, 4 + npb)
+  // chunks of at most CH tile pairs: [0, n0), [CH, CH + n1), [2·CH, 2·CH + n2).  CH = 3 with dropout (24 registers of score tiles
+  // beside the hash state: 135 µs per config-2 launch against 145 at CH = 4, which spills), CH = 4 without (107 µs against 200:
+  // the compiler's schedule of the three-chunk form serialises there)
+  constexpr int CH = DROP ? 3 : 4;
+  const int n0 = min(np, CH), n1 = min(max(np - CH, 0), CH), n2 = max(np - 2 * CH, 0);
 
   u32x4 qf_next[2];
   auto request_q = [&](int qbn) { eload_frags(qf_next, qbase, a.qst * 2, qbn < qb_end ? qbn * 16 + l15 : Lq, Lq, g); };
@@ -262,9 +266,12 @@ __global__ __launch_bounds__(FWD_NW * 64, FWD_NW / 2) void enc_fwd_kernel(AttnAr
     f32x4 oacc[4];
 #pragma unroll
     for (int db = 0; db < 4; ++db) oacc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
-#define ECH(N, P0, LAST) case N: efwd_chunk<DROP, N>(Kimg, Vimg, P0, LAST, tail, bptr, qf, el, pblk, a.drop_key, drc, t_hi, m, l, oacc); break;
-    switch (npa) { ECH(1, 0, npb == 0) ECH(2, 0, npb == 0) ECH(3, 0, npb == 0) ECH(4, 0, npb == 0) default: break; }
-    switch (npb) { ECH(1, 4, true) ECH(2, 4, true) ECH(3, 4, true) ECH(4, 4, true) default: break; }
+#define ECH(N, P0, LAST) case N: if constexpr (N <= CH) efwd_chunk<DROP, N>(Kimg, Vimg, P0, LAST, tail, bptr, qf, el, pblk, a.drop_key, drc, t_hi, m, l, oacc); break;
+    switch (n0) { ECH(1, 0, n1 == 0) ECH(2, 0, n1 == 0) ECH(3, 0, n1 == 0) ECH(4, 0, n1 == 0) default: break; }
+    switch (n1) { ECH(1, CH, n2 == 0) ECH(2, CH, n2 == 0) ECH(3, CH, n2 == 0) ECH(4, CH, n2 == 0) default: break; }
+    if constexpr (CH == 3) {
+      switch (n2) { ECH(1, 2 * CH, true) ECH(2, 2 * CH, true) default: break; }
+    }
 #undef ECH
     l = egroup_sum(l);
     if (qi < Lq) {

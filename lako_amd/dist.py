@@ -14,6 +14,11 @@ reports finished ranges through `Engine.grad_hook`.  Two modes:
                         encoder layer, coalesced to `bucket_bytes`), issued while backward is still running;
                         `LAKO_DP_MODE=overlap`.  Correct (2-rank gloo test) — to be measured on 8 GPUs.
 
+`LAKO_DP_GRAD_DTYPE=bf16` (or `grad_dtype=torch.bfloat16`): the gradients travel as bf16 — half the bytes over the xGMI links (446 MB
+instead of 892 MB at T5-base; it is the 2- and 4-GPU runs, with one link per peer, that pay most for the collective) — through a
+bf16 staging buffer: cast → all-reduce → cast back, two extra passes over the flat buffer (≈0.5 ms).  The sum of world-size bf16
+gradients carries one more rounding than the single-GPU path has; the default stays fp32.
+
 `finish()` makes the compute stream wait for the collectives; the 1/world factor is folded into the fused
 optimizer step (lako_adamw_step grad_scale) and into the clip norm, so gradients are never rescaled in a
 separate pass.
@@ -26,7 +31,8 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, model, group=None, bucket_bytes: int = 64 << 20, force: bool = False, mode: str | None = None):
+    def __init__(self, model, group=None, bucket_bytes: int = 64 << 20, force: bool = False, mode: str | None = None,
+                 grad_dtype=None):
         self.force = force          # issue the collectives even at world size 1 (single-GPU test of the RCCL path)
         self.model = model
         self.group = group
@@ -38,6 +44,10 @@ class GradSync:
         self.handles = []
         self._pending = None
         self._dirty = False
+        if grad_dtype is None:
+            grad_dtype = {"bf16": __import__("torch").bfloat16, "fp32": None, "f32": None}[os.environ.get("LAKO_DP_GRAD_DTYPE", "fp32")]
+        self.grad_dtype = grad_dtype      # None: all-reduce the fp32 buffer in place
+        self._stage = None                # low-precision staging buffer, same layout as G
         eng = model._get_engine()
         eng.grad_hook = self._on_ready
         model._grad_sync = self
@@ -52,7 +62,12 @@ class GradSync:
         lo, hi = self._pending
         self._pending = None
         g = self.model._engine.G[lo:hi]
-        self.handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self.grad_dtype is None:
+            self.handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            st = self._staging()[lo:hi]
+            st.copy_(g)
+            self.handles.append((dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group, async_op=True), g, st))
 
     def _on_ready(self, lo: int, hi: int):
         if not self.active:
@@ -73,12 +88,29 @@ class GradSync:
             return
         self._dirty = False
         if self.mode == "deferred":
-            dist.all_reduce(self.model._engine.G, op=dist.ReduceOp.SUM, group=self.group)
+            G = self.model._engine.G
+            if self.grad_dtype is None:
+                dist.all_reduce(G, op=dist.ReduceOp.SUM, group=self.group)
+            else:
+                st = self._staging()
+                st.copy_(G)
+                dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group)
+                G.copy_(st)
             return
         self._flush()
         for h in self.handles:
-            h.wait()
+            if isinstance(h, tuple):
+                h[0].wait()
+                h[1].copy_(h[2])
+            else:
+                h.wait()
         self.handles = []
+
+    def _staging(self):
+        G = self.model._engine.G
+        if self._stage is None or self._stage.numel() != G.numel():
+            self._stage = G.new_empty(G.shape, dtype=self.grad_dtype)
+        return self._stage
 
 
 def broadcast_parameters(model, src: int = 0, group=None):
