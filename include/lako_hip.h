@@ -135,7 +135,8 @@ int lako_relpos_reduce(const float* drel, const int32_t* lut, float* dtable, int
  * NOT scaled by 1/sqrt(dk) — then dropout(P)·V.  One call covers every (batch row, head).
  * Used for encoder self-attention (bidirectional bias + key padding mask), decoder self-attention
  * (causal + unidirectional bias) and cross-attention over the concatenated n_passages·L encoder
- * states (key padding mask only). */
+ * states (key padding mask only).  bf16 / d_head 64 / <= 256 keys / no key mask / no causal mask / no score capture (the ragged
+ * encoder self-attention of training) takes the fast path of csrc/attn_enc.hip; everything else the generic kernels. */
 typedef struct {
   const void *q, *k, *v; /* element (b, t, h, c) at ptr + b*stride_b + t*stride_t + h*d_head + c */
   void* out;             /* same addressing with o_stride_* */
@@ -148,9 +149,11 @@ typedef struct {
   int causal, causal_off;  /* causal: key j visible iff j <= i + causal_off */
   int Bn, H, Lq, Lk, d_head;
   int dtype;
-  lako_dropout_t drop; /* on the probabilities.  Attention uses a cheaper draw than the element-wise sites: keys 4c … 4c+3
-                          of score row (b,h,i) share h = hash32(key ^ (((b*H+h)*Lq+i)*ceil(Lk/4) + c)), w = h*0x9E3779B1;
-                          their 16-bit draws are h>>16, h&0xffff, w>>16, w&0xffff; keep iff draw >= round(p*65536) */
+  lako_dropout_t drop; /* on the probabilities.  Block recipe (csrc/attn_shared.h; mirrored in tests/ref_ops.py): the 4x4 block
+                          (queries 4a.., keys 4c..) of head-row bh = b*H+h shares hb = mix(((bh*ceil(Lq/4) + a)*ceil(Lk/4) + c) ^ key,
+                          0x5BD1E9, 13); element (q, k) draws 16 bits of W = mix(hb, M[q&3][(k&3)>>1], 6 + 2*(q&3) + 5*((k&3)>>1)):
+                          the high half for even k, the low half for odd k; keep iff draw >= round(p*65536);
+                          mix(x, c, s) = t ^ (t >> 16), t = (x mod 2^24)*c + (x >> s) mod 2^32 (full-rate instructions only) */
   float* scores_out;   /* optional [Bn, H, Lq, Lk] fp32 raw pre-softmax scores (+bias, masked keys = 0):
                           the quantity src/model.py:316-329 stores for get_crossattention_scores */
   /* RAGGED sequences (optional; NULL = the padded layout above).  q_off / k_off: device int32 [Bn + 1] row offsets into ONE
