@@ -5,6 +5,10 @@
 // 16-byte vector accesses per lane everywhere; wave-level (64-lane) shuffle reductions.
 #include <stdarg.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "common.h"
 
 // ---- error string (thread local) ------------------------------------------------------------
@@ -340,7 +344,16 @@ __global__ __launch_bounds__(256) void transpose_cast_batched_kernel(const float
 }
 
 // ---- cross-entropy --------------------------------------------------------------------------
-__global__ void ce_init_kernel(float* loss_out, const int64_t* labels, int64_t M) {
+// The mean is accumulated in 2^-40 fixed point (a 64-bit integer add is order-independent, so the loss does not depend on which
+// row's workgroup finishes first); the last row to finish converts it.  scratch = {u64 sum, u32 rows done}.
+struct CeScratch {
+  unsigned long long sum;
+  unsigned done;
+  unsigned pad;
+};
+constexpr float CE_FIX = 1099511627776.0f;   // 2^40
+
+__global__ void ce_init_kernel(float* loss_out, const int64_t* labels, int64_t M, CeScratch* sc) {
   // single block: count valid labels
   __shared__ int cnt;
   if (threadIdx.x == 0) cnt = 0;
@@ -352,13 +365,15 @@ __global__ void ce_init_kernel(float* loss_out, const int64_t* labels, int64_t M
   if (threadIdx.x == 0) {
     loss_out[0] = 0.f;
     loss_out[1] = (float)cnt;
+    sc->sum = 0ull;
+    sc->done = 0u;
   }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
                                                  float* __restrict__ loss_out, T* __restrict__ dlogits,
-                                                 const float* __restrict__ upstream, int64_t V) {
+                                                 const float* __restrict__ upstream, int64_t V, CeScratch* sc) {
   __shared__ float red[4];
   __shared__ float bc;
   const int64_t row = blockIdx.x;
@@ -391,7 +406,14 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
   __syncthreads();
   se = bc;
   const float lse = mx + __logf(se);
-  if (threadIdx.x == 0 && valid) atomicAdd(loss_out, (lse - lr[label]) / n_valid);
+  if (threadIdx.x == 0) {
+    if (valid) atomicAdd(&sc->sum, (unsigned long long)(long long)((double)(lse - lr[label]) * (double)CE_FIX));
+    __threadfence();
+    if (atomicAdd(&sc->done, 1u) == gridDim.x - 1) {
+      const long long tot = (long long)atomicAdd(&sc->sum, 0ull);
+      loss_out[0] = (float)((double)tot / (double)CE_FIX / (double)n_valid);
+    }
+  }
   if (dlogits) {
     T* dr = dlogits + row * V;
     const float inv = valid ? (upstream ? upstream[0] : 1.0f) / n_valid : 0.f;
@@ -738,14 +760,31 @@ extern "C" int lako_transpose_cast_batched(const float* src_base, void* dst_base
   return LAKO_OK;
 }
 
+// 16 bytes of accumulator per (device, stream): calls on one stream are ordered, calls on different streams get different scratch
+static CeScratch* ce_scratch(hipStream_t stream) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, CeScratch*> tab;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  CeScratch*& p = tab[{dev, stream}];
+  if (!p && hipMalloc(reinterpret_cast<void**>(&p), sizeof(CeScratch)) != hipSuccess) p = nullptr;
+  return p;
+}
+
 extern "C" int lako_ce_fwd_bwd(const float* logits, const int64_t* labels, float* loss_out, void* dlogits,
                                const float* upstream, int64_t M, int64_t V, int dtype, lako_stream_t stream) {
   CHECK_DTYPE("lako_ce_fwd_bwd", dtype);
   LAKO_CHECK_ARG(M > 0 && V > 0 && V % 4 == 0, "lako_ce_fwd_bwd: M=%lld V=%lld (V %% 4 == 0)", (long long)M, (long long)V);
   LAKO_CHECK_ALIGN(logits, 16);
-  hipLaunchKernelGGL(ce_init_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_out, labels, M);
+  CeScratch* sc = ce_scratch((hipStream_t)stream);
+  if (!sc) {
+    lako_set_error("lako_ce_fwd_bwd: could not allocate the loss accumulator");
+    return LAKO_E_LAUNCH;
+  }
+  hipLaunchKernelGGL(ce_init_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_out, labels, M, sc);
   DISPATCH_T(dtype, hipLaunchKernelGGL((ce_kernel<T>), dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream, logits,
-                                       labels, loss_out, (T*)dlogits, upstream, V));
+                                       labels, loss_out, (T*)dlogits, upstream, V, sc));
   LAKO_LAUNCH_CHECK();
   return LAKO_OK;
 }
