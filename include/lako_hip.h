@@ -184,6 +184,57 @@ typedef struct {
 } lako_attn_bwd_t;
 int lako_attn_bwd(const lako_attn_bwd_t* p, lako_stream_t stream);
 
+/* ---- cross-attention in the encoder-state space (the decoder's EncDecAttention over the concatenated n_passages·L encoder
+ * states, src/model.py:286-349 / HF5:281-369; bf16, d_kv 64, ragged keys) --------------------------------------------------
+ * Same result as projecting every encoder state to K and V and calling lako_attn_fwd, re-associated so that the per-head
+ * projections act on the R = T·H query rows of a sample instead of on its keys (csrc/xattn.hip):
+ *   Q'[b][t·H + h][:] = q[b,t,h,:]·Wk_h          lako_headbatch_nt   ("expand": [B·T, 64] x [64, D] per head)
+ *   S  = Q'·E_bᵀ                                 lako_xattn_scores   (raw scores, no 1/sqrt(d) as in T5)
+ *   P  = dropout(softmax_keys(S))                lako_xattn_softmax_fwd
+ *   C' = P·E_b                                   lako_xattn_context  (fp32, accumulated with atomics: zero it first)
+ *   ctx[b,t,h,:] = C'[b][t·H + h][:]·Wv_hᵀ       lako_headbatch_nt   ("contract": [B·T, D] x [D, 64] per head)
+ * backward: dC' = expand(dctx, Wv), dP = lako_xattn_scores(dC'), dS = lako_xattn_softmax_bwd, dQ' = lako_xattn_context(dS),
+ * dq = contract(dQ', Wk), dWk_h += q_hᵀ·dQ'_h and dWv_h += dctx_hᵀ·C'_h (lako_headbatch_tn), and after the last layer
+ * dE_b = Σ_layers [P; dS]ᵀ·[dC'; Q'] (lako_gemm_tn_grouped, one item per sample).
+ * Key layout: E is the packed [rows, D] encoder output, sample b owns rows [k_off[b], k_off[b+1]); score / probability matrices
+ * are [R, p_total] with sample b's keys in columns [p_off[b], p_off[b] + n_keys(b)), every p_off[b] a multiple of 256 and the
+ * columns up to p_off[b+1] zero padding (written by these functions).  k_off / p_off: device int32 [B + 1], B <= 256. */
+int lako_xattn_scores(const void* q, int64_t q_sb, int64_t q_ld, /* bf16 rows: sample b, row r at q + b*q_sb + r*q_ld (elements) */
+                      const void* e, int64_t e_ld, const int32_t* k_off, const int32_t* p_off, int64_t p_total,
+                      float* s, int64_t s_ld, /* fp32 [R, s_ld] */
+                      int R, int D, int B, lako_stream_t stream);
+/* p bf16 [R, p_ld] (layout as s); out fp32: sample b, row r at out + b*out_sb + r*out_ld, += with atomics; key_splits
+ * workgroups share the keys of a sample */
+int lako_xattn_context(const void* p, int64_t p_ld, const void* e, int64_t e_ld, const int32_t* k_off, const int32_t* p_off,
+                       float* out, int64_t out_sb, int64_t out_ld, int R, int D, int B, int key_splits, lako_stream_t stream);
+/* row r = t*H + h of sample b: stats[b][r] = (max, 1 / sum exp); p = dropout(softmax) as bf16, zeros in the padding columns.
+ * Dropout: the attention block recipe of lako_attn_fwd with bh = b*H + h, q = t, k = key index in the sample, Lq = T,
+ * Lk = max_keys (so that both formulations of the cross-attention drop the same probabilities). */
+int lako_xattn_softmax_fwd(const float* s, int64_t s_ld, float* stats, void* p, int64_t p_ld, const int32_t* k_off,
+                           const int32_t* p_off, int B, int T, int H, int max_keys, lako_dropout_t drop, lako_stream_t stream);
+/* ds = P∘(dropout_bwd(dp) − Σ_keys dropout(P)·dp) as bf16 (P recomputed from s and stats) */
+int lako_xattn_softmax_bwd(const float* s, const float* dp, int64_t s_ld, const float* stats, void* ds, int64_t p_ld,
+                           const int32_t* k_off, const int32_t* p_off, int B, int T, int H, int max_keys, lako_dropout_t drop,
+                           lako_stream_t stream);
+
+/* Head-batched small products over the M = B·T decoder rows.  A row m = (b, t) of head h starts at element offset
+ * b*sb + t*st + h*sh of its buffer (two-level rows: the rows of a sample may sit inside a per-sample block of a bigger buffer).
+ *   lako_headbatch_nt:  C_h[m, n] = Σ_k A_h[m, k]·B_h[n, k];  A bf16 or fp32 (a_dtype), B_h[n, k] bf16 at b + h*b_sh + n*ldb + k,
+ *                       C bf16 rows addressed like A's.  K % 32 == 0, N % 16 == 0.
+ *   lako_headbatch_tn:  C_h[j, c] += Σ_m A[m][h*a_sh + j]·B_h[m][c], j < 64 (K), c < N;  A bf16, B rows bf16 or fp32 (b_dtype)
+ *                       addressed like A's, C fp32 at c + h*c_sh + j*c_st + c (plain read-modify-write: one launch owns C). */
+typedef struct {
+  const void *a, *b;
+  void* c;
+  int64_t a_sb, a_st, a_sh;
+  int64_t b_sb, b_st, b_sh, ldb;
+  int64_t c_sb, c_st, c_sh;
+  int M, T, H, N, K;
+  int a_dtype, b_dtype;
+} lako_headbatch_t;
+int lako_headbatch_nt(const lako_headbatch_t* p, lako_stream_t stream);
+int lako_headbatch_tn(const lako_headbatch_t* p, lako_stream_t stream);
+
 /* ---- LM-head loss (HF5:1051-1054): CrossEntropyLoss(ignore_index=-100), mean over valid labels ----
  * logits fp32 [M, V]; loss_out[0] = mean loss, loss_out[1] = number of valid labels;
  * dlogits (dtype, [M, V], optional) = upstream * (softmax - onehot) / n_valid, 0 on ignored rows;

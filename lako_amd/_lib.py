@@ -42,6 +42,12 @@ class GemmTNItem(C.Structure):
 TN_GROUP_MAX = 8
 
 
+class HeadBatch(C.Structure):
+    _fields_ = [("a", vp), ("b", vp), ("c", vp), ("a_sb", i64), ("a_st", i64), ("a_sh", i64),
+                ("b_sb", i64), ("b_st", i64), ("b_sh", i64), ("ldb", i64), ("c_sb", i64), ("c_st", i64), ("c_sh", i64),
+                ("M", i32), ("T", i32), ("H", i32), ("N", i32), ("K", i32), ("a_dtype", i32), ("b_dtype", i32)]
+
+
 class AttnFwd(C.Structure):
     _fields_ = [("q", vp), ("k", vp), ("v", vp), ("out", vp), ("lse", vp),
                 ("q_stride_b", i64), ("q_stride_t", i64), ("k_stride_b", i64), ("k_stride_t", i64),
@@ -79,6 +85,12 @@ SIGNATURES = {
     "lako_relpos_reduce": [vp, vp, vp, i32, i32, i32, vp],
     "lako_attn_fwd": [C.POINTER(AttnFwd), vp],
     "lako_attn_bwd": [C.POINTER(AttnBwd), vp],
+    "lako_xattn_scores": [vp, i64, i64, vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, vp],
+    "lako_xattn_context": [vp, i64, vp, i64, vp, vp, vp, i64, i64, i32, i32, i32, i32, vp],
+    "lako_xattn_softmax_fwd": [vp, i64, vp, vp, i64, vp, vp, i32, i32, i32, i32, Dropout, vp],
+    "lako_xattn_softmax_bwd": [vp, vp, i64, vp, vp, i64, vp, vp, i32, i32, i32, i32, Dropout, vp],
+    "lako_headbatch_nt": [C.POINTER(HeadBatch), vp],
+    "lako_headbatch_tn": [C.POINTER(HeadBatch), vp],
     "lako_ce_fwd_bwd": [vp, vp, vp, vp, vp, i64, i64, i32, vp],
     "lako_sumsq": [vp, i64, vp, vp],
     "lako_adamw_step": [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, f32, f32, i32, vp],

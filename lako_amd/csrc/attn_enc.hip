@@ -26,38 +26,13 @@
 // other held per wave as MFMA fragments loaded straight from HBM; the score tile leaves the MFMA with the LDS-side index in
 // the accumulator registers, so it is directly the B operand of the product that contracts over that index.
 #include "attn_shared.h"
+#include "lds_image.h"
 
 namespace {
 
-constexpr int EROW = 128;                 // bytes per image row: 64 bf16, unpadded
 constexpr int EB_PADLO = 16;              // bias table: entries in front of index 0 (queries past Lq in the last block)
 constexpr int EB_ST = 592;                // floats per shifted copy: ≥ 511 + 16 + 36, ≡ 16 (mod 64) → the 4 copies sit 16 banks apart
 constexpr float LOG2E = 1.4426950408889634f;
-
-// 16-byte chunk c (0..7) of image row r lives at chunk position ((c >> 1) ^ ((r >> 1) & 3)) << 1 | (c & 1)
-__device__ __forceinline__ int eswz(int c, int r) { return ((((c >> 1) ^ ((r >> 1) & 3)) << 1) | (c & 1)); }
-
-// Stage rows [0, nrows) of a strided [L, 64] bf16 tensor into a swizzled image; rows >= L are zero-filled.
-template <int NT = 256>
-__device__ __forceinline__ void estage(char* img, const char* base, int64_t stride_b, int nrows, int L) {
-  const int total = nrows * 8;
-  for (int idx0 = threadIdx.x; idx0 < total; idx0 += NT * 8) {
-    u32x4 v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int idx = idx0 + u * NT;
-      const int row = idx >> 3, c = idx & 7;
-      v[u] = u32x4{0u, 0u, 0u, 0u};
-      if (idx < total && row < L) v[u] = *reinterpret_cast<const u32x4*>(base + (int64_t)row * stride_b + c * 16);
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int idx = idx0 + u * NT;
-      const int row = idx >> 3, c = idx & 7;
-      if (idx < total) *reinterpret_cast<u32x4*>(img + row * EROW + eswz(c, row) * 16) = v[u];
-    }
-  }
-}
 
 // The four shifted copies of the (optionally reversed) bias table of head h:  copy c, float j  =  T'[j + c],
 // T'[t] = rel_bias[h][t − PADLO] inside [0, R) and 0 outside (only masked keys / discarded queries ever read the padding);
@@ -92,10 +67,6 @@ __device__ __forceinline__ void eload_frags(u32x4 (&f)[2], const char* base, int
   }
 }
 
-__device__ __forceinline__ f32x4 emma(u32x4 a, u32x4 b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-
 // tile[image row row0 + 4g + r][register side = lane & 15] = init + Σ_d X[row0 + ·][d]·Y[·][d];  roff[i]: the lane's byte
 // offset of fragment step i inside the 16-row block (a constant of the lane: the swizzle key repeats every 8 rows)
 __device__ __forceinline__ f32x4 escore(const char* img, int row0, const u32x4 (&yf)[2], const uint32_t (&roff)[2], f32x4 acc) {
@@ -122,21 +93,6 @@ __device__ __forceinline__ void epv(f32x4 (&acc)[4], f32x4 w0, f32x4 w1, const c
     u32x4 afrag = {u0[0], u0[1], u1[0], u1[1]};
     acc[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, afrag), bfrag, acc[db], 0, 0, 0);
   }
-}
-
-struct ELane {          // loop-invariant per-lane addressing
-  uint32_t roff[2];     // row-fragment reads (ds_read_b128)
-  uint32_t toff[4];     // transposed reads (ds_read_b64_tr_b16)
-};
-__device__ __forceinline__ ELane elane(int lane) {
-  ELane e;
-  const int l15 = lane & 15, g = lane >> 4, qq = l15 >> 2, pp = l15 & 3;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) e.roff[i] = (uint32_t)(l15 * EROW + eswz(i * 4 + g, l15) * 16);
-  const int tr = 4 * g + qq;                      // row inside the 16-row block
-#pragma unroll
-  for (int db = 0; db < 4; ++db) e.toff[db] = (uint32_t)(tr * EROW + ((db ^ ((tr >> 1) & 3)) << 5) + pp * 8);
-  return e;
 }
 
 // DPP move of a float inside 16-lane rows (CTRL: 0x100 + n row_shl:n — lane j reads lane j + n; 0x110 + n row_shr:n — lane j

@@ -304,6 +304,80 @@ class HipOps:
         self._timed("attn_bwd", 8.0 * Bn * H * Lq * Lk * dk, lambda: check(self.lib.lako_attn_bwd(C.byref(p), self._stream()), "lako_attn_bwd"))
 
     # ---- loss / optimizer -----------------------------------------------------------------------
+    # ---- cross-attention in the encoder-state space (csrc/xattn.hip) ------------------------------------
+    @staticmethod
+    def _bthx(t, name):
+        """[B, T, H, X] view, last dim contiguous → (element strides of b, t, h)"""
+        if t.dim() != 4 or t.stride(3) != 1:
+            raise LakoError(f"{name}: expected a [B, T, H, X] view with a contiguous last dim, got {tuple(t.shape)} / {t.stride()}")
+        return t.stride(0), t.stride(1), t.stride(2)
+
+    def headbatch_nt(self, A, Bw, Cm):
+        """Cm[b,t,h,n] = Σ_k A[b,t,h,k]·Bw[h,n,k]:  A [B,T,H,K] bf16|fp32, Bw [H,N,K] bf16, Cm [B,T,H,N] bf16 (strided views)"""
+        from ._lib import HeadBatch
+        Bz, T, H, K = A.shape
+        N = Bw.shape[1]
+        if Bw.shape != (H, N, K) or Cm.shape != (Bz, T, H, N) or Bw.stride(2) != 1:
+            raise LakoError(f"headbatch_nt: shapes A{tuple(A.shape)} B{tuple(Bw.shape)} C{tuple(Cm.shape)}")
+        hb = HeadBatch()
+        hb.a, hb.b, hb.c = _p(A), _p(Bw), _p(Cm)
+        hb.a_sb, hb.a_st, hb.a_sh = self._bthx(A, "headbatch_nt A")
+        hb.b_sh, hb.ldb = Bw.stride(0), Bw.stride(1)
+        hb.c_sb, hb.c_st, hb.c_sh = self._bthx(Cm, "headbatch_nt C")
+        hb.M, hb.T, hb.H, hb.N, hb.K = Bz * T, T, H, N, K
+        hb.a_dtype, hb.b_dtype = _dt(A), _dt(Bw)
+        self._timed("headbatch", 2.0 * Bz * T * H * N * K, lambda: check(self.lib.lako_headbatch_nt(hb, self._stream()), "lako_headbatch_nt"))
+
+    def headbatch_tn(self, A, Bm, Cw):
+        """Cw[h,j,c] += Σ_{b,t} A[b,t,h,j]·Bm[b,t,h,c]:  A [B,T,H,64] bf16, Bm [B,T,H,N] bf16|fp32, Cw [H,64,N] fp32 (views)"""
+        from ._lib import HeadBatch
+        Bz, T, H, K = A.shape
+        N = Bm.shape[3]
+        if Bm.shape != (Bz, T, H, N) or Cw.shape != (H, K, N) or Cw.stride(2) != 1 or Cw.dtype != torch.float32:
+            raise LakoError(f"headbatch_tn: shapes A{tuple(A.shape)} B{tuple(Bm.shape)} C{tuple(Cw.shape)}")
+        hb = HeadBatch()
+        hb.a, hb.b, hb.c = _p(A), _p(Bm), _p(Cw)
+        hb.a_sb, hb.a_st, hb.a_sh = self._bthx(A, "headbatch_tn A")
+        hb.b_sb, hb.b_st, hb.b_sh = self._bthx(Bm, "headbatch_tn B")
+        hb.c_sh, hb.c_st = Cw.stride(0), Cw.stride(1)
+        hb.M, hb.T, hb.H, hb.N, hb.K = Bz * T, T, H, N, K
+        hb.a_dtype, hb.b_dtype = _dt(A), _dt(Bm)
+        self._timed("headbatch", 2.0 * Bz * T * H * N * K, lambda: check(self.lib.lako_headbatch_tn(hb, self._stream()), "lako_headbatch_tn"))
+
+    def xattn_scores(self, Q, E, k_off, p_off, p_total, S):
+        """S[r, p_off[b] + s] = Q[b, r, :]·E[k_off[b] + s, :]:  Q [B, R, D] bf16 view, E [rows, D] bf16, S [R, >= p_total] fp32"""
+        Bz, R, D = Q.shape
+        if Q.stride(2) != 1 or E.stride(1) != 1 or S.stride(1) != 1 or S.shape[0] != R or E.shape[1] != D:
+            raise LakoError(f"xattn_scores: shapes Q{tuple(Q.shape)} E{tuple(E.shape)} S{tuple(S.shape)}")
+        self._timed("xattn", 2.0 * R * D * E.shape[0], lambda: check(self.lib.lako_xattn_scores(
+            _p(Q), Q.stride(0), Q.stride(1), _p(E), E.stride(0), _p(k_off), _p(p_off), int(p_total), _p(S), S.stride(0), R, D, Bz,
+            self._stream()), "lako_xattn_scores"))
+
+    def xattn_context(self, P, E, k_off, p_off, out, key_splits=1):
+        """out[b, r, :] += Σ_s P[r, p_off[b] + s]·E[k_off[b] + s, :]:  P [R, ld] bf16, out [B, R, D] fp32 view (zeroed by the caller)"""
+        Bz, R, D = out.shape
+        if P.stride(1) != 1 or P.shape[0] != R or out.stride(2) != 1 or out.dtype != torch.float32 or E.shape[1] != D:
+            raise LakoError(f"xattn_context: shapes P{tuple(P.shape)} E{tuple(E.shape)} out{tuple(out.shape)}")
+        self._timed("xattn", 2.0 * R * D * E.shape[0], lambda: check(self.lib.lako_xattn_context(
+            _p(P), P.stride(0), _p(E), E.stride(0), _p(k_off), _p(p_off), _p(out), out.stride(0), out.stride(1), R, D, Bz,
+            int(key_splits), self._stream()), "lako_xattn_context"))
+
+    def xattn_softmax_fwd(self, S, stats, P, k_off, p_off, T, H, max_keys, drop=None):
+        """stats [B, T·H, 2] fp32, P [T·H, ld] bf16 = dropout(softmax over each sample's keys of S)"""
+        Bz = stats.shape[0]
+        self._timed("xattn_softmax", 0.0, lambda: check(self.lib.lako_xattn_softmax_fwd(
+            _p(S), S.stride(0), _p(stats), _p(P), P.stride(0), _p(k_off), _p(p_off), Bz, T, H, int(max_keys), _drop(drop),
+            self._stream()), "lako_xattn_softmax_fwd"))
+
+    def xattn_softmax_bwd(self, S, dP, stats, dS, k_off, p_off, T, H, max_keys, drop=None):
+        Bz = stats.shape[0]
+        if dP.stride(0) != S.stride(0):
+            raise LakoError("xattn_softmax_bwd: S and dP must share their row stride")
+        self._timed("xattn_softmax", 0.0, lambda: check(self.lib.lako_xattn_softmax_bwd(
+            _p(S), _p(dP), S.stride(0), _p(stats), _p(dS), dS.stride(0), _p(k_off), _p(p_off), Bz, T, H, int(max_keys),
+            _drop(drop), self._stream()), "lako_xattn_softmax_bwd"))
+
+    # ---- loss / optimizer ---------------------------------------------------------------------------
     def ce_fwd_bwd(self, logits, labels, loss_out, dlogits, upstream=None):
         M, V = logits.shape
         self._timed("ce_fwd_bwd", 0.0, lambda: check(self.lib.lako_ce_fwd_bwd(_p(logits), _p(labels), _p(loss_out), _p(dlogits), _p(upstream), M, V,

@@ -276,6 +276,64 @@ class RefOps:
         if drel is not None:
             drel += gs[3]
 
+    # ---- cross-attention in the encoder-state space (csrc/xattn.hip) --------------------------------
+    def headbatch_nt(self, A, Bw, Cm):
+        Cm.copy_(torch.einsum("bthk,hnk->bthn", f(A).to(Bw.dtype).float(), f(Bw)))
+
+    def headbatch_tn(self, A, Bm, Cw):
+        Cw += torch.einsum("bthj,bthc->hjc", f(A), f(Bm).to(A.dtype).float())
+
+    def xattn_scores(self, Q, E, k_off, p_off, p_total, S):
+        ko, po = k_off.tolist(), p_off.tolist()
+        for b in range(Q.shape[0]):
+            n = ko[b + 1] - ko[b]
+            S[:, po[b]:po[b + 1]] = 0
+            S[:, po[b]:po[b] + n] = f(Q[b]) @ f(E[ko[b]:ko[b + 1]]).T
+
+    def xattn_context(self, P, E, k_off, p_off, out, key_splits=1):
+        ko, po = k_off.tolist(), p_off.tolist()
+        for b in range(out.shape[0]):
+            n = ko[b + 1] - ko[b]
+            out[b] += f(P[:, po[b]:po[b] + n]) @ f(E[ko[b]:ko[b + 1]])
+
+    @staticmethod
+    def _xkeep(b, T, H, n, max_keys, drop, dev):
+        """keep[r = t·H + h, s] and the scale of sample b (the attention recipe with bh = b·H + h, q = t, k = s, Lk = max_keys)"""
+        pr, seed, site = drop
+        BH = (b + 1) * H
+        keep = attn_keep_mask(BH, T, max_keys, drop_key(int(seed) & M32, int(site) & M32), pr, dev)[b * H:, :, :n]   # [H, T, n]
+        return keep.permute(1, 0, 2).reshape(T * H, n), float(np.float32(1.0) / (np.float32(1.0) - np.float32(pr)))
+
+    def xattn_softmax_fwd(self, S, stats, P, k_off, p_off, T, H, max_keys, drop=None):
+        ko, po = k_off.tolist(), p_off.tolist()
+        for b in range(stats.shape[0]):
+            n = ko[b + 1] - ko[b]
+            s = f(S[:, po[b]:po[b] + n])
+            m = s.max(-1).values
+            e = torch.exp(s - m[:, None])
+            l = e.sum(-1)
+            pn = e / l[:, None]
+            if _on(drop):
+                keep, scale = self._xkeep(b, T, H, n, max_keys, drop, S.device)
+                pn = torch.where(keep, pn * scale, torch.zeros_like(pn))
+            P[:, po[b]:po[b + 1]] = 0
+            P[:, po[b]:po[b] + n] = pn.to(P.dtype)
+            stats[b, :, 0] = m
+            stats[b, :, 1] = 1.0 / l
+
+    def xattn_softmax_bwd(self, S, dP, stats, dS, k_off, p_off, T, H, max_keys, drop=None):
+        ko, po = k_off.tolist(), p_off.tolist()
+        for b in range(stats.shape[0]):
+            n = ko[b + 1] - ko[b]
+            pn = torch.exp(f(S[:, po[b]:po[b] + n]) - stats[b, :, 0:1]) * stats[b, :, 1:2]
+            d = f(dP[:, po[b]:po[b] + n])
+            if _on(drop):
+                keep, scale = self._xkeep(b, T, H, n, max_keys, drop, S.device)
+                d = torch.where(keep, d * scale, torch.zeros_like(d))
+            delta = (pn * d).sum(-1, keepdim=True)
+            dS[:, po[b]:po[b + 1]] = 0
+            dS[:, po[b]:po[b] + n] = (pn * (d - delta)).to(dS.dtype)
+
     # ---- loss / optimizer -----------------------------------------------------------------------
     def ce_fwd_bwd(self, logits, labels, loss_out, dlogits, upstream=None):
         valid = labels != -100
