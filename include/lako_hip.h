@@ -91,7 +91,10 @@ int lako_gemm_tn(const void* A, const void* B, float* C, int64_t M, int64_t N, i
 /* Several weight gradients in ONE launch: C_i[M_i,N_i] += alpha_i * A_iᵀ·B_i for i < n_items (<= LAKO_TN_GROUP_MAX), all with
  * the same K (= tokens) and input dtype.  The four dW of a transformer layer fill the chip with ~3 K-splits instead of 7-28
  * each, and every split costs one fp32 atomic pass over the output (≈1.3 TB/s chip-wide).  Falls back to one lako_gemm_tn
- * per item for shapes the 256x256 kernel does not take (fp32 inputs, M or N < 256).  `items` is a HOST array. */
+ * per item for shapes the 256x256 kernel does not take (fp32 inputs, M or N < 256).  `items` is a HOST array.
+ * split_k: 0 = choose; 1 = every output element has ONE contributor (into a zeroed C the result is then independent of the
+ * order workgroups finish in — used where the product feeds further bf16 arithmetic, the encoder-state gradient of the
+ * cross-attention, instead of being a final fp32 gradient). */
 #define LAKO_TN_GROUP_MAX 8
 typedef struct {
   const void* a; /* [K, M] row-major, lda */
@@ -100,7 +103,8 @@ typedef struct {
   int64_t M, N, lda, ldb, ldc;
   float alpha;
 } lako_gemm_tn_item_t;
-int lako_gemm_tn_grouped(const lako_gemm_tn_item_t* items, int n_items, int64_t K, int in_dtype, lako_stream_t stream);
+int lako_gemm_tn_grouped(const lako_gemm_tn_item_t* items, int n_items, int64_t K, int in_dtype, int split_k,
+                         lako_stream_t stream);
 
 /* ---- T5LayerNorm (RMSNorm, HF5:59-72): y = dropout(x * rsqrt(mean(x²) + eps) * w) ----------------
  * rstd [rows] fp32 is written for the backward.  w is fp32 [d]. */
@@ -191,7 +195,7 @@ int lako_attn_bwd(const lako_attn_bwd_t* p, lako_stream_t stream);
  *   Q'[b][t·H + h][:] = q[b,t,h,:]·Wk_h          lako_headbatch_nt   ("expand": [B·T, 64] x [64, D] per head)
  *   S  = Q'·E_bᵀ                                 lako_xattn_scores   (raw scores, no 1/sqrt(d) as in T5)
  *   P  = dropout(softmax_keys(S))                lako_xattn_softmax_fwd
- *   C' = P·E_b                                   lako_xattn_context  (fp32, accumulated with atomics: zero it first)
+ *   C' = P·E_b                                   lako_xattn_context  (fp32; the key ranges of a sample write separate slabs)
  *   ctx[b,t,h,:] = C'[b][t·H + h][:]·Wv_hᵀ       lako_headbatch_nt   ("contract": [B·T, D] x [D, 64] per head)
  * backward: dC' = expand(dctx, Wv), dP = lako_xattn_scores(dC'), dS = lako_xattn_softmax_bwd, dQ' = lako_xattn_context(dS),
  * dq = contract(dQ', Wk), dWk_h += q_hᵀ·dQ'_h and dWv_h += dctx_hᵀ·C'_h (lako_headbatch_tn), and after the last layer
@@ -203,10 +207,12 @@ int lako_xattn_scores(const void* q, int64_t q_sb, int64_t q_ld, /* bf16 rows: s
                       const void* e, int64_t e_ld, const int32_t* k_off, const int32_t* p_off, int64_t p_total,
                       float* s, int64_t s_ld, /* fp32 [R, s_ld] */
                       int R, int D, int B, lako_stream_t stream);
-/* p bf16 [R, p_ld] (layout as s); out fp32: sample b, row r at out + b*out_sb + r*out_ld, += with atomics; key_splits
- * workgroups share the keys of a sample */
+/* p bf16 [R, p_ld] (layout as s); out fp32: key range z (< key_splits) of sample b, row r at out + z*out_zs + b*out_sb + r*out_ld.
+ * The keys of a sample are split over key_splits workgroups, each WRITES its own slab (no atomics: the result does not depend
+ * on the order workgroups finish in); the consumer adds the slabs in order (lako_headbatch_t.n_slabs). */
 int lako_xattn_context(const void* p, int64_t p_ld, const void* e, int64_t e_ld, const int32_t* k_off, const int32_t* p_off,
-                       float* out, int64_t out_sb, int64_t out_ld, int R, int D, int B, int key_splits, lako_stream_t stream);
+                       float* out, int64_t out_zs, int64_t out_sb, int64_t out_ld, int R, int D, int B, int key_splits,
+                       lako_stream_t stream);
 /* row r = t*H + h of sample b: stats[b][r] = (max, 1 / sum exp); p = dropout(softmax) as bf16, zeros in the padding columns.
  * Dropout: the attention block recipe of lako_attn_fwd with bh = b*H + h, q = t, k = key index in the sample, Lq = T,
  * Lk = max_keys (so that both formulations of the cross-attention drop the same probabilities). */
@@ -231,6 +237,8 @@ typedef struct {
   int64_t c_sb, c_st, c_sh;
   int M, T, H, N, K;
   int a_dtype, b_dtype;
+  int n_slabs;          /* 0 / 1: plain.  > 1: the fp32 operand (nt: A, tn: B) is the sum of n_slabs buffers */
+  int64_t slab_stride;  /* slab_stride elements apart, added in slab order */
 } lako_headbatch_t;
 int lako_headbatch_nt(const lako_headbatch_t* p, lako_stream_t stream);
 int lako_headbatch_tn(const lako_headbatch_t* p, lako_stream_t stream);

@@ -45,7 +45,8 @@ TN_GROUP_MAX = 8
 class HeadBatch(C.Structure):
     _fields_ = [("a", vp), ("b", vp), ("c", vp), ("a_sb", i64), ("a_st", i64), ("a_sh", i64),
                 ("b_sb", i64), ("b_st", i64), ("b_sh", i64), ("ldb", i64), ("c_sb", i64), ("c_st", i64), ("c_sh", i64),
-                ("M", i32), ("T", i32), ("H", i32), ("N", i32), ("K", i32), ("a_dtype", i32), ("b_dtype", i32)]
+                ("M", i32), ("T", i32), ("H", i32), ("N", i32), ("K", i32), ("a_dtype", i32), ("b_dtype", i32),
+                ("n_slabs", i32), ("slab_stride", i64)]
 
 
 class AttnFwd(C.Structure):
@@ -76,7 +77,7 @@ SIGNATURES = {
     "lako_mx_quantize": [vp, i64, i64, i64, vp, vp, vp],
     "lako_gemm_nt_mx": [C.POINTER(GemmNT), vp, vp, vp],
     "lako_gemm_tn": [vp, vp, vp, i64, i64, i64, i64, i64, i64, i32, f32, i32, vp],
-    "lako_gemm_tn_grouped": [C.POINTER(GemmTNItem), i32, i64, i32, vp],
+    "lako_gemm_tn_grouped": [C.POINTER(GemmTNItem), i32, i64, i32, i32, vp],
     "lako_rmsnorm_fwd": [vp, vp, vp, vp, i64, i32, f32, i32, Dropout, vp],
     "lako_rmsnorm_bwd": [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, Dropout, vp, Dropout, vp],
     "lako_embed_fwd": [vp, vp, vp, i64, i32, i64, i32, Dropout, vp],
@@ -86,7 +87,7 @@ SIGNATURES = {
     "lako_attn_fwd": [C.POINTER(AttnFwd), vp],
     "lako_attn_bwd": [C.POINTER(AttnBwd), vp],
     "lako_xattn_scores": [vp, i64, i64, vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, vp],
-    "lako_xattn_context": [vp, i64, vp, i64, vp, vp, vp, i64, i64, i32, i32, i32, i32, vp],
+    "lako_xattn_context": [vp, i64, vp, i64, vp, vp, vp, i64, i64, i64, i32, i32, i32, i32, vp],
     "lako_xattn_softmax_fwd": [vp, i64, vp, vp, i64, vp, vp, i32, i32, i32, i32, Dropout, vp],
     "lako_xattn_softmax_bwd": [vp, vp, i64, vp, vp, i64, vp, vp, i32, i32, i32, i32, Dropout, vp],
     "lako_headbatch_nt": [C.POINTER(HeadBatch), vp],

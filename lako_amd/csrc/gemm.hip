@@ -1697,7 +1697,7 @@ extern "C" int lako_gemm_tn(const void* A, const void* B, float* C, int64_t M, i
   return LAKO_OK;
 }
 
-extern "C" int lako_gemm_tn_grouped(const lako_gemm_tn_item_t* items, int n_items, int64_t K, int in_dtype,
+extern "C" int lako_gemm_tn_grouped(const lako_gemm_tn_item_t* items, int n_items, int64_t K, int in_dtype, int split_k,
                                     lako_stream_t stream) {
   LAKO_CHECK_ARG(items && n_items >= 1 && n_items <= LAKO_TN_GROUP_MAX, "lako_gemm_tn_grouped: 1..%d items", LAKO_TN_GROUP_MAX);
   LAKO_CHECK_ARG(K > 0 && K < (1 << 30), "lako_gemm_tn_grouped: bad K");
@@ -1706,7 +1706,7 @@ extern "C" int lako_gemm_tn_grouped(const lako_gemm_tn_item_t* items, int n_item
   if (!big || n_items == 1) {   // shapes the 256×256 kernel does not take: one launch per problem
     for (int i = 0; i < n_items; ++i) {
       int rc = lako_gemm_tn(items[i].a, items[i].b, items[i].c, items[i].M, items[i].N, K, items[i].lda, items[i].ldb,
-                            items[i].ldc, in_dtype, items[i].alpha, 0, stream);
+                            items[i].ldc, in_dtype, items[i].alpha, split_k, stream);
       if (rc != LAKO_OK) return rc;
     }
     return LAKO_OK;
@@ -1738,6 +1738,7 @@ extern "C" int lako_gemm_tn_grouped(const lako_gemm_tn_item_t* items, int n_item
   int sk = (256 + tiles / 2) / tiles;
   const int max_split = cdiv(K, 64 * 4);
   if (g_tn_split > 0) sk = g_tn_split;
+  if (split_k > 0) sk = split_k;
   if (sk > max_split) sk = max_split;
   if (sk < 1) sk = 1;
   const int chunk = cdiv(cdiv(K, sk), 64) * 64;

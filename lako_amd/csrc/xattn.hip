@@ -35,8 +35,8 @@ struct XArgs {
   int64_t s_ld;
   const char* p;        // bf16 [R, p_ld] probabilities (xcontext input)
   int64_t p_ld;
-  float* out;           // fp32 context rows: sample b, row r at out + b·out_sb + r·out_ld (accumulated with atomics)
-  int64_t out_sb, out_ld;
+  float* out;           // fp32 context rows: key split z, sample b, row r at out + z·out_zs + b·out_sb + r·out_ld
+  int64_t out_zs, out_sb, out_ld;
   int R, D, B, Z;
 };
 
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(512, 1) void xscores_kernel(XArgs a) {
 }
 
 // --------------------------------------------------------------------------------------------------------------------
-// out[b][r][c0 .. c0+127] += Σ_{keys of the workgroup's range} P[r][p_off[b] + s]·E[k_off[b] + s][c]
+// out[z][b][r][c0 .. c0+127] = Σ_{keys of key range z of sample b} P[r][p_off[b] + s]·E[k_off[b] + s][c]
 // grid (D / 128, B·Z, ⌈R / 128⌉), 512 threads.  The keys run in stages of 64 through a ring of four LDS stages (two 64-key × 64-column
 // images of E with permuted rows + the [128 rows × 64 keys] image of P, 32 KiB) filled by LDS-DMA three stages ahead.
 // Wave w: column half w >> 2, row tiles 2(w & 3) and 2(w & 3) + 1 — every output element has one owner, no cross-wave reduction.
@@ -179,8 +179,7 @@ __global__ __launch_bounds__(512, 1) void xcontext_kernel(XArgs a) {
   const int Sb = __builtin_amdgcn_readfirstlane(a.k_off[b + 1]) - kfirst;
   const int nst_all = (Sb + 63) >> 6;
   const int st_begin = (int)((int64_t)z * nst_all / a.Z), st_end = (int)((int64_t)(z + 1) * nst_all / a.Z);
-  const int nst = st_end - st_begin;
-  if (nst <= 0) return;   // (workgroup-uniform)
+  const int nst = st_end - st_begin;     // may be 0 (fewer stages than splits): the slab still gets its zeros
   const int r0 = blockIdx.z * 128, nr = min(128, a.R - r0), nrt = (nr + 15) >> 4;
   const char* ebase = a.e + ((int64_t)kfirst * a.e_ld + c0) * 2;
   const uint32_t est = (uint32_t)(a.e_ld * 2), pst = (uint32_t)(a.p_ld * 2);
@@ -209,7 +208,7 @@ __global__ __launch_bounds__(512, 1) void xcontext_kernel(XArgs a) {
 #pragma unroll
     for (int db = 0; db < 4; ++db) acc[rtl][db] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  issue(0);
+  if (nst > 0) issue(0);
   if (nst > 1) issue(1);
   if (nst > 2) issue(2);
   for (int i = 0; i < nst; ++i) {
@@ -244,8 +243,9 @@ __global__ __launch_bounds__(512, 1) void xcontext_kernel(XArgs a) {
     }
   }
   // acc[rtl][db][i] = out[r0 + 16·(rt0 + rtl) + l15][c0 + 64·ch + 16·db + 4g + i] over this workgroup's keys.  Each wave turns its
-  // 32 × 64 block around in LDS so that one atomic instruction adds 64 CONSECUTIVE floats of a row (two cache lines; in the
-  // accumulator layout an instruction scatters 4-byte adds over 16 rows and the write-out cost more than the product)
+  // 32 × 64 block around in LDS so that one store instruction writes 64 CONSECUTIVE floats of a row (in the accumulator layout an
+  // instruction scatters 16-byte pieces over 16 rows, and the write-out cost more than the product).  Key splits write separate
+  // slabs that the consumer adds in a fixed order: no atomics, results do not depend on the order workgroups finish in.
   __syncthreads();                                   // every wave is done with the stages
   float* tr = reinterpret_cast<float*>(smem) + wave * (32 * XC_TST);
 #pragma unroll
@@ -253,12 +253,8 @@ __global__ __launch_bounds__(512, 1) void xcontext_kernel(XArgs a) {
 #pragma unroll
     for (int db = 0; db < 4; ++db) *reinterpret_cast<f32x4*>(tr + (rtl * 16 + l15) * XC_TST + 16 * db + 4 * g) = acc[rtl][db];
   const int nrows = min(32, nr - rt0 * 16);          // rows of this wave that exist
-  float* op = a.out + (int64_t)b * a.out_sb + (int64_t)(r0 + rt0 * 16) * a.out_ld + c0 + 64 * ch + lane;
-  for (int k = 0; k < nrows; ++k) {
-    const float v = tr[k * XC_TST + lane];
-    if (a.Z == 1) op[(int64_t)k * a.out_ld] += v;
-    else atomicAdd(op + (int64_t)k * a.out_ld, v);
-  }
+  float* op = a.out + (int64_t)z * a.out_zs + (int64_t)b * a.out_sb + (int64_t)(r0 + rt0 * 16) * a.out_ld + c0 + 64 * ch + lane;
+  for (int k = 0; k < nrows; ++k) op[(int64_t)k * a.out_ld] = tr[k * XC_TST + lane];
 }
 
 // --------------------------------------------------------------------------------------------------------------------
@@ -385,14 +381,20 @@ struct HbArgs {
   char* C;
   int64_t c_sb, c_st, c_sh;   // hb_nt: bf16 rows like A's;  hb_tn: fp32 C_h[j, c] at h·c_sh + j·c_st + c
   int M, T, N, K, H;
+  int n_slabs;                // the fp32 operand (hb_nt: A, hb_tn: B) is the sum of n_slabs buffers slab_stride elements apart
+  int64_t slab_stride;        // (the key splits of xcontext_kernel), added in slab order
 };
 
-__device__ __forceinline__ u32x4 hb_load8(const char* base, int64_t off, bool f32, bool ok) {
+__device__ __forceinline__ u32x4 hb_load8(const char* base, int64_t off, bool f32, bool ok, int n_slabs = 1, int64_t slab_stride = 0) {
   u32x4 v = {0u, 0u, 0u, 0u};
   if (!ok) return v;
   if (!f32) return *reinterpret_cast<const u32x4*>(base + off * 2);
-  const f32x4 x = *reinterpret_cast<const f32x4*>(base + off * 4);
-  const f32x4 y = *reinterpret_cast<const f32x4*>(base + off * 4 + 16);
+  f32x4 x = *reinterpret_cast<const f32x4*>(base + off * 4);
+  f32x4 y = *reinterpret_cast<const f32x4*>(base + off * 4 + 16);
+  for (int z = 1; z < n_slabs; ++z) {
+    x += *reinterpret_cast<const f32x4*>(base + (off + z * slab_stride) * 4);
+    y += *reinterpret_cast<const f32x4*>(base + (off + z * slab_stride) * 4 + 16);
+  }
   bf16x8 o = {(bf16_t)x[0], (bf16_t)x[1], (bf16_t)x[2], (bf16_t)x[3], (bf16_t)y[0], (bf16_t)y[1], (bf16_t)y[2], (bf16_t)y[3]};
   return __builtin_bit_cast(u32x4, o);
 }
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(256) void hb_nt_kernel(HbArgs a) {
     u32x4 af[KU], bf[KU][NT];
 #pragma unroll
     for (int u = 0; u < KU; ++u) {
-      af[u] = hb_load8(a.A, aoff + k0 + 32 * u, AF32, mok);
+      af[u] = hb_load8(a.A, aoff + k0 + 32 * u, AF32, mok, a.n_slabs, a.slab_stride);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
         bf[u][nt] = *reinterpret_cast<const u32x4*>(a.B + (boff + (int64_t)nt * 16 * a.ldb + k0 + 32 * u) * 2);
@@ -453,7 +455,8 @@ __global__ __launch_bounds__(256) void hb_tn_kernel(HbArgs a) {
       const bool ok = m < a.M;
       const int mb = ok ? m / a.T : 0, mtt = ok ? m - mb * a.T : 0;
       const u32x4 va = hb_load8(a.A, (int64_t)mb * a.a_sb + (int64_t)mtt * a.a_st + (int64_t)h * a.a_sh + c * 8, false, ok);
-      const u32x4 vb = hb_load8(a.B, (int64_t)mb * a.b_sb + (int64_t)mtt * a.b_st + (int64_t)h * a.b_sh + c0 + c * 8, BF32, ok);
+      const u32x4 vb = hb_load8(a.B, (int64_t)mb * a.b_sb + (int64_t)mtt * a.b_st + (int64_t)h * a.b_sh + c0 + c * 8, BF32, ok,
+                                a.n_slabs, a.slab_stride);
       *reinterpret_cast<u32x4*>(img + row * EROW + eswz(c, row) * 16) = va;
       *reinterpret_cast<u32x4*>(img + XS_IMG + row * EROW + eswz(c, row) * 16) = vb;
     }
@@ -530,20 +533,20 @@ extern "C" int lako_xattn_scores(const void* q, int64_t q_sb, int64_t q_ld, cons
 }
 
 extern "C" int lako_xattn_context(const void* p, int64_t p_ld, const void* e, int64_t e_ld, const int32_t* k_off,
-                                  const int32_t* p_off, float* out, int64_t out_sb, int64_t out_ld, int R, int D, int B,
-                                  int key_splits, lako_stream_t stream) {
+                                  const int32_t* p_off, float* out, int64_t out_zs, int64_t out_sb, int64_t out_ld, int R, int D,
+                                  int B, int key_splits, lako_stream_t stream) {
   int rc = xcheck_common("lako_xattn_context", e, e_ld, k_off, p_off, R, D, B);
   if (rc) return rc;
-  LAKO_CHECK_ARG(p && out && p_ld % 8 == 0 && p_ld < (1 << 23) && out_ld % 4 == 0 && out_sb % 4 == 0 && key_splits >= 1 &&
-                     key_splits <= 64,
-                 "lako_xattn_context: p_ld %% 8, out_ld / out_sb %% 4, 1 <= key_splits <= 64");
+  LAKO_CHECK_ARG(p && out && p_ld % 8 == 0 && p_ld < (1 << 23) && out_ld % 4 == 0 && out_sb % 4 == 0 && out_zs % 4 == 0 &&
+                     key_splits >= 1 && key_splits <= 64,
+                 "lako_xattn_context: p_ld %% 8, out_ld / out_sb / out_zs %% 4, 1 <= key_splits <= 64");
   LAKO_CHECK_ALIGN(p, 16);
   LAKO_CHECK_ALIGN(out, 16);
   XArgs a{};
   a.p = (const char*)p; a.p_ld = p_ld;
   a.e = (const char*)e; a.e_ld = e_ld;
   a.k_off = k_off; a.p_off = p_off;
-  a.out = out; a.out_sb = out_sb; a.out_ld = out_ld;
+  a.out = out; a.out_zs = out_zs; a.out_sb = out_sb; a.out_ld = out_ld;
   a.R = R; a.D = D; a.B = B; a.Z = key_splits;
   const int lds = XC_NSTG * XC_STAGE;
   static bool done = false;
@@ -624,6 +627,8 @@ extern "C" int lako_headbatch_nt(const lako_headbatch_t* p, lako_stream_t stream
   a.B = (const char*)p->b; a.b_sh = p->b_sh; a.ldb = p->ldb;
   a.C = (char*)p->c; a.c_sb = p->c_sb; a.c_st = p->c_st; a.c_sh = p->c_sh;
   a.M = p->M; a.T = p->T; a.N = p->N; a.K = p->K; a.H = p->H;
+  a.n_slabs = p->n_slabs > 0 ? p->n_slabs : 1; a.slab_stride = p->slab_stride;
+  LAKO_CHECK_ARG(a.n_slabs == 1 || (p->a_dtype == LAKO_F32 && p->slab_stride % 4 == 0), "lako_headbatch_nt: slabs need an fp32 A");
   const bool f32 = p->a_dtype == LAKO_F32;
   const int nt = p->N % 64 == 0 && p->N > 64 ? 4 : 1;
   const int ku = nt == 4 ? (p->K % 64 == 0 ? 2 : 1) : (p->K % 256 == 0 ? 8 : 1);
@@ -659,6 +664,8 @@ extern "C" int lako_headbatch_tn(const lako_headbatch_t* p, lako_stream_t stream
   a.B = (const char*)p->b; a.b_sb = p->b_sb; a.b_st = p->b_st; a.b_sh = p->b_sh;
   a.C = (char*)p->c; a.c_st = p->c_st; a.c_sh = p->c_sh;
   a.M = p->M; a.T = p->T; a.N = p->N; a.K = p->K; a.H = p->H;
+  a.n_slabs = p->n_slabs > 0 ? p->n_slabs : 1; a.slab_stride = p->slab_stride;
+  LAKO_CHECK_ARG(a.n_slabs == 1 || (p->b_dtype == LAKO_F32 && p->slab_stride % 4 == 0), "lako_headbatch_tn: slabs need an fp32 B");
   const dim3 grid((unsigned)(p->N / 64), (unsigned)p->H);
   if (p->b_dtype == LAKO_F32) hipLaunchKernelGGL((hb_tn_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((hb_tn_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, a);

@@ -130,6 +130,19 @@ class _Ragged:
     off: torch.Tensor       # int32 [B·N + 1] row offset of each passage
     soff: torch.Tensor      # int32 [B + 1]   row offset of each sample (its N passages are consecutive)
     idx: torch.Tensor       # int64 [M] position of each packed token in the flat [B·N·L] input
+    soff_h: list = None     # the sample offsets on the host
+
+
+@dataclass
+class _XPlan:
+    """Key layout of the encoder-state-space cross-attention (csrc/xattn.hip): sample b owns the encoder rows
+    [k_h[b], k_h[b+1]) and the score columns [p_h[b], p_h[b] + n_keys(b)) of a [·, ptot] matrix (segments padded to 256)."""
+    k_off: torch.Tensor     # int32 [B + 1] device
+    p_off: torch.Tensor     # int32 [B + 1] device
+    k_h: list = None
+    p_h: list = None
+    ptot: int = 0
+    splits: int = 1         # workgroups sharing the keys of a sample in xattn_context
 
 
 @dataclass
@@ -147,6 +160,7 @@ class _Ctx:
     dec_ids: torch.Tensor = None
     ckpt: bool = False
     rag: object = None      # _Ragged: the encoder ran on the valid tokens only
+    xa: object = None       # _XPlan: cross-attention ran in the encoder-state space
     enc_ids: torch.Tensor = None   # the encoder's token ids: all [B·N·L], or the valid ones when rag is set
     ws: dict = field(default_factory=dict)
 
@@ -176,6 +190,9 @@ class Engine:
         self._ws_cache: dict = {}
         self._tr_table = None
         self._rag_cache: dict = {}
+        self._xplan_cache: dict = {}
+        self.ctx_splits = 1      # key-split slabs of the current batch's xattn_context launches
+        self._all_valid = False
         self._row_cap: dict = {}     # {rows of the current unpadded batch: padded row count}
         self._lut_cache: dict = {}
         self.ctx: _Ctx | None = None
@@ -357,7 +374,7 @@ class Engine:
             return BN, L, dict(key_mask=mask_u8)
         return 1, rag.M, dict(q_off=rag.off, k_off=rag.off, max_q=L, max_k=L)
 
-    def _encode(self, ws, ids_flat, mask_u8, BN, L, p, seed, save, rag=None):
+    def _encode(self, ws, ids_flat, mask_u8, BN, L, p, seed, save, rag=None, want_kv=True):
         """save: True  — keep every intermediate of every layer (training; 288 GB of HBM make this the default);
                  "ckpt" — keep only each block's input and recompute the block in backward (`set_checkpoint(True)`,
                           the reference's CheckpointWrapper, src/model.py:237-283);
@@ -377,6 +394,8 @@ class Engine:
         enc_out = self._buf(ws, "e.out", (Me, d))
         ops.rmsnorm_fwd(ws[f"e.h{hx(Le)}"], self.enc_final.p, enc_out, self._buf(ws, "e.rsf", (Me,), torch.float32),
                         eps, dr(S_ENC_FINAL))
+        if not want_kv:      # cross-attention in the encoder-state space: the keys and values ARE enc_out
+            return enc_out, None
         # K/V projections of every decoder layer's cross-attention in ONE GEMM (reads enc_out once)
         kv = self._buf(ws, "e.kv", (Me, self.kv_all.w.shape[0]))
         self._gemm_w(ws, enc_out, "dec.kv_all", self.kv_all.w, kv)
@@ -394,6 +413,7 @@ class Engine:
         prefix form, so no device→host sync is needed: offsets are built on the host, uploaded from pinned memory, and the
         packed-row index is expanded on the device.  Without it the lengths are read back from the mask (one host sync per
         new mask tensor; repeated batches hit a cache keyed by the tensor's identity and version)."""
+        self._all_valid = False
         if os.environ.get("LAKO_UNPAD", "1") == "0":
             return None
         dev = attention_mask.device
@@ -404,6 +424,7 @@ class Engine:
             if int(lens_h.min()) < 0 or int(lens_h.max()) > L:
                 raise ValueError("passage_lengths out of range [0, L]")
             M = int(lens_h.sum())
+            self._all_valid = M == B * N * L
             if int(lens_h.view(B, N).sum(1).min()) <= 0 or M >= B * N * L:
                 return None
             off = torch.zeros(B * N + 1, dtype=torch.int32)
@@ -414,10 +435,11 @@ class Engine:
             base = torch.arange(B * N, device=dev, dtype=torch.int64) * L - off_d[:-1].long()
             idx = torch.repeat_interleave(base, off_d[1:].long() - off_d[:-1].long(), output_size=M) + \
                 torch.arange(M, device=dev, dtype=torch.int64)
-            return _Ragged(M=M, off=off_d, soff=off_d[::N].contiguous(), idx=idx)
+            return _Ragged(M=M, off=off_d, soff=off_d[::N].contiguous(), idx=idx, soff_h=off[::N].tolist())
         key = (attention_mask.data_ptr(), attention_mask._version, B, N, L)
         hit = self._rag_cache.get(key)
         if hit is not None:
+            self._all_valid = hit[2]
             return hit[0]
         m = attention_mask.reshape(B * N, L).bool()
         lens = m.sum(1, dtype=torch.int32)
@@ -430,11 +452,125 @@ class Engine:
             off = torch.zeros(B * N + 1, dtype=torch.int32)
             off[1:] = torch.cumsum(lens_h, 0)
             rag = _Ragged(M=int(off[-1]), off=off.to(dev), soff=off[::N].contiguous().to(dev),
-                          idx=m.reshape(-1).nonzero().reshape(-1))
+                          idx=m.reshape(-1).nonzero().reshape(-1), soff_h=off[::N].tolist())
+        self._all_valid = ok and int(lens_h.sum()) == B * N * L
         if len(self._rag_cache) >= 16:
             self._rag_cache.clear()
-        self._rag_cache[key] = (rag, attention_mask)      # holding the tensor keeps (data_ptr, version) unambiguous
+        self._rag_cache[key] = (rag, attention_mask, self._all_valid)   # holding the tensor keeps (data_ptr, version) unambiguous
         return rag
+
+    def _xattn_plan(self, rag, B, N, L, rows_q):
+        """The cross-attention runs in the encoder-state space (csrc/xattn.hip: no K/V projection of the N·L encoder states, the
+        per-head projections act on the T·H query rows instead) whenever every sample's keys are a contiguous run of encoder rows:
+        the unpadded batch, or a batch without any padding.  Masks with holes / LAKO_UNPAD=0 / LAKO_XATTN=0 / shapes the kernels
+        do not take (fp32 engine, d_kv != 64, d_model % 128) keep the projected formulation (lako_attn_fwd with a key mask)."""
+        cfg = self.cfg
+        ok = getattr(self.ops, "xattn_ok", None)
+        if os.environ.get("LAKO_XATTN", "1") == "0" or ok is None or not ok(self.dtype, cfg.d_kv, cfg.d_model) or B > 512:
+            return None
+        if rag is not None:
+            k_h = list(rag.soff_h)
+        elif self._all_valid:
+            k_h = [b * N * L for b in range(B + 1)]
+        else:
+            return None
+        key = (tuple(k_h), rows_q)
+        hit = self._xplan_cache.get(key)
+        if hit is not None:
+            self.ctx_splits = hit.splits
+            return hit
+        p_h = [0]
+        for b in range(B):
+            p_h.append(p_h[-1] + -(-(k_h[b + 1] - k_h[b]) // 256) * 256)
+        host = torch.tensor([k_h, p_h], dtype=torch.int32)
+        if self.device.type == "cuda":
+            host = host.pin_memory()
+        dev = host.to(self.device, non_blocking=True)
+        # one 512-thread workgroup per CU: split a sample's keys until ≈256 workgroups are in flight
+        per = max(1, cfg.d_model // 128) * B * -(-rows_q // 128)
+        splits = int(os.environ.get("LAKO_XATTN_SPLITS", "0")) or max(1, min(8, 256 // per))
+        plan = _XPlan(k_off=dev[0], p_off=dev[1], k_h=k_h, p_h=p_h, ptot=p_h[-1], splits=splits)
+        self.ctx_splits = splits
+        if len(self._xplan_cache) >= 8:
+            self._xplan_cache.clear()
+        self._xplan_cache[key] = plan
+        return plan
+
+    def _xw(self, i, which, transposed=False):
+        """Per-head views of decoder layer i's cross-attention K ("k") or V ("v") projection inside the kv_all block:
+        [H, dk, d] of the weight, or (transposed) [H, d, dk] of its transposed shadow — the B operands of headbatch_nt."""
+        inner, H, dk = self.cfg.inner_dim, self.cfg.num_heads, self.cfg.d_kv
+        r0 = (2 * i + (which == "v")) * inner
+        if transposed:
+            return self.kv_all.wt[:, r0:r0 + inner].unflatten(1, (H, dk)).permute(1, 0, 2)
+        return self.kv_all.w[r0:r0 + inner].unflatten(0, (H, dk))
+
+    def _xg(self, i, which):
+        inner, H, dk = self.cfg.inner_dim, self.cfg.num_heads, self.cfg.d_kv
+        r0 = (2 * i + (which == "v")) * inner
+        return self.kv_all.g[r0:r0 + inner].unflatten(0, (H, dk))
+
+    def _xattn_buffers(self, ws, B, N, L, T, Ld):
+        """Workspace of the encoder-state-space cross-attention, sized for the padded batch (the column count of a batch's score
+        matrices, xa.ptot, is a prefix of the allocation).  Per decoder layer l and R = T·H query rows per sample:
+          dq [B, Ld·2R, d]   rows l·2R … : dC' (written in backward), rows l·2R + R … : Q'          — B operand of the dE product
+          ps [Ld·2R, cap]    rows l·2R … : dropout(P),               rows l·2R + R … : dS (backward) — A operand of the dE product
+          s  [Ld, R, cap] fp32 raw scores, st [Ld, B, R, 2] softmax statistics, c [Ld, Z, B, R, d] fp32 C' = P·E in Z key-split slabs"""
+        cfg = self.cfg
+        R, d = T * cfg.num_heads, cfg.d_model
+        cap = B * (-(-(N * L) // 256) * 256)
+        Z = self.ctx_splits
+        return dict(R=R, cap=cap, rows=B * N * L,
+                    dq=self._buf(ws, "x.dq", (B, Ld * 2 * R, d)),
+                    ps=self._buf(ws, "x.ps", (Ld * 2 * R, cap)),
+                    s=self._buf(ws, "x.s", (Ld, R, cap), torch.float32),
+                    st=self._buf(ws, "x.st", (Ld, B, R, 2), torch.float32),
+                    c=self._buf(ws, "x.c", (Ld, Z, B, R, d), torch.float32))
+
+    def _xattn_fwd(self, xb, xa, i, qc, enc_out, c2, B, T, max_keys, drop):
+        """Cross-attention of decoder layer i in the encoder-state space (see csrc/xattn.hip): qc [B·T, inner] → c2 [B·T, inner]"""
+        ops, H, dk, R = self.ops, self.cfg.num_heads, self.cfg.d_kv, xb["R"]
+        qp = xb["dq"][:, (2 * i + 1) * R:(2 * i + 2) * R]
+        ops.headbatch_nt(qc.view(B, T, H, dk), self._xw(i, "k", transposed=True), qp.unflatten(1, (T, H)))
+        s = xb["s"][i][:, :xa.ptot]
+        ops.xattn_scores(qp, enc_out, xa.k_off, xa.p_off, xa.ptot, s)
+        pr = xb["ps"][2 * i * R:(2 * i + 1) * R, :xa.ptot]
+        ops.xattn_softmax_fwd(s, xb["st"][i], pr, xa.k_off, xa.p_off, T, H, max_keys, drop)
+        ops.xattn_context(pr, enc_out, xa.k_off, xa.p_off, xb["c"][i])
+        ops.headbatch_nt(xb["c"][i].unflatten(2, (T, H)), self._xw(i, "v"), c2.view(B, T, H, dk))
+
+    def _xattn_bwd(self, xb, xa, tmp, i, qc, enc_out, dctx, dqc, B, T, max_keys, drop):
+        """Backward of _xattn_fwd: dctx [B·T, inner] → dqc [B·T, inner], the layer's Wk / Wv gradients, and the rows (dC', dS) the
+        encoder-state gradient is assembled from after the last layer (_xattn_denc)."""
+        ops, H, dk, R, d = self.ops, self.cfg.num_heads, self.cfg.d_kv, xb["R"], self.cfg.d_model
+        dcp = xb["dq"][:, 2 * i * R:(2 * i + 1) * R]
+        d4 = dctx.view(B, T, H, dk)
+        ops.headbatch_nt(d4, self._xw(i, "v", transposed=True), dcp.unflatten(1, (T, H)))
+        ops.headbatch_tn(d4, xb["c"][i].unflatten(2, (T, H)), self._xg(i, "v"))
+        dp = self._buf(tmp, "x.dp", (R, xb["cap"]), torch.float32)[:, :xa.ptot]
+        ops.xattn_scores(dcp, enc_out, xa.k_off, xa.p_off, xa.ptot, dp)
+        ds = xb["ps"][(2 * i + 1) * R:(2 * i + 2) * R, :xa.ptot]
+        ops.xattn_softmax_bwd(xb["s"][i][:, :xa.ptot], dp, xb["st"][i], ds, xa.k_off, xa.p_off, T, H, max_keys, drop)
+        dqp = self._buf(tmp, "x.dqp", (self.ctx_splits, B, R, d), torch.float32)
+        ops.xattn_context(ds, enc_out, xa.k_off, xa.p_off, dqp)
+        ops.headbatch_nt(dqp.unflatten(2, (T, H)), self._xw(i, "k"), dqc.view(B, T, H, dk))
+        ops.headbatch_tn(qc.view(B, T, H, dk), dqp.unflatten(2, (T, H)), self._xg(i, "k"))
+
+    def _xattn_denc(self, xb, xa, tmp, Me, dxe):
+        """dE[s, :] = Σ_layers Σ_r P[r, s]·dC'[r, :] + dS[r, s]·Q'[r, :] — per sample one [keys, d] = psᵀ·dq product with
+        K = layers·2R (weight-gradient form: both operands K-major), fp32, then rounded once to the compute dtype."""
+        ops, d = self.ops, self.cfg.d_model
+        de = self._buf(tmp, "x.de", (xb["rows"] + 8, d), torch.float32)[:Me + 8]    # sized for the padded batch
+        ops.zero_(de)
+        items = []
+        for b in range(len(xa.k_h) - 1):
+            n8 = -(-(xa.k_h[b + 1] - xa.k_h[b]) // 8) * 8      # rows past the sample's keys add its zero padding columns
+            items.append((xb["ps"][:, xa.p_h[b]:xa.p_h[b] + n8], xb["dq"][b], de[xa.k_h[b]:xa.k_h[b] + n8], 1.0))
+        ops.gemm_tn_grouped(items, split_k=1)      # one contributor per element: dE feeds the encoder's bf16 backward, keep it
+        if dxe.dtype == torch.float32:                 # independent of the order workgroups finish in
+            dxe.copy_(de[:Me])
+        else:
+            ops.cast(de[:Me].view(-1), dxe.view(-1))
 
     def forward_loss(self, input_ids, attention_mask, labels, training: bool, lengths=None):
         """input_ids/attention_mask [B,N,L], labels [B,T] (−100 = ignore) → (loss 0-d fp32, logits [B,T,V] fp32).
@@ -459,7 +595,9 @@ class Engine:
         self._row_cap = {rag.M: B * N * L} if rag is not None else {}
         enc_ids = ctx.ids if rag is None else ctx.ids[rag.idx]
         ctx.enc_ids = enc_ids
-        enc_out, kv = self._encode(ws, enc_ids, ctx.mask_u8, B * N, L, p, seed, save="ckpt" if ctx.ckpt else True, rag=rag)
+        xa = ctx.xa = self._xattn_plan(rag, B, N, L, T * H)
+        enc_out, kv = self._encode(ws, enc_ids, ctx.mask_u8, B * N, L, p, seed, save="ckpt" if ctx.ckpt else True, rag=rag,
+                                   want_kv=xa is None)
         # ---- decoder ------------------------------------------------------------------------
         Md, S, Ld = B * T, N * L, cfg.num_decoder_layers
         if rag is None:      # cross-attention keys: [B, N·L] with the padding mask, or each sample's packed valid tokens
@@ -472,6 +610,8 @@ class Engine:
         ops.embed_fwd(dec_ids.view(-1), self.shared.w, self._buf(ws, "d.h0", (Md, d)), dr(S_DEC_EMBED))
         rel = self._buf(ws, "d.rel", (H, 2 * T - 1), torch.float32)
         ops.relpos_expand(self.dec_rel.p, self._lut(T, T, False), rel)
+        if xa is not None:
+            xb = self._xattn_buffers(ws, B, N, L, T, Ld)
         for i in range(Ld):
             lw = self.dec[i]
             h = ws[f"d.h{i}"]
@@ -490,9 +630,12 @@ class Engine:
             qc = self._buf(ws, f"d.qc.{i}", (Md, inner))
             ops.gemm_nt(xn2, lw["cq"].w, qc)
             c2 = self._buf(ws, f"d.cctx.{i}", (Md, inner))
-            ops.attn_fwd(self._heads(qc, B, T, 0), self._heads(kv, kb, kt, 2 * i * inner),
-                         self._heads(kv, kb, kt, (2 * i + 1) * inner), self._heads(c2, B, T, 0),
-                         self._buf(ws, f"d.cst.{i}", (B, H, T, 4), torch.float32), drop=dr(_dec_site(i, 2)), **ckw)
+            if xa is not None:
+                self._xattn_fwd(xb, xa, i, qc, enc_out, c2, B, T, S, dr(_dec_site(i, 2)))
+            else:
+                ops.attn_fwd(self._heads(qc, B, T, 0), self._heads(kv, kb, kt, 2 * i * inner),
+                             self._heads(kv, kb, kt, (2 * i + 1) * inner), self._heads(c2, B, T, 0),
+                             self._buf(ws, f"d.cst.{i}", (B, H, T, 4), torch.float32), drop=dr(_dec_site(i, 2)), **ckw)
             h2 = self._buf(ws, f"d.h2.{i}", (Md, d))
             ops.gemm_nt(c2, lw["co"].w, h2, resid=h1, drop=dr(_dec_site(i, 3)))
             xn3 = self._buf(ws, f"d.xn3.{i}", (Md, d))
@@ -591,10 +734,14 @@ class Engine:
         dy_s = self._buf(tmp, "d.dy", (Md, d)) if fused else None
         ops.rmsnorm_bwd(dout, ws[f"d.h{Ld}"], self.dec_final.p, ws["d.rsf"], None, dh, self.dec_final.g, dr(S_DEC_FINAL),
                         **self._nxt((dy_f, dr(_dec_site(Ld - 1, 5))) if fused else None))
-        dkv = self._buf(tmp, "dkv", (Me, self.kv_all.w.shape[0]))
+        xa = ctx.xa
+        if xa is not None:
+            xb = self._xattn_buffers(ws, B, N, L, T, Ld)
+        else:
+            dkv = self._buf(tmp, "dkv", (Me, self.kv_all.w.shape[0]))
+            kv = ws["e.kv"]
         drel = self._buf(tmp, "d.drel", (H, 2 * T - 1), torch.float32)
         ops.zero_(drel)
-        kv = ws["e.kv"]
         for i in reversed(range(Ld)):
             lw = self.dec[i]
             # the layer's six weight gradients (K = B·T rows: two K-steps each) as one grouped launch at the end of the layer
@@ -613,11 +760,14 @@ class Engine:
             dctx = self._buf(tmp, "d.dctx", (Md, inner))
             ops.gemm_nt(dy, lw["co"].wt, dctx)
             dqc = self._buf(tmp, "d.dqc", (Md, inner))
-            ops.attn_bwd(self._heads(ws[f"d.qc.{i}"], B, T, 0), self._heads(kv, kb, kt, 2 * i * inner),
-                         self._heads(kv, kb, kt, (2 * i + 1) * inner), self._heads(ws[f"d.cctx.{i}"], B, T, 0),
-                         self._heads(dctx, B, T, 0), ws[f"d.cst.{i}"], self._heads(dqc, B, T, 0),
-                         self._heads(dkv, kb, kt, 2 * i * inner), self._heads(dkv, kb, kt, (2 * i + 1) * inner),
-                         drop=dr(_dec_site(i, 2)), **ckw)
+            if xa is not None:
+                self._xattn_bwd(xb, xa, tmp, i, ws[f"d.qc.{i}"], ws["e.out"], dctx, dqc, B, T, S, dr(_dec_site(i, 2)))
+            else:
+                ops.attn_bwd(self._heads(ws[f"d.qc.{i}"], B, T, 0), self._heads(kv, kb, kt, 2 * i * inner),
+                             self._heads(kv, kb, kt, (2 * i + 1) * inner), self._heads(ws[f"d.cctx.{i}"], B, T, 0),
+                             self._heads(dctx, B, T, 0), ws[f"d.cst.{i}"], self._heads(dqc, B, T, 0),
+                             self._heads(dkv, kb, kt, 2 * i * inner), self._heads(dkv, kb, kt, (2 * i + 1) * inner),
+                             drop=dr(_dec_site(i, 2)), **ckw)
             dw.append((dqc, ws[f"d.xn2.{i}"], lw["cq"].g, 1.0))
             dxn = self._buf(tmp, "d.dxn", (Md, d))
             ops.gemm_nt(dqc, lw["cq"].wt, dxn)
@@ -647,10 +797,13 @@ class Engine:
         ops.embed_bwd(ctx.dec_ids.view(-1), dh, self.shared.g, dr(S_DEC_EMBED))
         ops.relpos_reduce(drel, self._lut(T, T, False), self.dec_rel.g)
         # ---- cross K/V projection of all decoder layers -----------------------------------------
-        ops.gemm_tn(dkv, ws["e.out"], self.kv_all.g)
         deh = self._buf(tmp, "e.dh", (Me, d))
         dxe = self._buf(tmp, "e.dxn", (Me, d))
-        ops.gemm_nt(dkv, self.kv_all.wt, dxe)
+        if xa is not None:
+            self._xattn_denc(xb, xa, tmp, Me, dxe)
+        else:
+            ops.gemm_tn(dkv, ws["e.out"], self.kv_all.g)
+            ops.gemm_nt(dkv, self.kv_all.wt, dxe)
         dy_f = self._buf(tmp, "e.dy.ffn", (Me, d)) if fused else None
         dy_s = self._buf(tmp, "e.dy", (Me, d)) if fused else None
         ops.rmsnorm_bwd(dxe, ws[f"e.h{Le}"], self.enc_final.p, ws["e.rsf"], None, deh, self.enc_final.g, dr(S_ENC_FINAL),

@@ -176,9 +176,9 @@ class HipOps:
         self._timed("gemm_tn", 2.0 * M * N * K, lambda: check(self.lib.lako_gemm_tn(_p(A), _p(B), _p(Cm), M, N, K, lda, ldb, ldc, _dt(A), float(alpha), int(split_k),
                                     self._stream()), "lako_gemm_tn"))
 
-    def gemm_tn_grouped(self, problems):
+    def gemm_tn_grouped(self, problems, split_k=0):
         """[(A [K, M], B [K, N], C [M, N] fp32, alpha), …] with one K: every C += alpha·Aᵀ·B, one launch per
-        TN_GROUP_MAX problems (see lako_gemm_tn_grouped in include/lako_hip.h)."""
+        TN_GROUP_MAX problems (see lako_gemm_tn_grouped in include/lako_hip.h).  split_k=1: one contributor per output element."""
         from ._lib import TN_GROUP_MAX, GemmTNItem
         for g0 in range(0, len(problems), TN_GROUP_MAX):
             grp = problems[g0:g0 + TN_GROUP_MAX]
@@ -197,7 +197,7 @@ class HipOps:
                 it.a, it.b, it.c = _p(A), _p(B), _p(Cm)
                 it.M, it.N, it.lda, it.ldb, it.ldc, it.alpha = M, N, lda, ldb, ldc, float(alpha)
                 flops += 2.0 * M * N * K
-            self._timed("gemm_tn", flops, lambda: check(self.lib.lako_gemm_tn_grouped(arr, len(grp), K0, _dt(grp[0][0]), self._stream()),
+            self._timed("gemm_tn", flops, lambda: check(self.lib.lako_gemm_tn_grouped(arr, len(grp), K0, _dt(grp[0][0]), int(split_k), self._stream()),
                                                         "lako_gemm_tn_grouped"))
 
     # ---- norm / embedding / dropout ---------------------------------------------------------------
@@ -306,6 +306,11 @@ class HipOps:
     # ---- loss / optimizer -----------------------------------------------------------------------
     # ---- cross-attention in the encoder-state space (csrc/xattn.hip) ------------------------------------
     @staticmethod
+    def xattn_ok(dtype, d_kv, d_model):
+        """shapes the kernels take (everything else stays on lako_attn_fwd over projected K / V)"""
+        return dtype == torch.bfloat16 and d_kv == 64 and d_model % 128 == 0
+
+    @staticmethod
     def _bthx(t, name):
         """[B, T, H, X] view, last dim contiguous → (element strides of b, t, h)"""
         if t.dim() != 4 or t.stride(3) != 1:
@@ -315,6 +320,9 @@ class HipOps:
     def headbatch_nt(self, A, Bw, Cm):
         """Cm[b,t,h,n] = Σ_k A[b,t,h,k]·Bw[h,n,k]:  A [B,T,H,K] bf16|fp32, Bw [H,N,K] bf16, Cm [B,T,H,N] bf16 (strided views)"""
         from ._lib import HeadBatch
+        slabs, slab_stride = 1, 0
+        if A.dim() == 5:      # [Z, B, T, H, K] fp32: the key-split slabs of xattn_context, added in order
+            slabs, slab_stride, A = A.shape[0], A.stride(0), A[0]
         Bz, T, H, K = A.shape
         N = Bw.shape[1]
         if Bw.shape != (H, N, K) or Cm.shape != (Bz, T, H, N) or Bw.stride(2) != 1:
@@ -326,11 +334,15 @@ class HipOps:
         hb.c_sb, hb.c_st, hb.c_sh = self._bthx(Cm, "headbatch_nt C")
         hb.M, hb.T, hb.H, hb.N, hb.K = Bz * T, T, H, N, K
         hb.a_dtype, hb.b_dtype = _dt(A), _dt(Bw)
+        hb.n_slabs, hb.slab_stride = slabs, slab_stride
         self._timed("headbatch", 2.0 * Bz * T * H * N * K, lambda: check(self.lib.lako_headbatch_nt(hb, self._stream()), "lako_headbatch_nt"))
 
     def headbatch_tn(self, A, Bm, Cw):
         """Cw[h,j,c] += Σ_{b,t} A[b,t,h,j]·Bm[b,t,h,c]:  A [B,T,H,64] bf16, Bm [B,T,H,N] bf16|fp32, Cw [H,64,N] fp32 (views)"""
         from ._lib import HeadBatch
+        slabs, slab_stride = 1, 0
+        if Bm.dim() == 5:
+            slabs, slab_stride, Bm = Bm.shape[0], Bm.stride(0), Bm[0]
         Bz, T, H, K = A.shape
         N = Bm.shape[3]
         if Bm.shape != (Bz, T, H, N) or Cw.shape != (H, K, N) or Cw.stride(2) != 1 or Cw.dtype != torch.float32:
@@ -342,6 +354,7 @@ class HipOps:
         hb.c_sh, hb.c_st = Cw.stride(0), Cw.stride(1)
         hb.M, hb.T, hb.H, hb.N, hb.K = Bz * T, T, H, N, K
         hb.a_dtype, hb.b_dtype = _dt(A), _dt(Bm)
+        hb.n_slabs, hb.slab_stride = slabs, slab_stride
         self._timed("headbatch", 2.0 * Bz * T * H * N * K, lambda: check(self.lib.lako_headbatch_tn(hb, self._stream()), "lako_headbatch_tn"))
 
     def xattn_scores(self, Q, E, k_off, p_off, p_total, S):
@@ -353,14 +366,15 @@ class HipOps:
             _p(Q), Q.stride(0), Q.stride(1), _p(E), E.stride(0), _p(k_off), _p(p_off), int(p_total), _p(S), S.stride(0), R, D, Bz,
             self._stream()), "lako_xattn_scores"))
 
-    def xattn_context(self, P, E, k_off, p_off, out, key_splits=1):
-        """out[b, r, :] += Σ_s P[r, p_off[b] + s]·E[k_off[b] + s, :]:  P [R, ld] bf16, out [B, R, D] fp32 view (zeroed by the caller)"""
-        Bz, R, D = out.shape
-        if P.stride(1) != 1 or P.shape[0] != R or out.stride(2) != 1 or out.dtype != torch.float32 or E.shape[1] != D:
+    def xattn_context(self, P, E, k_off, p_off, out):
+        """Σ_z out[z, b, r, :] = Σ_s P[r, p_off[b] + s]·E[k_off[b] + s, :]:  P [R, ld] bf16, out [Z, B, R, D] fp32 view — slab z gets
+        the z-th key range of every sample (plain stores; the consumers add the slabs)"""
+        Z, Bz, R, D = out.shape
+        if P.stride(1) != 1 or P.shape[0] != R or out.stride(3) != 1 or out.dtype != torch.float32 or E.shape[1] != D:
             raise LakoError(f"xattn_context: shapes P{tuple(P.shape)} E{tuple(E.shape)} out{tuple(out.shape)}")
         self._timed("xattn", 2.0 * R * D * E.shape[0], lambda: check(self.lib.lako_xattn_context(
-            _p(P), P.stride(0), _p(E), E.stride(0), _p(k_off), _p(p_off), _p(out), out.stride(0), out.stride(1), R, D, Bz,
-            int(key_splits), self._stream()), "lako_xattn_context"))
+            _p(P), P.stride(0), _p(E), E.stride(0), _p(k_off), _p(p_off), _p(out), out.stride(0), out.stride(1), out.stride(2),
+            R, D, Bz, Z, self._stream()), "lako_xattn_context"))
 
     def xattn_softmax_fwd(self, S, stats, P, k_off, p_off, T, H, max_keys, drop=None):
         """stats [B, T·H, 2] fp32, P [T·H, ld] bf16 = dropout(softmax over each sample's keys of S)"""

@@ -127,7 +127,7 @@ class RefOps:
     def gemm_tn(self, A, B, Cm, *, alpha=1.0, split_k=0):
         Cm += (f(A).t() @ f(B)) * alpha
 
-    def gemm_tn_grouped(self, problems):
+    def gemm_tn_grouped(self, problems, split_k=0):
         for A, B, Cm, alpha in problems:
             self.gemm_tn(A, B, Cm, alpha=alpha)
 
@@ -277,10 +277,18 @@ class RefOps:
             drel += gs[3]
 
     # ---- cross-attention in the encoder-state space (csrc/xattn.hip) --------------------------------
+    @staticmethod
+    def xattn_ok(dtype, d_kv, d_model):
+        return True
+
     def headbatch_nt(self, A, Bw, Cm):
+        if A.dim() == 5:           # key-split slabs, added in order
+            A = A.sum(0)
         Cm.copy_(torch.einsum("bthk,hnk->bthn", f(A).to(Bw.dtype).float(), f(Bw)))
 
     def headbatch_tn(self, A, Bm, Cw):
+        if Bm.dim() == 5:
+            Bm = Bm.sum(0)
         Cw += torch.einsum("bthj,bthc->hjc", f(A), f(Bm).to(A.dtype).float())
 
     def xattn_scores(self, Q, E, k_off, p_off, p_total, S):
@@ -290,11 +298,12 @@ class RefOps:
             S[:, po[b]:po[b + 1]] = 0
             S[:, po[b]:po[b] + n] = f(Q[b]) @ f(E[ko[b]:ko[b + 1]]).T
 
-    def xattn_context(self, P, E, k_off, p_off, out, key_splits=1):
+    def xattn_context(self, P, E, k_off, p_off, out):
         ko, po = k_off.tolist(), p_off.tolist()
-        for b in range(out.shape[0]):
+        out.zero_()                # [Z, B, R, D]: the double puts everything into slab 0
+        for b in range(out.shape[1]):
             n = ko[b + 1] - ko[b]
-            out[b] += f(P[:, po[b]:po[b] + n]) @ f(E[ko[b]:ko[b + 1]])
+            out[0, b] = f(P[:, po[b]:po[b] + n]) @ f(E[ko[b]:ko[b + 1]])
 
     @staticmethod
     def _xkeep(b, T, H, n, max_keys, drop, dev):

@@ -257,6 +257,35 @@ def test_unpadded_path_equals_padded_path(name, monkeypatch):
     assert eng._workspace(("train",) + tuple(ids.shape) + (labels.shape[1],))["^e.xn1.0"] is base
 
 
+@pytest.mark.parametrize("name", ["tiny_a", "mid_a"])
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_encoder_space_cross_attention_equals_projected(name, dropout, monkeypatch):
+    """engine.py runs the decoder's cross-attention in the encoder-state space whenever a sample's keys are contiguous encoder
+    rows (unpadded batch, or no padding at all): per-head projections on the T·H query rows, no K/V projection of the
+    N·L encoder states.  Same loss, logits and gradients as the projected formulation (LAKO_XATTN=0) — with dropout too: both
+    drop the same probabilities."""
+    z, dims, w, model = build(name, dropout)
+    ids, mask, labels = (torch.from_numpy(z[k]) for k in ("input_ids", "attention_mask", "labels"))
+    model.train()
+    for m in (mask, torch.ones_like(mask)):
+        model._engine and setattr(model._engine, "step_count", 0)
+        monkeypatch.setenv("LAKO_XATTN", "0")
+        l0, lg0, g0, eng = _run_fb(model, ids, m, labels)
+        eng.step_count = 0                        # same dropout seeds for the second run
+        monkeypatch.setenv("LAKO_XATTN", "1")
+        model(input_ids=ids, attention_mask=m, labels=labels)
+        assert eng.ctx.xa is not None and eng.ctx.xa.ptot % 256 == 0
+        eng.step_count = 0
+        l1, lg1, g1, _ = _run_fb(model, ids, m, labels)
+        assert abs(l1 - l0) < 2e-6 * max(1.0, abs(l0))
+        torch.testing.assert_close(lg1, lg0, atol=2e-5, rtol=1e-5)
+        torch.testing.assert_close(g1, g0, atol=5e-6, rtol=1e-4)
+    holey = mask.clone()
+    holey[0, 0, 1] = False                        # masks with holes keep the projected formulation
+    model(input_ids=ids, attention_mask=holey, labels=labels)
+    assert eng.ctx.xa is None
+
+
 def _ws_footprint(eng):
     n, nbytes = 0, 0
     for ws in eng._ws_cache.values():

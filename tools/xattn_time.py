@@ -33,12 +33,12 @@ S = torch.zeros(R, ptot, device=dev)
 dP = torch.zeros(R, ptot, device=dev)
 PS = torch.zeros(2 * R, ptot, dtype=BF, device=dev)
 st = torch.zeros(B, R, 2, device=dev)
-Cp = torch.zeros(B, R, D, device=dev)
+Z = int(os.environ.get("XZ", 2))
+Cp = torch.zeros(Z, B, R, D, device=dev)
 ctx = torch.zeros(B * T, inner, dtype=BF, device=dev)
 G = torch.zeros(2 * inner, D, device=dev)
 dE = torch.zeros(M + 8, D, device=dev)
 drop = (0.1, 1, 2) if os.environ.get("NODROP") != "1" else None
-Z = int(os.environ.get("XZ", 2))
 
 
 def timeit(fn, n=20):
@@ -62,12 +62,11 @@ steps = {
     "expand (Q')": lambda: ops.headbatch_nt(q.view(B, T, H, 64), Wt[:, :inner].unflatten(1, (H, 64)).permute(1, 0, 2), DQ[:, R:].unflatten(1, (T, H))),
     "scores": lambda: ops.xattn_scores(DQ[:, R:], E, k_off, p_off, ptot, S),
     "softmax fwd": lambda: ops.xattn_softmax_fwd(S, st, PS[:R], k_off, p_off, T, H, NL, drop),
-    "zero C'": lambda: Cp.zero_(),
-    f"context (Z={Z})": lambda: ops.xattn_context(PS[:R], E, k_off, p_off, Cp, key_splits=Z),
-    "contract (ctx)": lambda: ops.headbatch_nt(Cp.unflatten(1, (T, H)), W[inner:].unflatten(0, (H, 64)), ctx.view(B, T, H, 64)),
-    "wgrad": lambda: ops.headbatch_tn(q.view(B, T, H, 64), Cp.unflatten(1, (T, H)), G[:inner].unflatten(0, (H, 64))),
+    f"context (Z={Z})": lambda: ops.xattn_context(PS[:R], E, k_off, p_off, Cp),
+    "contract (ctx)": lambda: ops.headbatch_nt(Cp.unflatten(2, (T, H)), W[inner:].unflatten(0, (H, 64)), ctx.view(B, T, H, 64)),
+    "wgrad": lambda: ops.headbatch_tn(q.view(B, T, H, 64), Cp.unflatten(2, (T, H)), G[:inner].unflatten(0, (H, 64))),
     "softmax bwd": lambda: ops.xattn_softmax_bwd(S, dP, st, PS[R:], k_off, p_off, T, H, NL, drop),
-    "dE (1 layer's K)": lambda: ops.gemm_tn_grouped(items),
+    "dE (1 layer's K)": lambda: ops.gemm_tn_grouped(items, split_k=1),
 }
 tot = 0.0
 print(f"B {B}  keys {M} (padded {ptot})  R {R}  D {D}")
