@@ -72,16 +72,19 @@ def train_flops_per_sample(cfg, N, L, T):
     return 3.0 * fwd
 
 
-def executed_train_flops(cfg, lens, T):
+def executed_train_flops(cfg, lens, T, xattn=False):
     """The same formula evaluated on the tokens that exist (lens: [B, N] valid lengths): what an implementation that
-    skips padded positions executes — linear terms ∝ Σ len, encoder self-attention ∝ Σ len², cross-attention ∝ Σ len."""
-    d, inner, f, V = cfg.d_model, cfg.inner_dim, cfg.d_ff, cfg.vocab_size
+    skips padded positions executes — linear terms ∝ Σ len, encoder self-attention ∝ Σ len², cross-attention ∝ Σ len.
+    xattn: the cross-attention in the encoder-state space (csrc/xattn.hip) — no K/V projection of the tokens (4·tok·d·inner per
+    decoder layer); instead the per-head projections on the T·H query rows (4·T·d·inner per sample) and scores / context products
+    with K = d instead of d_kv (4·T·H·tok·d instead of 4·T·tok·inner)."""
+    d, inner, f, V, H = cfg.d_model, cfg.inner_dim, cfg.d_ff, cfg.vocab_size, cfg.num_heads
     Le, Ld = cfg.num_layers, cfg.num_decoder_layers
     lens = lens.double()
     tok, sq, B = float(lens.sum()), float((lens * lens).sum()), lens.shape[0]
+    cross = (B * 4 * T * d * inner + 4 * T * H * tok * d) if xattn else (4 * tok * d * inner + 4 * T * tok * inner)
     fwd = Le * (tok * (8 * d * inner + 4 * d * f) + 4 * sq * inner) \
-        + Ld * (B * T * (8 * d * inner + 4 * T * inner) + 4 * tok * d * inner + B * 4 * T * d * inner + 4 * T * tok * inner
-                + B * 4 * T * d * f) + B * 2 * T * d * V
+        + Ld * (B * T * (8 * d * inner + 4 * T * inner) + cross + B * 4 * T * d * inner + B * 4 * T * d * f) + B * 2 * T * d * V
     return 3.0 * fwd
 
 
@@ -319,8 +322,12 @@ def main():
             elapsed = float(t.item())
         lens_all = torch.stack([b[3] for b in batches])                       # [NB, B, N]
         # what this implementation executes: padded positions are skipped on the unpadded path (exact: DESIGN.md §4)
-        fl_exec = (sum(executed_train_flops(cfg, lens_all[i % NB], T) for i in range(warmup, warmup + steps))
-                   / (steps * B)) if unpadded else fl
+        xattn = bool(getattr(model._engine, "xattn_active", False))
+        full = torch.full_like(lens_all[0], L)
+        fl_exec = sum(executed_train_flops(cfg, lens_all[i % NB] if unpadded else full, T, xattn)
+                      for i in range(warmup, warmup + steps)) / (steps * B)
+        fl_proj = sum(executed_train_flops(cfg, lens_all[i % NB] if unpadded else full, T, False)
+                      for i in range(warmup, warmup + steps)) / (steps * B)
         n_l, t_ms, f_tot = probe.get(dom, (0, 0.0, 0.0))
         achieved = f_tot / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0
         nb, tb, fb = probe.get("gemm_nt.11", (0, 0.0, 0.0))
@@ -328,7 +335,7 @@ def main():
                      "ms_per_step": round(tb, 3)}
         mxq = probe.get("mx_quantize", (0, 0.0, 0.0))
         return dict(bf16_gemm=bf16_gemm, mxq_ms=mxq[1], elapsed=elapsed, ms=elapsed / steps * 1e3, median_ms=per_step[len(per_step) // 2], host_ms=host_ms,
-                    probe=probe, fl_exec=fl_exec, valid_frac=float(lens_all.double().mean()) / L, n_l=n_l, t_ms=t_ms,
+                    probe=probe, fl_exec=fl_exec, fl_proj=fl_proj, xattn=xattn, valid_frac=float(lens_all.double().mean()) / L, n_l=n_l, t_ms=t_ms,
                     achieved=achieved, value=world * B * steps / elapsed,
                     step_frac=world * B / (elapsed / steps) * fl_exec / 1e12 / (PEAK_BF16_TFLOPS * world if args.fp8 else peak * world))
 
@@ -364,18 +371,25 @@ def main():
                        "ragged_prep": "in timed region (offsets + packed-row index rebuilt every step from the collator's host-side "
                                       "lengths; no mask read-back, no per-batch cache)" if unpadded else "n/a (padded path)",
                        "padding": "skipped: encoder runs on valid tokens only (results identical)" if unpadded
-                                  else "computed like the reference (LAKO_UNPAD=0)"},
+                                  else "computed like the reference (LAKO_UNPAD=0)",
+                       "cross_attention": "encoder-state space (Q' = q.Wk per head, S = Q'.E^T, ctx = (P.E).Wv^T: same results, no K/V "
+                                          "projection of the n_passages*L encoder states; LAKO_XATTN=0 = projected K/V)" if r["xattn"]
+                                          else "projected K/V (reference formulation)"},
             "roofline": {"bound": "mfma", "achieved": round(r["achieved"], 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(r["achieved"] / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": ("gemm_nt_mx_kernel (256x256 tile, v_mfma_scale_f32_16x16x128_f8f6f4, e4m3 x e4m3 with E8M0 block scales: "
                                     "forward QKV / FFN-in / cross-K/V projections)") if args.fp8 else
                                    ("gemm_nt_kernel<bf16,bf16,2,4,8,4> (256x256 tile, both epilogue instantiations; calls with M > 256"
-                                    " rows: encoder + cross-K/V GEMMs incl. their small-tile row tails)") if args.dtype == "bf16"
+                                    " rows: the encoder's GEMMs incl. their small-tile row tails; + the cross-K/V projection under LAKO_XATTN=0)") if args.dtype == "bf16"
                                    else "gemm_nt_kernel<f32,f32>",
                          "launches_per_step": r["n_l"], "avg_launch_us": round(r["t_ms"] * 1e3 / max(r["n_l"], 1), 2),
                          "step_mfma_frac": round(r["step_frac"], 4),
                          "train_gflop_per_sample": round(fl / 1e9, 1),
-                         "executed_gflop_per_sample": round(r["fl_exec"] / 1e9, 1)},
+                         "executed_gflop_per_sample": round(r["fl_exec"] / 1e9, 1),
+                         "flop_note": "train_gflop_per_sample: SURVEY.md §8a formula on every position of [B, N, L]; executed_…: the FLOPs this "
+                                      "implementation issues (valid tokens only" + (", cross-attention in the encoder-state space: no K/V "
+                                      "projection of the encoder states; the reference formulation on the same valid tokens would be "
+                                      f"{r['fl_proj'] / 1e9:.1f} GFLOP/sample" if r["xattn"] else "") + "); step_mfma_frac prices the executed FLOPs"},
         }
         if args.fp8:
             out["roofline"]["bf16_gemm"] = r["bf16_gemm"]          # the GEMMs that stay bf16 in the same run (backward, o / wo projections)

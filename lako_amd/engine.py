@@ -191,6 +191,7 @@ class Engine:
         self._tr_table = None
         self._rag_cache: dict = {}
         self._xplan_cache: dict = {}
+        self.xattn_active = False
         self.ctx_splits = 1      # key-split slabs of the current batch's xattn_context launches
         self._all_valid = False
         self._row_cap: dict = {}     # {rows of the current unpadded batch: padded row count}
@@ -596,6 +597,7 @@ class Engine:
         enc_ids = ctx.ids if rag is None else ctx.ids[rag.idx]
         ctx.enc_ids = enc_ids
         xa = ctx.xa = self._xattn_plan(rag, B, N, L, T * H)
+        self.xattn_active = xa is not None         # (bench.py / tests: which formulation the last forward ran)
         enc_out, kv = self._encode(ws, enc_ids, ctx.mask_u8, B * N, L, p, seed, save="ckpt" if ctx.ckpt else True, rag=rag,
                                    want_kv=xa is None)
         # ---- decoder ------------------------------------------------------------------------
@@ -875,7 +877,21 @@ class Engine:
             kb, kt, ckw = B, S, dict(key_mask=mask_u8.view(B, S))
         else:
             ids, kb, kt, ckw = ids[rag.idx], 1, rag.M, dict(k_off=rag.soff, max_k=S)
-        _, kv = self._encode(ws, ids, mask_u8, B * N, L, 0.0, 0, save=False, rag=rag)
+        # cross-attention in the encoder-state space (R = H query rows per sample and step; no K/V projection of the N·L encoder
+        # states): five launches per layer and step instead of one.  The decode loop is bound by the host's launch rate
+        # (tools/generate_probe.py: 113 ms against 93 ms for 50 tokens at config 2), so it is opt-in (LAKO_XATTN_GENERATE=1) here;
+        # never when the raw scores are captured: those come out of the projected kernel in the reference's layout
+        use_x = os.environ.get("LAKO_XATTN_GENERATE", "0") == "1" and not capture_scores
+        xa = self._xattn_plan(rag, B, N, L, H) if use_x else None
+        self.xattn_active = xa is not None
+        enc_out, kv = self._encode(ws, ids, mask_u8, B * N, L, 0.0, 0, save=False, rag=rag, want_kv=xa is None)
+        if xa is not None:
+            cap = B * (-(-S // 256) * 256)
+            xq = self._buf(ws, "g.xq", (B, H, d))
+            xs = self._buf(ws, "g.xs", (H, cap), torch.float32)[:, :xa.ptot]
+            xp = self._buf(ws, "g.xp", (H, cap))[:, :xa.ptot]
+            xst = self._buf(ws, "g.xst", (B, H, 2), torch.float32)
+            xc = self._buf(ws, "g.xc", (xa.splits, B, H, d), torch.float32)
         ML = max_length
         seq = self._buf(ws, "g.seq", (B, ML), torch.int64)
         nxt = self._buf(ws, "g.next", (B,), torch.int64)
@@ -916,9 +932,16 @@ class Engine:
                 ops.gemm_nt(c1, lw["o"].w, h1, resid=h)
                 ops.rmsnorm_fwd(h1, lw["ln2"].p, xn, rs, eps)
                 ops.gemm_nt(xn, lw["cq"].w, qc)
-                ops.attn_fwd(qc.view(B, 1, H, dk), self._heads(kv, kb, kt, 2 * i * inner),
-                             self._heads(kv, kb, kt, (2 * i + 1) * inner), c2.view(B, 1, H, dk), st,
-                             scores_out=scores[i] if (capture_scores and t == 0) else None, **ckw)
+                if xa is not None:
+                    ops.headbatch_nt(qc.view(B, 1, H, dk), self._xw(i, "k", transposed=True), xq.view(B, 1, H, d))
+                    ops.xattn_scores(xq, enc_out, xa.k_off, xa.p_off, xa.ptot, xs)
+                    ops.xattn_softmax_fwd(xs, xst, xp, xa.k_off, xa.p_off, 1, H, S)
+                    ops.xattn_context(xp, enc_out, xa.k_off, xa.p_off, xc)
+                    ops.headbatch_nt(xc.view(xa.splits, B, 1, H, d), self._xw(i, "v"), c2.view(B, 1, H, dk))
+                else:
+                    ops.attn_fwd(qc.view(B, 1, H, dk), self._heads(kv, kb, kt, 2 * i * inner),
+                                 self._heads(kv, kb, kt, (2 * i + 1) * inner), c2.view(B, 1, H, dk), st,
+                                 scores_out=scores[i] if (capture_scores and t == 0) else None, **ckw)
                 ops.gemm_nt(c2, lw["co"].w, h2, resid=h1)
                 ops.rmsnorm_fwd(h2, lw["ln3"].p, xn, rs, eps)
                 ops.gemm_nt(xn, lw["wi"].w, a1, relu=True)
