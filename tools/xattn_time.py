@@ -76,3 +76,14 @@ for name, fn in steps.items():
     print(f"  {name:22s} {us:8.1f} us")
 fwd = sum(timeit(steps[k_]) for k_ in ["expand (Q')", "scores", "softmax fwd", f"context (Z={Z})", "contract (ctx)"])
 print(f"forward chain (5 launches) ≈ {fwd:.1f} us per layer")
+
+# the encoder-state gradient at its real depth (12 layers: K = 24·R), for two row strides of the probability matrix
+for ld in (ptot, 65536, 65536 + 64):
+    LD = 12
+    PSb = torch.zeros(LD * 2 * R, ld, dtype=BF, device=dev)
+    DQb = torch.zeros(B, LD * 2 * R, D, dtype=BF, device=dev)
+    its = []
+    for b, n in enumerate(lens):
+        n8 = (n + 7) // 8 * 8
+        its.append((PSb[:, int(p[b]):int(p[b]) + n8], DQb[b], dE[int(k[b]):int(k[b]) + n8], 1.0))
+    print(f"  dE K={LD * 2 * R} row stride {ld:6d}: {timeit(lambda: ops.gemm_tn_grouped(its, split_k=1)):8.1f} us (two launches of 8 samples)")
