@@ -88,6 +88,7 @@ __global__ __launch_bounds__(512, 1) void xscores_kernel(XArgs a) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, l15 = lane & 15;
   const int col0 = blockIdx.x * 256;
+  if (col0 >= __builtin_amdgcn_readfirstlane(a.p_off[a.B])) return;   // launched over the padded batch's columns (captured decode steps)
   const int b = xsample_of(a.p_off, a.B, col0, &slot);
   const int key0 = col0 - __builtin_amdgcn_readfirstlane(a.p_off[b]);
   const int kfirst = __builtin_amdgcn_readfirstlane(a.k_off[b]) + key0;

@@ -873,23 +873,35 @@ class Engine:
         # valid tokens only (as in forward_loss) unless the raw scores are captured: those are laid out per padded position
         rag = None if capture_scores else self._ragged_batch(attention_mask, B, N, L, lengths)
         self._row_cap = {rag.M: B * N * L} if rag is not None else {}
+        # what changes from call to call is COPIED into workspace buffers (stable addresses: the decode steps below are captured
+        # into HIP graphs): the samples' key offsets of the unpadded batch, or the key mask of the padded one
         if rag is None:
-            kb, kt, ckw = B, S, dict(key_mask=mask_u8.view(B, S))
+            kmask = self._buf(ws, "g.kmask", (B, S), torch.uint8)
+            kmask.copy_(mask_u8.view(B, S))
+            kb, kt, ckw, mode = B, S, dict(key_mask=kmask), "p"
         else:
-            ids, kb, kt, ckw = ids[rag.idx], 1, rag.M, dict(k_off=rag.soff, max_k=S)
+            koff = self._buf(ws, "g.koff", (B + 1,), torch.int32)
+            koff.copy_(rag.soff)
+            ids, kb, kt, ckw, mode = ids[rag.idx], 1, rag.M, dict(k_off=koff, max_k=S), "r"
         # cross-attention in the encoder-state space (R = H query rows per sample and step; no K/V projection of the N·L encoder
-        # states): five launches per layer and step instead of one.  The decode loop is bound by the host's launch rate
-        # (tools/generate_probe.py: 113 ms against 93 ms for 50 tokens at config 2), so it is opt-in (LAKO_XATTN_GENERATE=1) here;
-        # never when the raw scores are captured: those come out of the projected kernel in the reference's layout
-        use_x = os.environ.get("LAKO_XATTN_GENERATE", "0") == "1" and not capture_scores
+        # states): five launches per layer and step instead of one — slower while the host's launch rate bounds the loop (eager:
+        # 113 ms against 93 ms for 50 tokens at config 2), faster once a step is one graph launch.  Never when the raw scores are
+        # captured: those come out of the projected kernel in the reference's layout.  LAKO_XATTN_GENERATE=0/1 overrides.
+        use_graph = self.device.type == "cuda" and not capture_scores and getattr(ops, "probe", None) is None and \
+            os.environ.get("LAKO_GEN_GRAPH", "1") != "0"
+        use_x = os.environ.get("LAKO_XATTN_GENERATE", "1" if use_graph else "0") == "1" and not capture_scores
         xa = self._xattn_plan(rag, B, N, L, H) if use_x else None
         self.xattn_active = xa is not None
         enc_out, kv = self._encode(ws, ids, mask_u8, B * N, L, 0.0, 0, save=False, rag=rag, want_kv=xa is None)
         if xa is not None:
+            mode += "x"
             cap = B * (-(-S // 256) * 256)
+            xoff = self._buf(ws, "g.xoff", (2, B + 1), torch.int32)
+            xoff[0].copy_(xa.k_off)
+            xoff[1].copy_(xa.p_off)
             xq = self._buf(ws, "g.xq", (B, H, d))
-            xs = self._buf(ws, "g.xs", (H, cap), torch.float32)[:, :xa.ptot]
-            xp = self._buf(ws, "g.xp", (H, cap))[:, :xa.ptot]
+            xs = self._buf(ws, "g.xs", (H, cap), torch.float32)      # launched over all `cap` columns: tiles past the batch's
+            xp = self._buf(ws, "g.xp", (H, cap))                      # last key column exit at once
             xst = self._buf(ws, "g.xst", (B, H, 2), torch.float32)
             xc = self._buf(ws, "g.xc", (xa.splits, B, H, d), torch.float32)
         ML = max_length
@@ -918,8 +930,8 @@ class Engine:
         st = self._buf(ws, "g.st", (B, H, 1, 4), torch.float32)
         a1 = self._buf(ws, "g.a1", (B, f))
         logits = self._buf(ws, "g.logits", (B, V), torch.float32)
-        n_out = 1
-        for t in range(ML - 1):
+        def step(t):
+            """enqueue decode step t (reads nxt, writes seq[:, t + 1], nxt, done, ndone[t])"""
             ops.embed_fwd(nxt, self.shared.w, h)
             for i in range(Ld):
                 lw = self.dec[i]
@@ -934,9 +946,9 @@ class Engine:
                 ops.gemm_nt(xn, lw["cq"].w, qc)
                 if xa is not None:
                     ops.headbatch_nt(qc.view(B, 1, H, dk), self._xw(i, "k", transposed=True), xq.view(B, 1, H, d))
-                    ops.xattn_scores(xq, enc_out, xa.k_off, xa.p_off, xa.ptot, xs)
-                    ops.xattn_softmax_fwd(xs, xst, xp, xa.k_off, xa.p_off, 1, H, S)
-                    ops.xattn_context(xp, enc_out, xa.k_off, xa.p_off, xc)
+                    ops.xattn_scores(xq, enc_out, xoff[0], xoff[1], cap, xs)
+                    ops.xattn_softmax_fwd(xs, xst, xp, xoff[0], xoff[1], 1, H, S)
+                    ops.xattn_context(xp, enc_out, xoff[0], xoff[1], xc)
                     ops.headbatch_nt(xc.view(xa.splits, B, 1, H, d), self._xw(i, "v"), c2.view(B, 1, H, dk))
                 else:
                     ops.attn_fwd(qc.view(B, 1, H, dk), self._heads(kv, kb, kt, 2 * i * inner),
@@ -949,6 +961,34 @@ class Engine:
             ops.rmsnorm_fwd(h, self.dec_final.p, xn, rs, eps)
             ops.gemm_nt(xn, self.shared.w, logits, alpha=d ** -0.5)
             ops.greedy_step(logits, seq, t + 1, nxt, done, ndone[t:t + 1], cfg.eos_token_id, cfg.pad_token_id)
+
+        # A decode step is ≈130 dependent launches of a few µs each: the host's launch rate bounds the loop.  After one eager call
+        # per (shape, mode) — the kernels' one-time setup must not happen under capture — every step position is captured ONCE into a
+        # HIP graph (kernel arguments that depend on t are baked in; everything that changes from call to call lives in workspace
+        # buffers whose addresses do not: the offsets / key mask are COPIED into them above) and replayed: one launch per token.
+        graphs = None
+        if use_graph:
+            gs = ws.setdefault("g.graphs", {}).get(mode)
+            ptrs = {k_: v.data_ptr() for k_, v in ws.items() if k_.startswith("^")}
+            if gs is None or any(ptrs.get(k_) != p_ for k_, p_ in gs["ptrs"].items()):      # a workspace buffer moved: start over
+                gs = ws["g.graphs"][mode] = dict(ptrs=ptrs, warm=False, steps={}, pool=None)
+            if gs["warm"]:
+                graphs = gs
+            gs["warm"] = True
+        n_out = 1
+        for t in range(ML - 1):
+            if graphs is None:
+                step(t)
+            else:
+                g = graphs["steps"].get(t)
+                if g is None:
+                    g = torch.cuda.CUDAGraph()
+                    if graphs["pool"] is None:
+                        graphs["pool"] = torch.cuda.graph_pool_handle()
+                    with torch.cuda.graph(g, pool=graphs["pool"]):
+                        step(t)
+                    graphs["steps"][t] = g
+                g.replay()
             n_out = t + 2
             ndone_host[t:t + 1].copy_(ndone[t:t + 1], non_blocking=True)
             if ndone.is_cuda:

@@ -284,6 +284,14 @@ def test_encoder_space_cross_attention_equals_projected(name, dropout, monkeypat
     holey[0, 0, 1] = False                        # masks with holes keep the projected formulation
     model(input_ids=ids, attention_mask=holey, labels=labels)
     assert eng.ctx.xa is None
+    # greedy decode: the same tokens with the decode steps' cross-attention in either formulation
+    model.eval()
+    monkeypatch.setenv("LAKO_XATTN_GENERATE", "0")
+    t0 = model.generate(input_ids=ids, attention_mask=mask, max_length=8)
+    assert not eng.xattn_active
+    monkeypatch.setenv("LAKO_XATTN_GENERATE", "1")
+    t1 = model.generate(input_ids=ids, attention_mask=mask, max_length=8)
+    assert eng.xattn_active and torch.equal(t0, t1)
 
 
 def _ws_footprint(eng):

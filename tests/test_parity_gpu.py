@@ -374,3 +374,34 @@ def test_fp32_edge_shapes_vs_oracle(B, N, L, T):
                                    msg=lambda m, n=n: f"{n}: {m}")
     toks = model.eval().generate(input_ids=ids.to(DEV), attention_mask=mask.to(DEV), max_length=6)
     assert toks.cpu().tolist() == O.fid_generate(w, dims, ids, mask, 6).tolist()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_generate_graph_replay_equals_eager(dtype, monkeypatch):
+    """Greedy decode through captured HIP graphs (engine.generate: one graph per step position, replayed from the second call
+    of a shape on) against the eager launch sequence of the same kernels: same tokens for batches that differ in content, valid
+    lengths (unpadded offsets copied into the workspace) and in where the rows finish.  In bf16 the decode steps run the
+    cross-attention in the encoder-state space (bf16 roundings differ from the projected formulation: near-tie argmaxes of a
+    random-init model may flip, so that pair is compared on the fp32 CPU double, tests/test_engine_cpu.py)."""
+    cfg = FiDConfig.named("small", dropout_rate=0.0)
+    model = FiDT5(cfg, dtype=dtype, seed=11).cuda().eval()
+    with torch.no_grad():
+        model._params_by_plain["shared.weight"].mul_(0.05)
+    B, N, L, ML = 3, 4, 72, 9
+    batches = [dev(*O.synthetic_batch(B, N, L, 4, cfg.vocab_size, seed=s))[:2] for s in (1, 2, 3)]
+    full = torch.ones_like(batches[0][1])
+    batches.append((batches[0][0], full))                  # no padding at all: the padded layout, its own graphs
+    monkeypatch.setenv("LAKO_GEN_GRAPH", "0")
+    monkeypatch.setenv("LAKO_XATTN_GENERATE", "1")         # (the fp32 engine keeps the projected formulation regardless)
+    eager = [model.generate(input_ids=i, attention_mask=m, max_length=ML).clone() for i, m in batches]
+    monkeypatch.delenv("LAKO_XATTN_GENERATE")
+    monkeypatch.setenv("LAKO_GEN_GRAPH", "1")
+    for rnd in range(3):                                    # round 0: eager warm-up of each mode, 1: capture, 2: pure replay
+        for (i, m), want in zip(batches, eager):
+            got = model.generate(input_ids=i, attention_mask=m, max_length=ML)
+            assert torch.equal(got, want), (rnd, got.tolist(), want.tolist())
+    ws = model._engine._workspace(("gen", B, N, L, ML))
+    assert sorted(ws["g.graphs"]) == (["p", "r"] if dtype == torch.float32 else ["px", "rx"])
+    assert all(len(g["steps"]) >= 1 for g in ws["g.graphs"].values())
+    assert model._engine.xattn_active == (dtype == torch.bfloat16)
