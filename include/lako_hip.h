@@ -228,7 +228,7 @@ int lako_xattn_softmax_bwd(const float* s, const float* dp, int64_t s_ld, const 
  *   lako_headbatch_nt:  C_h[m, n] = Σ_k A_h[m, k]·B_h[n, k];  A bf16 or fp32 (a_dtype), B_h[n, k] bf16 at b + h*b_sh + n*ldb + k,
  *                       C bf16 rows addressed like A's.  K % 32 == 0, N % 16 == 0.
  *   lako_headbatch_tn:  C_h[j, c] += Σ_m A[m][h*a_sh + j]·B_h[m][c], j < 64 (K), c < N;  A bf16, B rows bf16 or fp32 (b_dtype)
- *                       addressed like A's, C fp32 at c + h*c_sh + j*c_st + c (plain read-modify-write: one launch owns C). */
+ *                       addressed like A's, C fp32 at c + h*c_sh + j*c_st + c (one atomic add per element and launch). */
 typedef struct {
   const void *a, *b;
   void* c;

@@ -1410,8 +1410,11 @@ void launch_nt_cfg(NtArgs a, hipStream_t s) {
   a.stagger = g_nt_stagger;
   a.store_aux = (int64_t)256 * a.ldc * 2 < (1ll << 31) ? g_nt_store_aux : 0;   // tile-relative 32-bit store offsets
   a.debug = g_nt_debug;
-  // narrow outputs already give an XCD a compact block; a negative knob forces |value| on every shape (tests)
-  a.group_m = g_nt_group_m < 0 ? -g_nt_group_m : (a.tiles_n >= 16 ? g_nt_group_m : 0);
+  // narrow outputs (≤ 7 tile columns) already give an XCD a compact block; a negative knob forces |value| on every shape (tests).
+  // Measured at 48 000 rows (profiles/r02g_gemm_group_m_traffic.txt): banding takes the wi projection's L2 misses (FETCH_SIZE) from
+  // 217 to 163 MiB-units per launch with no change in time (244 → 241 µs) — the L2-miss traffic is not what bounds the kernel —
+  // and the QKV projection from 185 to 178 µs at unchanged misses
+  a.group_m = g_nt_group_m < 0 ? -g_nt_group_m : (a.tiles_n >= 8 ? g_nt_group_m : 0);
   // measured (tools/bench_ops.py --variants 2,32): +6…12 % on plain stores, a LOSS when a residual / aux operand must
   // be fetched in the row-major layout too — those keep the accumulator-layout epilogue
   a.wide_epi = g_nt_wide_epi && !(a.flags & (LAKO_EPI_ATOMIC | LAKO_EPI_RESID | LAKO_EPI_AUXMASK)) && a.N % 8 == 0 &&

@@ -437,6 +437,50 @@ __global__ __launch_bounds__(256) void hb_nt_kernel(HbArgs a) {
   }
 }
 
+// "contract" shape (N = 64 columns per head, K = d): one workgroup per (16-row tile, head), its four waves take a quarter of K
+// each — ALL of a wave's operand loads (KS K-steps × (slabs of A + 4 column tiles of B)) are in flight at once, one latency
+// instead of K / 256 dependent batches — and add their partial tiles through LDS.  (The one-wave-per-tile form above took 18 µs
+// for 0.3 GFLOP at config 2.)
+template <bool AF32, int KS>
+__global__ __launch_bounds__(256) void hb_contract_kernel(HbArgs a) {
+  __shared__ __attribute__((aligned(16))) float part[4][16][68];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, l15 = lane & 15;
+  const int mt = blockIdx.x, h = blockIdx.y;
+  const int m = mt * 16 + l15;
+  const bool mok = m < a.M;
+  const int mb = m / a.T, mtt = m - mb * a.T;
+  const int kbase = wave * KS * 32;
+  const int64_t aoff = (int64_t)mb * a.a_sb + (int64_t)mtt * a.a_st + (int64_t)h * a.a_sh + 8 * g + kbase;
+  const int64_t boff = (int64_t)h * a.b_sh + (int64_t)l15 * a.ldb + 8 * g + kbase;
+  u32x4 af[KS], bf[KS][4];
+#pragma unroll
+  for (int u = 0; u < KS; ++u) {
+    af[u] = hb_load8(a.A, aoff + 32 * u, AF32, mok, a.n_slabs, a.slab_stride);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+      bf[u][nt] = *reinterpret_cast<const u32x4*>(a.B + (boff + (int64_t)nt * 16 * a.ldb + 32 * u) * 2);
+  }
+  f32x4 acc[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < KS; ++u)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[nt] = emma(bf[u][nt], af[u], acc[nt]);     // acc[nt][i] = C[m = l15][16·nt + 4g + i]
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<f32x4*>(&part[wave][l15][16 * nt + 4 * g]) = acc[nt];
+  __syncthreads();
+  const int row = threadIdx.x >> 4, c4 = (threadIdx.x & 15) * 4;
+  const int mr = mt * 16 + row;
+  if (mr < a.M) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(&part[0][row][c4]);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(&part[w][row][c4]);
+    const int rb = mr / a.T, rt = mr - rb * a.T;
+    store4(reinterpret_cast<bf16_t*>(a.C) + (int64_t)rb * a.c_sb + (int64_t)rt * a.c_st + (int64_t)h * a.c_sh + c4, v);
+  }
+}
+
 template <bool BF32>
 __global__ __launch_bounds__(256) void hb_tn_kernel(HbArgs a) {
   __shared__ __attribute__((aligned(16))) char img[2 * XS_IMG];   // A image [128 m][64 j] | B image [128 m][64 c]
@@ -484,8 +528,8 @@ __global__ __launch_bounds__(256) void hb_tn_kernel(HbArgs a) {
   for (int db = 0; db < 4; ++db)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      float* p = cbase + (int64_t)(db * 16 + 4 * g + i) * a.c_st;
-      *p += acc[db][i];
+      atomicAdd(cbase + (int64_t)(db * 16 + 4 * g + i) * a.c_st, acc[db][i]);   // one contributor per element and launch: no
+                                                                                // read-modify-write round trip, still deterministic
     }
 }
 
@@ -631,11 +675,21 @@ extern "C" int lako_headbatch_nt(const lako_headbatch_t* p, lako_stream_t stream
   a.n_slabs = p->n_slabs > 0 ? p->n_slabs : 1; a.slab_stride = p->slab_stride;
   LAKO_CHECK_ARG(a.n_slabs == 1 || (p->a_dtype == LAKO_F32 && p->slab_stride % 4 == 0), "lako_headbatch_nt: slabs need an fp32 A");
   const bool f32 = p->a_dtype == LAKO_F32;
+  hipStream_t s = (hipStream_t)stream;
+  if (p->N == 64 && p->K % 128 == 0 && (p->K == 512 || p->K == 768 || p->K == 1024)) {
+    const dim3 grid((unsigned)((p->M + 15) / 16), (unsigned)p->H);
+#define HC_GO(F32, KSV) hipLaunchKernelGGL((hb_contract_kernel<F32, KSV>), grid, dim3(256), 0, s, a)
+    if (p->K == 512) { if (f32) HC_GO(true, 4); else HC_GO(false, 4); }
+    else if (p->K == 768) { if (f32) HC_GO(true, 6); else HC_GO(false, 6); }
+    else { if (f32) HC_GO(true, 8); else HC_GO(false, 8); }
+#undef HC_GO
+    LAKO_LAUNCH_CHECK();
+    return LAKO_OK;
+  }
   const int nt = p->N % 64 == 0 && p->N > 64 ? 4 : 1;
   const int ku = nt == 4 ? (p->K % 64 == 0 ? 2 : 1) : (p->K % 256 == 0 ? 8 : 1);
   const int waves = ((p->M + 15) / 16) * (p->N / (16 * nt)) * p->H;
   const dim3 grid((unsigned)((waves + 3) / 4));
-  hipStream_t s = (hipStream_t)stream;
 #define HB_GO(F32, NTV, KUV) hipLaunchKernelGGL((hb_nt_kernel<F32, NTV, KUV>), grid, dim3(256), 0, s, a)
   if (nt == 4) {
     if (ku == 2) { if (f32) HB_GO(true, 4, 2); else HB_GO(false, 4, 2); }
