@@ -188,6 +188,40 @@ def test_c2_batch16_benchmark_kernels_equal_pinned_kernels():
     assert g_rel < 0.06, g_rel
 
 
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_c2_batch16_encoder_space_cross_attention_equals_projected(dropout, monkeypatch):
+    """The benchmark's batch (16 × 20 × 200, bf16, with and without dropout): the decoder's cross-attention in the encoder-state
+    space (default: csrc/xattn.hip, no K/V projection of the ≈48 k encoder states) against the projected formulation
+    (LAKO_XATTN=0: K/V GEMM + key-split attention kernels, the reference's own order of operations).  Same math, the same dropout
+    masks; bf16 rounding points differ (Q′ = q·Wk and C′ = P·E instead of K and V), so the two agree to bf16 noise — the level
+    at which two tilings of one GEMM differ (test above)."""
+    from bench import synthetic_batch
+    cfg = FiDConfig.named("base", dropout_rate=dropout)
+    torch.manual_seed(0)
+    model = FiDT5(cfg, dtype=torch.bfloat16, seed=0)
+    with torch.no_grad():
+        model._params_by_plain["shared.weight"].mul_(0.05)
+    model = model.cuda().train()
+    ids, mask, labels, lens = synthetic_batch(16, 20, 200, 8, cfg.vocab_size, seed=9, device=DEV, with_lengths=True)
+    res = []
+    for x in ("0", "1"):
+        monkeypatch.setenv("LAKO_XATTN", x)
+        model.zero_grad()
+        model._get_engine().step_count = 0                  # the same dropout seeds in both runs
+        out = model(input_ids=ids, attention_mask=mask, labels=labels, passage_lengths=lens)
+        assert model._engine.xattn_active == (x == "1")
+        out[0].backward()
+        torch.cuda.synchronize()
+        res.append((out[0].item(), out.logits.float().clone(), model._engine.G.clone()))
+    g_rel = _rel_l2(res[1][2], res[0][2])
+    l_rel = _rel_l2(res[1][1], res[0][1])
+    _report(f"c2_b16_xattn_vs_projected_p{dropout}", {"loss_projected": res[0][0], "loss_xattn": res[1][0], "logits_rel_l2": l_rel,
+                                                       "grad_rel_l2": g_rel})
+    assert abs(res[0][0] - res[1][0]) < 1e-3 * abs(res[0][0]), (res[0][0], res[1][0])
+    assert l_rel < 0.02, l_rel
+    assert g_rel < 0.06, g_rel
+
+
 def test_c4_batch1_fp32_vs_oracle(large_case):
     """T5-large, n_passages 40 (8 000 keys per sample, d 1024, 16 heads, 24 + 24 layers) — BASELINE config 4 at one sample."""
     _check_fp32(large_case, _run_hip(large_case, torch.float32), "c4_b1_fp32")
