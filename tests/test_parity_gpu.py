@@ -405,3 +405,32 @@ def test_generate_graph_replay_equals_eager(dtype, monkeypatch):
     assert sorted(ws["g.graphs"]) == (["p", "r"] if dtype == torch.float32 else ["px", "rx"])
     assert all(len(g["steps"]) >= 1 for g in ws["g.graphs"].values())
     assert model._engine.xattn_active == (dtype == torch.bfloat16)
+
+
+@pytest.mark.gpu
+def test_encoder_space_cross_attention_long_answers_and_small_model(monkeypatch):
+    """T5-small (d_model 512, 8 heads) with 20 answer positions: R = T·H = 160 query rows per sample — two row chunks of the
+    scores / context kernels — and samples of very different key counts (one passage of a sample empty, one sample short).
+    Both cross-attention formulations on the HIP path, bf16, dropout on (the same masks): agreement to bf16 noise."""
+    cfg = FiDConfig.named("small", dropout_rate=0.1)
+    model = FiDT5(cfg, dtype=torch.bfloat16, seed=21).cuda().train()
+    with torch.no_grad():
+        model._params_by_plain["shared.weight"].mul_(0.05)
+    B, N, L, T = 3, 5, 64, 20
+    ids, mask, labels = dev(*O.synthetic_batch(B, N, L, T, cfg.vocab_size, seed=31))
+    mask[1, 2] = False
+    mask[2, 1:, 8:] = False
+    ids = ids.masked_fill(~mask, 0)
+    res = []
+    for x in ("0", "1"):
+        monkeypatch.setenv("LAKO_XATTN", x)
+        model.zero_grad()
+        model._get_engine().step_count = 0
+        out = model(input_ids=ids, attention_mask=mask, labels=labels)
+        assert model._engine.xattn_active == (x == "1")
+        out[0].backward()
+        res.append((out[0].item(), out.logits.float().clone(), model._engine.G.clone()))
+    assert abs(res[0][0] - res[1][0]) < 2e-3 * abs(res[0][0]), (res[0][0], res[1][0])
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    assert rel(res[1][1], res[0][1]) < 0.02, rel(res[1][1], res[0][1])
+    assert rel(res[1][2], res[0][2]) < 0.06, rel(res[1][2], res[0][2])
