@@ -223,6 +223,15 @@ int lako_xattn_softmax_bwd(const float* s, const float* dp, int64_t s_ld, const 
                            const int32_t* k_off, const int32_t* p_off, int B, int T, int H, int max_keys, lako_dropout_t drop,
                            lako_stream_t stream);
 
+/* One decode step (R = H <= 16 expanded query rows per sample, D in {512, 768, 1024}) in one pass over the encoder states:
+ * key range z (< key_splits) of sample b -> part_ml[z][b][r] = (max, sum exp), part_c[z][b][r][:] = sum exp(s - max) * E[key][:]
+ * (fp32, 16 rows per (z, b)); lako_xattn_decode_combine merges the ranges and applies the V projection of head h = r:
+ * ctx[b][h*64 + j] = softmax-weighted mean of E . Wv[h*64 + j][:]  (bf16, row stride ctx_ld). */
+int lako_xattn_decode(const void* q, int64_t q_sb, int64_t q_ld, const void* e, int64_t e_ld, const int32_t* k_off,
+                      float* part_ml, float* part_c, int R, int D, int B, int key_splits, lako_stream_t stream);
+int lako_xattn_decode_combine(const float* part_ml, const float* part_c, const void* wv, int64_t ldw, void* ctx, int64_t ctx_ld,
+                              int H, int D, int B, int key_splits, lako_stream_t stream);
+
 /* Head-batched small products over the M = B·T decoder rows.  A row m = (b, t) of head h starts at element offset
  * b*sb + t*st + h*sh of its buffer (two-level rows: the rows of a sample may sit inside a per-sample block of a bigger buffer).
  *   lako_headbatch_nt:  C_h[m, n] = Σ_k A_h[m, k]·B_h[n, k];  A bf16 or fp32 (a_dtype), B_h[n, k] bf16 at b + h*b_sh + n*ldb + k,

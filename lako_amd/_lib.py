@@ -90,6 +90,8 @@ SIGNATURES = {
     "lako_xattn_context": [vp, i64, vp, i64, vp, vp, vp, i64, i64, i64, i32, i32, i32, i32, vp],
     "lako_xattn_softmax_fwd": [vp, i64, vp, vp, i64, vp, vp, i32, i32, i32, i32, Dropout, vp],
     "lako_xattn_softmax_bwd": [vp, vp, i64, vp, vp, i64, vp, vp, i32, i32, i32, i32, Dropout, vp],
+    "lako_xattn_decode": [vp, i64, i64, vp, i64, vp, vp, vp, i32, i32, i32, i32, vp],
+    "lako_xattn_decode_combine": [vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp],
     "lako_headbatch_nt": [C.POINTER(HeadBatch), vp],
     "lako_headbatch_tn": [C.POINTER(HeadBatch), vp],
     "lako_ce_fwd_bwd": [vp, vp, vp, vp, vp, i64, i64, i32, vp],

@@ -259,6 +259,230 @@ __global__ __launch_bounds__(512, 1) void xcontext_kernel(XArgs a) {
 }
 
 // --------------------------------------------------------------------------------------------------------------------
+// One decode step (T = 1: R = H ≤ 16 query rows per sample) in ONE pass over the encoder states: scores, softmax and context of a
+// key range per workgroup, flash-decoding style — the encoder states are read once instead of once by the scores and once by the
+// context kernel, and no score / probability matrix exists.  grid (Z key ranges, B), 512 threads.
+//   keys run in stages of 32 through two LDS stages ([32 keys × D] as D/64 images with PERMUTED rows, filled by LDS-DMA one stage
+//   ahead); wave w owns the D/8 columns [w·D/8, (w+1)·D/8) of E for BOTH products: its slice of the contraction of S = Q′·Eᵀ (the
+//   eight partial score tiles meet in LDS) and its columns of C′ = P·E; the summed score tile is already the context product's
+//   operand (registers: 4 keys of tile 0 and of tile 1 per lane — the transposed reads' K order), online softmax per row.
+//   out: part_ml[z][b][r] = (row max, Σ exp), part_c[z][b][r][:] = Σ_keys exp(s − max)·E[key][:]   (xdecode_combine_kernel merges)
+// --------------------------------------------------------------------------------------------------------------------
+struct XdArgs {
+  const char* q;        // bf16 [B][R][D] expanded queries (row stride q_ld, sample stride q_sb)
+  int64_t q_sb, q_ld;
+  const char* e;
+  int64_t e_ld;
+  const int32_t* k_off;
+  float* part_ml;       // [Z][B][16][2]
+  float* part_c;        // [Z][B][16][D]
+  int R, D, B, Z;
+};
+
+template <int KS>      // K-steps (of 32 dims) per wave: D = 256·KS
+__global__ __launch_bounds__(512, 1) void xdecode_kernel(XdArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];   // 2 stages [32][D] | partial score tiles [8][32][16] fp32
+  constexpr int D = 256 * KS, STAGE = 32 * D * 2, NIMG = D / 64, NDB = D / 128;   // NDB: 16-column blocks per wave
+  constexpr int NSTG = 3 * STAGE + 8 * 32 * 16 * 4 <= 160 * 1024 ? 3 : 2;        // stages of the ring (one or two in flight)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, l15 = lane & 15;
+  const int z = blockIdx.x, b = blockIdx.y;
+  const int kfirst = __builtin_amdgcn_readfirstlane(a.k_off[b]);
+  const int Sb = __builtin_amdgcn_readfirstlane(a.k_off[b + 1]) - kfirst;
+  const int nst_all = (Sb + 31) >> 5;
+  const int st_begin = (int)((int64_t)z * nst_all / a.Z), st_end = (int)((int64_t)(z + 1) * nst_all / a.Z);
+  const int nst = st_end - st_begin;
+  const char* ebase = a.e + (int64_t)kfirst * a.e_ld * 2;
+  const uint32_t est = (uint32_t)(a.e_ld * 2);
+  float* sred = reinterpret_cast<float*>(smem + NSTG * STAGE);
+
+  // the wave's slice of the expanded queries: row l15, dims (wave·KS + t)·32 + 8g … as MFMA fragments
+  u32x4 qf[KS];
+#pragma unroll
+  for (int t = 0; t < KS; ++t) {
+    qf[t] = u32x4{0u, 0u, 0u, 0u};
+    if (l15 < a.R) qf[t] = *reinterpret_cast<const u32x4*>(a.q + ((int64_t)b * a.q_sb + (int64_t)l15 * a.q_ld + (wave * KS + t) * 32 + 8 * g) * 2);
+  }
+  // a USE of the loaded registers that the compiler sees: it waits for these loads HERE, not at their first use inside the loop
+  // (an s_waitcnt vmcnt(0) there would also wait for every LDS-DMA stage in flight)
+#pragma unroll
+  for (int t = 0; t < KS; ++t) asm volatile("" : "+v"(qf[t]));
+
+  auto issue = [&](int i) {      // stage i of this workgroup: keys (st_begin + i)·32 …, NIMG images of 4 instructions
+    char* stage = smem + (i % NSTG) * STAGE;
+    const int key0 = (st_begin + i) * 32, valid = min(32, Sb - key0);
+#pragma unroll
+    for (int k = 0; k < NIMG / 2; ++k) {
+      const int j = wave * (NIMG / 2) + k;          // instruction j: image j >> 2, rows 8·(j & 3) …
+      const lako_u32x4_t re = xrsrc(ebase + (int64_t)key0 * est + (j >> 2) * 128, valid, est);
+      xdma8<true>(stage + (j >> 2) * 32 * EROW, re, est, j & 3, lane, valid);
+    }
+  };
+
+  f32x4 cacc[NDB];
+  // byte offset of the wave's column block db inside a stage (image + transposed-read offset), computed — NOT el.toff[runtime index]:
+  // at D = 768 the block index depends on the wave, a dynamically indexed register array lands in scratch memory, and every
+  // scratch reload is a vector-memory operation whose s_waitcnt vmcnt(0) also waits for the LDS-DMA stages in flight (the ring
+  // ran one stage at a time: 31.7 µs instead of 17 for config 2's decode step)
+  uint32_t coff[NDB];
+#pragma unroll
+  for (int db = 0; db < NDB; ++db) {
+    cacc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int col = wave * (D / 8) + db * 16, tr = 4 * g + (l15 >> 2);
+    coff[db] = (uint32_t)((col >> 6) * 32 * EROW + tr * EROW + ((((col & 63) >> 4) ^ ((tr >> 1) & 3)) << 5) + (l15 & 3) * 8);
+  }
+  uint32_t soff[KS];      // 32-dim step wave·KS + t of the contraction: image (step >> 1), row-fragment half (step & 1) — computed too
+#pragma unroll
+  for (int t = 0; t < KS; ++t) {
+    const int sidx = wave * KS + t;
+    soff[t] = (uint32_t)((sidx >> 1) * 32 * EROW + l15 * EROW + eswz((sidx & 1) * 4 + g, l15) * 16);
+  }
+  float m_run = -INFINITY, l_run = 0.f;
+
+  if (nst > 0) issue(0);
+  if (NSTG == 3 && nst > 1) issue(1);
+  for (int i = 0; i < nst; ++i) {
+    if (NSTG == 3 && i + 1 < nst) xwait_vm<NIMG / 2>();      // stage i + 1 (this wave's NIMG / 2 instructions) may still be in flight
+    else xwait_vm<0>();
+    __syncthreads();                       // stage i has landed; every wave is past stage i − 1 (and past reading its score tiles)
+    if (i + NSTG - 1 < nst) issue(i + NSTG - 1);
+    const char* stage = smem + (i % NSTG) * STAGE;
+    // partial scores over this wave's dims: tile kt, lane (r = l15, g): image rows 16·kt + 4g … + 3
+    f32x4 sp[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int t = 0; t < KS; ++t)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+        sp[kt] = emma(*reinterpret_cast<const u32x4*>(stage + soff[t] + 16 * kt * EROW), qf[t], sp[kt]);
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) *reinterpret_cast<f32x4*>(sred + ((wave * 2 + kt) * 16 + l15) * 16 + 4 * g) = sp[kt];
+    __syncthreads();
+    f32x4 sv[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      sv[kt] = *reinterpret_cast<const f32x4*>(sred + (kt * 16 + l15) * 16 + 4 * g);
+#pragma unroll
+      for (int w = 1; w < 8; ++w) sv[kt] += *reinterpret_cast<const f32x4*>(sred + ((w * 2 + kt) * 16 + l15) * 16 + 4 * g);
+    }
+    // image row 16·kt + 4g + e holds key 8g + 4·kt + e of the stage (xdma8<PERM>)
+    const int kbase = (st_begin + i) * 32 + 8 * g;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (kbase + 4 * kt + e >= Sb) sv[kt][e] = -INFINITY;
+        mx = fmaxf(mx, sv[kt][e]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);                 // finite: every stage of a range holds at least one key
+    const float alpha = __expf(m_run - m_new);
+    bf16x8 pf;
+    float ps = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float pv = __expf(sv[kt][e] - m_new);
+        ps += pv;
+        pf[kt * 4 + e] = (bf16_t)pv;
+      }
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+    const u32x4 pfrag = __builtin_bit_cast(u32x4, pf);
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) {
+      const char* ap = stage + coff[db];
+      s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ap));
+      s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ap + 16 * EROW));
+      const u32x2 u0 = __builtin_bit_cast(u32x2, t0), u1 = __builtin_bit_cast(u32x2, t1);
+      cacc[db] = emma(u32x4{u0[0], u0[1], u1[0], u1[1]}, pfrag, cacc[db] * alpha);
+    }
+  }
+  // lane (r = l15, g): cacc[db][i] = Σ exp(s − m)·E[key][wave·D/8 + 16·db + 4g + i]
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
+  const int64_t pr = ((int64_t)z * a.B + b) * 16 + l15;
+  if (wave == 0 && g == 0) {
+    a.part_ml[pr * 2] = m_run;
+    a.part_ml[pr * 2 + 1] = l_run;
+  }
+#pragma unroll
+  for (int db = 0; db < NDB; ++db) *reinterpret_cast<f32x4*>(a.part_c + pr * D + wave * (D / 8) + db * 16 + 4 * g) = cacc[db];
+}
+
+// ctx[b][h][j] = (Σ_z w_z·C′_z[b][h][:] / Σ_z w_z·l_z)·Wv[h·64 + j][:],  w_z = exp(m_z − max_z m_z):  grid (H, B), 256 threads
+struct XcArgs {
+  const float *part_ml, *part_c;
+  const char* wv;       // bf16 [H·64][ldw] rows of the layer's V projection
+  int64_t ldw;
+  char* ctx;            // bf16 [B][H·64] (row stride ctx_ld)
+  int64_t ctx_ld;
+  int D, B, Z;
+};
+
+template <int SPAN8>     // 16-byte weight loads per thread: D = 32·SPAN8
+__global__ __launch_bounds__(256) void xdecode_combine_kernel(XcArgs a) {
+  // every global load of a thread — the ranges' statistics, its 4 columns of up to 16 partial contexts, its quarter of a weight
+  // row — is issued before the first use: the kernel is a handful of dependent latencies otherwise (12 µs for 0.2 MFLOP)
+  __shared__ float cl[1024];
+  __shared__ float wz[64], lz[64];
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int j = threadIdx.x >> 2, qd = threadIdx.x & 3, span = SPAN8 * 8;
+  const char* wr = a.wv + ((int64_t)(h * 64 + j) * a.ldw + qd * span) * 2;
+  u32x4 w8[SPAN8];
+#pragma unroll
+  for (int u = 0; u < SPAN8; ++u) w8[u] = *reinterpret_cast<const u32x4*>(wr + u * 16);
+  const int c = threadIdx.x * 4;
+  f32x4 t[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    t[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (u < a.Z && c < a.D) t[u] = *reinterpret_cast<const f32x4*>(a.part_c + (((int64_t)u * a.B + b) * 16 + h) * a.D + c);
+  }
+  if (threadIdx.x < 64) {
+    float mz = -INFINITY, l = 0.f;
+    if ((int)threadIdx.x < a.Z) {
+      const float* ml = a.part_ml + (((int64_t)threadIdx.x * a.B + b) * 16 + h) * 2;
+      mz = ml[0];
+      l = ml[1];
+    }
+    float M = mz;                                   // max over the ranges: one wave holds them all
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) M = fmaxf(M, __shfl_xor(M, o, 64));
+    wz[threadIdx.x] = mz == -INFINITY ? 0.f : __expf(mz - M);
+    lz[threadIdx.x] = l;
+  }
+  __syncthreads();
+  float L = 0.f;
+  for (int z = 0; z < a.Z; ++z) L += wz[z] * lz[z];
+  const float invL = 1.0f / L;
+  if (c < a.D) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v += t[u] * wz[u];
+    for (int z0 = 16; z0 < a.Z; z0 += 16) {          // more than 16 key ranges: further batches
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (z0 + u < a.Z) v += *reinterpret_cast<const f32x4*>(a.part_c + (((int64_t)(z0 + u) * a.B + b) * 16 + h) * a.D + c) * wz[z0 + u];
+    }
+    *reinterpret_cast<f32x4*>(cl + c) = v * invL;
+  }
+  __syncthreads();
+  float acc = 0.f;
+#pragma unroll
+  for (int u = 0; u < SPAN8; ++u) {
+    const bf16x8 wv8 = __builtin_bit_cast(bf16x8, w8[u]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc = __builtin_fmaf((float)wv8[e], cl[qd * span + u * 8 + e], acc);
+  }
+  acc += __shfl_xor(acc, 1, 64);
+  acc += __shfl_xor(acc, 2, 64);
+  if (qd == 0) reinterpret_cast<bf16_t*>(a.ctx)[(int64_t)b * a.ctx_ld + h * 64 + j] = (bf16_t)acc;
+}
+
+// --------------------------------------------------------------------------------------------------------------------
 // softmax over the keys of one (sample, row): grid (R, B), 256 threads
 // --------------------------------------------------------------------------------------------------------------------
 struct SmArgs {
@@ -724,6 +948,56 @@ extern "C" int lako_headbatch_tn(const lako_headbatch_t* p, lako_stream_t stream
   const dim3 grid((unsigned)(p->N / 64), (unsigned)p->H);
   if (p->b_dtype == LAKO_F32) hipLaunchKernelGGL((hb_tn_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((hb_tn_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  LAKO_LAUNCH_CHECK();
+  return LAKO_OK;
+}
+
+extern "C" int lako_xattn_decode(const void* q, int64_t q_sb, int64_t q_ld, const void* e, int64_t e_ld, const int32_t* k_off,
+                                 float* part_ml, float* part_c, int R, int D, int B, int key_splits, lako_stream_t stream) {
+  LAKO_CHECK_ARG(q && e && k_off && part_ml && part_c, "lako_xattn_decode: null operand");
+  LAKO_CHECK_ARG(R >= 1 && R <= 16 && (D == 512 || D == 768 || D == 1024) && B >= 1 && key_splits >= 1 && key_splits <= 64 &&
+                     e_ld % 8 == 0 && e_ld >= D && e_ld < (1 << 20) && q_ld % 8 == 0 && q_sb % 8 == 0,
+                 "lako_xattn_decode: R <= 16, D in {512, 768, 1024}, 1 <= key_splits <= 64, 16-byte rows (R=%d D=%d)", R, D);
+  LAKO_CHECK_ALIGN(q, 16);
+  LAKO_CHECK_ALIGN(e, 16);
+  LAKO_CHECK_ALIGN(part_c, 16);
+  XdArgs a{};
+  a.q = (const char*)q; a.q_sb = q_sb; a.q_ld = q_ld;
+  a.e = (const char*)e; a.e_ld = e_ld; a.k_off = k_off;
+  a.part_ml = part_ml; a.part_c = part_c;
+  a.R = R; a.D = D; a.B = B; a.Z = key_splits;
+  const int stage_b = 32 * D * 2, red_b = 8 * 32 * 16 * 4;
+  const int lds = (3 * stage_b + red_b <= 160 * 1024 ? 3 : 2) * stage_b + red_b;
+  const dim3 grid((unsigned)key_splits, (unsigned)B);
+  hipStream_t s = (hipStream_t)stream;
+#define XD_GO(KSV)                                                                                                     \
+  do {                                                                                                                 \
+    static bool done = false;                                                                                          \
+    xset_lds(reinterpret_cast<const void*>(&xdecode_kernel<KSV>), lds, done);                                          \
+    hipLaunchKernelGGL((xdecode_kernel<KSV>), grid, dim3(512), lds, s, a);                                             \
+  } while (0)
+  if (D == 512) XD_GO(2);
+  else if (D == 768) XD_GO(3);
+  else XD_GO(4);
+#undef XD_GO
+  LAKO_LAUNCH_CHECK();
+  return LAKO_OK;
+}
+
+extern "C" int lako_xattn_decode_combine(const float* part_ml, const float* part_c, const void* wv, int64_t ldw, void* ctx,
+                                         int64_t ctx_ld, int H, int D, int B, int key_splits, lako_stream_t stream) {
+  LAKO_CHECK_ARG(part_ml && part_c && wv && ctx, "lako_xattn_decode_combine: null operand");
+  LAKO_CHECK_ARG(H >= 1 && H <= 16 && (D == 512 || D == 768 || D == 1024) && B >= 1 && key_splits >= 1 && key_splits <= 64 &&
+                     ldw % 8 == 0,
+                 "lako_xattn_decode_combine: H <= 16, D in {512, 768, 1024}, 1 <= key_splits <= 64");
+  LAKO_CHECK_ALIGN(wv, 16);
+  XcArgs a{};
+  a.part_ml = part_ml; a.part_c = part_c; a.wv = (const char*)wv; a.ldw = ldw; a.ctx = (char*)ctx; a.ctx_ld = ctx_ld;
+  a.D = D; a.B = B; a.Z = key_splits;
+  const dim3 grid((unsigned)H, (unsigned)B);
+  if (D == 512) hipLaunchKernelGGL((xdecode_combine_kernel<16>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  else if (D == 768) hipLaunchKernelGGL((xdecode_combine_kernel<24>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((xdecode_combine_kernel<32>), grid, dim3(256), 0, (hipStream_t)stream, a);
   LAKO_LAUNCH_CHECK();
   return LAKO_OK;
 }

@@ -904,6 +904,13 @@ class Engine:
             xp = self._buf(ws, "g.xp", (H, cap))                      # last key column exit at once
             xst = self._buf(ws, "g.xst", (B, H, 2), torch.float32)
             xc = self._buf(ws, "g.xc", (xa.splits, B, H, d), torch.float32)
+            # scores, softmax and context of a decode step in one pass over the encoder states when the shapes allow
+            fused = dk == 64 and getattr(ops, "xattn_decode_ok", lambda *_: False)(H, d) and os.environ.get("LAKO_XATTN_DECODE", "1") != "0"
+            if fused:
+                zd = max(1, min(64, 256 // B))
+                pml = self._buf(ws, "g.xpml", (zd, B, 16, 2), torch.float32)
+                pc = self._buf(ws, "g.xpc", (zd, B, 16, d), torch.float32)
+                mode += "f"
         ML = max_length
         seq = self._buf(ws, "g.seq", (B, ML), torch.int64)
         nxt = self._buf(ws, "g.next", (B,), torch.int64)
@@ -944,16 +951,21 @@ class Engine:
                 ops.gemm_nt(c1, lw["o"].w, h1, resid=h)
                 ops.rmsnorm_fwd(h1, lw["ln2"].p, xn, rs, eps)
                 ops.gemm_nt(xn, lw["cq"].w, qc)
-                if xa is not None:
-                    ops.headbatch_nt(qc.view(B, 1, H, dk), self._xw(i, "k", transposed=True), xq.view(B, 1, H, d))
-                    ops.xattn_scores(xq, enc_out, xoff[0], xoff[1], cap, xs)
-                    ops.xattn_softmax_fwd(xs, xst, xp, xoff[0], xoff[1], 1, H, S)
-                    ops.xattn_context(xp, enc_out, xoff[0], xoff[1], xc)
-                    ops.headbatch_nt(xc.view(xa.splits, B, 1, H, d), self._xw(i, "v"), c2.view(B, 1, H, dk))
-                else:
+                if xa is None:
                     ops.attn_fwd(qc.view(B, 1, H, dk), self._heads(kv, kb, kt, 2 * i * inner),
                                  self._heads(kv, kb, kt, (2 * i + 1) * inner), c2.view(B, 1, H, dk), st,
                                  scores_out=scores[i] if (capture_scores and t == 0) else None, **ckw)
+                else:
+                    ops.headbatch_nt(qc.view(B, 1, H, dk), self._xw(i, "k", transposed=True), xq.view(B, 1, H, d))
+                    if fused:
+                        ops.xattn_decode(xq, enc_out, xoff[0], pml, pc)
+                        r0 = (2 * i + 1) * inner
+                        ops.xattn_decode_combine(pml, pc, self.kv_all.w[r0:r0 + inner], c2, H)
+                    else:
+                        ops.xattn_scores(xq, enc_out, xoff[0], xoff[1], cap, xs)
+                        ops.xattn_softmax_fwd(xs, xst, xp, xoff[0], xoff[1], 1, H, S)
+                        ops.xattn_context(xp, enc_out, xoff[0], xoff[1], xc)
+                        ops.headbatch_nt(xc.view(xa.splits, B, 1, H, d), self._xw(i, "v"), c2.view(B, 1, H, dk))
                 ops.gemm_nt(c2, lw["co"].w, h2, resid=h1)
                 ops.rmsnorm_fwd(h2, lw["ln3"].p, xn, rs, eps)
                 ops.gemm_nt(xn, lw["wi"].w, a1, relu=True)

@@ -376,6 +376,31 @@ class HipOps:
             _p(P), P.stride(0), _p(E), E.stride(0), _p(k_off), _p(p_off), _p(out), out.stride(0), out.stride(1), out.stride(2),
             R, D, Bz, Z, self._stream()), "lako_xattn_context"))
 
+    @staticmethod
+    def xattn_decode_ok(H, d_model):
+        return H <= 16 and d_model in (512, 768, 1024)
+
+    def xattn_decode(self, Q, E, k_off, part_ml, part_c):
+        """one decode step, scores + softmax + context of a key range per workgroup: Q [B, R <= 16, D] bf16 view,
+        part_ml [Z, B, 16, 2] / part_c [Z, B, 16, D] fp32 (contiguous) receive every range's (max, Σ exp) and Σ exp·E"""
+        Bz, R, D = Q.shape
+        Z = part_c.shape[0]
+        if part_c.shape != (Z, Bz, 16, D) or part_ml.shape != (Z, Bz, 16, 2) or not part_c.is_contiguous() or not part_ml.is_contiguous() \
+                or Q.stride(2) != 1 or E.stride(1) != 1 or E.shape[1] != D:
+            raise LakoError(f"xattn_decode: shapes Q{tuple(Q.shape)} E{tuple(E.shape)} part{tuple(part_c.shape)}")
+        self._timed("xattn", 4.0 * R * D * E.shape[0], lambda: check(self.lib.lako_xattn_decode(
+            _p(Q), Q.stride(0), Q.stride(1), _p(E), E.stride(0), _p(k_off), _p(part_ml), _p(part_c), R, D, Bz, Z, self._stream()),
+            "lako_xattn_decode"))
+
+    def xattn_decode_combine(self, part_ml, part_c, Wv, ctx, H):
+        """ctx [B, H·64] bf16 = (merged ranges of xattn_decode)·Wvᵀ per head; Wv [H·64, D] bf16 rows of the V projection"""
+        Z, Bz, _, D = part_c.shape
+        if Wv.shape != (H * 64, D) or Wv.stride(1) != 1 or ctx.shape != (Bz, H * 64) or ctx.stride(1) != 1:
+            raise LakoError(f"xattn_decode_combine: shapes Wv{tuple(Wv.shape)} ctx{tuple(ctx.shape)}")
+        self._timed("xattn", 2.0 * Bz * H * 64 * D, lambda: check(self.lib.lako_xattn_decode_combine(
+            _p(part_ml), _p(part_c), _p(Wv), Wv.stride(0), _p(ctx), ctx.stride(0), H, D, Bz, Z, self._stream()),
+            "lako_xattn_decode_combine"))
+
     def xattn_softmax_fwd(self, S, stats, P, k_off, p_off, T, H, max_keys, drop=None):
         """stats [B, T·H, 2] fp32, P [T·H, ld] bf16 = dropout(softmax over each sample's keys of S)"""
         Bz = stats.shape[0]

@@ -306,6 +306,41 @@ class RefOps:
             out[0, b] = f(P[:, po[b]:po[b] + n]) @ f(E[ko[b]:ko[b + 1]])
 
     @staticmethod
+    def xattn_decode_ok(H, d_model):
+        return H <= 16
+
+    def xattn_decode(self, Q, E, k_off, part_ml, part_c):
+        ko = k_off.tolist()
+        Z, Bz, _, D = part_c.shape
+        R = Q.shape[1]
+        part_ml[..., 0] = -float("inf")
+        part_ml[..., 1] = 0
+        part_c.zero_()
+        for b in range(Bz):
+            n = ko[b + 1] - ko[b]
+            nst = -(-n // 32)
+            for z in range(Z):
+                lo, hi = min(n, (z * nst // Z) * 32), min(n, ((z + 1) * nst // Z) * 32)
+                if hi <= lo:
+                    continue
+                e = f(E[ko[b] + lo:ko[b] + hi])
+                s = f(Q[b]) @ e.T
+                m = s.max(-1).values
+                p = torch.exp(s - m[:, None])
+                part_ml[z, b, :R, 0] = m
+                part_ml[z, b, :R, 1] = p.sum(-1)
+                part_c[z, b, :R] = p.to(Q.dtype).float() @ e
+
+    def xattn_decode_combine(self, part_ml, part_c, Wv, ctx, H):
+        Z, Bz, _, D = part_c.shape
+        m = part_ml[:, :, :H, 0]
+        M = m.max(0).values
+        w = torch.where(torch.isinf(m), torch.zeros_like(m), torch.exp(m - M[None]))
+        L = (w * part_ml[:, :, :H, 1]).sum(0)
+        c = (w[..., None] * part_c[:, :, :H]).sum(0) / L[..., None]              # [B, H, D]
+        ctx.copy_(torch.einsum("bhc,hjc->bhj", c, f(Wv).view(H, 64, D)).reshape(Bz, H * 64))
+
+    @staticmethod
     def _xkeep(b, T, H, n, max_keys, drop, dev):
         """keep[r = t·H + h, s] and the scale of sample b (the attention recipe with bh = b·H + h, q = t, k = s, Lk = max_keys)"""
         pr, seed, site = drop

@@ -402,7 +402,7 @@ def test_generate_graph_replay_equals_eager(dtype, monkeypatch):
             got = model.generate(input_ids=i, attention_mask=m, max_length=ML)
             assert torch.equal(got, want), (rnd, got.tolist(), want.tolist())
     ws = model._engine._workspace(("gen", B, N, L, ML))
-    assert sorted(ws["g.graphs"]) == (["p", "r"] if dtype == torch.float32 else ["px", "rx"])
+    assert sorted(ws["g.graphs"]) == (["p", "r"] if dtype == torch.float32 else ["pxf", "rxf"])
     assert all(len(g["steps"]) >= 1 for g in ws["g.graphs"].values())
     assert model._engine.xattn_active == (dtype == torch.bfloat16)
 

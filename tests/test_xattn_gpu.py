@@ -217,3 +217,31 @@ def test_reassociated_cross_attention_equals_projected(ops, ref, p):
     assert rel_l2(G, gW) < 1.5e-2, rel_l2(G, gW)
     assert rel_l2(dE[:sum(lens)], gE) < 1.5e-2, rel_l2(dE[:sum(lens)], gE)
     assert float(dE[sum(lens):].abs().max()) == 0
+
+
+@pytest.mark.parametrize("lens,H,D,Z", [([300, 129, 1, 33], 12, 768, 4), ([1000, 777], 16, 1024, 16), ([64, 5000, 31], 8, 512, 7)])
+def test_decode_step_one_pass(ops, ref, lens, H, D, Z):
+    """lako_xattn_decode + lako_xattn_decode_combine (one decode step: scores, softmax and context in one pass over the encoder
+    states, key ranges merged afterwards) against the fp32 restatement and against softmax(Q′·Eᵀ)·E·Wvᵀ computed directly."""
+    B = len(lens)
+    k_off, _, _ = offsets(lens)
+    E = rnd(sum(lens), D, dtype=BF, seed=1)
+    Q = rnd(B, H + 3, D, dtype=BF, scale=0.08, seed=2)[:, 1:1 + H]
+    Wv = rnd(H * 64, D, dtype=BF, scale=0.05, seed=3)
+    pml, pc = torch.zeros(Z, B, 16, 2, device=dev()), torch.zeros(Z, B, 16, D, device=dev())
+    pml_r, pc_r = torch.zeros_like(pml), torch.zeros_like(pc)
+    ops.xattn_decode(Q, E, k_off, pml, pc)
+    ref.xattn_decode(Q, E, k_off, pml_r, pc_r)
+    assert torch.equal(torch.isinf(pml[:, :, :H, 0]), torch.isinf(pml_r[:, :, :H, 0]))
+    fin = ~torch.isinf(pml_r[:, :, :H, 0])
+    assert torch.allclose(pml[:, :, :H][fin], pml_r[:, :, :H][fin], rtol=2e-3, atol=1e-4)       # Σ exp of bf16-rounded … no: fp32 exps
+    ctx, ctx_r = torch.zeros(B, H * 64, dtype=BF, device=dev()), torch.zeros(B, H * 64, dtype=BF, device=dev())
+    ops.xattn_decode_combine(pml, pc, Wv, ctx, H)
+    ref.xattn_decode_combine(pml_r, pc_r, Wv, ctx_r, H)
+    assert rel_l2(ctx.float(), ctx_r.float()) < 6e-3, rel_l2(ctx.float(), ctx_r.float())
+    direct = torch.zeros(B, H, 64, device=dev())
+    for b, n in enumerate(lens):
+        e = E[int(k_off[b]):int(k_off[b]) + n].float()
+        p = torch.softmax(Q[b].float() @ e.T, -1)
+        direct[b] = torch.einsum("hc,hjc->hj", p @ e, Wv.float().view(H, 64, D))
+    assert rel_l2(ctx.float().view(B, H, 64), direct) < 1e-2, rel_l2(ctx.float().view(B, H, 64), direct)
