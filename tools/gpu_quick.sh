@@ -1,5 +1,7 @@
-python -m pytest tests/test_xattn_gpu.py tests/test_parity_gpu.py tests/test_drivers_gpu.py -m gpu -q -x -k "decode_step or generate or decode or collated or greedy" 2>&1 | tail -3
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats -d /tmp/pg -o b -- python3 tools/generate_probe.py > /tmp/gp.txt 2>&1; grep max_length /tmp/gp.txt
-python tools/rocpd_stats.py /tmp/pg/b_results.db | grep -E "xdecode|hb_nt" | cut -c1-150
+# scratch: the command list of the current gpurun call (edited per call; see tools/gpu_round.sh for the round-end sequence)
+mkdir -p gpurun_out/r02i
+( time python -m pytest tests -m gpu -q --durations=6 ) > gpurun_out/r02i/pytest.log 2>&1; tail -12 gpurun_out/r02i/pytest.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+python bench.py --fp8 --no-cpu-baseline --all-valid-steps 0 --steps 10 --warmup 4 2>/dev/null | cut -c1-200
+( time python bench.py ) > gpurun_out/r02i/bench.json 2> gpurun_out/r02i/bench.err; cut -c1-260 gpurun_out/r02i/bench.json
 python tools/generate_probe.py 2>&1 | tail -2
