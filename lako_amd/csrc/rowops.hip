@@ -343,6 +343,94 @@ __global__ __launch_bounds__(256) void transpose_cast_batched_kernel(const float
   }
 }
 
+// ---- RMSNorm at d = 768 (T5-base): TWO rows per wave ------------------------------------------------------------------
+// One wave per row leaves a third of the lanes idle on the row's second 512-element slice (768 = 512 + 256), reads the row twice
+// in the forward and runs one dependent load → reduce → load → store chain per row.  Here a wave takes rows 2p and 2p + 1 as three
+// full slices of 512 elements (row A: columns 0…511 | row A: 512…767 on lanes 0…31, row B: 0…255 on lanes 32…63 | row B: 256…767),
+// keeps them in registers, and requests the next pair's slices before it reduces the current pair.  Same arithmetic per element
+// as the generic kernel; the sums run over the same elements in another order.  Forward at 48 k rows: 43 → 28 µs (5.3 TB/s).
+// (The backward in the same form measured 82 µs against 83: with three input and two output streams it sits at the 4.5 TB/s the
+// mixed read / write traffic reaches either way — and 128 µs with the next pair double-buffered in 256 registers; not kept.)
+struct Pair768 {
+  int c0, c1, c2;      // the lane's first column of each slice
+  bool lo;             // lanes 0…31: slice 1 belongs to row A
+};
+__device__ __forceinline__ Pair768 pair768(int lane) {
+  Pair768 p;
+  p.lo = lane < 32;
+  p.c0 = lane * 8;
+  p.c1 = p.lo ? 512 + lane * 8 : (lane - 32) * 8;
+  p.c2 = 256 + lane * 8;
+  return p;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_fwd768_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                             T* __restrict__ y, float* __restrict__ rstd, int64_t rows,
+                                                             float eps, DropDev dr) {
+  constexpr int D = 768;
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
+  const int64_t npairs = (rows + 1) >> 1;
+  const Pair768 pc = pair768(lane);
+  float w0[8], w1[8], w2[8];
+  load8(w + pc.c0, w0);
+  load8(w + pc.c1, w1);
+  load8(w + pc.c2, w2);
+  auto fetch = [&](int64_t pair, float (&v0)[8], float (&v1)[8], float (&v2)[8]) {
+    const int64_t rA = 2 * pair, rB = rA + 1;
+    const bool hasB = rB < rows;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v0[i] = v1[i] = v2[i] = 0.f;
+    if (pair < npairs) {
+      load8(x + rA * D + pc.c0, v0);
+      if (pc.lo) load8(x + rA * D + pc.c1, v1);
+      else if (hasB) load8(x + rB * D + pc.c1, v1);
+      if (hasB) load8(x + rB * D + pc.c2, v2);
+    }
+  };
+  float n0[8], n1[8], n2[8];
+  fetch(wid, n0, n1, n2);
+  for (int64_t pair = wid; pair < npairs; pair += nw) {
+    float v0[8], v1[8], v2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { v0[i] = n0[i]; v1[i] = n1[i]; v2[i] = n2[i]; }
+    fetch(pair + nw, n0, n1, n2);
+    const int64_t rA = 2 * pair, rB = rA + 1;
+    const bool hasB = rB < rows;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s0 += v0[i] * v0[i]; s1 += v1[i] * v1[i]; s2 += v2[i] * v2[i]; }
+    const float ssA = wave_sum(s0 + (pc.lo ? s1 : 0.f)), ssB = wave_sum(s2 + (pc.lo ? 0.f : s1));
+    const float rsA = rsqrtf(ssA / (float)D + eps), rsB = rsqrtf(ssB / (float)D + eps);
+    if (lane == 0) {
+      rstd[rA] = rsA;
+      if (hasB) rstd[rB] = rsB;
+    }
+    const float rs1 = pc.lo ? rsA : rsB;
+    const int64_t r1 = pc.lo ? rA : rB;
+    bool k0[8], k1[8], k2[8];
+    if (dr.thresh) {
+      keep8(dr.key, (uint64_t)rA * D + pc.c0, dr.thresh, k0);
+      keep8(dr.key, (uint64_t)r1 * D + pc.c1, dr.thresh, k1);
+      keep8(dr.key, (uint64_t)rB * D + pc.c2, dr.thresh, k2);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float o0 = w0[i] * (v0[i] * rsA), o1 = w1[i] * (v1[i] * rs1), o2 = w2[i] * (v2[i] * rsB);
+      if (dr.thresh) {
+        o0 = k0[i] ? o0 * dr.scale : 0.f;
+        o1 = k1[i] ? o1 * dr.scale : 0.f;
+        o2 = k2[i] ? o2 * dr.scale : 0.f;
+      }
+      v0[i] = o0; v1[i] = o1; v2[i] = o2;
+    }
+    store8(y + rA * D + pc.c0, v0);
+    if (pc.lo || hasB) store8(y + r1 * D + pc.c1, v1);
+    if (hasB) store8(y + rB * D + pc.c2, v2);
+  }
+}
+
 // ---- cross-entropy --------------------------------------------------------------------------
 // The mean is accumulated in 2^-40 fixed point (a 64-bit integer add is order-independent, so the loss does not depend on which
 // row's workgroup finishes first); the last row to finish converts it.  scratch = {u64 sum, u32 rows done}.
@@ -658,6 +746,12 @@ extern "C" int lako_rmsnorm_fwd(const void* x, const float* w, void* y, float* r
   LAKO_CHECK_ALIGN(y, 16);
   LAKO_CHECK_ALIGN(w, 16);
   DropDev dr = make_drop(drop);
+  if (d == 768) {      // two rows per wave
+    DISPATCH_T(dtype, hipLaunchKernelGGL((rmsnorm_fwd768_kernel<T>), dim3(rows_grid((rows + 1) / 2)), dim3(256), 0,
+                                         (hipStream_t)stream, (const T*)x, w, (T*)y, rstd, rows, eps, dr));
+    LAKO_LAUNCH_CHECK();
+    return LAKO_OK;
+  }
   DISPATCH_T(dtype, hipLaunchKernelGGL((rmsnorm_fwd_kernel<T>), dim3(rows_grid(rows)), dim3(256), 0,
                                        (hipStream_t)stream, (const T*)x, w, (T*)y, rstd, rows, d, eps, dr));
   LAKO_LAUNCH_CHECK();

@@ -257,7 +257,7 @@ def test_gemm_tn(ops, ref, dt, K, M, N, split):
 
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("rows,d", [(37, 32), (1000, 768), (513, 1024), (64, 512)])
+@pytest.mark.parametrize("rows,d", [(37, 32), (1000, 768), (1001, 768), (1, 768), (513, 1024), (64, 512)])
 def test_rmsnorm(ops, ref, dt, rows, d):
     T = DT[dt]
     x = rnd(rows, d, dtype=T, seed=12)
