@@ -997,7 +997,8 @@ class Engine:
                     g = torch.cuda.CUDAGraph()
                     if graphs["pool"] is None:
                         graphs["pool"] = torch.cuda.graph_pool_handle()
-                    with torch.cuda.graph(g, pool=graphs["pool"]):
+                    # thread_local: a data-loader / pin-memory thread may touch the runtime while this thread captures
+                    with torch.cuda.graph(g, pool=graphs["pool"], capture_error_mode="thread_local"):
                         step(t)
                     graphs["steps"][t] = g
                 g.replay()
