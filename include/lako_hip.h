@@ -215,7 +215,8 @@ int lako_xattn_context(const void* p, int64_t p_ld, const void* e, int64_t e_ld,
                        lako_stream_t stream);
 /* row r = t*H + h of sample b: stats[b][r] = (max, 1 / sum exp); p = dropout(softmax) as bf16, zeros in the padding columns.
  * Dropout: the attention block recipe of lako_attn_fwd with bh = b*H + h, q = t, k = key index in the sample, Lq = T,
- * Lk = max_keys (so that both formulations of the cross-attention drop the same probabilities). */
+ * Lk = max_keys (so that both formulations of the cross-attention drop the same probabilities); max_keys must be at least
+ * every sample's key count (rows of up to 8 192 keys are processed from registers). */
 int lako_xattn_softmax_fwd(const float* s, int64_t s_ld, float* stats, void* p, int64_t p_ld, const int32_t* k_off,
                            const int32_t* p_off, int B, int T, int H, int max_keys, lako_dropout_t drop, lako_stream_t stream);
 /* ds = P∘(dropout_bwd(dp) − Σ_keys dropout(P)·dp) as bf16 (P recomputed from s and stats) */

@@ -520,6 +520,94 @@ __device__ __forceinline__ void xkeep4(const SmArgs& a, uint32_t prow, const Dro
   drop_keep_row(drop_base(prow + (uint32_t)c, a.drop_key), drc, a.drop_t16 << 16, kp);
 }
 
+// Rows of at most 1024·NV keys (config 2: 4 000): the row — and in backward dP — is read ONCE into registers (NV 16-byte vectors per
+// thread, all loads in flight together) instead of two / three times from L2 with a reduction between the passes.
+template <bool BWD, int NV>
+__global__ __launch_bounds__(256) void xsoftmax_reg_kernel(SmArgs a) {
+  __shared__ float sh[4];
+  const int r = blockIdx.x, b = blockIdx.y;
+  const int t = r / a.H, h = r - t * a.H;
+  const int pc0 = a.p_off[b], Sb = a.k_off[b + 1] - a.k_off[b], Sp = a.p_off[b + 1] - pc0;
+  const float* srow = a.s + (int64_t)r * a.s_ld + pc0;
+  const float* drow = BWD ? a.dp + (int64_t)r * a.s_ld + pc0 : nullptr;
+  bf16_t* prow_out = reinterpret_cast<bf16_t*>(a.p + ((int64_t)r * a.p_ld + pc0) * 2);
+  const uint32_t prow = (uint32_t)(((b * a.H + h) * a.QB + (t >> 2)) * a.KB);
+  const DropRow drc = drop_row_consts(t);
+  const int n4 = (Sb + 3) >> 2, np4 = Sp >> 2;
+  f32x4 v[NV], d[NV];
+#pragma unroll
+  for (int u = 0; u < NV; ++u) {
+    const int c = threadIdx.x + u * 256;
+    v[u] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    d[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c < n4) {
+      v[u] = *reinterpret_cast<const f32x4*>(srow + 4 * c);
+      if (BWD) d[u] = *reinterpret_cast<const f32x4*>(drow + 4 * c);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (4 * c + i >= Sb) v[u][i] = -INFINITY;
+    }
+  }
+  float m, inv;
+  if (!BWD) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) mx = fmaxf(fmaxf(mx, fmaxf(v[u][0], v[u][1])), fmaxf(v[u][2], v[u][3]));
+    m = xblock_max(mx, sh);
+    float sum = 0.f;
+#pragma unroll
+    for (int u = 0; u < NV; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[u][i] = __expf(v[u][i] - m);        // exp(−inf) = 0 for keys past the end
+        sum += v[u][i];
+      }
+    sum = xblock_sum(sum, sh);
+    inv = 1.0f / sum;
+    if (threadIdx.x == 0) {
+      a.stats[((int64_t)b * a.R + r) * 2] = m;
+      a.stats[((int64_t)b * a.R + r) * 2 + 1] = inv;
+    }
+  } else {
+    m = a.stats[((int64_t)b * a.R + r) * 2];
+    inv = a.stats[((int64_t)b * a.R + r) * 2 + 1];
+#pragma unroll
+    for (int u = 0; u < NV; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[u][i] = __expf(v[u][i] - m);
+  }
+  const float keep_scale = a.drop_t16 ? a.drop_scale : 1.0f;
+  float delta = 0.f;
+#pragma unroll
+  for (int u = 0; u < NV; ++u) {
+    const int c = threadIdx.x + u * 256;
+    bool kp[4] = {true, true, true, true};
+    if (a.drop_t16 && c < n4) xkeep4(a, prow, drc, c, kp);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float p = v[u][i] * inv;
+      if (!BWD) v[u][i] = kp[i] ? p * keep_scale : 0.f;
+      else {
+        d[u][i] = kp[i] ? keep_scale * d[u][i] : 0.f;      // dropout_bwd(dP)
+        delta += p * d[u][i];
+        v[u][i] = p;
+      }
+    }
+  }
+  if (BWD) {
+    delta = xblock_sum(delta, sh);
+#pragma unroll
+    for (int u = 0; u < NV; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[u][i] = v[u][i] * (d[u][i] - delta);
+  }
+#pragma unroll
+  for (int u = 0; u < NV; ++u) {
+    const int c = threadIdx.x + u * 256;
+    if (c < np4) store4(prow_out + 4 * c, c < n4 ? v[u] : f32x4{0.f, 0.f, 0.f, 0.f});
+  }
+}
+
 template <bool BWD>
 __global__ __launch_bounds__(256) void xsoftmax_kernel(SmArgs a) {
   __shared__ float sh[4];
@@ -858,7 +946,11 @@ extern "C" int lako_xattn_softmax_fwd(const float* s, int64_t s_ld, float* stats
   if (rc) return rc;
   LAKO_CHECK_ALIGN(s, 16);
   LAKO_CHECK_ALIGN(p, 8);
-  hipLaunchKernelGGL((xsoftmax_kernel<false>), dim3((unsigned)(T * H), (unsigned)B), dim3(256), 0, (hipStream_t)stream, a);
+  const dim3 grid((unsigned)(T * H), (unsigned)B);
+  const int seg = (max_keys + 255) / 256 * 256;     // no sample's padded segment is longer
+  if (seg <= 4096) hipLaunchKernelGGL((xsoftmax_reg_kernel<false, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  else if (seg <= 8192) hipLaunchKernelGGL((xsoftmax_reg_kernel<false, 8>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((xsoftmax_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, a);
   LAKO_LAUNCH_CHECK();
   return LAKO_OK;
 }
@@ -875,7 +967,11 @@ extern "C" int lako_xattn_softmax_bwd(const float* s, const float* dp, int64_t s
   LAKO_CHECK_ALIGN(dp, 16);
   LAKO_CHECK_ALIGN(ds, 8);
   a.dp = dp;
-  hipLaunchKernelGGL((xsoftmax_kernel<true>), dim3((unsigned)(T * H), (unsigned)B), dim3(256), 0, (hipStream_t)stream, a);
+  const dim3 grid((unsigned)(T * H), (unsigned)B);
+  const int seg = (max_keys + 255) / 256 * 256;
+  if (seg <= 4096) hipLaunchKernelGGL((xsoftmax_reg_kernel<true, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  else if (seg <= 8192) hipLaunchKernelGGL((xsoftmax_reg_kernel<true, 8>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((xsoftmax_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, a);
   LAKO_LAUNCH_CHECK();
   return LAKO_OK;
 }
