@@ -1,4 +1,3 @@
-python -m pytest tests/test_xattn_gpu.py tests/test_real_size_gpu.py -m gpu -q -x -k "softmax or reassoc or encoder_space or cross_attention_20000 or c4_batch1_bf16" 2>&1 | tail -3
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats -d /tmp/px -o b -- python3 tools/xattn_time.py > /dev/null 2>&1
-python tools/rocpd_stats.py /tmp/px/b_results.db | grep -E "softmax" | awk -F, '{print substr($1,1,70), $2, $4, $6, $7}'
+python -m pytest tests/test_kernels_gpu.py tests/test_parity_gpu.py -m gpu -q -x -k "adam or optim or train_steps or overfit" 2>&1 | tail -2
+python bench.py --breakdown --no-cpu-baseline --all-valid-steps 0 --steps 10 --warmup 5 2>&1 >/dev/null | grep -E "adamw|sum of"
+python bench.py --model large --n-passages 40 --batch 8 --breakdown --no-cpu-baseline --all-valid-steps 0 --steps 5 --warmup 3 2>&1 >/dev/null | grep -E "adamw|sum of"
