@@ -1625,6 +1625,26 @@ extern "C" int lako_gemm_nt(const lako_gemm_nt_t* p, lako_stream_t stream) {
   return LAKO_OK;
 }
 
+// K-splits of the 256×256 weight-gradient kernel.  One workgroup per CU is resident, so `tiles·sk` workgroups run in
+// ⌈tiles·sk / 256⌉ rounds of K/sk rows each, and every split pays one fp32 atomic pass over its 256 KiB tile (≈1.3 TB/s chip-wide,
+// i.e. ≈51 µs per tile and split against ≈1.65 µs per 64-row K-step).  Pick the split that minimises rounds × (steps/sk × 1.65 + 51):
+// 108 tiles (a T5-base layer's four weight gradients) → 2 splits as before; 192 tiles (T5-large) → 4 splits, three full rounds of a
+// quarter of K instead of one round on 75 % of the CUs (config 4: −16 % on the weight-gradient launches).
+static int tn_pick_split(int tiles, int64_t K, int max_split) {
+  const double steps = (double)((K + 63) / 64);
+  int best = 1;
+  double best_cost = 1e300;
+  for (int sk = 1; sk <= 16 && sk <= max_split; ++sk) {
+    const int rounds = (tiles * sk + 255) / 256;
+    const double cost = rounds * (steps / sk * 1.65 + (sk > 1 ? 51.0 : 25.0));
+    if (cost < best_cost * 0.97) {      // a larger split must win by 3 %: more atomics, more launch
+      best_cost = cost;
+      best = sk;
+    }
+  }
+  return best;
+}
+
 extern "C" int lako_gemm_tn(const void* A, const void* B, float* C, int64_t M, int64_t N, int64_t K, int64_t lda,
                             int64_t ldb, int64_t ldc, int in_dtype, float alpha, int split_k, lako_stream_t stream) {
   LAKO_CHECK_ARG(M > 0 && N > 0 && K > 0, "lako_gemm_tn: bad dims");
@@ -1657,8 +1677,8 @@ extern "C" int lako_gemm_tn(const void* A, const void* B, float* C, int64_t M, i
     const int tiles = a.tiles_m * a.tiles_n;
     int sk = split_k;
     if (sk <= 0) {   // one workgroup per CU (128 KiB LDS): aim at ~256 workgroups, >= 4 K-steps per split
-      sk = (256 + tiles / 2) / tiles;
       const int max_split = cdiv(K, 64 * 4);
+      sk = tn_pick_split(tiles, K, max_split);
       if (g_tn_split > 0) sk = g_tn_split;
       if (sk > max_split) sk = max_split;
       if (sk < 1) sk = 1;
@@ -1738,8 +1758,8 @@ extern "C" int lako_gemm_tn_grouped(const lako_gemm_tn_item_t* items, int n_item
   }
   a.tiles_m = tiles;     // the kernel only uses the product
   a.tiles_n = 1;
-  int sk = (256 + tiles / 2) / tiles;
   const int max_split = cdiv(K, 64 * 4);
+  int sk = tn_pick_split(tiles, K, max_split);
   if (g_tn_split > 0) sk = g_tn_split;
   if (split_k > 0) sk = split_k;
   if (sk > max_split) sk = max_split;
