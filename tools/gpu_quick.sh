@@ -1,3 +1,4 @@
-python -m pytest tests/test_kernels_gpu.py -m gpu -q -x -k "gemm_tn" 2>&1 | tail -2
-python bench.py --model large --n-passages 40 --batch 8 --breakdown --no-cpu-baseline --all-valid-steps 0 --steps 8 --warmup 3 2>gpurun_out/c4b.txt | cut -c1-220; grep -E "gemm_tn|sum of" gpurun_out/c4b.txt
-python bench.py --breakdown --no-cpu-baseline --all-valid-steps 0 --steps 10 --warmup 5 2>gpurun_out/c2b.txt | cut -c1-200; grep -E "gemm_tn|sum of" gpurun_out/c2b.txt
+mkdir -p gpurun_out/r02j
+python bench.py --model large --n-passages 40 --batch 8 --no-cpu-baseline --all-valid-steps 0 --steps 15 --warmup 4 > gpurun_out/r02j/bench_c4.json 2>/dev/null; cut -c1-200 gpurun_out/r02j/bench_c4.json
+python bench.py --model large --n-passages 100 --batch 8 --no-cpu-baseline --all-valid-steps 0 --steps 8 --warmup 3 > gpurun_out/r02j/bench_c5.json 2>/dev/null; cut -c1-200 gpurun_out/r02j/bench_c5.json
+python bench.py --model large --n-passages 100 --batch 8 --fp8 --no-cpu-baseline --all-valid-steps 0 --steps 8 --warmup 3 > gpurun_out/r02j/bench_c5_fp8.json 2>/dev/null; cut -c1-200 gpurun_out/r02j/bench_c5_fp8.json
