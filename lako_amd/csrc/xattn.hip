@@ -749,47 +749,75 @@ __global__ __launch_bounds__(256) void hb_nt_kernel(HbArgs a) {
   }
 }
 
-// "contract" shape (N = 64 columns per head, K = d): one workgroup per (16-row tile, head), its four waves take a quarter of K
-// each — ALL of a wave's operand loads (KS K-steps × (slabs of A + 4 column tiles of B)) are in flight at once, one latency
-// instead of K / 256 dependent batches — and add their partial tiles through LDS.  (The one-wave-per-tile form above took 18 µs
-// for 0.3 GFLOP at config 2.)
+// "contract" shape (N = 64 columns per head, K = d): one workgroup per 16 × 16 output tile, its four waves take a quarter of K each —
+// ALL of a wave's operand loads (KS K-steps × (up to four key-split slabs of A + B)) are in flight at once, one latency instead of
+// K / 256 dependent batches — and add their partial tiles through LDS.  (The one-wave-per-tile form above took 18 µs for
+// 0.3 GFLOP at config 2; with the slabs read one after the other and 64 workgroups, T5-large took 15 µs.)
 template <bool AF32, int KS>
 __global__ __launch_bounds__(256) void hb_contract_kernel(HbArgs a) {
-  __shared__ __attribute__((aligned(16))) float part[4][16][68];
+  __shared__ __attribute__((aligned(16))) float part[4][16][20];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, l15 = lane & 15;
-  const int mt = blockIdx.x, h = blockIdx.y;
+  const int mt = blockIdx.x, h = blockIdx.y, nt = blockIdx.z;        // one 16 × 16 output tile per workgroup
   const int m = mt * 16 + l15;
   const bool mok = m < a.M;
   const int mb = m / a.T, mtt = m - mb * a.T;
   const int kbase = wave * KS * 32;
   const int64_t aoff = (int64_t)mb * a.a_sb + (int64_t)mtt * a.a_st + (int64_t)h * a.a_sh + 8 * g + kbase;
-  const int64_t boff = (int64_t)h * a.b_sh + (int64_t)l15 * a.ldb + 8 * g + kbase;
-  u32x4 af[KS], bf[KS][4];
+  const int64_t boff = (int64_t)h * a.b_sh + (int64_t)(nt * 16 + l15) * a.ldb + 8 * g + kbase;
+  // every load of the wave in flight at once: KS K-steps × (up to 4 slabs of A, two 16-byte halves each when fp32) + KS of B
+  constexpr int NSL = AF32 ? 4 : 1;
+  f32x4 ax[KS][NSL], ay[KS][NSL];
+  u32x4 ab[KS], bf[KS];
 #pragma unroll
   for (int u = 0; u < KS; ++u) {
-    af[u] = hb_load8(a.A, aoff + 32 * u, AF32, mok, a.n_slabs, a.slab_stride);
+    bf[u] = *reinterpret_cast<const u32x4*>(a.B + (boff + 32 * u) * 2);
+    if (AF32) {
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-      bf[u][nt] = *reinterpret_cast<const u32x4*>(a.B + (boff + (int64_t)nt * 16 * a.ldb + 32 * u) * 2);
+      for (int z = 0; z < NSL; ++z) {
+        ax[u][z] = ay[u][z] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (mok && z < a.n_slabs) {
+          const char* ap = a.A + (aoff + 32 * u + z * a.slab_stride) * 4;
+          ax[u][z] = *reinterpret_cast<const f32x4*>(ap);
+          ay[u][z] = *reinterpret_cast<const f32x4*>(ap + 16);
+        }
+      }
+    } else {
+      ab[u] = mok ? *reinterpret_cast<const u32x4*>(a.A + (aoff + 32 * u) * 2) : u32x4{0u, 0u, 0u, 0u};
+    }
   }
-  f32x4 acc[4];
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int u = 0; u < KS; ++u) {
+    u32x4 af;
+    if (AF32) {
+      f32x4 x = ax[u][0], y = ay[u][0];
 #pragma unroll
-  for (int u = 0; u < KS; ++u)
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) acc[nt] = emma(bf[u][nt], af[u], acc[nt]);     // acc[nt][i] = C[m = l15][16·nt + 4g + i]
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<f32x4*>(&part[wave][l15][16 * nt + 4 * g]) = acc[nt];
+      for (int z = 1; z < NSL; ++z) { x += ax[u][z]; y += ay[u][z]; }
+      if (a.n_slabs > NSL) {                      // more than four key-split slabs: the rest in order (rare)
+        for (int z = NSL; z < a.n_slabs; ++z) {
+          const char* ap = a.A + (aoff + 32 * u + z * a.slab_stride) * 4;
+          if (mok) { x += *reinterpret_cast<const f32x4*>(ap); y += *reinterpret_cast<const f32x4*>(ap + 16); }
+        }
+      }
+      bf16x8 o = {(bf16_t)x[0], (bf16_t)x[1], (bf16_t)x[2], (bf16_t)x[3], (bf16_t)y[0], (bf16_t)y[1], (bf16_t)y[2], (bf16_t)y[3]};
+      af = __builtin_bit_cast(u32x4, o);
+    } else {
+      af = ab[u];
+    }
+    acc = emma(bf[u], af, acc);                   // acc[i] = C[m = l15][16·nt + 4g + i]
+  }
+  *reinterpret_cast<f32x4*>(&part[wave][l15][4 * g]) = acc;
   __syncthreads();
-  const int row = threadIdx.x >> 4, c4 = (threadIdx.x & 15) * 4;
-  const int mr = mt * 16 + row;
-  if (mr < a.M) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(&part[0][row][c4]);
+  if (threadIdx.x < 64) {
+    const int row = threadIdx.x >> 2, c4 = (threadIdx.x & 3) * 4;
+    const int mr = mt * 16 + row;
+    if (mr < a.M) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(&part[0][row][c4]);
 #pragma unroll
-    for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(&part[w][row][c4]);
-    const int rb = mr / a.T, rt = mr - rb * a.T;
-    store4(reinterpret_cast<bf16_t*>(a.C) + (int64_t)rb * a.c_sb + (int64_t)rt * a.c_st + (int64_t)h * a.c_sh + c4, v);
+      for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(&part[w][row][c4]);
+      const int rb = mr / a.T, rt = mr - rb * a.T;
+      store4(reinterpret_cast<bf16_t*>(a.C) + (int64_t)rb * a.c_sb + (int64_t)rt * a.c_st + (int64_t)h * a.c_sh + nt * 16 + c4, v);
+    }
   }
 }
 
@@ -997,7 +1025,7 @@ extern "C" int lako_headbatch_nt(const lako_headbatch_t* p, lako_stream_t stream
   const bool f32 = p->a_dtype == LAKO_F32;
   hipStream_t s = (hipStream_t)stream;
   if (p->N == 64 && p->K % 128 == 0 && (p->K == 512 || p->K == 768 || p->K == 1024)) {
-    const dim3 grid((unsigned)((p->M + 15) / 16), (unsigned)p->H);
+    const dim3 grid((unsigned)((p->M + 15) / 16), (unsigned)p->H, 4);
 #define HC_GO(F32, KSV) hipLaunchKernelGGL((hb_contract_kernel<F32, KSV>), grid, dim3(256), 0, s, a)
     if (p->K == 512) { if (f32) HC_GO(true, 4); else HC_GO(false, 4); }
     else if (p->K == 768) { if (f32) HC_GO(true, 6); else HC_GO(false, 6); }

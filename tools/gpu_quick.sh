@@ -1,4 +1,6 @@
-mkdir -p gpurun_out/r02j
-python bench.py --model large --n-passages 40 --batch 8 --no-cpu-baseline --all-valid-steps 0 --steps 15 --warmup 4 > gpurun_out/r02j/bench_c4.json 2>/dev/null; cut -c1-200 gpurun_out/r02j/bench_c4.json
-python bench.py --model large --n-passages 100 --batch 8 --no-cpu-baseline --all-valid-steps 0 --steps 8 --warmup 3 > gpurun_out/r02j/bench_c5.json 2>/dev/null; cut -c1-200 gpurun_out/r02j/bench_c5.json
-python bench.py --model large --n-passages 100 --batch 8 --fp8 --no-cpu-baseline --all-valid-steps 0 --steps 8 --warmup 3 > gpurun_out/r02j/bench_c5_fp8.json 2>/dev/null; cut -c1-200 gpurun_out/r02j/bench_c5_fp8.json
+python -m pytest tests/test_xattn_gpu.py -m gpu -q -x 2>&1 | tail -2
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --stats -d /tmp/px -o b -- python3 tools/xattn_time.py > /dev/null 2>&1
+python tools/rocpd_stats.py /tmp/px/b_results.db | grep -E "contract" | cut -c1-40,95-160
+XB=8 XKEYS=8000 XH=16 XZ=4 rocprofv3 --kernel-trace --stats -d /tmp/px2 -o b -- python3 tools/xattn_time.py > /dev/null 2>&1
+python tools/rocpd_stats.py /tmp/px2/b_results.db | grep -E "contract|xscores|xcontext" | cut -c1-40,85-160
