@@ -54,7 +54,8 @@ def test_struct_layouts_match_header_order():
     from lako_amd import _lib
     src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
     for cname, py in (("lako_gemm_nt_t", _lib.GemmNT), ("lako_attn_fwd_t", _lib.AttnFwd), ("lako_attn_bwd_t", _lib.AttnBwd),
-                      ("lako_dropout_t", _lib.Dropout)):
+                      ("lako_dropout_t", _lib.Dropout), ("lako_headbatch_t", _lib.HeadBatch),
+                      ("lako_gemm_tn_item_t", _lib.GemmTNItem)):
         body = re.search(r"typedef struct \{([^{}]*)\}\s*" + cname, src, re.S).group(1)
         names = []
         for decl in body.split(";"):
@@ -83,6 +84,16 @@ def test_bad_arguments_return_error_codes(lib):
     assert L.lako_attn_fwd(ctypes.byref(a), None) == -4
     assert L.lako_rmsnorm_fwd(None, None, None, None, 4, 12, 1e-6, 1, _lib.NO_DROP, None) == -1   # d % 8 != 0
     assert L.lako_set_tuning(b"no_such_knob", 1) == -1
+    # the encoder-space cross-attention entry points (round 2)
+    hb = _lib.HeadBatch()
+    assert L.lako_headbatch_nt(ctypes.byref(hb), None) == -1 and L.lako_headbatch_tn(ctypes.byref(hb), None) == -1
+    assert L.lako_xattn_scores(None, 0, 0, None, 0, None, None, 256, None, 256, 96, 768, 16, None) == -1      # null operands
+    x = ctypes.c_void_p(4096)         # never dereferenced: the shape checks come first
+    assert L.lako_xattn_scores(x, 8, 8, x, 800, x, x, 256, x, 256, 96, 800, 16, None) == -1                    # d_model % 128
+    assert L.lako_xattn_context(x, 256, x, 768, x, x, x, 0, 0, 768, 96, 768, 16, 0, None) == -1                # key_splits < 1
+    assert L.lako_xattn_decode(x, 8, 8, x, 768, x, x, x, 17, 768, 16, 16, None) == -1                          # R > 16
+    assert L.lako_xattn_decode_combine(x, x, x, 768, x, 768, 12, 640, 16, 16, None) == -1                      # D not in {512, 768, 1024}
+    assert L.lako_xattn_softmax_fwd(x, 255, x, x, 256, x, x, 16, 8, 12, 4000, _lib.NO_DROP, None) == -1        # s_ld % 4
 
 
 def test_product_fails_loudly_without_library(monkeypatch, tmp_path):
