@@ -1,5 +1,9 @@
-mkdir -p gpurun_out/r02j
+# scratch: the command list of the current gpurun call (edited per call; see tools/gpu_round.sh for the round-end sequence)
+mkdir -p gpurun_out/r02k
+( time python -m pytest tests -m gpu -q --durations=5 ) > gpurun_out/r02k/pytest.log 2>&1; tail -9 gpurun_out/r02k/pytest.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+( time python bench.py ) > gpurun_out/r02k/bench.json 2> gpurun_out/r02k/bench.err; cut -c1-230 gpurun_out/r02k/bench.json
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats -d /tmp/pc5 -o b -- python3 bench.py --model large --n-passages 100 --batch 8 --steps 4 --warmup 2 --no-cpu-baseline --all-valid-steps 0 > /dev/null 2>&1
-python tools/rocpd_stats.py /tmp/pc5/b_results.db > gpurun_out/r02j/c5_kernel_stats.csv; head -24 gpurun_out/r02j/c5_kernel_stats.csv | awk -F, '{n=$1; if (length(n)>60) n=substr(n,1,60); print n, $(NF-5), $(NF-4), $(NF-3), $(NF-2)}'
-python tools/rocpd_timeline.py /tmp/pc5/b_results.db 3 | head -3
+rocprofv3 --kernel-trace --stats -d /tmp/pk -o b -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --all-valid-steps 0 > gpurun_out/r02k/bench_under_rocprof.json 2> gpurun_out/r02k/prof.log
+python tools/rocpd_stats.py /tmp/pk/b_results.db > gpurun_out/r02k/bench_kernel_stats.csv
+python tools/rocpd_timeline.py /tmp/pk/b_results.db 6 > gpurun_out/r02k/step_timeline.txt; head -30 gpurun_out/r02k/step_timeline.txt
