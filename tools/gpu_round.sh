@@ -1,16 +1,20 @@
+# The round-end sequence on an MI355X box (one `gpurun` call): full GPU tests, smoke, the default bench line, a kernel trace of a short
+# bench run with the per-kernel table and one step's timeline, and the benches of configs 4 / 5.  Outputs under gpurun_out/$TAG;
+# copy what is to be judged into profiles/ (see profiles/README.md).
+#   gpurun --timeout 3600 -- 'TAG=r03a bash tools/gpu_round.sh'
 set -x
-mkdir -p gpurun_out/r02c
-( time timeout 2400 python -m pytest tests -m gpu -x -q --durations=15 ) > gpurun_out/r02c/pytest.log 2>&1
-echo "pytest rc=$?" >> gpurun_out/r02c/pytest.log
-( time python bench.py ) > gpurun_out/r02c/bench.json 2> gpurun_out/r02c/bench.err
-python bench.py --breakdown --no-cpu-baseline --all-valid-steps 0 --steps 10 --warmup 5 > gpurun_out/r02c/bench_breakdown.json 2> gpurun_out/r02c/bench_breakdown.txt
+TAG=${TAG:-round}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+( time timeout 2400 python -m pytest tests -m gpu -x -q --durations=10 ) > $OUT/pytest.log 2>&1
+echo "pytest rc=$?" >> $OUT/pytest.log
+python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
+( time python bench.py ) > $OUT/bench.json 2> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats -d gpurun_out/r02c/prof -o b -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --all-valid-steps 0 > gpurun_out/r02c/bench_under_rocprof.json 2> gpurun_out/r02c/prof.log
-ls -R gpurun_out/r02c/prof | head -20
-tools/run_pmc.sh gpurun_out/r02c/pmc_attn tools/attn_probe.py sq1 sq2 mfma
-LAKO_PROBE_TOKENS=48000 tools/run_pmc.sh gpurun_out/r02c/pmc_gemm tools/gemm_probe.py mfma
-python tools/pmc_summary.py gpurun_out/r02c/pmc_attn --match attn_,enc_ > gpurun_out/r02c/attn_pmc.txt
-python tools/pmc_summary.py gpurun_out/r02c/pmc_gemm --match gemm_ > gpurun_out/r02c/gemm_pmc.txt
-# keep the merged output small: drop the raw per-dispatch CSVs of the PMC passes
-find gpurun_out/r02c/pmc_attn gpurun_out/r02c/pmc_gemm -name "*.csv" -size +2M -delete
-tail -5 gpurun_out/r02c/pytest.log; cat gpurun_out/r02c/bench.json
+rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o b -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --all-valid-steps 0 > $OUT/bench_under_rocprof.json 2> $OUT/prof.log
+python tools/rocpd_stats.py /tmp/prof_$TAG/b_results.db > $OUT/bench_kernel_stats.csv
+python tools/rocpd_timeline.py /tmp/prof_$TAG/b_results.db 6 > $OUT/step_timeline.txt
+python bench.py --model large --n-passages 40 --batch 8 --no-cpu-baseline --all-valid-steps 0 --steps 15 --warmup 4 > $OUT/bench_c4.json 2> $OUT/bench_c4.err
+python bench.py --model large --n-passages 100 --batch 8 --no-cpu-baseline --all-valid-steps 0 --steps 8 --warmup 3 > $OUT/bench_c5.json 2> $OUT/bench_c5.err
+python tools/generate_probe.py > $OUT/generate_probe.txt 2>&1
+tail -5 $OUT/pytest.log; cat $OUT/bench.json | cut -c1-300; tail -2 $OUT/generate_probe.txt
