@@ -192,7 +192,6 @@ class Engine:
         self._rag_cache: dict = {}
         self._xplan_cache: dict = {}
         self.xattn_active = False
-        self.ctx_splits = 1      # key-split slabs of the current batch's xattn_context launches
         self._all_valid = False
         self._row_cap: dict = {}     # {rows of the current unpadded batch: padded row count}
         self._lut_cache: dict = {}
@@ -478,7 +477,6 @@ class Engine:
         key = (tuple(k_h), rows_q)
         hit = self._xplan_cache.get(key)
         if hit is not None:
-            self.ctx_splits = hit.splits
             return hit
         p_h = [0]
         for b in range(B):
@@ -491,7 +489,6 @@ class Engine:
         per = max(1, cfg.d_model // 128) * B * -(-rows_q // 128)
         splits = int(os.environ.get("LAKO_XATTN_SPLITS", "0")) or max(1, min(8, 256 // per))
         plan = _XPlan(k_off=dev[0], p_off=dev[1], k_h=k_h, p_h=p_h, ptot=p_h[-1], splits=splits)
-        self.ctx_splits = splits
         if len(self._xplan_cache) >= 8:
             self._xplan_cache.clear()
         self._xplan_cache[key] = plan
@@ -511,7 +508,7 @@ class Engine:
         r0 = (2 * i + (which == "v")) * inner
         return self.kv_all.g[r0:r0 + inner].unflatten(0, (H, dk))
 
-    def _xattn_buffers(self, ws, B, N, L, T, Ld):
+    def _xattn_buffers(self, ws, B, N, L, T, Ld, Z):
         """Workspace of the encoder-state-space cross-attention, sized for the padded batch (the column count of a batch's score
         matrices, xa.ptot, is a prefix of the allocation).  Per decoder layer l and R = T·H query rows per sample:
           dq [B, Ld·2R, d]   rows l·2R … : dC' (written in backward), rows l·2R + R … : Q'          — B operand of the dE product
@@ -520,7 +517,6 @@ class Engine:
         cfg = self.cfg
         R, d = T * cfg.num_heads, cfg.d_model
         cap = B * (-(-(N * L) // 256) * 256)
-        Z = self.ctx_splits
         return dict(R=R, cap=cap, rows=B * N * L,
                     dq=self._buf(ws, "x.dq", (B, Ld * 2 * R, d)),
                     ps=self._buf(ws, "x.ps", (Ld * 2 * R, cap)),
@@ -552,7 +548,7 @@ class Engine:
         ops.xattn_scores(dcp, enc_out, xa.k_off, xa.p_off, xa.ptot, dp)
         ds = xb["ps"][(2 * i + 1) * R:(2 * i + 2) * R, :xa.ptot]
         ops.xattn_softmax_bwd(xb["s"][i][:, :xa.ptot], dp, xb["st"][i], ds, xa.k_off, xa.p_off, T, H, max_keys, drop)
-        dqp = self._buf(tmp, "x.dqp", (self.ctx_splits, B, R, d), torch.float32)
+        dqp = self._buf(tmp, "x.dqp", (xa.splits, B, R, d), torch.float32)
         ops.xattn_context(ds, enc_out, xa.k_off, xa.p_off, dqp)
         ops.headbatch_nt(dqp.unflatten(2, (T, H)), self._xw(i, "k"), dqc.view(B, T, H, dk))
         ops.headbatch_tn(qc.view(B, T, H, dk), dqp.unflatten(2, (T, H)), self._xg(i, "k"))
@@ -613,7 +609,7 @@ class Engine:
         rel = self._buf(ws, "d.rel", (H, 2 * T - 1), torch.float32)
         ops.relpos_expand(self.dec_rel.p, self._lut(T, T, False), rel)
         if xa is not None:
-            xb = self._xattn_buffers(ws, B, N, L, T, Ld)
+            xb = self._xattn_buffers(ws, B, N, L, T, Ld, xa.splits)
         for i in range(Ld):
             lw = self.dec[i]
             h = ws[f"d.h{i}"]
@@ -738,7 +734,7 @@ class Engine:
                         **self._nxt((dy_f, dr(_dec_site(Ld - 1, 5))) if fused else None))
         xa = ctx.xa
         if xa is not None:
-            xb = self._xattn_buffers(ws, B, N, L, T, Ld)
+            xb = self._xattn_buffers(ws, B, N, L, T, Ld, xa.splits)
         else:
             dkv = self._buf(tmp, "dkv", (Me, self.kv_all.w.shape[0]))
             kv = ws["e.kv"]
