@@ -130,7 +130,7 @@ __device__ __forceinline__ void efwd_chunk(const char* Kimg, const char* Vimg, i
   }
   float m = -INFINITY;
 #pragma unroll
-  for (int t = 0; t < 2 * NPC; ++t) m = fmaxf(fmaxf(m, fmaxf(s[t][0], s[t][1])), fmaxf(s[t][2], s[t][3]));
+  for (int t = 0; t < 2 * NPC; ++t) m = fmaxf(fmaxf(fmaxf(fmaxf(m, s[t][0]), s[t][1]), s[t][2]), s[t][3]);   // two v_max3_f32 per tile
   m = fmaxf(egroup_max(m), m_run);
   const float alpha = __builtin_amdgcn_exp2f((m_run - m) * LOG2E);       // first chunk: exp2(−inf) = 0
   const float mneg = -m * LOG2E;
@@ -497,7 +497,9 @@ __global__ __launch_bounds__(DKV_NW * 64, 2) void enc_bwd_dkv_kernel(AttnArgs a)
     const DropCol dcc = drop_col_consts(ki);
     const uint32_t cblk = (uint32_t)((b * a.H + h) * QB + g) * (uint32_t)KB + (uint32_t)(ki >> 2);
     const f32x4 kaddv = {kadd_lane, kadd_lane, kadd_lane, kadd_lane};
-    for (int tp = 0; tp < npq; ++tp) {
+    uint32_t cblk_tp = cblk;                                // + (row0 >> 2)·KB, advanced by additions (a 32-bit multiply is quarter rate)
+    const uint32_t kb4 = 4u * (uint32_t)KB;
+    for (int tp = 0; tp < npq; ++tp, cblk_tp += 2 * kb4) {
       f32x4 pt[2], ds[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -513,7 +515,7 @@ __global__ __launch_bounds__(DKV_NW * 64, 2) void enc_bwd_dkv_kernel(AttnArgs a)
         pt[u] = p;
         if (DROP) {
           bool kp[4];
-          drop_keep_col(drop_base(cblk + (uint32_t)((row0 >> 2) * KB), a.drop_key), dcc, t_hi, kp);
+          drop_keep_col(drop_base(cblk_tp + (uint32_t)u * kb4, a.drop_key), dcc, t_hi, kp);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             pt[u][r] = kp[r] ? p[r] : 0.f;

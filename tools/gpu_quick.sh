@@ -1,1 +1,2 @@
-python -m pytest tests/test_parity_gpu.py tests/test_real_size_gpu.py -m gpu -q -x -k "encoder_space or generate or bf16 or determinism or checkpoint" 2>&1 | tail -2
+python -m pytest tests/test_kernels_gpu.py -m gpu -q -x -k "attn or enc or dropout" 2>&1 | tail -2
+python tools/attn_time.py 2>&1 | tail -1
