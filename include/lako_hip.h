@@ -295,10 +295,11 @@ int lako_greedy_step(const float* logits, int64_t V, int B, int64_t* seq, int64_
  * scores fp32 [B, H, n_layers, N·L] (raw pre-softmax scores as lako_attn_fwd's scores_out lays them out per layer),
  * mask uint8 [B, N, L], ids int64 [B, N, L], out fp64 [B, n_context].  Per sample: vals[l] = Σ over heads and the layers
  * [layer0, layer0 + layers_used) of the scores of passage `passage` (masked positions 0); the passage is cut into spans that end
- * at token id 5, starting at index 2; span j -> style 0 mean | 1 max | 2 "21mean" (mean of the larger half); an unterminated
+ * at token id 5 in the token ids of passage `ids_passage` (the reference takes the scores of passage ceil(N/2) and the ids of
+ * passage 1, src/model.py:164-174: the same passage for N = 2), starting at index 2; span j -> style 0 mean | 1 max | 2 "21mean" (mean of the larger half); an unterminated
  * last span counts when the passage's last token is not pad(0); missing spans are -5; all divided by layers_used * H. */
 int lako_fact_scores(const float* scores, const uint8_t* mask, const int64_t* ids, double* out, int B, int H, int n_layers,
-                     int layer0, int layers_used, int N, int L, int passage, int n_context, int style, lako_stream_t stream);
+                     int layer0, int layers_used, int N, int L, int passage, int ids_passage, int n_context, int style, lako_stream_t stream);
 
 /* ---- exact inner-product search (src/index.py:19-50 faiss.IndexFlatIP.search; the scores are one
  * lako_gemm_nt of the queries against the stored embeddings) -----------------------------------------------------------

@@ -433,11 +433,13 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd768_kernel(const T* __restrict
 
 // ---- cross-entropy --------------------------------------------------------------------------
 // The mean is accumulated in 2^-40 fixed point (a 64-bit integer add is order-independent, so the loss does not depend on which
-// row's workgroup finishes first); the last row to finish converts it.  scratch = {u64 sum, u32 rows done}.
+// row's workgroup finishes first); the last row to finish converts it.  scratch = {u64 sum, u32 rows done, u32 non-finite flags}.
+// A row whose loss is NaN / ±Inf (diverged run) or too large for the fixed-point sum (|loss| > 2^22 / rows) is not added: it sets a
+// flag bit instead (1 NaN, 2 +Inf / overflow, 4 −Inf) and the reported mean is then NaN / ±Inf like a float sum's would be.
 struct CeScratch {
   unsigned long long sum;
   unsigned done;
-  unsigned pad;
+  unsigned bad;
 };
 constexpr float CE_FIX = 1099511627776.0f;   // 2^40
 
@@ -455,6 +457,7 @@ __global__ void ce_init_kernel(float* loss_out, const int64_t* labels, int64_t M
     loss_out[1] = (float)cnt;
     sc->sum = 0ull;
     sc->done = 0u;
+    sc->bad = 0u;
   }
 }
 
@@ -495,11 +498,23 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
   se = bc;
   const float lse = mx + __logf(se);
   if (threadIdx.x == 0) {
-    if (valid) atomicAdd(&sc->sum, (unsigned long long)(long long)((double)(lse - lr[label]) * (double)CE_FIX));
+    if (valid) {
+      const float lrow = lse - lr[label];
+      const float lim = 4194304.0f / (float)gridDim.x;     // Σ rows·|loss|·2^40 stays below 2^62
+      if (lrow != lrow) atomicOr(&sc->bad, 1u);
+      else if (lrow > lim) atomicOr(&sc->bad, 2u);
+      else if (lrow < -lim) atomicOr(&sc->bad, 4u);
+      else atomicAdd(&sc->sum, (unsigned long long)(long long)((double)lrow * (double)CE_FIX));
+    }
     __threadfence();
     if (atomicAdd(&sc->done, 1u) == gridDim.x - 1) {
       const long long tot = (long long)atomicAdd(&sc->sum, 0ull);
-      loss_out[0] = (float)((double)tot / (double)CE_FIX / (double)n_valid);
+      const unsigned bad = atomicOr(&sc->bad, 0u);
+      float mean = (float)((double)tot / (double)CE_FIX / (double)n_valid);
+      if ((bad & 1u) || (bad & 6u) == 6u) mean = __builtin_nanf("");
+      else if (bad & 2u) mean = INFINITY;
+      else if (bad & 4u) mean = -INFINITY;
+      loss_out[0] = mean;
     }
   }
   if (dlogits) {
@@ -655,14 +670,16 @@ __global__ void count_done_kernel(const uint8_t* done, int B, int32_t* n_done) {
 
 // ---- per-fact aggregation of captured cross-attention scores (src/model.py:100-115,143-204) ----------------
 // One workgroup per sample.  vals[l] = Σ_{head, layer} scores[b, h, layer, p0·L + l] over the layers [ly0, ly0 + nly), masked
-// positions 0 (the reference's masked_fill + sum(dim=[1,2]), rounded to fp32 like its tensor).  The fact passage p0 is then cut
+// positions 0 (the reference's masked_fill + sum(dim=[1,2]), rounded to fp32 like its tensor).  The token ids that define the spans
+// are those of passage `pid` — the reference reads context_ids[b][1] (src/model.py:173) while the scores come from the first
+// passage of the second chunk, p0 = ceil(N / 2) (:164,174): the same passage only for N = 2 (stream 2).  Passage p0 is then cut
 // into spans ending at token id 5 ('.'), starting at index 2 (after '▁fact', ':'); an unterminated last span counts when the
 // passage is not padded; each of the first n_ctx spans is reduced by mean | max | mean of the larger half ("21mean": the
 // reference's heapq.nlargest(max(int((len+1)/2), 1))), in double and in the reference's summation order; missing facts get −5;
 // everything is divided by (layers · heads).
 __global__ __launch_bounds__(256) void fact_scores_kernel(const float* __restrict__ scores, const uint8_t* __restrict__ mask,
                                                           const int64_t* __restrict__ ids, double* __restrict__ out, int H, int nl,
-                                                          int ly0, int nly, int N, int L, int p0, int n_ctx, int style) {
+                                                          int ly0, int nly, int N, int L, int p0, int pid, int n_ctx, int style) {
   extern __shared__ __attribute__((aligned(16))) char fs_smem[];
   float* vals = reinterpret_cast<float*>(fs_smem);        // [L]
   int* tok = reinterpret_cast<int*>(vals + L);             // [L]  (only == 5 / != 0 matter)
@@ -676,7 +693,7 @@ __global__ __launch_bounds__(256) void fact_scores_kernel(const float* __restric
         for (int ly = ly0; ly < ly0 + nly; ++ly) acc += (double)scores[(((int64_t)b * H + h) * nl + ly) * S + (int64_t)p0 * L + l];
     }
     vals[l] = (float)acc;
-    const int64_t t = ids[((int64_t)b * N + p0) * L + l];
+    const int64_t t = ids[((int64_t)b * N + pid) * L + l];
     tok[l] = t == 5 ? 5 : (t == 0 ? 0 : 1);
   }
   __syncthreads();
@@ -964,17 +981,17 @@ extern "C" int lako_greedy_step(const float* logits, int64_t V, int B, int64_t* 
 }
 
 extern "C" int lako_fact_scores(const float* scores, const uint8_t* mask, const int64_t* ids, double* out, int B, int H, int n_layers,
-                                int layer0, int layers_used, int N, int L, int passage, int n_context, int style,
+                                int layer0, int layers_used, int N, int L, int passage, int ids_passage, int n_context, int style,
                                 lako_stream_t stream) {
   LAKO_CHECK_ARG(scores && mask && ids && out, "lako_fact_scores: null tensor");
   LAKO_CHECK_ARG(B > 0 && H > 0 && n_layers > 0 && N > 0 && L >= 3 && n_context > 0, "lako_fact_scores: bad dims");
   LAKO_CHECK_ARG(layer0 >= 0 && layers_used > 0 && layer0 + layers_used <= n_layers, "lako_fact_scores: bad layer range");
-  LAKO_CHECK_ARG(passage >= 0 && passage < N, "lako_fact_scores: bad passage index");
+  LAKO_CHECK_ARG(passage >= 0 && passage < N && ids_passage >= 0 && ids_passage < N, "lako_fact_scores: bad passage index");
   LAKO_CHECK_ARG(style >= 0 && style <= 2, "lako_fact_scores: style 0 mean | 1 max | 2 21mean");
   const size_t lds = (size_t)L * 8 + (size_t)(2 * n_context + 1) * 4;
   LAKO_CHECK_ARG(lds <= 60 * 1024, "lako_fact_scores: L / n_context too large for one workgroup's LDS");
   hipLaunchKernelGGL(fact_scores_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, scores, mask, ids, out, H, n_layers, layer0,
-                     layers_used, N, L, passage, n_context, style);
+                     layers_used, N, L, passage, ids_passage, n_context, style);
   LAKO_LAUNCH_CHECK();
   return LAKO_OK;
 }

@@ -274,6 +274,14 @@ class Engine:
             self.refresh_fp8()
         self.shadows_stale = False
 
+    def refresh_after_step(self):
+        """After the fused optimizer step (which wrote P and the compute-dtype shadow W in one pass): every DERIVED copy of the
+        weights — the transposed shadows and, in fp8 mode, the e4m3 + block-scale shadows the forward GEMMs multiply with."""
+        self.refresh_transposed()
+        if self.fp8:
+            self.refresh_fp8()
+        self.shadows_stale = False
+
     def _fp8_blocks(self):
         names = [f"enc.{i}.{m}" for i in range(self.cfg.num_layers) for m in ("qkv", "wi")] + ["dec.kv_all"]
         return [self.by_name[n] for n in names if self.by_name[n].shape[1] % 128 == 0]
@@ -283,8 +291,8 @@ class Engine:
         for b in self._fp8_blocks():
             if b.name not in self._w8:
                 n, k = b.shape
-                self._w8[b.name] = (torch.empty(n, k, dtype=torch.uint8, device=self.device),
-                                    torch.empty(n, self.ops.mx_scale_cols(k), dtype=torch.uint8, device=self.device))
+                self._w8[b.name] = (torch.empty(n, k, dtype=torch.uint8, device=self.device),      # (scale padding bytes stay 0)
+                                    torch.zeros(n, self.ops.mx_scale_cols(k), dtype=torch.uint8, device=self.device))
             q, sc = self._w8[b.name]
             self.ops.mx_quantize(self._view(self.W, b), q, sc)
 
@@ -296,7 +304,10 @@ class Engine:
             return self.ops.gemm_nt(x, w, out, **epi)
         M, K = x.shape
         xq = self._buf(ws, f"q8.{K}", (M, K), torch.uint8)
+        fresh = ws.get(f"^s8.{K}")
         xs = self._buf(ws, f"s8.{K}", (M, self.ops.mx_scale_cols(K)), torch.uint8)
+        if ws[f"^s8.{K}"] is not fresh:
+            self.ops.zero_(ws[f"^s8.{K}"])      # the quantiser writes ⌈K/128⌉ of the KSP scale columns: the padding stays 0
         self.ops.mx_quantize(x, xq, xs)
         self.ops.gemm_nt_mx(xq, xs, w8[0], w8[1], out, **epi)
 
@@ -425,6 +436,7 @@ class Engine:
                 raise ValueError("passage_lengths out of range [0, L]")
             M = int(lens_h.sum())
             self._all_valid = M == B * N * L
+            self._check_lengths(attention_mask, lens_h, B, N, L)
             if int(lens_h.view(B, N).sum(1).min()) <= 0 or M >= B * N * L:
                 return None
             off = torch.zeros(B * N + 1, dtype=torch.int32)
@@ -458,6 +470,26 @@ class Engine:
             self._rag_cache.clear()
         self._rag_cache[key] = (rag, attention_mask, self._all_valid)   # holding the tensor keeps (data_ptr, version) unambiguous
         return rag
+
+    def _check_lengths(self, attention_mask, lens_h, B, N, L):
+        """`passage_lengths` is trusted (no device→host sync on the training path): lengths that do not describe the mask — not
+        valid-tokens-first, or another batch's — silently pack the wrong tokens.  With LAKO_CHECK_LENGTHS=1 every batch's mask is
+        compared with the uploaded lengths ON THE DEVICE (asynchronously) and the verdict of batch k is read when batch k + 1
+        arrives (or by `check_lengths_now()`), so a mismatch raises one step late instead of never.  Off by default: mismatched
+        lengths are undefined behaviour, as documented in FiDT5.forward."""
+        if os.environ.get("LAKO_CHECK_LENGTHS", "0") != "1":
+            return
+        self.check_lengths_now()
+        dev = attention_mask.device
+        m = attention_mask.reshape(B * N, L).bool()
+        want = torch.arange(L, device=dev)[None, :] < lens_h.to(dev, non_blocking=True)[:, None]
+        self._len_verdict = (m != want).any()
+
+    def check_lengths_now(self):
+        v, self._len_verdict = getattr(self, "_len_verdict", None), None
+        if v is not None and bool(v):
+            raise ValueError("passage_lengths do not describe the attention mask of the previous batch (LAKO_CHECK_LENGTHS=1): "
+                             "the mask must be valid-tokens-first with exactly lengths[b, n] valid tokens per passage")
 
     def _xattn_plan(self, rag, B, N, L, rows_q):
         """The cross-attention runs in the encoder-state space (csrc/xattn.hip: no K/V projection of the N·L encoder states, the

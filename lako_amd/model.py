@@ -190,7 +190,10 @@ class FiDT5(nn.Module):
     def forward(self, input_ids=None, attention_mask=None, labels=None, passage_lengths=None, **kwargs):
         """src/model.py:39-51: accepts [B,N,L] or already-flattened [B,N·L] (n_passages remembered).
         `passage_lengths` (extension, optional): HOST int tensor [B, N] of valid tokens per passage, for masks of the
-        collator's form (valid tokens first) — lets the unpadded encoder skip the device→host read-back of the mask."""
+        collator's form (valid tokens first) — lets the unpadded encoder skip the device→host read-back of the mask.  The
+        lengths are TRUSTED: they must describe `attention_mask` exactly (lengths[b, n] valid tokens, then padding); anything else
+        is undefined behaviour (wrong tokens are packed).  LAKO_CHECK_LENGTHS=1 verifies every batch on the device and raises one
+        step late (engine.Engine._check_lengths)."""
         if input_ids is None or labels is None:
             raise ValueError("FiDT5.forward needs input_ids and labels (train_reader.py:67-71)")
         if input_ids.dim() == 3:
@@ -322,10 +325,13 @@ class FiDT5(nn.Module):
             raise ValueError(f"stored scores cover {S} keys, the batch has {N}x{L}")
         # torch.chunk(·, 2): the second chunk starts at ceil(n / 2) — the later half of the layers, the fact passage(s)
         layer0 = -(-nl // 2) if opt.use_last_half_layer_attention == "yes" else 0
-        passage = -(-N // 2)
+        passage = -(-N // 2)       # scores: first passage of the second chunk (src/model.py:164,174) …
+        ids_passage = 1            # … token ids: context_ids[b][1] (:173) — the same passage when N = 2
+        if N < 2:
+            raise ValueError("get_crossattention_scores needs the stream-2 layout: at least 2 passages")
         dev = scores.device
         out = torch.empty(B, opt.n_context, dtype=torch.float64, device=dev)
         eng.ops.fact_scores(scores.contiguous(), context_mask.to(dev).to(torch.uint8).contiguous(),
                             context_ids.to(dev).contiguous(), out, layer0=layer0, layers_used=nl - layer0, passage=passage,
-                            style=opt.attention_score_style)
+                            ids_passage=ids_passage, style=opt.attention_score_style)
         return out.cpu()

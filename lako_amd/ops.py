@@ -448,7 +448,7 @@ class HipOps:
     # ---- per-fact aggregation of captured cross-attention scores ---------------------------
     FACT_STYLES = {"mean": 0, "max": 1, "21mean": 2}
 
-    def fact_scores(self, scores, mask, ids, out, *, layer0, layers_used, passage, style):
+    def fact_scores(self, scores, mask, ids, out, *, layer0, layers_used, passage, style, ids_passage=None):
         """scores fp32 [B, H, nl, N·L], mask uint8/bool [B, N, L], ids int64 [B, N, L] → out fp64 [B, n_context]
         (see lako_fact_scores in include/lako_hip.h; src/model.py:143-204)"""
         B, H, nl, S = scores.shape
@@ -460,7 +460,8 @@ class HipOps:
         if style not in self.FACT_STYLES:
             raise LakoError(f"fact_scores: attention_score_style {style!r} (mean | max | 21mean)")
         self._timed("fact_scores", 0.0, lambda: check(self.lib.lako_fact_scores(
-            _p(scores), _p(mask), _p(ids), _p(out), B, H, nl, int(layer0), int(layers_used), N, L, int(passage), out.shape[1],
+            _p(scores), _p(mask), _p(ids), _p(out), B, H, nl, int(layer0), int(layers_used), N, L, int(passage),
+            int(passage if ids_passage is None else ids_passage), out.shape[1],
             self.FACT_STYLES[style], self._stream()), "lako_fact_scores"))
 
     # ---- exact inner-product search ---------------------------------------------------

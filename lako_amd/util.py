@@ -88,8 +88,7 @@ class AdamW(torch.optim.Optimizer):
                            gnorm_sq=eng.gnorm_sq if clip is not None else None,
                            max_norm=clip if clip is not None else 0.0, grad_scale=scale)
         model._pending_clip = None
-        eng.refresh_transposed()
-        eng.shadows_stale = False
+        eng.refresh_after_step()
 
     def state_dict(self):
         sd = super().state_dict()

@@ -476,8 +476,9 @@ class RefOps:
         n_done[0] = int(done.sum())
 
     # ---- per-fact aggregation (test double of lako_fact_scores: the reference's own loops, src/model.py:100-115,170-199) ----
-    def fact_scores(self, scores, mask, ids, out, *, layer0, layers_used, passage, style):
+    def fact_scores(self, scores, mask, ids, out, *, layer0, layers_used, passage, style, ids_passage=None):
         import heapq
+        ids_passage = passage if ids_passage is None else ids_passage
         B, H, nl, S = scores.shape
         _, N, L = ids.shape
         s = scores.view(B, H, nl, N, L)[:, :, layer0:layer0 + layers_used].masked_fill(~mask.bool()[:, None, None], 0.0)
@@ -492,7 +493,7 @@ class RefOps:
             return sum(heapq.nlargest(num, vals[a:b])) / num
         n_ctx = out.shape[1]
         for b in range(B):
-            toks, vals = ids[b][passage].tolist(), fact[b].tolist()
+            toks, vals = ids[b][ids_passage].tolist(), fact[b].tolist()
             res, start = [], 2
             for _ in range(n_ctx):
                 try:

@@ -14,6 +14,7 @@ import torch
 from lako_amd import FiDConfig, FiDT5
 from lako_amd import util as U
 from lako_amd.model import plain_name, wrapped_name
+from oracle import fid_t5_oracle as O
 from tests.ref_ops import RefOps
 from tests.util_golden import group, load_case
 
@@ -158,6 +159,28 @@ def test_generate_and_scores_vs_reference(name):
                 mine = model.get_crossattention_scores(o, ids, None, mask)
                 assert mine.dtype == torch.float64
                 np.testing.assert_allclose(mine.numpy(), z[f"fact_scores_{style}_{half}"], rtol=2e-5, atol=2e-6)
+
+
+def test_fact_scores_with_more_than_two_passages_follow_the_reference():
+    """get_crossattention_scores for N > 2: the reference sums the scores of passage ceil(N/2) — the first
+    passage of the second chunk — but cuts the spans with the token ids of passage 1 (src/model.py:164-174); the oracle
+    (oracle/fid_t5_oracle.py::crossattention_fact_scores, pinned to reference outputs at N = 2) states exactly that."""
+    z, dims, w, model = build("tiny_fact")
+    B, H, nl, N, L = 3, dims.num_heads, dims.num_decoder_layers, 4, 24
+    g = torch.Generator().manual_seed(3)
+    scores = torch.randn(B, H, nl, N * L, generator=g)
+    ids = torch.randint(11, 60, (B, N, L), generator=g)
+    ids[:, 1, [6, 11, 17]] = 5
+    ids[1, 1, 20:] = 0
+    mask = torch.ones(B, N, L, dtype=torch.bool)
+    mask[:, 2, 19:] = False
+    model._score_storage = scores
+    for style in ("mean", "max", "21mean"):
+        for half in ("no", "yes"):
+            o = types.SimpleNamespace(stream=2, n_context=5, use_last_half_layer_attention=half, attention_score_style=style)
+            mine = model.get_crossattention_scores(o, ids, None, mask)
+            want = O.crossattention_fact_scores(scores, ids, mask, 5, style, half == "yes")
+            np.testing.assert_allclose(mine.numpy(), want.numpy(), rtol=2e-5, atol=2e-6)
 
 
 def test_dropout_training_is_deterministic_and_unbiased():
@@ -351,6 +374,28 @@ def test_host_passage_lengths_equal_mask_readback(name):
     assert eng._ragged_batch(torch.ones_like(mask), *ids.shape, lengths=torch.full_like(lens, ids.shape[2])) is None
     with pytest.raises(ValueError):
         eng._ragged_batch(mask, *ids.shape, lengths=lens[:1])
+
+
+def test_check_lengths_switch_catches_a_mismatched_mask(monkeypatch):
+    """`passage_lengths` is trusted on the training path; LAKO_CHECK_LENGTHS=1 compares mask and lengths per batch (on the device,
+    asynchronously) and raises when the NEXT batch arrives — lengths of another batch, or a mask that is not valid-tokens-first."""
+    z, dims, w, model = build("mid_a")
+    ids, mask, labels = (torch.from_numpy(z[k]) for k in ("input_ids", "attention_mask", "labels"))
+    lens = mask.sum(-1).to(torch.int32)
+    model.train()
+    monkeypatch.setenv("LAKO_CHECK_LENGTHS", "1")
+    model(input_ids=ids, attention_mask=mask, labels=labels, passage_lengths=lens)       # consistent: nothing pending
+    model._engine.check_lengths_now()
+    holes = mask.clone()
+    holes[0, 0, 0] = False
+    holes[0, 0, int(lens[0, 0])] = True if int(lens[0, 0]) < mask.shape[2] else holes[0, 0, 0]   # same count, not a prefix
+    model(input_ids=ids, attention_mask=holes, labels=labels, passage_lengths=lens)
+    with pytest.raises(ValueError, match="passage_lengths"):
+        model(input_ids=ids, attention_mask=mask, labels=labels, passage_lengths=lens)
+    model._engine.check_lengths_now()                                                    # the verdict was consumed
+    monkeypatch.setenv("LAKO_CHECK_LENGTHS", "0")
+    model(input_ids=ids, attention_mask=holes, labels=labels, passage_lengths=lens)      # off: trusted (documented UB), no raise
+    model(input_ids=ids, attention_mask=mask, labels=labels, passage_lengths=lens)
 
 
 def test_noop_move_keeps_engine_state():

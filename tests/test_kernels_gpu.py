@@ -542,6 +542,24 @@ def test_cross_entropy(ops, ref, dt, M, V):
     close(dl, dlr, T, f"ce dlogits {dt}")
 
 
+def test_cross_entropy_non_finite_rows(ops):
+    """a NaN / Inf row loss must show in the reported mean (the fixed-point sum alone would hide it: ADVICE round 2)"""
+    M, V = 8, 512
+    for poison, check in ((float("nan"), torch.isnan), (float("-inf"), lambda t: torch.isinf(t) & (t > 0))):
+        logits = rnd(M, V, seed=33, scale=2.0)
+        labels = torch.randint(0, V, (M,), generator=torch.Generator().manual_seed(5)).to(dev())
+        logits[3, int(labels[3])] = poison          # NaN logit: NaN loss; -inf at the label: lse finite, loss +inf
+        lo = torch.zeros(2, device=dev())
+        ops.ce_fwd_bwd(logits, labels, lo, None)
+        assert bool(check(lo[0])), (poison, lo)
+    logits = rnd(M, V, seed=34, scale=2.0)          # finite rows still give the finite mean
+    labels = torch.randint(0, V, (M,), generator=torch.Generator().manual_seed(6)).to(dev())
+    lo = torch.zeros(2, device=dev())
+    ops.ce_fwd_bwd(logits, labels, lo, None)
+    want = torch.nn.functional.cross_entropy(logits.float().cpu(), labels.cpu())
+    assert abs(lo[0].item() - want.item()) < 1e-4 * max(1.0, abs(want.item()))
+
+
 def test_optimizer(ops, ref):
     n = 1000 * 4
     p, g = rnd(n, seed=27), rnd(n, seed=28, scale=3.0)
@@ -638,6 +656,19 @@ def test_fact_scores_segmented_reduce(ops, ref, style, half):
     torch.testing.assert_close(got.cpu(), want, atol=2e-6, rtol=2e-6)
     assert (got.cpu()[2] == -5.0 / ((nl - layer0) * H))[1:].all()          # no '.', not padded → ONE span, then the −5 filler
     assert (got.cpu()[5] == -5.0 / ((nl - layer0) * H))[1:].all()
+    # N > 2: the reference takes the SCORES of passage ceil(N/2) and the TOKEN IDS of passage 1 (src/model.py:164-174)
+    N4 = 4
+    scores4 = torch.randn(B, H, nl, N4 * L, generator=g) * 3
+    ids4 = torch.randint(11, 60, (B, N4, L), generator=g)
+    ids4[:, 1] = ids[:, 1]
+    mask4 = torch.ones(B, N4, L, dtype=torch.bool)
+    mask4[:, 2, 40:] = False
+    want4 = torch.zeros(B, n_ctx, dtype=torch.float64)
+    ref.fact_scores(scores4, mask4, ids4, want4, layer0=layer0, layers_used=nl - layer0, passage=2, ids_passage=1, style=style)
+    got4 = torch.zeros(B, n_ctx, dtype=torch.float64, device=dev())
+    ops.fact_scores(scores4.to(dev()), mask4.to(dev()).to(torch.uint8), ids4.to(dev()), got4, layer0=layer0, layers_used=nl - layer0,
+                    passage=2, ids_passage=1, style=style)
+    torch.testing.assert_close(got4.cpu(), want4, atol=2e-6, rtol=2e-6)
 
 
 @pytest.mark.gpu
@@ -702,6 +733,36 @@ def test_mx_quantize(ops, rows, K):
     qr, ex = mx_quantize_ref(xb.float().cpu())
     assert torch.equal(q.cpu().view(torch.float8_e4m3fn).float(), qr)
     assert torch.equal(sc.cpu(), mx_scales_layout(ex, K))
+
+
+@pytest.mark.gpu
+def test_mx_quantize_propagates_nan(ops):
+    """a NaN activation must stay visible in the fp8 forward: its element becomes the e4m3 NaN (0x7F), its
+    block's scale the E8M0 NaN (0xFF), the other blocks are untouched, and the product rows that meet the block are NaN"""
+    from tests.ref_ops import mx_quantize_ref, mx_scales_layout
+    rows, K = 64, 256
+    x = rnd(rows, K, seed=8, scale=2.0).to(torch.bfloat16)
+    x[5, 40] = float("nan")
+    q = torch.zeros(rows, K, dtype=torch.uint8, device=dev())
+    sc = torch.zeros(rows, ops.mx_scale_cols(K), dtype=torch.uint8, device=dev())
+    ops.mx_quantize(x, q, sc)
+    clean = x.clone()
+    clean[5, 32:64] = 0.0
+    qr, ex = mx_quantize_ref(clean.float().cpu())
+    want_sc = mx_scales_layout(ex, K).view(rows, 4, -1)
+    want_sc[5, 1, 0] = 0xFF                                  # block 1 of row 5
+    assert torch.equal(sc.cpu().view(rows, 4, -1), want_sc)
+    assert int(q[5, 40]) == 0x7F
+    keep = torch.ones(rows, K, dtype=torch.bool)
+    keep[5, 32:64] = False
+    assert torch.equal(q.cpu().view(torch.float8_e4m3fn).float()[keep], qr[keep])
+    B = rnd(256, K, seed=9).to(torch.bfloat16)
+    Bq = torch.zeros(256, K, dtype=torch.uint8, device=dev())
+    Bs = torch.zeros(256, ops.mx_scale_cols(K), dtype=torch.uint8, device=dev())
+    ops.mx_quantize(B, Bq, Bs)
+    Cm = torch.zeros(rows, 256, dtype=torch.bfloat16, device=dev())
+    ops.gemm_nt_mx(q, sc, Bq, Bs, Cm)
+    assert bool(torch.isnan(Cm[5].float()).all()) and not bool(torch.isnan(Cm[:5].float()).any()) and not bool(torch.isnan(Cm[6:].float()).any())
 
 
 @pytest.mark.gpu

@@ -93,3 +93,19 @@ def test_generate_and_scores(name):
             for half in ("no", "yes"):
                 mine = O.crossattention_fact_scores(ref, ids, mask, 5, style, half == "yes")
                 np.testing.assert_allclose(mine.numpy(), z[f"fact_scores_{style}_{half}"], rtol=1e-12, atol=1e-12)
+
+
+def test_chunked_oracle_evaluation_equals_direct():
+    """tests/test_real_size_gpu.py evaluates the oracle at BASELINE config 5 (T5-large, 100 passages) with the encoder walked 20
+    passages at a time to bound host memory; that evaluation must give the direct fid_forward + backward numbers."""
+    from tests.test_real_size_gpu import oracle_fwd_bwd_chunked
+    z, dims, w = load_case("mid_a")
+    ids, mask, labels = O.synthetic_batch(1, 6, 16, 5, dims.vocab_size, seed=8)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+    loss, logits = O.fid_forward(leaves, dims, ids, mask, labels, training=False)
+    loss.backward()
+    loss_c, logits_c, grads_c = oracle_fwd_bwd_chunked(w, dims, ids, mask, labels, chunk=4)      # chunks of 4 + 2 passages
+    assert abs(loss_c - loss.item()) < 1e-6
+    torch.testing.assert_close(logits_c, logits.detach(), atol=1e-5, rtol=1e-5)
+    for k, v in leaves.items():
+        torch.testing.assert_close(grads_c[k], v.grad, atol=1e-6, rtol=1e-4, msg=lambda m, k=k: f"{k}: {m}")

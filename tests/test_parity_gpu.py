@@ -408,6 +408,57 @@ def test_generate_graph_replay_equals_eager(dtype, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_bf16_generate_encoder_space_decode_vs_oracle_tokens():
+    """Greedy decode in bf16 on the DEFAULT decode path — HIP graphs, cross-attention in the encoder-state space, the one-pass
+    `xdecode_kernel` + combine (src/model.py:54-60, train_reader.py:142-146) — against the oracle's tokens on the same weights.
+    T5-small shapes (d_model 512, 8 heads: the smallest model the decode kernel takes), 10 passages x 200 tokens = up to 2 000
+    keys per sample, i.e. every sample spans all 64 key ranges of the decode kernel.  A random-init model's argmax margins are
+    within bf16 noise, so the weights are first trained on the batch (on the HIP path) until the answers are reproduced with
+    wide margins — the `tiny_eos` recipe of oracle/make_fixtures.py at a size the decode kernel accepts; the ORACLE then decodes
+    those weights in fp32 on the CPU and the bf16 HIP path must emit the same tokens, ragged EOS rows included."""
+    cfg = FiDConfig.named("small", dropout_rate=0.0)
+    dims = O.T5Dims.named("small")
+    dims.dropout = 0.0
+    torch.manual_seed(0)
+    m = FiDT5(cfg, dtype=torch.bfloat16, seed=1)
+    with torch.no_grad():
+        m._params_by_plain["shared.weight"].mul_(0.05)
+    m = m.cuda().train()
+    B, N, L, T, ML = 4, 10, 200, 6, 9
+    ids_c, mask_c, labels_c = O.synthetic_batch(B, N, L, T, cfg.vocab_size, seed=91)
+    ids, mask, labels = dev(ids_c, mask_c, labels_c)
+    opt = types.SimpleNamespace(optim="adamw", lr=1e-3, weight_decay=0.0, scheduler="fixed", fixed_lr=True,
+                                scheduler_steps=None, total_steps=1000, warmup_steps=0)
+    optimizer, scheduler = U.set_optim(opt, m)
+    last = None
+    for k in range(600):
+        loss = m(input_ids=ids, attention_mask=mask, labels=labels)[0]
+        loss.backward()
+        U.clip_grad_norm_(m, 1.0)
+        optimizer.step()
+        scheduler.step()
+        m.zero_grad()
+        if k % 20 == 19:
+            last = loss.item()
+            if last < 0.01:
+                break
+    assert last is not None and last < 0.05, last
+    w = {plain_name(n): p.detach().float().cpu().clone() for n, p in m.named_parameters()}
+    want = O.fid_generate(w, dims, ids_c, mask_c, ML)
+    # the oracle reproduces the training answers (so the comparison below is about trained margins, not about noise)
+    for b in range(B):
+        n_valid = int((labels_c[b] != -100).sum())
+        assert want[b, 1:1 + n_valid].tolist() == labels_c[b, :n_valid].tolist(), (b, want[b].tolist(), labels_c[b].tolist())
+    m.eval()
+    for rnd in range(3):                                    # eager warm-up of the mode, graph capture, pure replay
+        got = m.generate(input_ids=ids, attention_mask=mask, max_length=ML)
+        assert got.cpu().tolist() == want.tolist(), (rnd, got.cpu().tolist(), want.tolist())
+    assert m._engine.xattn_active
+    ws = m._engine._workspace(("gen", B, N, L, ML))
+    assert "rxf" in ws["g.graphs"] and len(ws["g.graphs"]["rxf"]["steps"]) >= 1      # ragged + encoder-space + one-pass decode
+
+
+@pytest.mark.gpu
 def test_encoder_space_cross_attention_long_answers_and_small_model(monkeypatch):
     """T5-small (d_model 512, 8 heads) with 20 answer positions: R = T·H = 160 query rows per sample — two row chunks of the
     scores / context kernels — and samples of very different key counts (one passage of a sample empty, one sample short).

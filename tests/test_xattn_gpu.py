@@ -49,7 +49,9 @@ CASES = [  # (lens, T, H, D)
     ([1000, 777], 8, 16, 1024),            # T5-large rows (R = 128)
     ([200, 90, 513], 1, 12, 768),          # one decoder step of generate (R = 12)
     ([257, 64], 13, 12, 768),              # R = 156 > 128: two row chunks
+    ([20000, 14873], 8, 16, 1024),         # BASELINE config 5: T5-large, 100 passages x 200 tokens per sample, full and ragged
 ]
+C5 = CASES[4]
 
 
 @pytest.mark.parametrize("lens,T,H,D", CASES)
@@ -85,7 +87,7 @@ def test_scores_and_context(ops, ref, lens, T, H, D):
 
 
 @pytest.mark.parametrize("p", [0.0, 0.1])
-@pytest.mark.parametrize("lens,T,H,D", CASES[:3])
+@pytest.mark.parametrize("lens,T,H,D", CASES[:3] + [C5])
 def test_softmax_fwd_bwd(ops, ref, lens, T, H, D, p):
     B, R = len(lens), T * H
     k_off, p_off, ptot = offsets(lens)
@@ -147,12 +149,14 @@ def test_headbatch(ops, ref, Bz, T, H, D):
 
 
 @pytest.mark.parametrize("p", [0.0, 0.1])
-def test_reassociated_cross_attention_equals_projected(ops, ref, p):
-    """The whole chain against the reference formulation in fp32: K = E·Wkᵀ, V = E·Wvᵀ, softmax(q·Kᵀ)·V and its autograd."""
-    lens, T, H, D = [333, 128, 50], 8, 12, 768
+@pytest.mark.parametrize("lens,T,H,D,tol", [([333, 128, 50], 8, 12, 768, 1.5e-2), (C5[0], 8, 16, 1024, 2e-2)], ids=["base_333", "c5_20000"])
+def test_reassociated_cross_attention_equals_projected(ops, ref, p, lens, T, H, D, tol):
+    """The whole chain against the reference formulation in fp32: K = E·Wkᵀ, V = E·Wvᵀ, softmax(q·Kᵀ)·V and its autograd
+    (src/model.py:286-349) — at T5-base rows with short ragged samples, and at BASELINE config 5's size: T5-large rows (16 heads,
+    d = 1024) over 20 000 and 14 873 keys per sample, the kernels the config-5 bench line runs."""
     B, R, inner = len(lens), T * H, H * 64
     k_off, p_off, ptot = offsets(lens)
-    max_keys = 400
+    max_keys = max(lens) + 67
     drop = (p, 99, 5) if p > 0 else None
     E = rnd(sum(lens), D, dtype=BF, seed=1)
     q = rnd(B * T, inner, dtype=BF, scale=0.3, seed=2)
@@ -193,7 +197,8 @@ def test_reassociated_cross_attention_equals_projected(ops, ref, p):
     ops.xattn_context(PS[:R], E, k_off, p_off, Cp)
     ctx = torch.zeros(B * T, inner, dtype=BF, device=dev())
     ops.headbatch_nt(Cp.unflatten(2, (T, H)), W[inner:].unflatten(0, (H, 64)), ctx.view(B, T, H, 64))
-    assert rel_l2(ctx.float().view(B, T, H, 64), ctx_ref) < 1e-2, rel_l2(ctx.float().view(B, T, H, 64), ctx_ref)
+    errs = {"ctx": rel_l2(ctx.float().view(B, T, H, 64), ctx_ref)}
+    assert errs["ctx"] < (1e-2 if tol < 2e-2 else tol), errs
     # backward
     G = torch.zeros(2 * inner, D, device=dev())
     dCp = DQ[:, :R]
@@ -213,9 +218,13 @@ def test_reassociated_cross_attention_equals_projected(ops, ref, p):
         n8 = (n + 7) // 8 * 8                                   # the rows past n add the zero padding columns of PS
         items.append((PS[:, int(p_off[b]):int(p_off[b]) + n8], DQ[b], dE[int(k_off[b]):int(k_off[b]) + n8], 1.0))
     ops.gemm_tn_grouped(items, split_k=1)
-    assert rel_l2(dq.float(), gq) < 1.5e-2, rel_l2(dq.float(), gq)
-    assert rel_l2(G, gW) < 1.5e-2, rel_l2(G, gW)
-    assert rel_l2(dE[:sum(lens)], gE) < 1.5e-2, rel_l2(dE[:sum(lens)], gE)
+    errs.update(dq=rel_l2(dq.float(), gq), dW=rel_l2(G, gW), dE=rel_l2(dE[:sum(lens)], gE))
+    import json, os
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, f"parity_xattn_chain_{max(lens)}keys_p{p}.json"), "w") as f:
+            json.dump(errs, f)
+    assert errs["dq"] < tol and errs["dW"] < tol and errs["dE"] < tol, errs
     assert float(dE[sum(lens):].abs().max()) == 0
 
 
