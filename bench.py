@@ -39,22 +39,24 @@ sys.path.insert(0, ROOT)
 
 def gemm_traffic_bytes(args):
     """HBM-side bytes per launch of the dominant kernel from the committed PMC profile (separate rocprofv3 --pmc passes
-    over tools/gemm_probe.py, FETCH_SIZE doubled as the gfx950 guide prescribes): the mean over the probe's four config-2
-    encoder GEMM shapes, measured at the row count this run executes (profiles/r01c_* ≈ 48 k valid tokens when padding is
-    skipped, profiles/r01b_* = 64 k rows on the padded path / --all-valid).  null for any other workload or when the file is absent —
-    counters cannot be collected from inside a timed run."""
+    over tools/gemm_probe.py, FETCH_SIZE doubled as the gfx950 guide prescribes; tools/gemm_traffic.py): the mean over the encoder's
+    NT GEMM shapes weighted by their launches per layer, measured at the row count this run executes (profiles/r03_gemm_traffic.json
+    = 48 k valid tokens when padding is skipped, …_padded.json = 64 k rows on the padded path / --all-valid; the r01 files are the
+    fallback).  null for any other workload or when the file is absent — counters cannot be collected from inside a timed run."""
     if (args.model, args.batch, args.n_passages, args.seq_len, args.dtype) != ("base", 16, 20, 200, "bf16"):
-        return None, None
+        return None, None, None
     padded = os.environ.get("LAKO_UNPAD", "1") == "0" or args.all_valid
-    for name in (("r02_gemm_traffic_padded.json", "r01b_gemm_traffic.json") if padded else
-                 ("r02_gemm_traffic.json", "r01c_gemm_traffic.json")):
+    for name in (("r03_gemm_traffic_padded.json", "r01b_gemm_traffic.json") if padded else
+                 ("r03_gemm_traffic.json", "r01c_gemm_traffic.json")):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
-                return json.load(f)["nt_mean_traffic_bytes_per_launch"], \
-                    f"static: profiles/{name} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/gemm_probe.py, not this run)"
+                j = json.load(f)
+                return j["nt_mean_traffic_bytes_per_launch"], \
+                    f"static: profiles/{name} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/gemm_probe.py, not this run)", \
+                    j.get("nt_mean_algorithmic_bytes_per_launch")
         except (OSError, KeyError, ValueError):
             continue
-    return None, None
+    return None, None, None
 
 
 PEAK_BF16_TFLOPS = 2500.0      # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (no 2:1 sparsity)
@@ -348,7 +350,7 @@ def main():
 
     if rank == 0:
         r = main_run
-        traffic, traffic_src = gemm_traffic_bytes(args)
+        traffic, traffic_src, traffic_alg = gemm_traffic_bytes(args)
         out = {
             "metric": "train samples/sec (question+n_passages) T5-base OKVQA, 1/2/4/8 GPU",
             "value": round(r["value"], 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
@@ -377,6 +379,7 @@ def main():
                                           else "projected K/V (reference formulation)"},
             "roofline": {"bound": "mfma", "achieved": round(r["achieved"], 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(r["achieved"] / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_over_algorithmic_bytes": round(traffic / traffic_alg, 3) if traffic and traffic_alg else None,
                          "kernel": ("gemm_nt_mx_kernel (256x256 tile, v_mfma_scale_f32_16x16x128_f8f6f4, e4m3 x e4m3 with E8M0 block scales: "
                                     "forward QKV / FFN-in / cross-K/V projections)") if args.fp8 else
                                    ("gemm_nt_kernel<bf16,bf16,2,4,8,4> (256x256 tile, both epilogue instantiations; calls with M > 256"

@@ -46,6 +46,36 @@ typedef struct {
   uint32_t site;
 } lako_dropout_t;
 
+/* ---- kernel-selection knobs (A/B measurements, tests that pin one kernel variant; training uses the defaults) ---------------
+ * The library holds NO mutable tuning state (re-entrant, thread-safe, no mutable globals): a caller that wants
+ * anything but the defaults OWNS a lako_tuning_t and passes it to the GEMM entry points; NULL there means the process defaults —
+ * built once from the LAKO_TUNING environment string and read-only afterwards.  Every knob selects between kernels / tilings that
+ * compute the same result; the two `experiment` fields change results or cache policy and are honoured only by a build with
+ * -DLAKO_EXPERIMENTS (lako_tuning_set refuses their keys in the release library with LAKO_E_UNSUPPORTED).
+ *   lako_tuning_init(t): defaults, then the LAKO_TUNING environment string "key=value,key=value" (error: LAKO_E_BADARG / _UNSUPPORTED)
+ *   lako_tuning_set(t, key, value): one field of the CALLER's struct by its key ("gemm_" + field name); unknown key: LAKO_E_BADARG */
+typedef struct lako_tuning {
+  int32_t nt_variant;    /* -1 heuristics (default); 0 = 128x128 tile / 4 waves, 1 = 256x128 / 8 waves, 2 = 256x256 / 8 waves,
+                            4 = 128x128 4-slot ring, 5 = small tiles with K split over the waves (M <= 256) */
+  int32_t nt_tail_split; /* 1: rows beyond the full rounds of 256x256 tiles go to a second launch with small tiles */
+  int32_t nt_ring;       /* 1: few-tile problems on the 4-slot ring kernel */
+  int32_t nt_skinny;     /* 1: M <= 256 on the split-K kernel; 2 / 3 / 4 force 64² / 32² / 16² tiles */
+  int32_t nt_side_lds;   /* 1: residual / aux operand of a 256x256 tile staged through LDS */
+  int32_t nt_wide_epi;   /* 1: LDS-transposed epilogue with 16-byte stores for plain bf16 outputs */
+  int32_t nt_group_m;    /* tile-rows per band of the banded tile order (default 8; 0 = row-major, < 0 forces |value|) */
+  int32_t nt_persistent; /* 1: at most one resident workgroup set, each walking several tiles */
+  int32_t nt_stagger;    /* 1: the second half of a workgroup's waves issues its LDS-DMA later in the K-step */
+  int32_t nt_dephase;    /* start offset between neighbouring workgroups of a multi-round launch, 10-ns ticks (default 100, 0 = lockstep) */
+  int32_t nt_dephase_n;  /* phases of that offset (default 2) */
+  int32_t tn_big;        /* 1: 256x256 weight-gradient kernel */
+  int32_t tn_split;      /* > 0 forces the K-split count of the 256x256 weight-gradient kernel */
+  int32_t nt_debug;      /* experiment */
+  int32_t nt_store_aux;  /* experiment */
+  int32_t reserved[17];  /* zero */
+} lako_tuning_t;
+int lako_tuning_init(lako_tuning_t* t);
+int lako_tuning_set(lako_tuning_t* t, const char* key, int value);
+
 /* ---- GEMM  (K3/K6/K7/K10/K12 of SURVEY.md §2.3: every nn.Linear(bias=False) on the path,
  *      HF5:304,325-326,367 (q,k,v,o), HF5:83-94 (wi,wo), HF5:1047 (lm_head)) --------------------- */
 enum {
@@ -68,6 +98,7 @@ typedef struct {
   int64_t ldaux;
   float aux_scale;
   lako_dropout_t drop; /* applied after relu / before the residual add; idx = m*N + n */
+  const lako_tuning_t* tuning; /* HOST pointer, NULL = process defaults */
 } lako_gemm_nt_t;
 int lako_gemm_nt(const lako_gemm_nt_t* p, lako_stream_t stream);
 
@@ -86,7 +117,8 @@ int lako_gemm_nt_mx(const lako_gemm_nt_t* p, const uint8_t* a_scales, const uint
 /* C[M,N] (fp32) += alpha * Aᵀ·B with A [K, M], B [K, N] row-major (weight gradients dW = dYᵀ·X —
  * the autograd of every nn.Linear above).  Split-K over `split_k` workgroups, fp32 atomics. */
 int lako_gemm_tn(const void* A, const void* B, float* C, int64_t M, int64_t N, int64_t K, int64_t lda,
-                 int64_t ldb, int64_t ldc, int in_dtype, float alpha, int split_k, lako_stream_t stream);
+                 int64_t ldb, int64_t ldc, int in_dtype, float alpha, int split_k, const lako_tuning_t* tuning,
+                 lako_stream_t stream);
 
 /* Several weight gradients in ONE launch: C_i[M_i,N_i] += alpha_i * A_iᵀ·B_i for i < n_items (<= LAKO_TN_GROUP_MAX), all with
  * the same K (= tokens) and input dtype.  The four dW of a transformer layer fill the chip with ~3 K-splits instead of 7-28
@@ -104,7 +136,7 @@ typedef struct {
   float alpha;
 } lako_gemm_tn_item_t;
 int lako_gemm_tn_grouped(const lako_gemm_tn_item_t* items, int n_items, int64_t K, int in_dtype, int split_k,
-                         lako_stream_t stream);
+                         const lako_tuning_t* tuning, lako_stream_t stream);
 
 /* ---- T5LayerNorm (RMSNorm, HF5:59-72): y = dropout(x * rsqrt(mean(x²) + eps) * w) ----------------
  * rstd [rows] fp32 is written for the backward.  w is fp32 [d]. */
@@ -328,16 +360,6 @@ int lako_bi_score(const float* q, const float* p, float* out, int B, int n, int 
 /* loss[0] = torch.nn.KLDivLoss()(log_softmax(score, -1), gold) over fp32 [B, n] (src/model.py:480-483); value only */
 int lako_kldiv_fwd(const float* score, const float* gold, float* loss, int B, int n, lako_stream_t stream);
 
-/* Development knob for A/B measurements (tools/bench_ops.py); training never calls it.
- * "gemm_nt_variant": -1 auto (default), 0 = 128x128 tile / 4 waves, 1 = 256x128 / 8 waves, 2 = 256x256 / 8 waves,
- *                    3 = 256x256 4-slot ring, 4 = 128x128 4-slot ring, 5 = 64x64 with K split over the four waves (M <= 256);
- *                    "gemm_nt_skinny" 0/1, "gemm_nt_side_lds" 0/1 (LDS-staged residual / aux operand);  "gemm_nt_persistent" 0/1;  "gemm_nt_stagger" 0/1;
- * "gemm_nt_wide_epi" 0/1 (LDS-transposed epilogue for plain bf16 stores);  "gemm_nt_group_m": tile-rows per band of
- * the banded tile order (0 = row-major, >0 applied when the output is >= 16 tiles wide, <0 forces |value|);
- * "gemm_tn_big" 0/1 (256x256 weight-gradient kernel);  "gemm_nt_dephase": start offset between neighbouring workgroups of a
- * multi-round persistent launch in 10-ns ticks (default 100, 0 = lockstep start), "gemm_nt_dephase_n": phases (default 2).
- * Unknown key: LAKO_E_BADARG. */
-int lako_set_tuning(const char* key, int value);
 
 #ifdef __cplusplus
 }

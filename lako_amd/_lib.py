@@ -28,10 +28,17 @@ class Dropout(C.Structure):
 NO_DROP = Dropout(0.0, 0, 0)
 
 
+class Tuning(C.Structure):
+    """lako_tuning_t: kernel-selection knobs, owned by the caller (one per HipOps — the library keeps no tuning state)"""
+    _fields_ = [(n, i32) for n in ("nt_variant", "nt_tail_split", "nt_ring", "nt_skinny", "nt_side_lds", "nt_wide_epi", "nt_group_m",
+                                   "nt_persistent", "nt_stagger", "nt_dephase", "nt_dephase_n", "tn_big", "tn_split", "nt_debug",
+                                   "nt_store_aux")] + [("reserved", i32 * 17)]
+
+
 class GemmNT(C.Structure):
     _fields_ = [("A", vp), ("B", vp), ("C", vp), ("M", i64), ("N", i64), ("K", i64), ("lda", i64), ("ldb", i64),
                 ("ldc", i64), ("in_dtype", i32), ("out_dtype", i32), ("alpha", f32), ("flags", i32), ("resid", vp),
-                ("ldr", i64), ("aux", vp), ("ldaux", i64), ("aux_scale", f32), ("drop", Dropout)]
+                ("ldr", i64), ("aux", vp), ("ldaux", i64), ("aux_scale", f32), ("drop", Dropout), ("tuning", vp)]
 
 
 class GemmTNItem(C.Structure):
@@ -76,8 +83,8 @@ SIGNATURES = {
     "lako_gemm_nt": [C.POINTER(GemmNT), vp],
     "lako_mx_quantize": [vp, i64, i64, i64, vp, vp, vp],
     "lako_gemm_nt_mx": [C.POINTER(GemmNT), vp, vp, vp],
-    "lako_gemm_tn": [vp, vp, vp, i64, i64, i64, i64, i64, i64, i32, f32, i32, vp],
-    "lako_gemm_tn_grouped": [C.POINTER(GemmTNItem), i32, i64, i32, i32, vp],
+    "lako_gemm_tn": [vp, vp, vp, i64, i64, i64, i64, i64, i64, i32, f32, i32, vp, vp],
+    "lako_gemm_tn_grouped": [C.POINTER(GemmTNItem), i32, i64, i32, i32, vp, vp],
     "lako_rmsnorm_fwd": [vp, vp, vp, vp, i64, i32, f32, i32, Dropout, vp],
     "lako_rmsnorm_bwd": [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, Dropout, vp, Dropout, vp],
     "lako_embed_fwd": [vp, vp, vp, i64, i32, i64, i32, Dropout, vp],
@@ -111,7 +118,8 @@ SIGNATURES = {
     "lako_seq_mean": [vp, vp, vp, i32, i32, i32, i32, vp],
     "lako_bi_score": [vp, vp, vp, i32, i32, i32, f32, vp],
     "lako_kldiv_fwd": [vp, vp, vp, i32, i32, vp],
-    "lako_set_tuning": [C.c_char_p, i32],
+    "lako_tuning_init": [C.POINTER(Tuning)],
+    "lako_tuning_set": [C.POINTER(Tuning), C.c_char_p, i32],
 }
 
 _lib = None

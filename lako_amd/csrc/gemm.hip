@@ -1392,21 +1392,100 @@ __global__ __launch_bounds__(256) void mx_quantize_kernel(const bf16_t* __restri
   }
 }
 
-int g_tn_big = 1;
-int g_tn_split = 0;   // > 0: force the number of K-splits of the 256x256 TN kernel (A/B measurements)
-int g_nt_wide_epi = 1;
-int g_nt_group_m = 8;
-int g_nt_debug = 0;
-int g_nt_skinny = 1;    // M <= 256 rows: gemm_nt_skinny_kernel ("gemm_nt_skinny" 0 disables, 2 / 3 force 64² / 32² tiles; variant 5 forces the kernel)
-int g_nt_ring = 1;      // skinny problems go to gemm_nt_ring_kernel ("gemm_nt_ring" 0 disables; variant 4 forces it)
-int g_nt_stagger = 1;
-int g_nt_store_aux = 0;    // cache-policy bits of the 256² kernel's output stores ("gemm_nt_store_aux"; 0 = default write-back — see store_b128_policy)
-int g_nt_dephase = 100, g_nt_dephase_n = 2;   // 10-ns ticks (s_memrealtime), phases
-int g_nt_persistent = 1;
-int g_nt_variant = -1;   // -1 auto; 0: 128x128/4 waves; 1: 256x128/8 waves; 2: 256x256/8 waves (lako_set_tuning)
+// ---- kernel-selection knobs -------------------------------------------------------------------------------------------------
+// The library keeps NO mutable tuning state: a caller that wants anything but the defaults owns a lako_tuning_t (lako_tuning_init
+// fills in the defaults and the LAKO_TUNING environment string, lako_tuning_set changes one field of the CALLER's struct) and hands
+// it to the GEMM entry points; NULL means the process defaults, built once (thread-safe static initialisation) and read-only after.
+struct TuneKey {
+  const char* name;
+  int32_t lako_tuning_t::*field;
+  bool experiment;     // a timing experiment with wrong results / non-default cache policy: -DLAKO_EXPERIMENTS builds only
+};
+const TuneKey TUNE_KEYS[] = {
+    {"gemm_nt_variant", &lako_tuning_t::nt_variant, false},       {"gemm_nt_tail_split", &lako_tuning_t::nt_tail_split, false},
+    {"gemm_nt_ring", &lako_tuning_t::nt_ring, false},             {"gemm_nt_skinny", &lako_tuning_t::nt_skinny, false},
+    {"gemm_nt_side_lds", &lako_tuning_t::nt_side_lds, false},     {"gemm_nt_wide_epi", &lako_tuning_t::nt_wide_epi, false},
+    {"gemm_nt_group_m", &lako_tuning_t::nt_group_m, false},       {"gemm_nt_persistent", &lako_tuning_t::nt_persistent, false},
+    {"gemm_nt_stagger", &lako_tuning_t::nt_stagger, false},       {"gemm_nt_dephase", &lako_tuning_t::nt_dephase, false},
+    {"gemm_nt_dephase_n", &lako_tuning_t::nt_dephase_n, false},   {"gemm_tn_big", &lako_tuning_t::tn_big, false},
+    {"gemm_tn_split", &lako_tuning_t::tn_split, false},           {"gemm_nt_debug", &lako_tuning_t::nt_debug, true},
+    {"gemm_nt_store_aux", &lako_tuning_t::nt_store_aux, true},
+};
+
+void tuning_defaults(lako_tuning_t* t) {
+  memset(t, 0, sizeof(*t));
+  t->nt_variant = -1;      // -1 auto; 0: 128x128 / 4 waves; 1: 256x128 / 8 waves; 2: 256x256 / 8 waves; 4: 128x128 ring; 5: split-K skinny
+  t->nt_tail_split = 1;
+  t->nt_ring = 1;          // skinny problems go to gemm_nt_ring_kernel (0 disables; variant 4 forces it)
+  t->nt_skinny = 1;        // M <= 256 rows: gemm_nt_skinny_kernel (0 disables, 2 / 3 / 4 force 64² / 32² / 16² tiles; variant 5 forces the kernel)
+  t->nt_side_lds = 1;      // 256² bf16 tiles with ONE side operand (residual or aux mask): LDS-DMA'd operand + row-major stores
+  t->nt_wide_epi = 1;
+  t->nt_group_m = 8;
+  t->nt_persistent = 1;
+  t->nt_stagger = 1;
+  t->nt_dephase = 100;     // 10-ns ticks (s_memrealtime)
+  t->nt_dephase_n = 2;     // phases
+  t->tn_big = 1;
+  t->tn_split = 0;         // > 0: force the number of K-splits of the 256x256 TN kernel (A/B measurements)
+}
+
+int tuning_set(lako_tuning_t* t, const char* key, int value) {
+  if (!t || !key) {
+    lako_set_error("lako_tuning_set: null argument");
+    return LAKO_E_BADARG;
+  }
+  for (const TuneKey& k : TUNE_KEYS) {
+    if (strcmp(key, k.name)) continue;
+#ifndef LAKO_EXPERIMENTS
+    if (k.experiment || (k.field == &lako_tuning_t::tn_big && value == 2)) {
+      lako_set_error("lako_tuning_set: '%s' is a timing experiment with wrong results / non-default cache policy; it exists only in the -DLAKO_EXPERIMENTS build", key);
+      return LAKO_E_UNSUPPORTED;
+    }
+#endif
+    if (k.field == &lako_tuning_t::nt_dephase_n && value < 2) value = 2;
+    t->*(k.field) = value;
+    return LAKO_OK;
+  }
+  lako_set_error("lako_tuning_set: unknown key '%s'", key);
+  return LAKO_E_BADARG;
+}
+
+// defaults + the LAKO_TUNING environment string "key=value,key=value" (A/B measurements); malformed or refused entries are an error
+int tuning_init(lako_tuning_t* t) {
+  tuning_defaults(t);
+  const char* env = getenv("LAKO_TUNING");
+  if (!env) return LAKO_OK;
+  char buf[512];
+  strncpy(buf, env, sizeof(buf) - 1);
+  buf[sizeof(buf) - 1] = 0;
+  for (char* tok = strtok(buf, ","); tok; tok = strtok(nullptr, ",")) {
+    while (*tok == ' ') ++tok;
+    if (!*tok) continue;
+    char* eq = strchr(tok, '=');
+    if (!eq) {
+      lako_set_error("LAKO_TUNING: '%s' is not key=value", tok);
+      return LAKO_E_BADARG;
+    }
+    *eq = 0;
+    char* end = eq;
+    while (end > tok && end[-1] == ' ') *--end = 0;
+    const int rc = tuning_set(t, tok, atoi(eq + 1));
+    if (rc != LAKO_OK) return rc;
+  }
+  return LAKO_OK;
+}
+
+const lako_tuning_t& process_tuning() {
+  static const lako_tuning_t t = [] {
+    lako_tuning_t x;
+    if (tuning_init(&x) != LAKO_OK) tuning_defaults(&x);      // a bad LAKO_TUNING is reported by lako_tuning_init to callers that ask
+    return x;
+  }();
+  return t;
+}
 
 template <typename T, typename TO, int WM, int WN, int MT, int NT, bool SIDE = false>
-void launch_nt_cfg(NtArgs a, hipStream_t s) {
+void launch_nt_cfg(NtArgs a, const lako_tuning_t& tu, hipStream_t s) {
   constexpr int BM = WM * MT * 16, BN = WN * NT * 16, LDS = 2 * (BM + BN) * TKB + (SIDE ? 32 * 1024 : 0);
   static bool attr_done = false;
   if (!attr_done) {
@@ -1416,56 +1495,53 @@ void launch_nt_cfg(NtArgs a, hipStream_t s) {
   }
   a.tiles_m = cdiv(a.M, BM);
   a.tiles_n = cdiv(a.N, BN);
-  a.stagger = g_nt_stagger;
-  a.store_aux = (int64_t)256 * a.ldc * 2 < (1ll << 31) ? g_nt_store_aux : 0;   // tile-relative 32-bit store offsets
-  a.debug = g_nt_debug;
+  a.stagger = tu.nt_stagger;
+  a.store_aux = (int64_t)256 * a.ldc * 2 < (1ll << 31) ? tu.nt_store_aux : 0;   // tile-relative 32-bit store offsets
+  a.debug = tu.nt_debug;
   // narrow outputs (≤ 7 tile columns) already give an XCD a compact block; a negative knob forces |value| on every shape (tests).
   // Measured at 48 000 rows (profiles/r02g_gemm_group_m_traffic.txt): banding takes the wi projection's L2 misses (FETCH_SIZE) from
   // 217 to 163 MiB-units per launch with no change in time (244 → 241 µs) — the L2-miss traffic is not what bounds the kernel —
   // and the QKV projection from 185 to 178 µs at unchanged misses
-  a.group_m = g_nt_group_m < 0 ? -g_nt_group_m : (a.tiles_n >= 8 ? g_nt_group_m : 0);
+  a.group_m = tu.nt_group_m < 0 ? -tu.nt_group_m : (a.tiles_n >= 8 ? tu.nt_group_m : 0);
   // measured (tools/bench_ops.py --variants 2,32): +6…12 % on plain stores, a LOSS when a residual / aux operand must
   // be fetched in the row-major layout too — those keep the accumulator-layout epilogue
-  a.wide_epi = g_nt_wide_epi && !(a.flags & (LAKO_EPI_ATOMIC | LAKO_EPI_RESID | LAKO_EPI_AUXMASK)) && a.N % 8 == 0 &&
+  a.wide_epi = tu.nt_wide_epi && !(a.flags & (LAKO_EPI_ATOMIC | LAKO_EPI_RESID | LAKO_EPI_AUXMASK)) && a.N % 8 == 0 &&
                a.ldc % 8 == 0 && reinterpret_cast<uintptr_t>(a.C) % 16 == 0;
   // persistent grid: resident workgroups only (LDS-limited: 160 KiB / CU), 256 CUs
   const int per_cu = (160 * 1024) / LDS > 0 ? (160 * 1024) / LDS : 1;
   int grid = a.tiles_m * a.tiles_n;
-  if (g_nt_persistent && grid > 256 * per_cu) grid = 256 * per_cu;
+  if (tu.nt_persistent && grid > 256 * per_cu) grid = 256 * per_cu;
 #ifdef LAKO_EXPERIMENTS
-  if ((g_nt_debug >> 8) > 0 && grid > (g_nt_debug >> 8)) grid = g_nt_debug >> 8;   // timing experiment: fewer resident workgroups
+  if ((tu.nt_debug >> 8) > 0 && grid > (tu.nt_debug >> 8)) grid = tu.nt_debug >> 8;   // timing experiment: fewer resident workgroups
 #endif
   // DEPHASE: every other workgroup of an XCD starts 1 µs late when the workgroups walk several tiles.  Measured (tools/bench_ops.py
   // --dephase 0,100,…): [64000,768]×[2304,768] 287 → 250 µs, o+res 140 → 134, wi 374 → 366, long launches unchanged; the size of
   // the delay (1…16 µs) and the number of phases (2, 4, 8) do not matter — the lockstep start is what costs.
-  a.dephase = (g_nt_dephase > 0 && a.tiles_m * a.tiles_n > grid) ? ((g_nt_dephase_n << 16) | (g_nt_dephase & 0xffff)) : 0;
+  a.dephase = (tu.nt_dephase > 0 && a.tiles_m * a.tiles_n > grid) ? ((tu.nt_dephase_n << 16) | (tu.nt_dephase & 0xffff)) : 0;
   hipLaunchKernelGGL((gemm_nt_kernel<T, TO, WM, WN, MT, NT, SIDE>), dim3(grid), dim3(WM * WN * 64), LDS, s, a);
 }
 
-int g_nt_tail_split = 1;
-int g_nt_side_lds = 1;   // 256² bf16 tiles with ONE side operand (residual or aux mask): LDS-DMA'd operand + row-major stores
-
 // the 256² kernel, with the LDS-staged side operand where the epilogue has exactly one (bf16 in and out, 16-B aligned rows)
 template <typename T, typename TO>
-void launch_nt_256(const NtArgs& a, hipStream_t s) {
+void launch_nt_256(const NtArgs& a, const lako_tuning_t& tu, hipStream_t s) {
   if constexpr (sizeof(T) == 2 && sizeof(TO) == 2) {
     const int side = a.flags & (LAKO_EPI_RESID | LAKO_EPI_AUXMASK);
     const char* sp = side == LAKO_EPI_RESID ? a.resid : a.aux;
     const int64_t ld = side == LAKO_EPI_RESID ? a.ldr : a.ldaux;
-    if (g_nt_side_lds && (side == LAKO_EPI_RESID || side == LAKO_EPI_AUXMASK) && !(a.flags & LAKO_EPI_ATOMIC) && a.N % 8 == 0 &&
+    if (tu.nt_side_lds && (side == LAKO_EPI_RESID || side == LAKO_EPI_AUXMASK) && !(a.flags & LAKO_EPI_ATOMIC) && a.N % 8 == 0 &&
         a.ldc % 8 == 0 && ld % 8 == 0 && reinterpret_cast<uintptr_t>(a.C) % 16 == 0 && reinterpret_cast<uintptr_t>(sp) % 16 == 0 &&
         (int64_t)256 * a.ldc * 2 < (1ll << 31) && (int64_t)256 * ld * 2 < (1ll << 31)) {
-      launch_nt_cfg<T, TO, 2, 4, 8, 4, true>(a, s);
+      launch_nt_cfg<T, TO, 2, 4, 8, 4, true>(a, tu, s);
       return;
     }
   }
-  launch_nt_cfg<T, TO, 2, 4, 8, 4>(a, s);
+  launch_nt_cfg<T, TO, 2, 4, 8, 4>(a, tu, s);
 }
 
 template <typename T, typename TO>
-int launch_nt(const NtArgs& a_in, hipStream_t s) {
+int launch_nt(const NtArgs& a_in, const lako_tuning_t& tu, hipStream_t s) {
   NtArgs a = a_in;
-  int v = g_nt_variant;
+  int v = tu.nt_variant;
   if (v < 0) {
     // big tiles once there is enough work to fill the chip with them (>= 1 tile per CU), else 128x128
     const int tn = cdiv(a.N, 256);
@@ -1475,13 +1551,13 @@ int launch_nt(const NtArgs& a_in, hipStream_t s) {
     // tokens × 768 columns) means 2 full rounds and a third with 52 tiles on 52 CUs: 3 tile-times for 2.2 of work.
     // The rows of the full rounds go to the 256² kernel, the remaining rows to a second launch with 128² tiles
     // (4 × as many, 2 workgroups per CU): ≈2.35 tile-times.  Only when the last round would be less than half full.
-    if (v == 2 && g_nt_tail_split && t256 > 256 && !(a.flags & LAKO_EPI_ATOMIC)) {
+    if (v == 2 && tu.nt_tail_split && t256 > 256 && !(a.flags & LAKO_EPI_ATOMIC)) {
       const int64_t full_rows = (t256 / 256) * 256 / tn;             // tile-rows covered by the full rounds
       const int64_t rest = t256 - full_rows * tn;                    // tiles left for the last round
       if (rest > 0 && rest < 128 && full_rows > 0) {
         NtArgs head = a;
         head.M = (int)(full_rows * 256);
-        launch_nt_256<T, TO>(head, s);
+        launch_nt_256<T, TO>(head, tu, s);
         const int64_t r0 = full_rows * 256;
         a.M -= (int)r0;
         a.row0 += r0;
@@ -1502,7 +1578,7 @@ int launch_nt(const NtArgs& a_in, hipStream_t s) {
                       (!(a.flags & LAKO_EPI_AUXMASK) || (a.ldaux % 8 == 0 && reinterpret_cast<uintptr_t>(a.aux) % 16 == 0)) &&
                       reinterpret_cast<uintptr_t>(a.A) % 16 == 0 && reinterpret_cast<uintptr_t>(a.B) % 16 == 0 &&
                       reinterpret_cast<uintptr_t>(a.C) % 16 == 0;
-    if (fits && (v == 5 || (g_nt_variant < 0 && g_nt_skinny && a.M <= 256 && a.N <= 4096))) {
+    if (fits && (v == 5 || (tu.nt_variant < 0 && tu.nt_skinny && a.M <= 256 && a.N <= 4096))) {
       static bool attr_done = false;
       if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_skinny_kernel<TO, 8, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384);
@@ -1513,11 +1589,11 @@ int launch_nt(const NtArgs& a_in, hipStream_t s) {
       // a CU pulls ≈45 GB/s through its L1 whatever the other CUs do, so the bytes have to be spread over many CUs: 32² tiles
       // (4 × the workgroups of 64² tiles, half the operand bytes each) — measured on the whole training step: 64² 50.4 ms,
       // 32² 49.4 ms, 16² 49.3 ms ("gemm_nt_skinny" 2 / 3 / 4 force them)
-      const bool small = g_nt_skinny != 2;
+      const bool small = tu.nt_skinny != 2;
       const int ts = small ? 32 : 64;
       const dim3 grid(cdiv(a.N, ts), cdiv(a.M, ts));
       const int per = cdiv(a.K / 32, 8);
-      if (g_nt_skinny == 4) {
+      if (tu.nt_skinny == 4) {
         const dim3 g16(cdiv(a.N, 16), cdiv(a.M, 16));
         if (per <= 4) hipLaunchKernelGGL((gemm_nt_skinny_kernel<TO, 8, 4, 1>), g16, dim3(512), 8 * 1024, s, a);
         else if (per <= 8) hipLaunchKernelGGL((gemm_nt_skinny_kernel<TO, 8, 8, 1>), g16, dim3(512), 8 * 1024, s, a);
@@ -1535,7 +1611,7 @@ int launch_nt(const NtArgs& a_in, hipStream_t s) {
     }
     if (v == 5) v = 4;
   }
-  if (v == 4 || (g_nt_variant < 0 && g_nt_ring && (int64_t)cdiv(a.M, RING_BM) * cdiv(a.N, RING_BM) <= 256)) {
+  if (v == 4 || (tu.nt_variant < 0 && tu.nt_ring && (int64_t)cdiv(a.M, RING_BM) * cdiv(a.N, RING_BM) <= 256)) {
     // skinny: at most one 128² tile per CU → the 4-slot ring hides the global→LDS latency inside the workgroup
     static bool attr_done = false;
     if (!attr_done) {
@@ -1558,9 +1634,9 @@ int launch_nt(const NtArgs& a_in, hipStream_t s) {
     hipLaunchKernelGGL((gemm_nt_ring_kernel<T, TO>), dim3(tiles * b.split_k), dim3(256), RING_NST * RING_STAGE, s, b);
     return 0;
   }
-  if (v == 2) launch_nt_256<T, TO>(a, s);
-  else if (v == 1) launch_nt_cfg<T, TO, 4, 2, 4, 4>(a, s);
-  else launch_nt_cfg<T, TO, 2, 2, 4, 4>(a, s);
+  if (v == 2) launch_nt_256<T, TO>(a, tu, s);
+  else if (v == 1) launch_nt_cfg<T, TO, 4, 2, 4, 4>(a, tu, s);
+  else launch_nt_cfg<T, TO, 2, 2, 4, 4>(a, tu, s);
   return 0;
 }
 
@@ -1623,12 +1699,13 @@ extern "C" int lako_gemm_nt(const lako_gemm_nt_t* p, lako_stream_t stream) {
   a.drop_scale = p->drop.p > 0.f ? 1.0f / (1.0f - p->drop.p) : 1.0f;
   a.drop_key = lako_drop_key(p->drop.seed, p->drop.site);
   hipStream_t s = (hipStream_t)stream;
+  const lako_tuning_t& tu = p->tuning ? *p->tuning : process_tuning();
   if (p->in_dtype == LAKO_BF16) {
-    if (p->out_dtype == LAKO_BF16) launch_nt<bf16_t, bf16_t>(a, s);
-    else launch_nt<bf16_t, float>(a, s);
+    if (p->out_dtype == LAKO_BF16) launch_nt<bf16_t, bf16_t>(a, tu, s);
+    else launch_nt<bf16_t, float>(a, tu, s);
   } else {
-    if (p->out_dtype == LAKO_BF16) launch_nt<float, bf16_t>(a, s);
-    else launch_nt<float, float>(a, s);
+    if (p->out_dtype == LAKO_BF16) launch_nt<float, bf16_t>(a, tu, s);
+    else launch_nt<float, float>(a, tu, s);
   }
   LAKO_LAUNCH_CHECK();
   return LAKO_OK;
@@ -1655,7 +1732,9 @@ static int tn_pick_split(int tiles, int64_t K, int max_split) {
 }
 
 extern "C" int lako_gemm_tn(const void* A, const void* B, float* C, int64_t M, int64_t N, int64_t K, int64_t lda,
-                            int64_t ldb, int64_t ldc, int in_dtype, float alpha, int split_k, lako_stream_t stream) {
+                            int64_t ldb, int64_t ldc, int in_dtype, float alpha, int split_k, const lako_tuning_t* tuning,
+                            lako_stream_t stream) {
+  const lako_tuning_t& tu = tuning ? *tuning : process_tuning();
   LAKO_CHECK_ARG(M > 0 && N > 0 && K > 0, "lako_gemm_tn: bad dims");
   LAKO_CHECK_ARG(in_dtype == LAKO_F32 || in_dtype == LAKO_BF16, "lako_gemm_tn: bad in_dtype");
   const int esz = in_dtype == LAKO_F32 ? 4 : 2;
@@ -1680,7 +1759,7 @@ extern "C" int lako_gemm_tn(const void* A, const void* B, float* C, int64_t M, i
   a.tiles_m = cdiv(M, TM);
   a.tiles_n = cdiv(N, TN_);
   hipStream_t s = (hipStream_t)stream;
-  if (in_dtype == LAKO_BF16 && M >= 256 && N >= 256 && g_tn_big) {
+  if (in_dtype == LAKO_BF16 && M >= 256 && N >= 256 && tu.tn_big) {
     a.tiles_m = cdiv(M, 256);
     a.tiles_n = cdiv(N, 256);
     const int tiles = a.tiles_m * a.tiles_n;
@@ -1688,14 +1767,14 @@ extern "C" int lako_gemm_tn(const void* A, const void* B, float* C, int64_t M, i
     if (sk <= 0) {   // one workgroup per CU (128 KiB LDS): aim at ~256 workgroups, >= 4 K-steps per split
       const int max_split = cdiv(K, 64 * 4);
       sk = tn_pick_split(tiles, K, max_split);
-      if (g_tn_split > 0) sk = g_tn_split;
+      if (tu.tn_split > 0) sk = tu.tn_split;
       if (sk > max_split) sk = max_split;
       if (sk < 1) sk = 1;
     }
     int chunk = cdiv(cdiv(K, sk), 64) * 64;
     a.split_k = cdiv(K, chunk);
     a.k_chunk = chunk;
-    a.no_atomics = g_tn_big == 2;
+    a.no_atomics = tu.tn_big == 2;
     LAKO_CHECK_ARG((int64_t)64 * lda * 2 < (1ll << 31) && (int64_t)64 * ldb * 2 < (1ll << 31),
                    "lako_gemm_tn: leading dimension too large");
     static bool attr_done = false;
@@ -1730,15 +1809,16 @@ extern "C" int lako_gemm_tn(const void* A, const void* B, float* C, int64_t M, i
 }
 
 extern "C" int lako_gemm_tn_grouped(const lako_gemm_tn_item_t* items, int n_items, int64_t K, int in_dtype, int split_k,
-                                    lako_stream_t stream) {
+                                    const lako_tuning_t* tuning, lako_stream_t stream) {
+  const lako_tuning_t& tu = tuning ? *tuning : process_tuning();
   LAKO_CHECK_ARG(items && n_items >= 1 && n_items <= LAKO_TN_GROUP_MAX, "lako_gemm_tn_grouped: 1..%d items", LAKO_TN_GROUP_MAX);
   LAKO_CHECK_ARG(K > 0 && K < (1 << 30), "lako_gemm_tn_grouped: bad K");
-  bool big = in_dtype == LAKO_BF16 && g_tn_big;
+  bool big = in_dtype == LAKO_BF16 && tu.tn_big;
   for (int i = 0; i < n_items; ++i) big = big && items[i].M >= 256 && items[i].N >= 256;
   if (!big || n_items == 1) {   // shapes the 256×256 kernel does not take: one launch per problem
     for (int i = 0; i < n_items; ++i) {
       int rc = lako_gemm_tn(items[i].a, items[i].b, items[i].c, items[i].M, items[i].N, K, items[i].lda, items[i].ldb,
-                            items[i].ldc, in_dtype, items[i].alpha, split_k, stream);
+                            items[i].ldc, in_dtype, items[i].alpha, split_k, tuning, stream);
       if (rc != LAKO_OK) return rc;
     }
     return LAKO_OK;
@@ -1746,7 +1826,7 @@ extern "C" int lako_gemm_tn_grouped(const lako_gemm_tn_item_t* items, int n_item
   TnArgs a;
   a.n_items = n_items;
   a.K = (int)K;
-  a.no_atomics = g_tn_big == 2;
+  a.no_atomics = tu.tn_big == 2;
   int tiles = 0;
   for (int i = 0; i < n_items; ++i) {
     const lako_gemm_tn_item_t& p = items[i];
@@ -1769,7 +1849,7 @@ extern "C" int lako_gemm_tn_grouped(const lako_gemm_tn_item_t* items, int n_item
   a.tiles_n = 1;
   const int max_split = cdiv(K, 64 * 4);
   int sk = tn_pick_split(tiles, K, max_split);
-  if (g_tn_split > 0) sk = g_tn_split;
+  if (tu.tn_split > 0) sk = tu.tn_split;
   if (split_k > 0) sk = split_k;
   if (sk > max_split) sk = max_split;
   if (sk < 1) sk = 1;
@@ -1841,14 +1921,15 @@ extern "C" int lako_gemm_nt_mx(const lako_gemm_nt_t* p, const uint8_t* a_scales,
   a.drop_key = lako_drop_key(p->drop.seed, p->drop.site);
   a.tiles_m = cdiv(a.M, 256);
   a.tiles_n = cdiv(a.N, 256);
-  a.group_m = a.tiles_n >= 16 ? (g_nt_group_m < 0 ? -g_nt_group_m : g_nt_group_m) : (g_nt_group_m < 0 ? -g_nt_group_m : 0);
+  const lako_tuning_t& tu = p->tuning ? *p->tuning : process_tuning();
+  a.group_m = a.tiles_n >= 16 ? (tu.nt_group_m < 0 ? -tu.nt_group_m : tu.nt_group_m) : (tu.nt_group_m < 0 ? -tu.nt_group_m : 0);
   a.wide_epi = !(a.flags & (LAKO_EPI_RESID | LAKO_EPI_AUXMASK));
   m.sa = a_scales;
   m.sb = b_scales;
   m.ksp = (int)(((p->K / 128) + 3) / 4 * 4);
   int grid = a.tiles_m * a.tiles_n;
   if (grid > 256) grid = 256;
-  a.dephase = (g_nt_dephase > 0 && a.tiles_m * a.tiles_n > grid) ? ((g_nt_dephase_n << 16) | (g_nt_dephase & 0xffff)) : 0;
+  a.dephase = (tu.nt_dephase > 0 && a.tiles_m * a.tiles_n > grid) ? ((tu.nt_dephase_n << 16) | (tu.nt_dephase & 0xffff)) : 0;
   constexpr int LDS = 2 * (256 + 256) * TKB;
   static bool attr_done = false;
   if (!attr_done) {
@@ -1860,76 +1941,11 @@ extern "C" int lako_gemm_nt_mx(const lako_gemm_nt_t* p, const uint8_t* a_scales,
   return LAKO_OK;
 }
 
-// Kernel-selection knobs for A/B measurements and tests.  Every key the release build accepts selects between kernels / tilings
-// that compute the SAME result; the process-global values are meant to be set once at start-up (LAKO_TUNING), not per call.
-extern "C" int lako_set_tuning(const char* key, int value) {
-  if (key && !strcmp(key, "gemm_nt_variant")) {
-    g_nt_variant = value;
-    return LAKO_OK;
-  }
-  if (key && !strcmp(key, "gemm_nt_tail_split")) {
-    g_nt_tail_split = value;
-    return 0;
-  }
-  if (key && !strcmp(key, "gemm_nt_ring")) {
-    g_nt_ring = value;
-    return 0;
-  }
-#ifdef LAKO_EXPERIMENTS
-  if (key && !strcmp(key, "gemm_nt_debug")) {
-    g_nt_debug = value;
-    return 0;
-  }
-  if (key && !strcmp(key, "gemm_nt_store_aux")) {
-    g_nt_store_aux = value;
-    return LAKO_OK;
-  }
-#else
-  if (key && (!strcmp(key, "gemm_nt_debug") || !strcmp(key, "gemm_nt_store_aux") || (!strcmp(key, "gemm_tn_big") && value == 2))) {
-    lako_set_error("lako_set_tuning: '%s' is a timing experiment with wrong results / non-default cache policy; it exists only in the -DLAKO_EXPERIMENTS build", key);
-    return LAKO_E_UNSUPPORTED;
-  }
-#endif
-  if (key && !strcmp(key, "gemm_nt_group_m")) {
-    g_nt_group_m = value;
-    return 0;
-  }
-  if (key && !strcmp(key, "gemm_nt_wide_epi")) {
-    g_nt_wide_epi = value;
-    return LAKO_OK;
-  }
-  if (key && !strcmp(key, "gemm_nt_skinny")) {
-    g_nt_skinny = value;
-    return LAKO_OK;
-  }
-  if (key && !strcmp(key, "gemm_nt_side_lds")) {
-    g_nt_side_lds = value;
-    return LAKO_OK;
-  }
-  if (key && !strcmp(key, "gemm_nt_dephase_n")) {
-    g_nt_dephase_n = value < 2 ? 2 : value;
-    return LAKO_OK;
-  }
-  if (key && !strcmp(key, "gemm_nt_dephase")) {
-    g_nt_dephase = value;
-    return LAKO_OK;
-  }
-  if (key && !strcmp(key, "gemm_nt_stagger")) {
-    g_nt_stagger = value;
-    return LAKO_OK;
-  }
-  if (key && !strcmp(key, "gemm_tn_split")) {
-    g_tn_split = value;
-    return 0;
-  }
-  if (key && !strcmp(key, "gemm_tn_big")) {
-    g_tn_big = value;
-    return LAKO_OK;
-  }
-  if (key && !strcmp(key, "gemm_nt_persistent")) {
-    g_nt_persistent = value;
-    return LAKO_OK;
-  }
-  lako_set_error("lako_set_tuning: unknown key");
-  return LAKO_E_BADARG;
+// Kernel-selection knobs for A/B measurements and tests (see the table above): every key the release build accepts selects between
+// kernels / tilings that compute the SAME result.  Both functions write only the caller's struct.
+extern "C" int lako_tuning_init(lako_tuning_t* t) {
+  LAKO_CHECK_ARG(t != nullptr, "lako_tuning_init: null struct");
+  return tuning_init(t);
 }
+
+extern "C" int lako_tuning_set(lako_tuning_t* t, const char* key, int value) { return tuning_set(t, key, value); }

@@ -62,10 +62,11 @@ class HipOps:
         self.lib = _lib.load()
         assert self.lib.lako_version() == 1
         self.probe = None   # list → every op records (name, algorithmic flops, start event, end event)
-        import os
-        for kv in filter(None, os.environ.get("LAKO_TUNING", "").split(",")):   # A/B measurements: "key=value,key=value"
-            k, v = kv.split("=")
-            self.set_tuning(k.strip(), int(v))
+        # kernel-selection knobs are THIS object's (the library keeps no tuning state): defaults + the LAKO_TUNING environment
+        # string ("key=value,key=value": A/B measurements), changed by set_tuning, handed to every GEMM call
+        self.tuning = _lib.Tuning()
+        check(self.lib.lako_tuning_init(C.byref(self.tuning)), "lako_tuning_init")
+        self._tuning_p = C.addressof(self.tuning)
 
     @staticmethod
     def _stream():
@@ -95,7 +96,7 @@ class HipOps:
         t.zero_()
 
     def set_tuning(self, key: str, value: int):
-        check(self.lib.lako_set_tuning(key.encode(), int(value)), "lako_set_tuning")
+        check(self.lib.lako_tuning_set(C.byref(self.tuning), key.encode(), int(value)), "lako_tuning_set")
 
     # ---- MX block-scaled fp8 GEMM (BASELINE config 5) -------------------------------------------------------------
     @staticmethod
@@ -137,6 +138,7 @@ class HipOps:
             p.aux, p.ldaux = aux.data_ptr(), aux.stride(0)
         p.aux_scale = float(aux_scale)
         p.drop = _drop(drop)
+        p.tuning = self._tuning_p
         self._timed("gemm_nt_mx", 2.0 * M * N * K, lambda: check(self.lib.lako_gemm_nt_mx(C.byref(p), _p(As), _p(Bs), self._stream()), "lako_gemm_nt_mx"))
 
     # ---- GEMMs -----------------------------------------------------------------------------
@@ -164,6 +166,7 @@ class HipOps:
             p.aux, p.ldaux = aux.data_ptr(), aux.stride(0)
         p.aux_scale = float(aux_scale)
         p.drop = _drop(drop)
+        p.tuning = self._tuning_p
         # probe classes follow the kernel the library picks: M <= 256 rows (the decoder) runs on the split-K / ring kernels
         self._timed(f"gemm_nt{'_skinny' if M <= 256 else ''}.{p.in_dtype}{p.out_dtype}", 2.0 * M * N * K, lambda: check(self.lib.lako_gemm_nt(C.byref(p), self._stream()), "lako_gemm_nt"))
 
@@ -174,7 +177,7 @@ class HipOps:
         if K != K2 or M != M2 or N != N2 or A.dtype != B.dtype or Cm.dtype != torch.float32:
             raise LakoError(f"gemm_tn: shape/dtype mismatch A{tuple(A.shape)} B{tuple(B.shape)} C{tuple(Cm.shape)}")
         self._timed("gemm_tn", 2.0 * M * N * K, lambda: check(self.lib.lako_gemm_tn(_p(A), _p(B), _p(Cm), M, N, K, lda, ldb, ldc, _dt(A), float(alpha), int(split_k),
-                                    self._stream()), "lako_gemm_tn"))
+                                    self._tuning_p, self._stream()), "lako_gemm_tn"))
 
     def gemm_tn_grouped(self, problems, split_k=0):
         """[(A [K, M], B [K, N], C [M, N] fp32, alpha), …] with one K: every C += alpha·Aᵀ·B, one launch per
@@ -197,7 +200,7 @@ class HipOps:
                 it.a, it.b, it.c = _p(A), _p(B), _p(Cm)
                 it.M, it.N, it.lda, it.ldb, it.ldc, it.alpha = M, N, lda, ldb, ldc, float(alpha)
                 flops += 2.0 * M * N * K
-            self._timed("gemm_tn", flops, lambda: check(self.lib.lako_gemm_tn_grouped(arr, len(grp), K0, _dt(grp[0][0]), int(split_k), self._stream()),
+            self._timed("gemm_tn", flops, lambda: check(self.lib.lako_gemm_tn_grouped(arr, len(grp), K0, _dt(grp[0][0]), int(split_k), self._tuning_p, self._stream()),
                                                         "lako_gemm_tn_grouped"))
 
     # ---- norm / embedding / dropout ---------------------------------------------------------------

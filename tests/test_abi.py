@@ -62,7 +62,7 @@ def test_struct_layouts_match_header_order():
             decl = decl.strip()
             if not decl:
                 continue
-            decl = re.sub(r"^(const\s+)?(void|float|int64_t|int32_t|int|uint8_t|uint32_t|lako_dropout_t)\b", "", decl)
+            decl = re.sub(r"^(const\s+)?(void|float|int64_t|int32_t|int|uint8_t|uint32_t|lako_dropout_t|lako_tuning_t)\b", "", decl)
             names += [n.strip(" *") for n in decl.split(",")]
         assert names == [f[0] for f in py._fields_], (cname, names)
 
@@ -83,7 +83,9 @@ def test_bad_arguments_return_error_codes(lib):
     a.Bn, a.H, a.Lq, a.Lk, a.d_head, a.dtype = 1, 1, 4, 4, 48, 1      # unsupported head dim
     assert L.lako_attn_fwd(ctypes.byref(a), None) == -4
     assert L.lako_rmsnorm_fwd(None, None, None, None, 4, 12, 1e-6, 1, _lib.NO_DROP, None) == -1   # d % 8 != 0
-    assert L.lako_set_tuning(b"no_such_knob", 1) == -1
+    t = _lib.Tuning()
+    assert L.lako_tuning_init(ctypes.byref(t)) == 0 and L.lako_tuning_set(ctypes.byref(t), b"no_such_knob", 1) == -1
+    assert L.lako_tuning_init(None) == -1 and L.lako_tuning_set(None, b"gemm_nt_variant", 1) == -1
     # the encoder-space cross-attention entry points (round 2)
     hb = _lib.HeadBatch()
     assert L.lako_headbatch_nt(ctypes.byref(hb), None) == -1 and L.lako_headbatch_tn(ctypes.byref(hb), None) == -1
@@ -109,13 +111,16 @@ def test_release_library_rejects_timing_experiments(lib):
     from lako_amd import _lib
     _lib._lib = None
     L = _lib.load()
+    t = _lib.Tuning()
+    assert L.lako_tuning_init(ctypes.byref(t)) == 0
     for key, val in ((b"gemm_nt_debug", 1), (b"gemm_nt_debug", 16), (b"gemm_nt_store_aux", 2), (b"gemm_tn_big", 2)):
-        assert L.lako_set_tuning(key, val) == -4, key
+        assert L.lako_tuning_set(ctypes.byref(t), key, val) == -4, key
         buf = ctypes.create_string_buffer(256)
         L.lako_last_error(buf, 256)
         assert b"LAKO_EXPERIMENTS" in buf.value
+    assert (t.nt_debug, t.nt_store_aux, t.tn_big) == (0, 0, 1)                  # a refused key leaves the struct untouched
     for key, val in ((b"gemm_nt_variant", -1), (b"gemm_nt_group_m", 8), (b"gemm_tn_big", 1), (b"gemm_nt_tail_split", 1)):
-        assert L.lako_set_tuning(key, val) == 0, key       # result-preserving kernel selection stays available
+        assert L.lako_tuning_set(ctypes.byref(t), key, val) == 0, key       # result-preserving kernel selection stays available
     src = open(os.path.join(ROOT, "lako_amd", "csrc", "gemm.hip")).read() + open(os.path.join(ROOT, "lako_amd", "csrc", "attn.hip")).read()
     assert "gemm_nt_pipe_kernel" not in src
     # no un-gated use of the experiment bits is left in the sources
@@ -126,8 +131,41 @@ def test_release_library_rejects_timing_experiments(lib):
             depth += 1
         elif t.startswith("#else") or t.startswith("#endif"):
             depth = max(depth - 1, 0) if t.startswith("#endif") or depth else depth
-        if depth == 0 and re.search(r"\ba\.debug\s*&|dbg_flags\s*&|g_nt_debug\s*>>", line):
+        if depth == 0 and re.search(r"\ba\.debug\s*&|dbg_flags\s*&|nt_debug\s*>>", line):
             assert False, f"ungated experiment test: {t}"
+
+
+def test_tuning_is_caller_owned_and_the_library_keeps_no_mutable_knobs(lib, monkeypatch):
+    """re-entrant, no mutable globals except once-initialised caches (fifteen process-global
+    tuning ints).  The knobs now live in a caller-owned lako_tuning_t: two structs are independent, the defaults are the documented
+    ones, LAKO_TUNING is parsed into the caller's struct (bad strings are an error, experiment keys refused), the ctypes layout
+    matches the header, and the shared object exports / defines no g_nt_* / g_tn_* data symbol any more."""
+    import subprocess
+    from lako_amd import _lib
+    _lib._lib = None
+    L = _lib.load()
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    body = re.search(r"typedef struct lako_tuning \{([^{}]*)\}\s*lako_tuning_t", src, re.S).group(1)
+    names = [re.sub(r"^int32_t\s+", "", d.strip()) for d in body.split(";") if d.strip()]
+    assert names == [f[0] for f in _lib.Tuning._fields_[:-1]] + ["reserved[17]"]
+    assert ctypes.sizeof(_lib.Tuning) == 32 * 4
+    monkeypatch.delenv("LAKO_TUNING", raising=False)
+    a, b = _lib.Tuning(), _lib.Tuning()
+    assert L.lako_tuning_init(ctypes.byref(a)) == 0 and L.lako_tuning_init(ctypes.byref(b)) == 0
+    assert (a.nt_variant, a.nt_tail_split, a.nt_ring, a.nt_skinny, a.nt_side_lds, a.nt_wide_epi, a.nt_group_m, a.nt_persistent,
+            a.nt_stagger, a.nt_dephase, a.nt_dephase_n, a.tn_big, a.tn_split, a.nt_debug, a.nt_store_aux) == \
+        (-1, 1, 1, 1, 1, 1, 8, 1, 1, 100, 2, 1, 0, 0, 0)
+    assert L.lako_tuning_set(ctypes.byref(a), b"gemm_nt_variant", 2) == 0 and L.lako_tuning_set(ctypes.byref(a), b"gemm_nt_dephase_n", 0) == 0
+    assert (a.nt_variant, a.nt_dephase_n, b.nt_variant, b.nt_dephase_n) == (2, 2, -1, 2)
+    monkeypatch.setenv("LAKO_TUNING", "gemm_nt_variant=0, gemm_tn_split = 3")
+    c = _lib.Tuning()
+    assert L.lako_tuning_init(ctypes.byref(c)) == 0 and (c.nt_variant, c.tn_split, c.nt_group_m) == (0, 3, 8)
+    for bad, rc in (("gemm_nt_variant", -1), ("nonsense=1", -1), ("gemm_nt_debug=1", -4)):
+        monkeypatch.setenv("LAKO_TUNING", bad)
+        assert L.lako_tuning_init(ctypes.byref(_lib.Tuning())) == rc, bad
+    out = subprocess.run(["nm", "-C", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert not re.search(r"\bg_(nt|tn)_\w+", out)
+    assert "lako_set_tuning" not in out
 
 
 def test_build_force_recompiles_every_source():
