@@ -1635,6 +1635,7 @@ int launch_nt(const NtArgs& a_in, const lako_tuning_t& tu, hipStream_t s) {
     return 0;
   }
   if (v == 2) launch_nt_256<T, TO>(a, tu, s);
+  else if (v == 6 && sizeof(T) == 2) launch_nt_cfg<T, TO, 2, 2, 8, 8>(a, tu, s);   // EXPERIMENT: 256x256 on 4 waves of 128x128 (hipBLASLt's MT256x256x64 MIWT8_8 shape)
   else if (v == 1) launch_nt_cfg<T, TO, 4, 2, 4, 4>(a, tu, s);
   else launch_nt_cfg<T, TO, 2, 2, 4, 4>(a, tu, s);
   return 0;

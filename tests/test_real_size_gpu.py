@@ -286,12 +286,24 @@ def test_c4_batch1_bf16_vs_oracle_and_properties(large_case):
     assert l2 == l0                                        # what sits under the mask is never read
 
 
-def test_c5_batch1_bf16_vs_oracle(c5_case):
+C5_BF16_GRAD_REL_L2 = 0.40       # worst single tensor at T5-large / 100 passages (measured 0.278; loss, logits and the global bound as at config 2 / 4)
+
+
+def test_c5_batch1_bf16_vs_oracle(c5_case, monkeypatch):
     """BASELINE config 5 at one sample (T5-large, n_passages 100, text_maxlength 200), bf16, on the path the config-5 bench line
     runs: unpadded encoder, cross-attention in the encoder-state space over the sample's ≈15 000 valid keys (csrc/xattn.hip:
     xscores / xsoftmax / xcontext / hb_* and the grouped dE product) — loss, logits and every parameter gradient against the
     oracle (src/model.py:42-51, 228-233 are N-generic; HF5 math) with the bf16 bounds of the config-2 / config-4 tests."""
-    _check_bf16(c5_case, _run_hip(c5_case, torch.bfloat16, want_xattn=True), "c5_b1_bf16")
+    got = _run_hip(c5_case, torch.bfloat16, want_xattn=True)
+    # Per-tensor bound: at 24 + 24 layers the decoder's self-attention q / k weights (gradient = a sum of 8 rank-1 terms of tiny norm)
+    # carry the most rounding noise — measured 0.278 here, 0.162 at config 4, 0.096 at config 2 — and the PROJECTED formulation on
+    # the same inputs shows the same level (checked below), so it is bf16 depth noise, not the encoder-space kernels.
+    _check_bf16(c5_case, got, "c5_b1_bf16", grad_rel=C5_BF16_GRAD_REL_L2)
+    monkeypatch.setenv("LAKO_XATTN", "0")
+    proj = _run_hip(c5_case, torch.bfloat16, want_xattn=False)
+    _check_bf16(c5_case, proj, "c5_b1_bf16_projected", grad_rel=C5_BF16_GRAD_REL_L2)
+    worst = lambda r: max(_rel_l2(r["grads"][n], g) for n, g in c5_case["grads"].items() if "SelfAttention" in n and n.startswith("decoder"))
+    assert worst(got) < 1.5 * worst(proj) + 0.02, (worst(got), worst(proj))
 
 
 # fp8 forward GEMMs (MX e4m3 operands: 3 mantissa bits per element + one power-of-two scale per 32 k) against the fp32 oracle.

@@ -149,7 +149,7 @@ def test_headbatch(ops, ref, Bz, T, H, D):
 
 
 @pytest.mark.parametrize("p", [0.0, 0.1])
-@pytest.mark.parametrize("lens,T,H,D,tol", [([333, 128, 50], 8, 12, 768, 1.5e-2), (C5[0], 8, 16, 1024, 2e-2)], ids=["base_333", "c5_20000"])
+@pytest.mark.parametrize("lens,T,H,D,tol", [([333, 128, 50], 8, 12, 768, 1.5e-2), (C5[0], 8, 16, 1024, 1e-2)], ids=["base_333", "c5_20000"])
 def test_reassociated_cross_attention_equals_projected(ops, ref, p, lens, T, H, D, tol):
     """The whole chain against the reference formulation in fp32: K = E·Wkᵀ, V = E·Wvᵀ, softmax(q·Kᵀ)·V and its autograd
     (src/model.py:286-349) — at T5-base rows with short ragged samples, and at BASELINE config 5's size: T5-large rows (16 heads,
@@ -198,7 +198,7 @@ def test_reassociated_cross_attention_equals_projected(ops, ref, p, lens, T, H, 
     ctx = torch.zeros(B * T, inner, dtype=BF, device=dev())
     ops.headbatch_nt(Cp.unflatten(2, (T, H)), W[inner:].unflatten(0, (H, 64)), ctx.view(B, T, H, 64))
     errs = {"ctx": rel_l2(ctx.float().view(B, T, H, 64), ctx_ref)}
-    assert errs["ctx"] < (1e-2 if tol < 2e-2 else tol), errs
+    assert errs["ctx"] < 1e-2, errs        # (measured at 20 000 keys: ctx 0.005, dq / dW / dE 0.005-0.006)
     # backward
     G = torch.zeros(2 * inner, D, device=dev())
     dCp = DQ[:, :R]

@@ -58,9 +58,11 @@ for variant, dephase in ([(int(v), int(dp)) for v in args.variants.split(",") fo
     ops.set_tuning("gemm_nt_persistent", 0 if 10 <= variant < 20 else 1)
     ops.set_tuning("gemm_nt_stagger", 0 if 20 <= variant < 30 else 1)
     ops.set_tuning("gemm_nt_wide_epi", 0 if 30 <= variant < 40 else 1)
-    ops.set_tuning("gemm_nt_debug", {7: 1, 8: 2, 9: 4, 14: 8, 15: 16, 11: 128 << 8, 12: 64 << 8, 13: (128 << 8) | 1}.get(variant // 10, 0))   # 7x: no K-loop DMA; 8x: every DMA hits L2 (timing experiments, wrong results)
+    dbg = {7: 1, 8: 2, 9: 4, 14: 8, 15: 16, 11: 128 << 8, 12: 64 << 8, 13: (128 << 8) | 1}.get(variant // 10, 0)   # 7x: no K-loop DMA; 8x: every DMA hits L2 (timing experiments, wrong results)
+    if dbg or os.environ.get("LAKO_LIB"):      # (the release library refuses the key: experiments need LAKO_LIB=…/liblako_hip_exp.so)
+        ops.set_tuning("gemm_nt_debug", dbg)
     ops.set_tuning("gemm_nt_group_m", {4: 0, 5: 4, 6: 16}.get(variant // 10, 8))
-    print(f"--- gemm_nt variant {variant if variant < 0 else variant % 10} (-1 auto, 0 128x128, 1 256x128, 2 256x256, 3 ring256, 4 ring128) "
+    print(f"--- gemm_nt variant {variant if variant < 0 else variant % 10} (-1 auto, 0 128x128, 1 256x128, 2 256x256 / 8 waves, 4 ring128, 6 256x256 / 4 waves) "
           f"persistent={not 10 <= variant < 20} stagger={not 20 <= variant < 30} wide_epi={not 30 <= variant < 40} "
           f"group_m={ {4: 0, 5: 4, 6: 16}.get(variant // 10, 8)}", flush=True)
     for nm, (M, Nn, K), kw in [
