@@ -25,6 +25,8 @@
 // Structure as in attn.hip: one workgroup (4 waves) per (sequence, head[, block group]); one operand side staged in LDS, the
 // other held per wave as MFMA fragments loaded straight from HBM; the score tile leaves the MFMA with the LDS-side index in
 // the accumulator registers, so it is directly the B operand of the product that contracts over that index.
+#include <algorithm>
+
 #include "attn_shared.h"
 #include "lds_image.h"
 
@@ -65,6 +67,16 @@ __device__ __forceinline__ void eload_frags(u32x4 (&f)[2], const char* base, int
     if (row < L) v = *reinterpret_cast<const u32x4*>(base + (int64_t)row * stride_b + (i * 4 + g) * 16);
     f[i] = v;
   }
+}
+
+// The same through a buffer descriptor (persistent kernels): rows [0, L) of the strided [L, 64] slice at `base`; the lane's 32-bit
+// offset row·stride + 16g is a constant of the lane, rows past L fall out of the descriptor's range (zeros) — no 64-bit per-lane
+// pointers, no branches.  `voff` = (lane & 15)·stride_b + 16·(lane >> 4), `row0` the (wave-uniform) first row.
+__device__ __forceinline__ void eload_frags_buf(u32x4 (&f)[2], const char* base, uint32_t stride_b, int row0, int L, uint32_t voff) {
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, L > 0 ? (int)((uint32_t)(L - 1) * stride_b + 128u) : 0, 0x00020000);
+  const int so = __builtin_amdgcn_readfirstlane(row0 * (int)stride_b);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) f[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff + i * 64, so, 0));
 }
 
 // tile[image row row0 + 4g + r][register side = lane & 15] = init + Σ_d X[row0 + ·][d]·Y[·][d];  roff[i]: the lane's byte
@@ -114,8 +126,8 @@ __device__ __forceinline__ f32x4 etail(int t, int g, int Lk) {
 // forward: 16 queries of one wave against the staged K / V, keys in chunks of at most 3 tile pairs (online softmax across the
 // up to three chunks of a sequence of <= 256 keys: the score tiles of a chunk are 24 registers, the kernel fits 128)
 // ---------------------------------------------------------------------------------------------------------------------
-template <bool DROP, int NPC>
-__device__ __forceinline__ void efwd_chunk(const char* Kimg, const char* Vimg, int pair0, bool last, const f32x4 (&tail)[2],
+template <bool DROP, int NPC, typename TAIL>
+__device__ __forceinline__ void efwd_chunk(const char* Kimg, const char* Vimg, int pair0, bool last, const TAIL& tail,
                                            const float* bptr, const u32x4 (&qf)[2], const ELane& el, uint32_t pblk, uint32_t dkey,
                                            const DropRow& drc, uint32_t t_hi, float& m_run, float& l_run, f32x4 (&oacc)[4]) {
   f32x4 s[2 * NPC];
@@ -214,6 +226,129 @@ __global__ __launch_bounds__(FWD_NW * 64, FWD_NW / 2) void enc_fwd_kernel(AttnAr
     request_q(qb + FWD_NW);
     // bias: tile row0, lane (query qi, group g), register r reads T[row0 + 4g + r − qi + rel_off]; the copy and the aligned
     // base are constants of the block (row0 is a multiple of 16)
+    const int i0 = 4 * g - qi + a.rel_off + EB_PADLO;
+    const float* bptr = b4 + (i0 & 3) * EB_ST + (i0 & ~3);
+    const uint32_t pblk = (uint32_t)((b * a.H + h) * QB + (qi >> 2)) * (uint32_t)KB + (uint32_t)g;
+    const DropRow drc = drop_row_consts(qi);
+    float m = -INFINITY, l = 0.f;
+    f32x4 oacc[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) oacc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define ECH(N, P0, LAST) case N: if constexpr (N <= CH) efwd_chunk<DROP, N>(Kimg, Vimg, P0, LAST, tail, bptr, qf, el, pblk, a.drop_key, drc, t_hi, m, l, oacc); break;
+    switch (n0) { ECH(1, 0, n1 == 0) ECH(2, 0, n1 == 0) ECH(3, 0, n1 == 0) ECH(4, 0, n1 == 0) default: break; }
+    switch (n1) { ECH(1, CH, n2 == 0) ECH(2, CH, n2 == 0) ECH(3, CH, n2 == 0) ECH(4, CH, n2 == 0) default: break; }
+    if constexpr (CH == 3) {
+      switch (n2) { ECH(1, 2 * CH, true) ECH(2, 2 * CH, true) default: break; }
+    }
+#undef ECH
+    l = egroup_sum(l);
+    if (qi < Lq) {
+      const float inv = 1.0f / l;
+      const float f = inv * oscale;
+      bf16_t* op = reinterpret_cast<bf16_t*>(obase + (int64_t)qi * a.ost * 2);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) store4(op + db * 16 + 4 * g, oacc[db] * f);
+      if (g == 0 && a.stats) {
+        float* st = a.stats + (((int64_t)b * a.H + h) * a.Lq + qi) * 4;
+        st[0] = m;
+        st[1] = inv;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward, PERSISTENT form (round 3).  The kernel above starts one workgroup per (sequence, head): 3 840 workgroups per config-2
+// launch, each of which stages its K / V images (a global → register → LDS round trip nothing overlaps), then walks ⌈L/16⌉ ≈ 7…13
+// query blocks with 8 waves — a second pass over the waves for 9…13 blocks with most of them idle (1.7 passes per item on the
+// benchmark's length distribution, 1.0 needed).  Here ONE 16-wave workgroup per CU walks a list of items of ONE head:
+//   * wave w owns query block w of every item (≤ 256 queries = 16 blocks: always one pass; waves past the item's last block only
+//     help with the staging);
+//   * the K / V images of item i + 1 arrive by LDS-DMA (buffer_load … lds, the swizzle applied to the per-lane SOURCE address,
+//     rows past the sequence's end zero-filled by the descriptor's range check) into the second image pair while item i is
+//     computed; one s_waitcnt + one barrier per item;
+//   * the four shifted bias copies are staged once per workgroup (the head never changes), Q fragments are requested an item ahead.
+// Same arithmetic per query block as the kernel above (efwd_chunk, the same chunking): results are bit-identical.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int PF_NW = 16;
+// LDS: 2 × (K image | V image) | 4 bias copies
+__host__ __device__ constexpr int efwdp_lds(int rows) { return 4 * rows * EROW + 4 * EB_ST * 4; }
+
+template <bool DROP>
+__global__ __launch_bounds__(PF_NW * 64) void enc_fwd_p_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int R = a.chunk_rows;                       // image rows (multiple of 32, >= every sequence's key count rounded up to 32)
+  float* b4 = reinterpret_cast<float*>(smem + 4 * R * EROW);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, l15 = lane & 15;
+  const int h = blockIdx.x % a.H, slot = blockIdx.x / a.H, nslots = gridDim.x / a.H;
+  if (slot >= a.Bn) return;
+  estage_bias<PF_NW * 64>(b4, a.rel_bias, h, a.R, false);
+  const ELane el = elane(lane);
+  const uint32_t t_hi = a.drop_t16 << 16;
+  const int KB = (a.Lk + 3) >> 2, QB = (a.Lq + 3) >> 2;
+  const float oscale = DROP ? a.drop_scale : 1.0f;
+  const int64_t hoff = (int64_t)h * 64;
+  constexpr int CH = DROP ? 3 : 4;
+  // DMA pieces (1 KiB = 8 image rows) of an image pair: K rows, then V rows; this wave issues pieces wave, wave + 16, … (always all
+  // of them, so that the image rows past a short sequence's end are rewritten with zeros).  Lane → (row, physical chunk) of the
+  // piece; its source is the logical chunk that the swizzle puts there.
+  const int ppi = R >> 3;                           // pieces per image
+  auto item_geom = [&](int b, int& q0, int& k0, int& Lq, int& Lk) {
+    q0 = a.q_off ? __builtin_amdgcn_readfirstlane(a.q_off[b]) : 0;
+    k0 = a.k_off ? __builtin_amdgcn_readfirstlane(a.k_off[b]) : 0;
+    Lq = a.q_off ? __builtin_amdgcn_readfirstlane(a.q_off[b + 1]) - q0 : a.Lq;
+    Lk = a.k_off ? __builtin_amdgcn_readfirstlane(a.k_off[b + 1]) - k0 : a.Lk;
+  };
+  auto issue = [&](int b, char* buf) {
+    int q0, k0, Lq, Lk;
+    item_geom(b, q0, k0, Lq, Lk);
+    const char* kbase = a.k + ((a.k_off ? (int64_t)k0 * a.kst : (int64_t)b * a.ksb) + hoff) * 2;
+    const char* vbase = a.v + ((a.k_off ? (int64_t)k0 * a.vst : (int64_t)b * a.vsb) + hoff) * 2;
+    const uint32_t kstb = (uint32_t)a.kst * 2u, vstb = (uint32_t)a.vst * 2u;
+    const auto krs = lds_dma_rsrc(kbase, Lk > 0 ? (uint32_t)(Lk - 1) * kstb + 128u : 0u);
+    const auto vrs = lds_dma_rsrc(vbase, Lk > 0 ? (uint32_t)(Lk - 1) * vstb + 128u : 0u);
+    int le = lane;
+    asm volatile("" : "+v"(le));                    // rebuilt per call: as loop invariants the offsets would stay live across the items
+    const int pr = le >> 3, pc = le & 7;
+    for (int p = wave; p < 2 * ppi; p += PF_NW) {
+      const bool isv = p >= ppi;
+      const int row = (isv ? p - ppi : p) * 8 + pr;
+      const uint32_t voff = (uint32_t)row * (isv ? vstb : kstb) + (uint32_t)eswz(pc, row) * 16u;   // eswz is its own inverse
+      lds_dma16(buf + (isv ? R * EROW : 0) + (row - pr) * EROW, isv ? vrs : krs, row < Lk ? voff : 0x80000000u);
+    }
+  };
+  u32x4 qf_next[2];
+  auto request_q = [&](int b) {
+    int q0, k0, Lq, Lk;
+    item_geom(b, q0, k0, Lq, Lk);
+    const char* qbase = a.q + ((a.q_off ? (int64_t)q0 * a.qst : (int64_t)b * a.qsb) + hoff) * 2;
+    eload_frags_buf(qf_next, qbase, (uint32_t)a.qst * 2u, wave * 16, Lq, (uint32_t)l15 * (uint32_t)a.qst * 2u + (uint32_t)g * 16u);
+  };
+  issue(slot, smem);
+  request_q(slot);
+  int cur = 0;
+  for (int b = slot; b < a.Bn; b += nslots) {
+    char* Kimg = smem + cur * 2 * R * EROW;
+    char* Vimg = Kimg + R * EROW;
+    u32x4 qf[2] = {qf_next[0], qf_next[1]};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of item b (and its Q fragments) have landed
+    __syncthreads();                                         // … everybody's; and every wave is done with the other image pair
+    if (b + nslots < a.Bn) {
+      issue(b + nslots, smem + (cur ^ 1) * 2 * R * EROW);
+      request_q(b + nslots);
+    }
+    cur ^= 1;
+    int q0, k0, Lq, Lk;
+    item_geom(b, q0, k0, Lq, Lk);
+    if (wave * 16 >= Lq || Lk <= 0) continue;               // (wave-uniform) no query block for this wave / an empty sequence
+    char* obase = a.out + ((a.q_off ? (int64_t)q0 * a.ost : (int64_t)b * a.osb) + hoff) * 2;
+    const int np = (Lk + 31) >> 5;
+    // (−inf for the keys past the sequence's end, built where the last chunk uses it: as two live vectors it costs 8 registers)
+    struct { int np, g, Lk; __device__ __forceinline__ f32x4 operator[](int u) const { return etail(2 * np - 2 + u, g, Lk); } } tail{np, g, Lk};
+    const int n0 = min(np, CH), n1 = min(max(np - CH, 0), CH), n2 = max(np - 2 * CH, 0);
+    const int qi = wave * 16 + l15;
     const int i0 = 4 * g - qi + a.rel_off + EB_PADLO;
     const float* bptr = b4 + (i0 & 3) * EB_ST + (i0 & ~3);
     const uint32_t pblk = (uint32_t)((b * a.H + h) * QB + (qi >> 2)) * (uint32_t)KB + (uint32_t)g;
@@ -417,6 +552,190 @@ __global__ __launch_bounds__(256, 2) void enc_bwd_dq_kernel(AttnArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// backward, dQ pass, PERSISTENT form (round 3) — as enc_fwd_p_kernel: one 16-wave workgroup per CU walks the sequences of ONE
+// head, wave w owns query block w of every item, the K / V images of the next item arrive by LDS-DMA under the current item's
+// arithmetic.  A wave's tiles (query block w, key tile t) lie on tile diagonal t − w whatever the item, so the bias-gradient
+// accumulators are indexed by t alone (16 × 2 registers, summed over all the workgroup's items) and flushed once at the end.
+// The Q / dO / O fragments and the row statistics of the item are requested right after the barrier, before the next item's DMA
+// is issued (an item ahead they would cost 19 registers across the key loop; ≤ 128 here).  Same arithmetic per query block as
+// enc_bwd_dq_kernel; the bias gradient is summed in another order (float atomics anyway).
+// ---------------------------------------------------------------------------------------------------------------------
+// LDS: 2 × (K image | V image) | 4 bias copies | drel_l[512]
+__host__ __device__ constexpr int ebwd0p_lds(int rows) { return 4 * rows * EROW + 4 * EB_ST * 4 + 512 * 4; }
+
+template <bool DROP>
+__global__ __launch_bounds__(PF_NW * 64) void enc_bwd_dq_p_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int R = a.chunk_rows;
+  float* b4 = reinterpret_cast<float*>(smem + 4 * R * EROW);
+  float* drel_l = b4 + 4 * EB_ST;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, l15 = lane & 15;
+  const int h = blockIdx.x % a.H, slot = blockIdx.x / a.H, nslots = gridDim.x / a.H;
+  if (slot >= a.Bn) return;
+  const bool want_drel = a.drel != nullptr;
+  for (int i = threadIdx.x; i < 512; i += PF_NW * 64) drel_l[i] = 0.f;
+  estage_bias<PF_NW * 64>(b4, a.rel_bias, h, a.R, false);
+  const ELane el = elane(lane);
+  const uint32_t t_hi = a.drop_t16 << 16;
+  const int KB = (a.Lk + 3) >> 2, QB = (a.Lq + 3) >> 2;
+  const float dscale = DROP ? a.drop_scale : 1.0f, inv_dscale = 1.0f / dscale;
+  const int64_t hoff = (int64_t)h * 64;
+  const int ppi = R >> 3;
+  // acc_lo[t]: lane j of a 16-lane row sums the tile's elements with register − query = −j; the elements that wrap around the row
+  // (register − query = 16 − j, lanes 13..15 only) of the FOUR tiles 4u … 4u + 3 share acc_hi[u]: tile 4u + k's three lanes are
+  // moved down by 3k lanes (one more DPP shift; the lanes it leaves are zero), 4 registers instead of 16
+  float acc_lo[16], acc_hi[4];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) acc_lo[t] = 0.f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc_hi[t] = 0.f;
+  auto item_geom = [&](int b, int& q0, int& k0, int& Lq, int& Lk) {
+    q0 = a.q_off ? __builtin_amdgcn_readfirstlane(a.q_off[b]) : 0;
+    k0 = a.k_off ? __builtin_amdgcn_readfirstlane(a.k_off[b]) : 0;
+    Lq = a.q_off ? __builtin_amdgcn_readfirstlane(a.q_off[b + 1]) - q0 : a.Lq;
+    Lk = a.k_off ? __builtin_amdgcn_readfirstlane(a.k_off[b + 1]) - k0 : a.Lk;
+  };
+  auto issue = [&](int b, char* buf) {
+    int q0, k0, Lq, Lk;
+    item_geom(b, q0, k0, Lq, Lk);
+    const char* kbase = a.k + ((a.k_off ? (int64_t)k0 * a.kst : (int64_t)b * a.ksb) + hoff) * 2;
+    const char* vbase = a.v + ((a.k_off ? (int64_t)k0 * a.vst : (int64_t)b * a.vsb) + hoff) * 2;
+    const uint32_t kstb = (uint32_t)a.kst * 2u, vstb = (uint32_t)a.vst * 2u;
+    const auto krs = lds_dma_rsrc(kbase, Lk > 0 ? (uint32_t)(Lk - 1) * kstb + 128u : 0u);
+    const auto vrs = lds_dma_rsrc(vbase, Lk > 0 ? (uint32_t)(Lk - 1) * vstb + 128u : 0u);
+    int le = lane;
+    asm volatile("" : "+v"(le));
+    const int pr = le >> 3, pc = le & 7;
+    for (int p = wave; p < 2 * ppi; p += PF_NW) {
+      const bool isv = p >= ppi;
+      const int row = (isv ? p - ppi : p) * 8 + pr;
+      const uint32_t voff = (uint32_t)row * (isv ? vstb : kstb) + (uint32_t)eswz(pc, row) * 16u;
+      lds_dma16(buf + (isv ? R * EROW : 0) + (row - pr) * EROW, isv ? vrs : krs, row < Lk ? voff : 0x80000000u);
+    }
+  };
+  issue(slot, smem);
+  int cur = 0;
+  for (int b = slot; b < a.Bn; b += nslots) {
+    char* Kimg = smem + cur * 2 * R * EROW;
+    char* Vimg = Kimg + R * EROW;
+    int q0, k0, Lq, Lk;
+    item_geom(b, q0, k0, Lq, Lk);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const bool mine = wave * 16 < Lq && Lk > 0;              // (wave-uniform)
+    const int qi = wave * 16 + l15;
+    u32x4 qf[2], dof[2], of[2];
+    float st_m = 0.f, st_il = 0.f;
+    float* stats = a.stats + ((int64_t)b * a.H + h) * a.Lq * 4;
+    if (mine) {
+      const char* qbase = a.q + ((a.q_off ? (int64_t)q0 * a.qst : (int64_t)b * a.qsb) + hoff) * 2;
+      const char* obase = a.o + ((a.q_off ? (int64_t)q0 * a.ost : (int64_t)b * a.osb) + hoff) * 2;
+      const char* dobase = a.dout + ((a.q_off ? (int64_t)q0 * a.ost : (int64_t)b * a.osb) + hoff) * 2;
+      eload_frags_buf(qf, qbase, (uint32_t)a.qst * 2u, wave * 16, Lq, (uint32_t)l15 * (uint32_t)a.qst * 2u + (uint32_t)g * 16u);
+      eload_frags_buf(dof, dobase, (uint32_t)a.ost * 2u, wave * 16, Lq, (uint32_t)l15 * (uint32_t)a.ost * 2u + (uint32_t)g * 16u);
+      eload_frags_buf(of, obase, (uint32_t)a.ost * 2u, wave * 16, Lq, (uint32_t)l15 * (uint32_t)a.ost * 2u + (uint32_t)g * 16u);
+      if (qi < Lq) {
+        st_m = stats[qi * 4];
+        st_il = stats[qi * 4 + 1];
+      }
+    }
+    if (b + nslots < a.Bn) issue(b + nslots, smem + (cur ^ 1) * 2 * R * EROW);
+    cur ^= 1;
+    if (!mine) continue;
+    char* dqbase = a.dq + ((a.q_off ? (int64_t)q0 * a.qst : (int64_t)b * a.qsb) + hoff) * 2;
+    const int np = (Lk + 31) >> 5;
+    // δ = rowsum(dO ∘ O), handed to the dK/dV pass through the statistics
+    float part = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      bf16x8 dv = __builtin_bit_cast(bf16x8, dof[i]), ov = __builtin_bit_cast(bf16x8, of[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) part += (float)dv[e] * (float)ov[e];
+    }
+    const float delta = egroup_sum(part);
+    if (qi < Lq && g == 0) stats[qi * 4 + 2] = delta;
+    const float lse2 = st_il > 0.f ? st_m * LOG2E - __builtin_amdgcn_logf(st_il * dscale) : INFINITY;
+    const float ndel = -delta * inv_dscale;
+    const int i0 = 4 * g - qi + a.rel_off + EB_PADLO;
+    int boff = (i0 & 3) * EB_ST + (i0 & ~3);
+    asm volatile("" : "+v"(boff));
+    const float* bptr = b4 + boff;
+    const uint32_t pblk = (uint32_t)((b * a.H + h) * QB + (qi >> 2)) * (uint32_t)KB + (uint32_t)g;
+    const DropRow drc = drop_row_consts(qi);
+    f32x4 dq[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) dq[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tp = 0; tp < 8; ++tp) {
+      if (tp < np) {
+        f32x4 ds[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int t = 2 * tp + u, row0 = t * 16;
+          f32x4 init = *reinterpret_cast<const f32x4*>(bptr + row0);
+          if (tp == np - 1) init += etail(t, g, Lk);
+          const f32x4 sv = escore(Kimg, row0, qf, el.roff, init);
+          f32x4 dp = escore(Vimg, row0, dof, el.roff, f32x4{ndel, ndel, ndel, ndel});
+          f32x4 p;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[r], LOG2E, -lse2));
+          if (DROP) {
+            bool kp[4];
+            drop_keep_row(drop_base(pblk + (uint32_t)(t * 4), a.drop_key), drc, t_hi, kp);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dp[r] = kp[r] ? dp[r] : ndel;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ds[u][r] = p[r] * dp[r];
+          acc_lo[t] += ds[u][0] + edpp<0x101>(ds[u][1]) + edpp<0x102>(ds[u][2]) + edpp<0x103>(ds[u][3]);
+          const float hi = edpp<0x11F>(ds[u][1]) + edpp<0x11E>(ds[u][2]) + edpp<0x11D>(ds[u][3]);    // lanes 13..15, 0 elsewhere
+          float hs = hi;                                           // row_shl:3k — lane j reads lane j + 3k (t is static after unrolling)
+          switch (t & 3) {
+            case 1: hs = edpp<0x103>(hi); break;
+            case 2: hs = edpp<0x106>(hi); break;
+            case 3: hs = edpp<0x109>(hi); break;
+            default: break;
+          }
+          acc_hi[t >> 2] += hs;
+        }
+        epv(dq, ds[0], ds[1], Kimg, tp * 32, el.toff);              // dQᵀ += Kᵀ·dSᵀ
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (qi < Lq) {
+      bf16_t* op = reinterpret_cast<bf16_t*>(dqbase + (int64_t)qi * a.qst * 2);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) store4(op + db * 16 + 4 * g, dq[db]);
+    }
+  }
+  if (want_drel) {
+    // accumulator t of wave w, lane (j = lane & 15, g): lo sums key − query = 16·(t − w) + 4g − j; the wrapped elements of tile
+    // t = 4u + k sit in acc_hi[u] at lane j − 3k (j = 13..15) and belong to key − query = 16·(t − w) + 4g + 16 − j
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int d0 = 16 * (t - wave) + 4 * g - l15 + a.rel_off;
+      if (acc_lo[t] != 0.f && d0 >= 0 && d0 < a.R) atomicAdd(&drel_l[d0], acc_lo[t]);
+    }
+    if (l15 >= 4) {
+      const int k = (15 - l15) / 3, j = l15 + 3 * k;               // lanes 13..15 → k 0, 10..12 → 1, 7..9 → 2, 4..6 → 3
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int d1 = 16 * (4 * u + k - wave) + 4 * g + 16 - j + a.rel_off;
+        if (acc_hi[u] != 0.f && d1 >= 0 && d1 < a.R) atomicAdd(&drel_l[d1], acc_hi[u]);
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.R; i += PF_NW * 64) {
+      const float v = drel_l[i];
+      if (v != 0.f) atomicAdd(a.drel + (int64_t)h * a.R + i, v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // backward, dK/dV pass: Q / dO in LDS, a wave owns 16 keys; S[query][key] and dP tiles → P̃, dS → dKᵀ += Qᵀ·dS, dVᵀ += dOᵀ·P̃
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int DKV_NW = 4;     // (8 waves on <= 128 registers measured 10 % slower: no room to request the next key block ahead)
@@ -540,6 +859,154 @@ __global__ __launch_bounds__(DKV_NW * 64, 2) void enc_bwd_dkv_kernel(AttnArgs a)
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// backward, dK/dV pass, PERSISTENT form (round 3) — the structure of enc_fwd_p_kernel: one 16-wave workgroup per CU walks the
+// sequences of ONE head, wave w owns key block w of every item (≤ 256 keys: one pass), the Q / dO images and the raw per-query
+// statistics of the next item arrive by LDS-DMA into the second image pair under the current item's arithmetic.  At the top of an
+// item: wait + barrier (images landed, everybody done with the other pair) → request this wave's K / V fragments → issue the next
+// item's DMA → convert the raw statistics to (lse2, −δ/scale) → barrier → arithmetic.  (K / V fragments requested an item ahead
+// cost 16 registers across the key loop, and with ≤ 128 registers the spill reloads — vector-memory operations in the same in-order
+// counter — made every item wait for the DMA it had just issued.)  The reversed bias copies are staged once per workgroup.
+// Same arithmetic per key block as enc_bwd_dkv_kernel: bit-identical results.
+// ---------------------------------------------------------------------------------------------------------------------
+// LDS: 2 × (Q image | dO image) | 4 reversed bias copies | 2 × raw statistics [R][4] | lse2[R] | −δ/scale[R]
+__host__ __device__ constexpr int ebwd1p_lds(int rows) { return 4 * rows * EROW + 4 * EB_ST * 4 + 2 * rows * 16 + 2 * rows * 4; }
+
+template <bool DROP>
+__global__ __launch_bounds__(PF_NW * 64) void enc_bwd_dkv_p_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int R = a.chunk_rows;                       // image rows: every sequence's query count rounded up to 32
+  float* b4 = reinterpret_cast<float*>(smem + 4 * R * EROW);
+  float* raw_l = b4 + 4 * EB_ST;                    // [2][R][4]
+  float* lse_l = raw_l + 2 * R * 4;
+  float* ndel_l = lse_l + R;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, l15 = lane & 15;
+  const int h = blockIdx.x % a.H, slot = blockIdx.x / a.H, nslots = gridDim.x / a.H;
+  if (slot >= a.Bn) return;
+  estage_bias<PF_NW * 64>(b4, a.rel_bias, h, a.R, true);
+  const ELane el = elane(lane);
+  const uint32_t t_hi = a.drop_t16 << 16;
+  const int KB = (a.Lk + 3) >> 2, QB = (a.Lq + 3) >> 2;
+  const float dscale = DROP ? a.drop_scale : 1.0f, inv_dscale = 1.0f / dscale;
+  const int64_t hoff = (int64_t)h * 64;
+  const int last = a.R - 1 + EB_PADLO + 36;
+  const int ppi = R >> 3;
+  auto item_geom = [&](int b, int& q0, int& k0, int& Lq, int& Lk) {
+    q0 = a.q_off ? __builtin_amdgcn_readfirstlane(a.q_off[b]) : 0;
+    k0 = a.k_off ? __builtin_amdgcn_readfirstlane(a.k_off[b]) : 0;
+    Lq = a.q_off ? __builtin_amdgcn_readfirstlane(a.q_off[b + 1]) - q0 : a.Lq;
+    Lk = a.k_off ? __builtin_amdgcn_readfirstlane(a.k_off[b + 1]) - k0 : a.Lk;
+  };
+  auto issue = [&](int b, int pair) {               // Q rows | dO rows | raw statistics of item b → image / statistics pair `pair`
+    int q0, k0, Lq, Lk;
+    item_geom(b, q0, k0, Lq, Lk);
+    char* buf = smem + pair * 2 * R * EROW;
+    const char* qbase = a.q + ((a.q_off ? (int64_t)q0 * a.qst : (int64_t)b * a.qsb) + hoff) * 2;
+    const char* dobase = a.dout + ((a.q_off ? (int64_t)q0 * a.ost : (int64_t)b * a.osb) + hoff) * 2;
+    const uint32_t qstb = (uint32_t)a.qst * 2u, ostb = (uint32_t)a.ost * 2u;
+    const auto qrs = lds_dma_rsrc(qbase, Lq > 0 ? (uint32_t)(Lq - 1) * qstb + 128u : 0u);
+    const auto drs = lds_dma_rsrc(dobase, Lq > 0 ? (uint32_t)(Lq - 1) * ostb + 128u : 0u);
+    int le = lane;
+    asm volatile("" : "+v"(le));
+    const int pr = le >> 3, pc = le & 7;
+    for (int p = wave; p < 2 * ppi; p += PF_NW) {
+      const bool isd = p >= ppi;
+      const int row = (isd ? p - ppi : p) * 8 + pr;
+      const uint32_t voff = (uint32_t)row * (isd ? ostb : qstb) + (uint32_t)eswz(pc, row) * 16u;
+      lds_dma16(buf + (isd ? R * EROW : 0) + (row - pr) * EROW, isd ? drs : qrs, row < Lq ? voff : 0x80000000u);
+    }
+    if (wave * 64 < R) {                            // statistics rows [64·wave, 64·wave + 64): 16 bytes per query, contiguous
+      const auto srs = lds_dma_rsrc(a.stats + ((int64_t)b * a.H + h) * a.Lq * 4, (uint32_t)max(Lq, 0) * 16u);
+      lds_dma16(raw_l + (pair * R + wave * 64) * 4, srs, (uint32_t)(wave * 64 + le) * 16u);
+    }
+  };
+  issue(slot, 0);
+  int cur = 0;
+  for (int b = slot; b < a.Bn; b += nslots) {
+    char* Qimg = smem + cur * 2 * R * EROW;
+    char* dOimg = Qimg + R * EROW;
+    int q0, k0, Lq, Lk;
+    item_geom(b, q0, k0, Lq, Lk);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of item b have landed (its stores of the last item are out)
+    __syncthreads();                                         // … everybody's; and every wave is done with the other pair and with lse / −δ
+    const bool mine = wave * 16 < Lk;                        // (wave-uniform) this wave's key block exists
+    u32x4 kf[2], vf[2];
+    if (mine) {
+      const char* kbase = a.k + ((a.k_off ? (int64_t)k0 * a.kst : (int64_t)b * a.ksb) + hoff) * 2;
+      const char* vbase = a.v + ((a.k_off ? (int64_t)k0 * a.vst : (int64_t)b * a.vsb) + hoff) * 2;
+      eload_frags_buf(kf, kbase, (uint32_t)a.kst * 2u, wave * 16, Lk, (uint32_t)l15 * (uint32_t)a.kst * 2u + (uint32_t)g * 16u);
+      eload_frags_buf(vf, vbase, (uint32_t)a.vst * 2u, wave * 16, Lk, (uint32_t)l15 * (uint32_t)a.vst * 2u + (uint32_t)g * 16u);
+    }
+    if (b + nslots < a.Bn) issue(b + nslots, cur ^ 1);
+    if ((int)threadIdx.x < R) {                              // rows past Lq arrive as zeros: p = exp2(−inf) = 0 there
+      const f32x4 st4 = *reinterpret_cast<const f32x4*>(raw_l + (cur * R + threadIdx.x) * 4);
+      lse_l[threadIdx.x] = st4[1] > 0.f ? st4[0] * LOG2E - __builtin_amdgcn_logf(st4[1] * dscale) : INFINITY;
+      ndel_l[threadIdx.x] = -st4[2] * inv_dscale;
+    }
+    __syncthreads();
+    cur ^= 1;
+    if (!mine) continue;
+    char* dkbase = a.dk + ((a.k_off ? (int64_t)k0 * a.kst : (int64_t)b * a.ksb) + hoff) * 2;
+    char* dvbase = a.dv + ((a.k_off ? (int64_t)k0 * a.vst : (int64_t)b * a.vsb) + hoff) * 2;
+    const int npq = (max(Lq, 1) + 31) >> 5;
+    const int ki = wave * 16 + l15;
+    const float kadd_lane = ki < Lk ? 0.f : -INFINITY;
+    f32x4 dkacc[4], dvacc[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      dkacc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dvacc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int j0 = last - (ki - 4 * g + a.rel_off + EB_PADLO);
+    const float* bptr = b4 + (j0 & 3) * EB_ST + (j0 & ~3);
+    const DropCol dcc = drop_col_consts(ki);
+    const uint32_t cblk = (uint32_t)((b * a.H + h) * QB + g) * (uint32_t)KB + (uint32_t)(ki >> 2);
+    const f32x4 kaddv = {kadd_lane, kadd_lane, kadd_lane, kadd_lane};
+    uint32_t cblk_tp = cblk;
+    const uint32_t kb4 = 4u * (uint32_t)KB;
+    for (int tp = 0; tp < npq; ++tp, cblk_tp += 2 * kb4) {
+      f32x4 pt[2], ds[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int row0 = tp * 32 + u * 16;
+        const f32x4 init = *reinterpret_cast<const f32x4*>(bptr + row0) + kaddv;
+        const f32x4 nd = *reinterpret_cast<const f32x4*>(ndel_l + row0 + 4 * g);
+        const f32x4 l2 = *reinterpret_cast<const f32x4*>(lse_l + row0 + 4 * g);
+        const f32x4 sv = escore(Qimg, row0, kf, el.roff, init);
+        f32x4 dp = escore(dOimg, row0, vf, el.roff, nd);
+        f32x4 p;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[r], LOG2E, -l2[r]));
+        pt[u] = p;
+        if (DROP) {
+          bool kp[4];
+          drop_keep_col(drop_base(cblk_tp + (uint32_t)u * kb4, a.drop_key), dcc, t_hi, kp);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            pt[u][r] = kp[r] ? p[r] : 0.f;
+            dp[r] = kp[r] ? dp[r] : nd[r];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ds[u][r] = p[r] * dp[r];
+      }
+      epv(dkacc, ds[0], ds[1], Qimg, tp * 32, el.toff);       // dKᵀ += Qᵀ·dS
+      epv(dvacc, pt[0], pt[1], dOimg, tp * 32, el.toff);      // dVᵀ += dOᵀ·P̃
+    }
+    if (ki < Lk) {
+      bf16_t* kp_ = reinterpret_cast<bf16_t*>(dkbase + (int64_t)ki * a.kst * 2);
+      bf16_t* vp_ = reinterpret_cast<bf16_t*>(dvbase + (int64_t)ki * a.vst * 2);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        store4(kp_ + db * 16 + 4 * g, dkacc[db]);
+        store4(vp_ + db * 16 + 4 * g, dvacc[db]);
+      }
+    }
+  }
+}
+
 template <typename K>
 void eset_lds(K kern, int bytes, int& cur) {
   if (bytes <= cur) return;
@@ -585,6 +1052,17 @@ int lako_attn_enc_fwd(AttnArgs& a, hipStream_t s) {
 #endif
   a.chunk_rows = ((a.Lk + 31) / 32) * 32;
   const int nqb = (a.Lq + 15) / 16;
+  // persistent form: one 16-wave workgroup per CU walking the sequences of one head (LAKO_ATTN_PERSIST=0: the kernel below, A/B)
+  // (LAKO_ATTN_PERSIST: 0 never, 2 whenever the shape allows — tests; read per call so that a test can switch it)
+  const char* pe = getenv("LAKO_ATTN_PERSIST");
+  const int persist = pe ? atoi(pe) : 1;
+  if (persist && a.H <= 256 && ((int64_t)a.Bn * a.H >= 1024 || persist == 2) && (int64_t)a.kst * 2 * 256 < (1ll << 31) &&
+      (int64_t)a.vst * 2 * 256 < (1ll << 31)) {
+    const int nslots = std::min(a.Bn, std::max(1, 256 / a.H));
+    const int lds = efwdp_lds(a.chunk_rows);
+    EDISPATCH(enc_fwd_p_kernel, PF_NW * 64, a.drop_t16 != 0, dim3(a.H * nslots), lds, s, a);
+    return 0;
+  }
   a.blocks_per_wg = eblocks_per_wg(nqb, (int64_t)a.Bn * a.H, FWD_NW);
   const int lds = efwd_lds(a.chunk_rows);
   const dim3 grid((nqb + a.blocks_per_wg - 1) / a.blocks_per_wg, a.H, a.Bn);
@@ -601,13 +1079,21 @@ int lako_attn_enc_bwd(AttnArgs& a, hipStream_t s) {
   {  // dQ pass: every query block of a sequence in one workgroup, several batch rows per workgroup (bias gradient in registers)
     AttnArgs q = a;
     q.chunk_rows = ((a.Lk + 31) / 32) * 32;
-    const int64_t wgs = (int64_t)a.Bn * a.H;
-    static const int wg_target = getenv("LAKO_ATTN_WGS") ? atoi(getenv("LAKO_ATTN_WGS")) : 1024;
-    q.bn_per_wg = (int)(wgs / wg_target > 1 ? wgs / wg_target : 1);
-    if (q.bn_per_wg > OFFS_MAX - 1) q.bn_per_wg = OFFS_MAX - 1;
-    const int lds = ebwd0_lds(q.chunk_rows);
-    const dim3 grid(1, a.H, (a.Bn + q.bn_per_wg - 1) / q.bn_per_wg);
-    EDISPATCH(enc_bwd_dq_kernel, 256, a.drop_t16 != 0, grid, lds, s, q);
+    const char* pe = getenv("LAKO_ATTN_PERSIST");
+    const int persist = pe ? atoi(pe) : 1;
+    if (persist && a.H <= 256 && ((int64_t)a.Bn * a.H >= 1024 || persist == 2) && (int64_t)a.kst * 2 * 256 < (1ll << 31) &&
+        (int64_t)a.vst * 2 * 256 < (1ll << 31) && !(persist & 8)) {
+      const int nslots = std::min(a.Bn, std::max(1, 256 / a.H));
+      EDISPATCH(enc_bwd_dq_p_kernel, PF_NW * 64, a.drop_t16 != 0, dim3(a.H * nslots), ebwd0p_lds(q.chunk_rows), s, q);
+    } else {
+      const int64_t wgs = (int64_t)a.Bn * a.H;
+      static const int wg_target = getenv("LAKO_ATTN_WGS") ? atoi(getenv("LAKO_ATTN_WGS")) : 1024;
+      q.bn_per_wg = (int)(wgs / wg_target > 1 ? wgs / wg_target : 1);
+      if (q.bn_per_wg > OFFS_MAX - 1) q.bn_per_wg = OFFS_MAX - 1;
+      const int lds = ebwd0_lds(q.chunk_rows);
+      const dim3 grid(1, a.H, (a.Bn + q.bn_per_wg - 1) / q.bn_per_wg);
+      EDISPATCH(enc_bwd_dq_kernel, 256, a.drop_t16 != 0, grid, lds, s, q);
+    }
   }
 #ifdef LAKO_EXPERIMENTS
   if (a.dbg_flags & 512) return 0;
@@ -617,6 +1103,15 @@ dkv_pass:
     AttnArgs k = a;
     k.chunk_rows = ((a.Lq + 31) / 32) * 32;
     const int nkb = (a.Lk + 15) / 16;
+    const char* pe = getenv("LAKO_ATTN_PERSIST");
+    const int persist = pe ? atoi(pe) : 1;
+    if (persist && a.H <= 256 && ((int64_t)a.Bn * a.H >= 1024 || persist == 2) && (int64_t)a.qst * 2 * 256 < (1ll << 31) &&
+        (int64_t)a.ost * 2 * 256 < (1ll << 31) && !(persist & 4)) {
+      const int nslots = std::min(a.Bn, std::max(1, 256 / a.H));
+      const int lds = ebwd1p_lds(k.chunk_rows);
+      EDISPATCH(enc_bwd_dkv_p_kernel, PF_NW * 64, a.drop_t16 != 0, dim3(a.H * nslots), lds, s, k);
+      return 0;
+    }
     k.blocks_per_wg = eblocks_per_wg(nkb, (int64_t)a.Bn * a.H, DKV_NW);
     const int lds = ebwd1_lds(k.chunk_rows);
     const dim3 grid((nkb + k.blocks_per_wg - 1) / k.blocks_per_wg, a.H, a.Bn);

@@ -375,9 +375,16 @@ def make_attn(case, T):
     return q, k, v, rel, rel_off, km, causal, drop
 
 
-@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("dt", ["f32", "bf16", "bf16_persistent"])
 @pytest.mark.parametrize("case", ATTN_CASES, ids=[c[0] for c in ATTN_CASES])
-def test_attention(ops, ref, dt, case):
+def test_attention(ops, ref, dt, case, monkeypatch):
+    if dt == "bf16_persistent":      # the encoder fast path's persistent kernels (backward here; forward: test_attention_fast_path_forward)
+        if not case[0].startswith("enc_fast"):
+            pytest.skip("persistent kernels serve the encoder fast path only")
+        monkeypatch.setenv("LAKO_ATTN_PERSIST", "2")
+        dt = "bf16"
+    else:
+        monkeypatch.setenv("LAKO_ATTN_PERSIST", "0")
     T = DT[dt]
     q, k, v, rel, rel_off, km, causal, drop = make_attn(case, T)
     Bn, Lq, H, dk = q.shape
@@ -423,10 +430,13 @@ def test_attention(ops, ref, dt, case):
         close(drel, drelr, T, f"attn_bwd drel {case[0]} {dt}", k=4)
 
 
+@pytest.mark.parametrize("persist", ["0", "2"], ids=["per_item", "persistent"])
 @pytest.mark.parametrize("case", [c for c in ATTN_CASES if c[0].startswith("enc_fast")], ids=lambda c: c[0])
-def test_attention_fast_path_forward(ops, ref, case):
+def test_attention_fast_path_forward(ops, ref, case, persist, monkeypatch):
     """Forward of the fast path (bf16, no score capture — test_attention's forward captures scores and therefore runs the generic
-    kernel): outputs and softmax statistics against the fp32 double, dropout included (same integer recipe)."""
+    kernel): outputs and softmax statistics against the fp32 double, dropout included (same integer recipe) — the kernel with one
+    workgroup per (sequence, head) and the persistent kernel (LDS-DMA prefetch of the next item's K / V images)."""
+    monkeypatch.setenv("LAKO_ATTN_PERSIST", persist)
     T = torch.bfloat16
     q, k, v, rel, rel_off, km, causal, drop = make_attn(case, T)
     Bn, Lq, H, dk = q.shape
@@ -439,6 +449,54 @@ def test_attention_fast_path_forward(ops, ref, case):
     close(stg[..., 0], st[..., 0], T, f"fast rowmax {case[0]}")
     close(stg[..., 1], st[..., 1], T, f"fast 1/rowsum {case[0]}", k=2)
     close(out, outr, T, f"fast attn_fwd out {case[0]}")
+
+
+@pytest.mark.parametrize("drop", [None, (0.1, 21, 8)], ids=["nodrop", "drop"])
+def test_attention_persistent_kernels_equal_per_item_kernels(ops, drop, monkeypatch):
+    """The persistent forward (one 16-wave workgroup per CU walking the sequences of a head, next item's images by LDS-DMA) runs the
+    same arithmetic per query block as the kernel with one workgroup per (sequence, head): bit-identical outputs and statistics —
+    on ragged packed sequences incl. empty ones, one-token ones, more sequences than a workgroup's first pass (several items per
+    workgroup, both image pairs in use), 13 heads (a head count that does not divide the CU count)."""
+    T = torch.bfloat16
+    H, dk, Lmax = 13, 64, 200
+    g = torch.Generator().manual_seed(5)
+    lens = torch.randint(1, Lmax + 1, (70,), generator=g).tolist()
+    lens[3], lens[17], lens[40], lens[69] = 0, 1, 200, 16
+    off = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=dev())
+    rows = int(off[-1])
+    inner = H * dk
+    qkv = rnd(1, rows, 3 * inner, dtype=T, seed=51, scale=0.5)
+    q, k, v = (qkv[:, :, i * inner:(i + 1) * inner].view(1, rows, H, dk) for i in range(3))
+    rel = rnd(H, 2 * Lmax - 1, seed=52)
+    res = []
+    for persist in ("0", "2"):
+        monkeypatch.setenv("LAKO_ATTN_PERSIST", persist)
+        out = torch.zeros(1, rows, H, dk, dtype=T, device=dev())
+        st = torch.zeros(len(lens), H, Lmax, 4, device=dev())
+        ops.attn_fwd(q, k, v, out, st, rel_bias=rel, rel_off=Lmax - 1, drop=drop, q_off=off, k_off=off, max_q=Lmax, max_k=Lmax)
+        torch.cuda.synchronize()
+        res.append((out, st))
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1][..., :2], res[1][1][..., :2])
+    assert float(res[1][0].float().abs().max()) > 0
+    # backward: the persistent dQ and dK/dV passes against the per-item kernels — dq / dk / dv and δ (handed from the dQ to the
+    # dK/dV pass through the statistics) bit for bit, the bias gradient to fp32 summation order (float atomics in both)
+    dout = rnd(1, rows, H, dk, dtype=T, seed=53)
+    outs = []
+    for persist in ("0", "2"):
+        monkeypatch.setenv("LAKO_ATTN_PERSIST", persist)
+        st = res[0][1].clone()
+        dqkv = torch.zeros(1, rows, 3 * inner, dtype=T, device=dev())
+        dq, dk_, dv = (dqkv[:, :, i * inner:(i + 1) * inner].view(1, rows, H, dk) for i in range(3))
+        drel = torch.zeros_like(rel)
+        ops.attn_bwd(q, k, v, res[0][0], dout, st, dq, dk_, dv, rel_bias=rel, drel=drel, rel_off=Lmax - 1, drop=drop, q_off=off,
+                     k_off=off, max_q=Lmax, max_k=Lmax)
+        torch.cuda.synchronize()
+        outs.append((dqkv, st, drel))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1][..., :3], outs[1][1][..., :3])
+    close(outs[1][2], outs[0][2], torch.float32, "persistent drel", k=5)
+    assert float(outs[1][0].float().abs().max()) > 0 and float(outs[1][2].abs().max()) > 0
 
 
 # ------------------------------------------------------------------------------------------------
