@@ -1045,11 +1045,24 @@ bool lako_attn_enc_supported(const AttnArgs& a, int dtype, int d_head) {
   return true;
 }
 
+// Without a bias table (R = 0, rel_off = 0) the kernels still read their four zero-filled copies at index key − query + rel_off + 16:
+// with rel_off = 0 that is NEGATIVE for queries past 16 + 4g, i.e. the bytes in front of the copies — the tail rows of an image
+// (zeros by luck while the sequence ends ≥ 4 rows before the image does; an image pair nothing was staged into in the persistent
+// kernels: found by tests/test_kernels_gpu.py::test_attention[enc_fast_nobias-bf16_persistent]).  Index like the encoder's table.
+static void enorm_nobias(AttnArgs& a) {
+  if (!a.rel_bias) {
+    a.R = a.Lq + a.Lk - 1;
+    a.rel_off = a.Lq - 1;
+    a.drel = nullptr;          // no table, no table gradient
+  }
+}
+
 int lako_attn_enc_fwd(AttnArgs& a, hipStream_t s) {
 #ifdef LAKO_EXPERIMENTS
   static const int dbg = getenv("LAKO_ATTN_DEBUG") ? atoi(getenv("LAKO_ATTN_DEBUG")) : 0;
   a.dbg_flags = dbg;
 #endif
+  enorm_nobias(a);
   a.chunk_rows = ((a.Lk + 31) / 32) * 32;
   const int nqb = (a.Lq + 15) / 16;
   // persistent form: one 16-wave workgroup per CU walking the sequences of one head (LAKO_ATTN_PERSIST=0: the kernel below, A/B)
@@ -1076,6 +1089,7 @@ int lako_attn_enc_bwd(AttnArgs& a, hipStream_t s) {
   a.dbg_flags = dbg;
   if (dbg & 256) goto dkv_pass;      // time the passes separately
 #endif
+  enorm_nobias(a);
   {  // dQ pass: every query block of a sequence in one workgroup, several batch rows per workgroup (bias gradient in registers)
     AttnArgs q = a;
     q.chunk_rows = ((a.Lk + 31) / 32) * 32;
