@@ -72,11 +72,14 @@ __device__ __forceinline__ void eload_frags(u32x4 (&f)[2], const char* base, int
 // The same through a buffer descriptor (persistent kernels): rows [0, L) of the strided [L, 64] slice at `base`; the lane's 32-bit
 // offset row·stride + 16g is a constant of the lane, rows past L fall out of the descriptor's range (zeros) — no 64-bit per-lane
 // pointers, no branches.  `voff` = (lane & 15)·stride_b + 16·(lane >> 4), `row0` the (wave-uniform) first row.
+// (The first row goes into the descriptor's BASE, not into the scalar offset operand: a raw buffer's range check covers the vector
+// offset + the instruction offset only.)
 __device__ __forceinline__ void eload_frags_buf(u32x4 (&f)[2], const char* base, uint32_t stride_b, int row0, int L, uint32_t voff) {
-  const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, L > 0 ? (int)((uint32_t)(L - 1) * stride_b + 128u) : 0, 0x00020000);
-  const int so = __builtin_amdgcn_readfirstlane(row0 * (int)stride_b);
+  const int left = L - row0;                       // rows of the slice from row0 on
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base) + (int64_t)row0 * stride_b, 0,
+                                                     left > 0 ? (int)((uint32_t)(left - 1) * stride_b + 128u) : 0, 0x00020000);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) f[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff + i * 64, so, 0));
+  for (int i = 0; i < 2; ++i) f[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff + i * 64, 0, 0));
 }
 
 // tile[image row row0 + 4g + r][register side = lane & 15] = init + Σ_d X[row0 + ·][d]·Y[·][d];  roff[i]: the lane's byte
@@ -1057,6 +1060,18 @@ static void enorm_nobias(AttnArgs& a) {
   }
 }
 
+// Which passes run their persistent kernel: LAKO_ATTN_PERSIST is a bit mask — 1 forward, 2 dQ pass, 4 dK/dV pass, 8 = also for
+// launches with fewer than 1024 (sequence, head) items (tests).  Default 2: measured per config-2 launch on MI355X (rocprofv3,
+// profiles/r03d_attn_persistent_kernels.txt) the persistent dQ pass takes 194 µs against 249, the dK/dV pass 197 against 189 and the
+// forward 146 against 126 — with one 16-wave workgroup per CU every item is a barrier-to-barrier phase whose length is ONE wave's
+// dependency chain; the per-item kernels' two independent workgroups per CU hide that better than the next item's DMA does, except
+// in the dQ pass, whose per-item kernel re-stages K / V three times per workgroup and keeps 4 query blocks per wave.
+static bool epersist(int bit, const AttnArgs& a) {
+  const char* pe = getenv("LAKO_ATTN_PERSIST");      // read per call: a test switches it
+  const int m = pe ? atoi(pe) : 2;
+  return (m & bit) && a.H <= 256 && ((int64_t)a.Bn * a.H >= 1024 || (m & 8));
+}
+
 int lako_attn_enc_fwd(AttnArgs& a, hipStream_t s) {
 #ifdef LAKO_EXPERIMENTS
   static const int dbg = getenv("LAKO_ATTN_DEBUG") ? atoi(getenv("LAKO_ATTN_DEBUG")) : 0;
@@ -1065,12 +1080,8 @@ int lako_attn_enc_fwd(AttnArgs& a, hipStream_t s) {
   enorm_nobias(a);
   a.chunk_rows = ((a.Lk + 31) / 32) * 32;
   const int nqb = (a.Lq + 15) / 16;
-  // persistent form: one 16-wave workgroup per CU walking the sequences of one head (LAKO_ATTN_PERSIST=0: the kernel below, A/B)
-  // (LAKO_ATTN_PERSIST: 0 never, 2 whenever the shape allows — tests; read per call so that a test can switch it)
-  const char* pe = getenv("LAKO_ATTN_PERSIST");
-  const int persist = pe ? atoi(pe) : 1;
-  if (persist && a.H <= 256 && ((int64_t)a.Bn * a.H >= 1024 || persist == 2) && (int64_t)a.kst * 2 * 256 < (1ll << 31) &&
-      (int64_t)a.vst * 2 * 256 < (1ll << 31)) {
+  // persistent form: one 16-wave workgroup per CU walking the sequences of one head (see epersist)
+  if (epersist(1, a) && (int64_t)a.kst * 2 * 256 < (1ll << 31) && (int64_t)a.vst * 2 * 256 < (1ll << 31)) {
     const int nslots = std::min(a.Bn, std::max(1, 256 / a.H));
     const int lds = efwdp_lds(a.chunk_rows);
     EDISPATCH(enc_fwd_p_kernel, PF_NW * 64, a.drop_t16 != 0, dim3(a.H * nslots), lds, s, a);
@@ -1093,10 +1104,7 @@ int lako_attn_enc_bwd(AttnArgs& a, hipStream_t s) {
   {  // dQ pass: every query block of a sequence in one workgroup, several batch rows per workgroup (bias gradient in registers)
     AttnArgs q = a;
     q.chunk_rows = ((a.Lk + 31) / 32) * 32;
-    const char* pe = getenv("LAKO_ATTN_PERSIST");
-    const int persist = pe ? atoi(pe) : 1;
-    if (persist && a.H <= 256 && ((int64_t)a.Bn * a.H >= 1024 || persist == 2) && (int64_t)a.kst * 2 * 256 < (1ll << 31) &&
-        (int64_t)a.vst * 2 * 256 < (1ll << 31) && !(persist & 8)) {
+    if (epersist(2, a) && (int64_t)a.kst * 2 * 256 < (1ll << 31) && (int64_t)a.vst * 2 * 256 < (1ll << 31)) {
       const int nslots = std::min(a.Bn, std::max(1, 256 / a.H));
       EDISPATCH(enc_bwd_dq_p_kernel, PF_NW * 64, a.drop_t16 != 0, dim3(a.H * nslots), ebwd0p_lds(q.chunk_rows), s, q);
     } else {
@@ -1117,10 +1125,7 @@ dkv_pass:
     AttnArgs k = a;
     k.chunk_rows = ((a.Lq + 31) / 32) * 32;
     const int nkb = (a.Lk + 15) / 16;
-    const char* pe = getenv("LAKO_ATTN_PERSIST");
-    const int persist = pe ? atoi(pe) : 1;
-    if (persist && a.H <= 256 && ((int64_t)a.Bn * a.H >= 1024 || persist == 2) && (int64_t)a.qst * 2 * 256 < (1ll << 31) &&
-        (int64_t)a.ost * 2 * 256 < (1ll << 31) && !(persist & 4)) {
+    if (epersist(4, a) && (int64_t)a.qst * 2 * 256 < (1ll << 31) && (int64_t)a.ost * 2 * 256 < (1ll << 31)) {
       const int nslots = std::min(a.Bn, std::max(1, 256 / a.H));
       const int lds = ebwd1p_lds(k.chunk_rows);
       EDISPATCH(enc_bwd_dkv_p_kernel, PF_NW * 64, a.drop_t16 != 0, dim3(a.H * nslots), lds, s, k);
