@@ -56,7 +56,8 @@ typedef struct {
  *   lako_tuning_set(t, key, value): one field of the CALLER's struct by its key ("gemm_" + field name); unknown key: LAKO_E_BADARG */
 typedef struct lako_tuning {
   int32_t nt_variant;    /* -1 heuristics (default); 0 = 128x128 tile / 4 waves, 1 = 256x128 / 8 waves, 2 = 256x256 / 8 waves,
-                            4 = 128x128 4-slot ring, 5 = small tiles with K split over the waves (M <= 256) */
+                            4 = 128x128 4-slot ring, 5 = small tiles with K split over the waves (M <= 256),
+                            6 = 256x256 / 4 waves (measured slower, kept for A/B), 7 = 192x256 / 8 waves */
   int32_t nt_tail_split; /* 1: rows beyond the full rounds of 256x256 tiles go to a second launch with small tiles */
   int32_t nt_ring;       /* 1: few-tile problems on the 4-slot ring kernel */
   int32_t nt_skinny;     /* 1: M <= 256 on the split-K kernel; 2 / 3 / 4 force 64² / 32² / 16² tiles */
@@ -71,7 +72,8 @@ typedef struct lako_tuning {
   int32_t tn_split;      /* > 0 forces the K-split count of the 256x256 weight-gradient kernel */
   int32_t nt_debug;      /* experiment */
   int32_t nt_store_aux;  /* experiment */
-  int32_t reserved[17];  /* zero */
+  int32_t nt_tile192;    /* 1: 192-row tiles (variant 7) where they save a round of tiles or the tail launch */
+  int32_t reserved[16];  /* zero */
 } lako_tuning_t;
 int lako_tuning_init(lako_tuning_t* t);
 int lako_tuning_set(lako_tuning_t* t, const char* key, int value);

@@ -297,6 +297,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int cur = 0;
+  // epilogue scratch of a wave: 8 KiB of the K-slice buffer the finished tile no longer reads; where that buffer is smaller than
+  // 8 waves × 8 KiB (192-row tiles: 56 KiB) the last wave(s) use an extra region behind the buffers (and the SIDE slots)
+  constexpr int SCR_IN_BUF = BUF / 8192 < NW ? BUF / 8192 : NW;
+  auto wave_scratch = [&](int free_buf) -> char* {
+    return wave < SCR_IN_BUF ? smem + free_buf * BUF + wave * 8192 : smem + 2 * BUF + (SIDE ? 32 * 1024 : 0) + (wave - SCR_IN_BUF) * 8192;
+  };
 
   // SIDE: pass p = rows [32p, 32p + 32) of this wave's 128×64 region of the residual / aux tile → 4 KiB of LDS, 16-B chunk c of
   // row r at position c ^ (r & 7) (the accumulator-layout reads below are then conflict-free); 4 DMA instructions, always
@@ -313,7 +319,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
       int l = lane;
       asm volatile("" : "+v"(l));
       const int col_t = wc * 64 + (((l & 7) ^ ((l >> 3) & 7)) * 8);
-      const uint32_t vb = col_t < cols_v ? (uint32_t)((wr * 128 + (l >> 3)) * ld_b + col_t * 2) : 0x80000000u;
+      const uint32_t vb = col_t < cols_v ? (uint32_t)((wr * (MT * 16) + (l >> 3)) * ld_b + col_t * 2) : 0x80000000u;
 #pragma unroll
       for (int j = 0; j < 4; ++j) lds_dma16(slot + j * 1024, rs, vb + (uint32_t)((pass * 32 + j * 8) * ld_b));
     }
@@ -442,22 +448,28 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
     asm volatile("" : "+v"(le));
     const int r16e = le & 15, ge = le >> 4;
     char* slot_a = smem + 2 * BUF + wave * 4096;
-    char* fr = smem + (cur ^ 1) * BUF + wave * 8192;
+    char* fr = wave_scratch(cur ^ 1);
     char* slot_b = fr + 4096;
+    constexpr int NP = MT / 2;          // 32-row passes of the wave's rows
     const int rows_v = min(BM, a.M - m0), cols_v = min(BN, a.N - n0), ldc_b = (int)a.ldc * 2;
     // rows past the edge fall out of the descriptor's range by themselves; columns past it start from an out-of-range base
     const auto crs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(C + (int64_t)m0 * a.ldc + n0), 0,
                                                         (rows_v - 1) * ldc_b + cols_v * 2, 0x00020000);
     const uint32_t cvb = (wc * 64 + (le & 7) * 8 < cols_v && !NT_DBG(a, 8))
-                             ? (uint32_t)((wr * 128 + (le >> 3)) * ldc_b + (wc * 64 + (le & 7) * 8) * 2) : 0x80000000u;
+                             ? (uint32_t)((wr * (MT * 16) + (le >> 3)) * ldc_b + (wc * 64 + (le & 7) * 8) * 2) : 0x80000000u;
     side_issue(1, slot_b, m0, n0);
 #pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
+    for (int pass = 0; pass < NP; ++pass) {
       char* slot = (pass & 1) ? slot_b : slot_a;
-      // in flight behind the pass needed now — pass 1: side 2 + stores of pass 0; pass 2: stores 0, side 3, stores 1; pass 3: stores 1, 2
-      if (pass == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (pass == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      else if (pass == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      // in flight behind the side pass needed now (4 DMA pieces per side pass, 4 stores per finished pass) — pass 1: side 2 + stores 0;
+      // pass p >= 2: stores p−2, side p+1 (if there is one), stores p−1
+      if (pass == 1) {
+        if (NP > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else if (pass >= 2) {
+        if (pass + 1 < NP) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      }
       bf16x4 sv[2][4];
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
@@ -466,7 +478,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
           const int row_l = mi * 16 + r16e;
           sv[mi][nt] = *reinterpret_cast<const bf16x4*>(slot + row_l * 128 + (((nt * 2 + (ge >> 1)) ^ (row_l & 7)) * 16) + (ge & 1) * 8);
         }
-      if (pass < 2) {
+      if (pass + 2 < NP) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot has been read: it may be overwritten
         side_issue(pass + 2, slot, m0, n0);
       }
@@ -524,7 +536,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
     rows_b = min(BN, a.N - n0);
     continue;
   }
-  if constexpr (sizeof(T) == 2 && sizeof(TO) == 2 && MT == 8 && NT == 4) {
+  if constexpr (sizeof(T) == 2 && sizeof(TO) == 2 && (MT == 8 || MT == 6) && NT == 4 && WM == 2 && WN == 4) {
     if (a.wide_epi) {
       // WIDE epilogue (256² bf16 tile).  In the accumulator layout a lane owns 4 consecutive columns of 32
       // different sub-tiles: 32 eight-byte stores per lane that land as 32-B granules — store-ISSUE bound, ≈9 µs
@@ -532,10 +544,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
       // its private 8 KiB of the free LDS buffer, 32 rows at a time (XOR-swizzled 16-B chunks), and leaves with
       // row-major data: 8 consecutive columns per lane, 8 rows × 128 B per wave-instruction, 16-B stores (16 store
       // instructions per wave instead of 32).  Only for epilogues WITHOUT a residual / aux operand (host-selected).
-      char* ep = smem + (cur ^ 1) * BUF + wave * 8192;
+      char* ep = wave_scratch(cur ^ 1);
       const int cj = lane & 7, n = n0 + wc * 64 + cj * 8;
 #pragma unroll
-      for (int pass = 0; pass < 4; ++pass) {
+      for (int pass = 0; pass < MT / 2; ++pass) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
           const int mt = 2 * pass + mi, row_l = mi * 16 + r16;
@@ -554,7 +566,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
           const int row_l = it * 8 + (lane >> 3);
           const f32x4 lo = *reinterpret_cast<const f32x4*>(ep + row_l * 256 + (((2 * cj) ^ (row_l & 15)) * 16));
           const f32x4 hi = *reinterpret_cast<const f32x4*>(ep + row_l * 256 + (((2 * cj + 1) ^ (row_l & 15)) * 16));
-          const int m = m0 + wr * 128 + pass * 32 + row_l;
+          const int m = m0 + wr * (MT * 16) + pass * 32 + row_l;
           if (m < a.M && n < a.N) {
             float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             if (drop) {
@@ -1409,12 +1421,12 @@ const TuneKey TUNE_KEYS[] = {
     {"gemm_nt_stagger", &lako_tuning_t::nt_stagger, false},       {"gemm_nt_dephase", &lako_tuning_t::nt_dephase, false},
     {"gemm_nt_dephase_n", &lako_tuning_t::nt_dephase_n, false},   {"gemm_tn_big", &lako_tuning_t::tn_big, false},
     {"gemm_tn_split", &lako_tuning_t::tn_split, false},           {"gemm_nt_debug", &lako_tuning_t::nt_debug, true},
-    {"gemm_nt_store_aux", &lako_tuning_t::nt_store_aux, true},
+    {"gemm_nt_store_aux", &lako_tuning_t::nt_store_aux, true},    {"gemm_nt_tile192", &lako_tuning_t::nt_tile192, false},
 };
 
 void tuning_defaults(lako_tuning_t* t) {
   memset(t, 0, sizeof(*t));
-  t->nt_variant = -1;      // -1 auto; 0: 128x128 / 4 waves; 1: 256x128 / 8 waves; 2: 256x256 / 8 waves; 4: 128x128 ring; 5: split-K skinny
+  t->nt_variant = -1;      // -1 auto; 0: 128x128 / 4 waves; 1: 256x128 / 8 waves; 2: 256x256 / 8 waves; 4: 128x128 ring; 5: split-K skinny; 6: 256x256 / 4 waves (experiment); 7: 192x256 / 8 waves
   t->nt_tail_split = 1;
   t->nt_ring = 1;          // skinny problems go to gemm_nt_ring_kernel (0 disables; variant 4 forces it)
   t->nt_skinny = 1;        // M <= 256 rows: gemm_nt_skinny_kernel (0 disables, 2 / 3 / 4 force 64² / 32² / 16² tiles; variant 5 forces the kernel)
@@ -1427,6 +1439,7 @@ void tuning_defaults(lako_tuning_t* t) {
   t->nt_dephase_n = 2;     // phases
   t->tn_big = 1;
   t->tn_split = 0;         // > 0: force the number of K-splits of the 256x256 TN kernel (A/B measurements)
+  t->nt_tile192 = 1;       // 192-row tiles where they save a round / the tail launch (launch_nt)
 }
 
 int tuning_set(lako_tuning_t* t, const char* key, int value) {
@@ -1486,7 +1499,10 @@ const lako_tuning_t& process_tuning() {
 
 template <typename T, typename TO, int WM, int WN, int MT, int NT, bool SIDE = false>
 void launch_nt_cfg(NtArgs a, const lako_tuning_t& tu, hipStream_t s) {
-  constexpr int BM = WM * MT * 16, BN = WN * NT * 16, LDS = 2 * (BM + BN) * TKB + (SIDE ? 32 * 1024 : 0);
+  constexpr int BM = WM * MT * 16, BN = WN * NT * 16, NW_ = WM * WN, BUF_ = (BM + BN) * TKB;
+  // + the epilogue scratch of the waves that do not fit the free K-slice buffer (8 KiB each; 192-row tiles: one wave)
+  constexpr int EXTRA = (sizeof(T) == 2 && NW_ == 8 && BUF_ / 8192 < NW_) ? (NW_ - BUF_ / 8192) * 8192 : 0;
+  constexpr int LDS = 2 * BUF_ + (SIDE ? 32 * 1024 : 0) + EXTRA;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, TO, WM, WN, MT, NT, SIDE>),
@@ -1522,7 +1538,7 @@ void launch_nt_cfg(NtArgs a, const lako_tuning_t& tu, hipStream_t s) {
 }
 
 // the 256² kernel, with the LDS-staged side operand where the epilogue has exactly one (bf16 in and out, 16-B aligned rows)
-template <typename T, typename TO>
+template <typename T, typename TO, int MT = 8>
 void launch_nt_256(const NtArgs& a, const lako_tuning_t& tu, hipStream_t s) {
   if constexpr (sizeof(T) == 2 && sizeof(TO) == 2) {
     const int side = a.flags & (LAKO_EPI_RESID | LAKO_EPI_AUXMASK);
@@ -1531,11 +1547,11 @@ void launch_nt_256(const NtArgs& a, const lako_tuning_t& tu, hipStream_t s) {
     if (tu.nt_side_lds && (side == LAKO_EPI_RESID || side == LAKO_EPI_AUXMASK) && !(a.flags & LAKO_EPI_ATOMIC) && a.N % 8 == 0 &&
         a.ldc % 8 == 0 && ld % 8 == 0 && reinterpret_cast<uintptr_t>(a.C) % 16 == 0 && reinterpret_cast<uintptr_t>(sp) % 16 == 0 &&
         (int64_t)256 * a.ldc * 2 < (1ll << 31) && (int64_t)256 * ld * 2 < (1ll << 31)) {
-      launch_nt_cfg<T, TO, 2, 4, 8, 4, true>(a, tu, s);
+      launch_nt_cfg<T, TO, 2, 4, MT, 4, true>(a, tu, s);
       return;
     }
   }
-  launch_nt_cfg<T, TO, 2, 4, 8, 4>(a, tu, s);
+  launch_nt_cfg<T, TO, 2, 4, MT, 4>(a, tu, s);
 }
 
 template <typename T, typename TO>
@@ -1551,14 +1567,41 @@ int launch_nt(const NtArgs& a_in, const lako_tuning_t& tu, hipStream_t s) {
     // tokens × 768 columns) means 2 full rounds and a third with 52 tiles on 52 CUs: 3 tile-times for 2.2 of work.
     // The rows of the full rounds go to the 256² kernel, the remaining rows to a second launch with 128² tiles
     // (4 × as many, 2 workgroups per CU): ≈2.35 tile-times.  Only when the last round would be less than half full.
-    if (v == 2 && tu.nt_tail_split && t256 > 256 && !(a.flags & LAKO_EPI_ATOMIC)) {
-      const int64_t full_rows = (t256 / 256) * 256 / tn;             // tile-rows covered by the full rounds
-      const int64_t rest = t256 - full_rows * tn;                    // tiles left for the last round
-      if (rest > 0 && rest < 128 && full_rows > 0) {
+    // TILE HEIGHT (round 3).  The same launch with 192-row tiles (the kernel's MT = 6 instantiation: ≈0.8 of a 256-row tile's time —
+    // three quarters of the FLOPs at 17 % more operand bytes per FLOP) can land on a whole number of rounds where the 256-row tiles
+    // do not: 47 757 rows × 768 columns are 747 tiles = 2.92 rounds → 3 × 0.8 = 2.4 tile-times and NO tail launch, against 2 + ≈0.7.
+    // Both plans are priced in 256-row tile-times and the cheaper one runs ("gemm_nt_tile192" 0 disables; variant 7 forces it).
+    struct Plan { double cost; int64_t full_rows; bool tail; };
+    auto plan = [&](int bm, double tile_time) {
+      const int64_t tiles = (int64_t)cdiv(a.M, bm) * tn;
+      const int64_t rounds = tiles / 256;
+      const int64_t full_rows = rounds * 256 / tn;                   // tile-rows covered by the full rounds
+      const int64_t rest = tiles - full_rows * tn;                   // tiles left for the last round
+      if (rest == 0) return Plan{rounds * tile_time, full_rows, false};
+      if (tu.nt_tail_split && rest < 128 && full_rows > 0 && !(a.flags & LAKO_EPI_ATOMIC)) return Plan{rounds * tile_time + 0.7, full_rows, true};
+      return Plan{(rounds + 1) * tile_time, full_rows, false};
+    };
+    if (v == 2 && t256 > 256) {
+      Plan pl = plan(256, 1.0);
+      int bm = 256;
+      if constexpr (sizeof(T) == 2 && sizeof(TO) == 2) {
+        if (tu.nt_tile192) {
+          const Plan p192 = plan(192, 0.8);
+          if (p192.cost < 0.97 * pl.cost) {
+            pl = p192;
+            bm = 192;
+          }
+        }
+      }
+      if (pl.tail) {
         NtArgs head = a;
-        head.M = (int)(full_rows * 256);
-        launch_nt_256<T, TO>(head, tu, s);
-        const int64_t r0 = full_rows * 256;
+        head.M = (int)(pl.full_rows * bm);
+        if (bm == 192) {
+          if constexpr (sizeof(T) == 2 && sizeof(TO) == 2) launch_nt_256<T, TO, 6>(head, tu, s);
+        } else {
+          launch_nt_256<T, TO>(head, tu, s);
+        }
+        const int64_t r0 = pl.full_rows * bm;
         a.M -= (int)r0;
         a.row0 += r0;
         a.A += r0 * a.lda * (int64_t)sizeof(T);
@@ -1566,6 +1609,8 @@ int launch_nt(const NtArgs& a_in, const lako_tuning_t& tu, hipStream_t s) {
         if (a.resid) a.resid += r0 * a.ldr * (int64_t)sizeof(TO);
         if (a.aux) a.aux += r0 * a.ldaux * (int64_t)sizeof(T);
         v = 0;      // the tail: 128² tiles
+      } else if (bm == 192) {
+        v = 7;
       }
     }
   }
@@ -1634,8 +1679,11 @@ int launch_nt(const NtArgs& a_in, const lako_tuning_t& tu, hipStream_t s) {
     hipLaunchKernelGGL((gemm_nt_ring_kernel<T, TO>), dim3(tiles * b.split_k), dim3(256), RING_NST * RING_STAGE, s, b);
     return 0;
   }
+  if (v == 7 && (sizeof(T) != 2 || sizeof(TO) != 2)) v = 2;
   if (v == 2) launch_nt_256<T, TO>(a, tu, s);
-  else if (v == 6 && sizeof(T) == 2) launch_nt_cfg<T, TO, 2, 2, 8, 8>(a, tu, s);   // EXPERIMENT: 256x256 on 4 waves of 128x128 (hipBLASLt's MT256x256x64 MIWT8_8 shape)
+  else if (v == 7) {
+    if constexpr (sizeof(T) == 2 && sizeof(TO) == 2) launch_nt_256<T, TO, 6>(a, tu, s);     // 192 x 256 tiles
+  } else if (v == 6 && sizeof(T) == 2) launch_nt_cfg<T, TO, 2, 2, 8, 8>(a, tu, s);   // EXPERIMENT: 256x256 on 4 waves of 128x128 (hipBLASLt's MT256x256x64 MIWT8_8 shape)
   else if (v == 1) launch_nt_cfg<T, TO, 4, 2, 4, 4>(a, tu, s);
   else launch_nt_cfg<T, TO, 2, 2, 4, 4>(a, tu, s);
   return 0;

@@ -62,13 +62,14 @@ def test_gemm_nt_plain(ops, ref, dt, M, N, K):
         close(C, Cr, T, f"gemm_nt {dt}->{out_t} {M}x{N}x{K}")
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 7])
 @pytest.mark.parametrize("M,N,K", [(1024, 768, 768), (700, 520, 200), (256, 256, 32), (2048, 2304, 768), (300, 264, 3072), (128, 768, 72),
                                    (128, 768, 768), (100, 200, 160), (16, 3072, 768), (130, 776, 3072)])
 def test_gemm_nt_tile_variants(ops, ref, variant, M, N, K):
     """every tile variant of the bf16 NT kernel (0: 128², 1: 256×128, 2: 256² 2-buffer, 3: 256² 4-slot ring, 4: the 128²
     4-slot ring that skinny problems are dispatched to, 5: the 64² kernel whose four waves split K, for M <= 256 rows — it
-    falls back to the ring when K is not a multiple of 32),
+    falls back to the ring when K is not a multiple of 32, 7: 192×256 tiles — the 256² kernel's MT = 6 instantiation, whose last
+    wave keeps its epilogue scratch behind the K-slice buffers),
     persistent and one-tile-per-workgroup grids, ragged edges, fused epilogues."""
     T = torch.bfloat16
     A, B = rnd(M, K, dtype=T, seed=41), rnd(N, K, dtype=T, seed=42)
@@ -106,20 +107,21 @@ def test_gemm_nt_side_operand_in_lds(ops, ref, M, N, K):
     cases = (dict(resid=R), dict(resid=R, drop=(0.1, 7, 8), alpha=0.5), dict(resid=R, relu=True), dict(aux=X, aux_scale=1.1),
              dict(aux=X, aux_scale=1.0 / 0.9, drop=(0.1, 3, 4)))
     try:
-        ops.set_tuning("gemm_nt_variant", 2)
-        for kw in cases:
-            got = {}
-            for side in (1, 0):
-                ops.set_tuning("gemm_nt_side_lds", side)
-                Cw.fill_(7.0)
-                C = Cw[:, 8:8 + N]
-                ops.gemm_nt(A, B, C, **kw)
-                assert torch.all(Cw[:, :8] == 7.0) and torch.all(Cw[:, 8 + N:] == 7.0), "stores outside the output columns"
-                got[side] = C.clone()
-            assert torch.equal(got[0], got[1]), f"side-in-LDS epilogue differs from the generic one {list(kw)} {M}x{N}x{K}"
-            Cr = torch.zeros(M, N, device=dev())
-            ref.gemm_nt(A, B, Cr, **kw)
-            close(got[1], Cr, T, f"gemm_nt side operand {list(kw)} {M}x{N}x{K}")
+        for variant in (2, 7):              # 256-row tiles (4 side passes per wave) and 192-row tiles (3)
+            ops.set_tuning("gemm_nt_variant", variant)
+            for kw in cases:
+                got = {}
+                for side in (1, 0):
+                    ops.set_tuning("gemm_nt_side_lds", side)
+                    Cw.fill_(7.0)
+                    C = Cw[:, 8:8 + N]
+                    ops.gemm_nt(A, B, C, **kw)
+                    assert torch.all(Cw[:, :8] == 7.0) and torch.all(Cw[:, 8 + N:] == 7.0), "stores outside the output columns"
+                    got[side] = C.clone()
+                assert torch.equal(got[0], got[1]), f"side-in-LDS epilogue differs from the generic one {list(kw)} {M}x{N}x{K} variant {variant}"
+                Cr = torch.zeros(M, N, device=dev())
+                ref.gemm_nt(A, B, Cr, **kw)
+                close(got[1], Cr, T, f"gemm_nt side operand {list(kw)} {M}x{N}x{K} variant {variant}")
     finally:
         ops.set_tuning("gemm_nt_variant", -1)
         ops.set_tuning("gemm_nt_side_lds", 1)
@@ -173,6 +175,35 @@ def test_gemm_nt_tail_split(ops, ref):
                     assert torch.equal(C == 0, Cr.to(T) == 0) or (C == 0).float().mean().item() > 0.05
     finally:
         ops.set_tuning("gemm_nt_tail_split", 1)
+
+
+def test_gemm_nt_tile_height_plan(ops, ref):
+    """The heuristics price 256-row and 192-row tiles per call (launch_nt): 47 757 rows x 768 columns — the benchmark's encoder
+    shape — take 192-row tiles in three full rounds and no tail launch; the same call with `gemm_nt_tile192` off runs 256-row
+    tiles + the tail launch.  Same result to bf16 rounding of identical fp32 sums (bit for bit: each output element's K-loop is the
+    same sequence of MFMAs), with every fused epilogue; dropout draws by global row."""
+    T = torch.bfloat16
+    M, N, K = 47757, 768, 96
+    A, B = rnd(M, K, dtype=T, seed=91), rnd(N, K, dtype=T, seed=92)
+    R, X = rnd(M, N, dtype=T, seed=93), rnd(M, N, dtype=T, seed=94)
+    try:
+        for kw in (dict(), dict(relu=True, drop=(0.1, 5, 6)), dict(resid=R, drop=(0.1, 7, 8), alpha=0.5), dict(aux=X, aux_scale=1.1)):
+            got = []
+            for t192 in (1, 0):
+                ops.set_tuning("gemm_nt_tile192", t192)
+                ops.probe = []
+                C = torch.empty(M, N, dtype=T, device=dev())
+                ops.gemm_nt(A, B, C, **kw)
+                torch.cuda.synchronize()
+                ops.probe = None
+                got.append(C)
+            assert torch.equal(got[0], got[1]), list(kw)
+            Cr = torch.zeros(M, N, device=dev())
+            ref.gemm_nt(A, B, Cr, **kw)
+            close(got[0], Cr, T, f"gemm_nt 192-row plan {list(kw)}")
+    finally:
+        ops.set_tuning("gemm_nt_tile192", 1)
+        ops.probe = None
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f32"])
