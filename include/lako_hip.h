@@ -72,7 +72,7 @@ typedef struct lako_tuning {
   int32_t tn_split;      /* > 0 forces the K-split count of the 256x256 weight-gradient kernel */
   int32_t nt_debug;      /* experiment */
   int32_t nt_store_aux;  /* experiment */
-  int32_t nt_tile192;    /* 1: 192-row tiles (variant 7) where they save a round of tiles or the tail launch */
+  int32_t nt_tile192;    /* 1: 192-row tiles (variant 7) where the round count favours them (default 0: measured no faster) */
   int32_t reserved[16];  /* zero */
 } lako_tuning_t;
 int lako_tuning_init(lako_tuning_t* t);

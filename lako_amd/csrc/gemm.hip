@@ -1439,7 +1439,7 @@ void tuning_defaults(lako_tuning_t* t) {
   t->nt_dephase_n = 2;     // phases
   t->tn_big = 1;
   t->tn_split = 0;         // > 0: force the number of K-splits of the 256x256 TN kernel (A/B measurements)
-  t->nt_tile192 = 1;       // 192-row tiles where they save a round / the tail launch (launch_nt)
+  t->nt_tile192 = 0;       // 1: 192-row tiles where the round count favours them (launch_nt) — measured no faster, off
 }
 
 int tuning_set(lako_tuning_t* t, const char* key, int value) {
@@ -1570,7 +1570,10 @@ int launch_nt(const NtArgs& a_in, const lako_tuning_t& tu, hipStream_t s) {
     // TILE HEIGHT (round 3).  The same launch with 192-row tiles (the kernel's MT = 6 instantiation: ≈0.8 of a 256-row tile's time —
     // three quarters of the FLOPs at 17 % more operand bytes per FLOP) can land on a whole number of rounds where the 256-row tiles
     // do not: 47 757 rows × 768 columns are 747 tiles = 2.92 rounds → 3 × 0.8 = 2.4 tile-times and NO tail launch, against 2 + ≈0.7.
-    // Both plans are priced in 256-row tile-times and the cheaper one runs ("gemm_nt_tile192" 0 disables; variant 7 forces it).
+    // Both plans are priced in 256-row tile-times and the cheaper one runs — when "gemm_nt_tile192" is 1.  It is 0 by default:
+    // measured (profiles/r03e_gemm_tile192.txt, 47 757 rows) a 192-row tile takes ≈0.93 of a 256-row tile's time, not 0.8 — the
+    // K-step is bound by the L2 → LDS path, whose bytes per tile fall by an eighth only — so three rounds of them (72.9 / 235 /
+    // 172 µs at K = 768 / 3072 / 2304) lose to two rounds + tail (71.4 / 228 / 165 µs).  Variant 7 forces the tile (tests).
     struct Plan { double cost; int64_t full_rows; bool tail; };
     auto plan = [&](int bm, double tile_time) {
       const int64_t tiles = (int64_t)cdiv(a.M, bm) * tn;
