@@ -73,7 +73,9 @@ typedef struct lako_tuning {
   int32_t nt_debug;      /* experiment */
   int32_t nt_store_aux;  /* experiment */
   int32_t nt_tile192;    /* 1: 192-row tiles (variant 7) where the round count favours them (default 0: measured no faster) */
-  int32_t reserved[16];  /* zero */
+  int32_t nt_queue;      /* 1: the persistent 256x256 kernel pulls its tiles from per-XCD ticket counters (a launch that shares the chip
+                            with RCCL kernels — LAKO_DP_MODE=overlap — ends when the tiles do, not when the last-started workgroup does) */
+  int32_t reserved[15];  /* zero */
 } lako_tuning_t;
 int lako_tuning_init(lako_tuning_t* t);
 int lako_tuning_set(lako_tuning_t* t, const char* key, int value);

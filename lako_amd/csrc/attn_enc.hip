@@ -873,15 +873,18 @@ __global__ __launch_bounds__(DKV_NW * 64, 2) void enc_bwd_dkv_kernel(AttnArgs a)
 // Same arithmetic per key block as enc_bwd_dkv_kernel: bit-identical results.
 // ---------------------------------------------------------------------------------------------------------------------
 // LDS: 2 × (Q image | dO image) | 4 reversed bias copies | 2 × raw statistics [R][4] | lse2[R] | −δ/scale[R]
-__host__ __device__ constexpr int ebwd1p_lds(int rows) { return 4 * rows * EROW + 4 * EB_ST * 4 + 2 * rows * 16 + 2 * rows * 4; }
+// (the raw statistics arrive in 64-row DMA pieces: each pair holds the row count rounded up to 64, or a piece would run over into the
+//  other pair / the converted vectors — found by test_attention_persistent_kernels_equal_per_item_kernels at 224 image rows)
+__host__ __device__ constexpr int ebwd1p_lds(int rows) { return 4 * rows * EROW + 4 * EB_ST * 4 + 2 * ((rows + 63) / 64 * 64) * 16 + 2 * rows * 4; }
 
 template <bool DROP>
 __global__ __launch_bounds__(PF_NW * 64) void enc_bwd_dkv_p_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int R = a.chunk_rows;                       // image rows: every sequence's query count rounded up to 32
   float* b4 = reinterpret_cast<float*>(smem + 4 * R * EROW);
-  float* raw_l = b4 + 4 * EB_ST;                    // [2][R][4]
-  float* lse_l = raw_l + 2 * R * 4;
+  const int RS = (R + 63) / 64 * 64;                // statistics rows per pair (whole 64-row DMA pieces)
+  float* raw_l = b4 + 4 * EB_ST;                    // [2][RS][4]
+  float* lse_l = raw_l + 2 * RS * 4;
   float* ndel_l = lse_l + R;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -922,7 +925,7 @@ __global__ __launch_bounds__(PF_NW * 64) void enc_bwd_dkv_p_kernel(AttnArgs a) {
     }
     if (wave * 64 < R) {                            // statistics rows [64·wave, 64·wave + 64): 16 bytes per query, contiguous
       const auto srs = lds_dma_rsrc(a.stats + ((int64_t)b * a.H + h) * a.Lq * 4, (uint32_t)max(Lq, 0) * 16u);
-      lds_dma16(raw_l + (pair * R + wave * 64) * 4, srs, (uint32_t)(wave * 64 + le) * 16u);
+      lds_dma16(raw_l + (pair * RS + wave * 64) * 4, srs, (uint32_t)(wave * 64 + le) * 16u);
     }
   };
   issue(slot, 0);
@@ -944,7 +947,7 @@ __global__ __launch_bounds__(PF_NW * 64) void enc_bwd_dkv_p_kernel(AttnArgs a) {
     }
     if (b + nslots < a.Bn) issue(b + nslots, cur ^ 1);
     if ((int)threadIdx.x < R) {                              // rows past Lq arrive as zeros: p = exp2(−inf) = 0 there
-      const f32x4 st4 = *reinterpret_cast<const f32x4*>(raw_l + (cur * R + threadIdx.x) * 4);
+      const f32x4 st4 = *reinterpret_cast<const f32x4*>(raw_l + (cur * RS + threadIdx.x) * 4);
       lse_l[threadIdx.x] = st4[1] > 0.f ? st4[0] * LOG2E - __builtin_amdgcn_logf(st4[1] * dscale) : INFINITY;
       ndel_l[threadIdx.x] = -st4[2] * inv_dscale;
     }

@@ -15,6 +15,8 @@
 #include <type_traits>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
 
 #include "common.h"
 
@@ -54,6 +56,7 @@ struct NtArgs {
   int store_aux;  // cache-policy bits for the 256² kernel's 16-byte output stores (store_b128_policy)
   int dephase;    // (phases << 16) | ticks: workgroup w of an XCD starts (w mod phases)·ticks·10 ns late (breaks the lockstep of main loops / epilogues)
   int wide_epi;   // 256² bf16 tile: LDS-transposed epilogue with 16-B row-major stores (needs N, ldc, ldr, ldaux % 8 == 0)
+  int* queue;     // QUEUE instantiation: [0..7] per-XCD tile tickets, [8] workgroups finished (all zero between launches)
 };
 
 // bijective XCD-aware remap (blocks b and b+8 share an XCD): give each XCD a contiguous id range
@@ -262,7 +265,8 @@ __device__ __forceinline__ void nt_store_tile(const NtArgs& a, f32x4 (&acc)[NT][
 //   <2,2,4,4> 128×128, 4 waves, 64 KiB LDS (2 workgroups / CU)      — small / skinny problems
 //   <2,4,8,4> 256×256, 8 waves, 128 KiB LDS (1 workgroup / CU)      — half the LDS+L2 bytes per FLOP
 //   SIDE (256² bf16 only): the residual / aux operand of the epilogue is LDS-DMA'd in four 32-row passes (see the epilogue)
-template <typename T, typename TO, int WM, int WN, int MT, int NT, bool SIDE = false>
+//   QUEUE: the tiles after a workgroup's first are PULLED from per-XCD ticket counters instead of strided by the grid size (below)
+template <typename T, typename TO, int WM, int WN, int MT, int NT, bool SIDE = false, bool QUEUE = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
   constexpr int NW = WM * WN, BM = WM * MT * 16, BN = WN * NT * 16;
   constexpr int A_BYTES = BM * TKB, B_BYTES = BN * TKB, BUF = A_BYTES + B_BYTES;
@@ -326,10 +330,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
   };
 
   while (true) {
-    const int next_tile = tile + gridDim.x;
-    const bool has_next = next_tile < nwg;
+    int next_tile = tile + gridDim.x;
+    bool has_next = next_tile < nwg;
     tile_coords(has_next ? next_tile : 0, a.tiles_m, a.tiles_n, a.group_m, tm_, tn_);
-    const int nm0 = tm_ * BM, nn0 = tn_ * BN;
+    int nm0 = tm_ * BM, nn0 = tn_ * BN;
+    // QUEUE (data-parallel overlap: RCCL kernels hold some CUs while this launch runs, so not all of its 256 workgroups are
+    // resident at once).  With tiles strided by the grid size a workgroup that starts late still owes its whole list and the launch
+    // ends a full pass later; here only a workgroup's FIRST tile is static, the rest of an XCD's share — the same tile ids the
+    // striding gives that XCD, so the operand panels stay in its L2 — is handed out by a ticket counter per XCD: late workgroups
+    // find the counter exhausted.  The ticket (one returning atomic by thread 0) is requested at the tile's start and consumed two
+    // K-steps before its end (a word in LDS, published by that K-step's barrier), in time for the next tile's first prefetch.
+    int ticket = 0;
+    if constexpr (QUEUE) {
+      if (threadIdx.x == 0) ticket = atomicAdd(&a.queue[blockIdx.x & 7], 1);
+    }
     // debug bit 1: every workgroup streams tile (0, 0)'s operands — all requests hit L2 (timing experiment)
     const char* Abase = a.A + (NT_DBG(a, 2) ? 0 : (int64_t)m0 * lda_b);
     const char* Bbase = a.B + (NT_DBG(a, 2) ? 0 : (int64_t)n0 * ldb_b);
@@ -344,6 +358,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
       const char* As = smem + cur * BUF;
       const char* Bs = As + A_BYTES;
       char* An = smem + (cur ^ 1) * BUF;
+      if constexpr (QUEUE) {       // (host: nk >= 2)
+        int* sh_next = reinterpret_cast<int*>(smem + 2 * BUF + (SIDE ? 32 * 1024 : 0) + (NW - SCR_IN_BUF) * 8192);
+        if (t == nk - 2 && threadIdx.x == 0) {
+          const int G = gridDim.x, x = blockIdx.x & 7, q = G >> 3, r = G & 7;
+          const int qx = q + (x < r ? 1 : 0), base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+          *sh_next = base + ticket % qx + (ticket / qx + 1) * G;       // the XCD's share in the order the striding walks it
+        }
+        if (t == nk - 1) {
+          next_tile = *sh_next;
+          has_next = next_tile < nwg;
+          tile_coords(has_next ? next_tile : 0, a.tiles_m, a.tiles_n, a.group_m, tm_, tn_);
+          nm0 = tm_ * BM;
+          nn0 = tn_ * BN;
+        }
+      }
       // source of the NEXT K-slice: this tile's slice t+1, or the first slice of the workgroup's next tile
       const bool more_k = t + 1 < nk;
       const bool pf = !NT_DBG(a, 1) && (more_k || has_next);
@@ -609,6 +638,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
     n0 = nn0;
     rows_a = min(BM, a.M - m0);
     rows_b = min(BN, a.N - n0);
+  }
+  if constexpr (QUEUE) {
+    // the workgroup that finishes last (every ticket of the launch has been drawn by then) leaves the counters zero for the next
+    // launch on this stream
+    if (threadIdx.x == 0 && atomicAdd(&a.queue[8], 1) == (int)gridDim.x - 1) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) atomicExch(&a.queue[i], 0);
+    }
   }
 }
 
@@ -1422,6 +1459,7 @@ const TuneKey TUNE_KEYS[] = {
     {"gemm_nt_dephase_n", &lako_tuning_t::nt_dephase_n, false},   {"gemm_tn_big", &lako_tuning_t::tn_big, false},
     {"gemm_tn_split", &lako_tuning_t::tn_split, false},           {"gemm_nt_debug", &lako_tuning_t::nt_debug, true},
     {"gemm_nt_store_aux", &lako_tuning_t::nt_store_aux, true},    {"gemm_nt_tile192", &lako_tuning_t::nt_tile192, false},
+    {"gemm_nt_queue", &lako_tuning_t::nt_queue, false},
 };
 
 void tuning_defaults(lako_tuning_t* t) {
@@ -1497,15 +1535,34 @@ const lako_tuning_t& process_tuning() {
   return t;
 }
 
-template <typename T, typename TO, int WM, int WN, int MT, int NT, bool SIDE = false>
+// ticket counters of the QUEUE instantiation: 9 ints per (device, stream), allocated and zeroed once (a launch leaves them zero);
+// launches on one stream run one after the other, launches on different streams never share counters
+static int* nt_queue_counters(hipStream_t stream) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, int*> tab;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  int*& p = tab[{dev, stream}];
+  if (!p) {
+    if (hipMalloc(reinterpret_cast<void**>(&p), 16 * sizeof(int)) != hipSuccess) {
+      p = nullptr;
+      return nullptr;
+    }
+    (void)hipMemsetAsync(p, 0, 16 * sizeof(int), stream);
+  }
+  return p;
+}
+
+template <typename T, typename TO, int WM, int WN, int MT, int NT, bool SIDE = false, bool QUEUE = false>
 void launch_nt_cfg(NtArgs a, const lako_tuning_t& tu, hipStream_t s) {
   constexpr int BM = WM * MT * 16, BN = WN * NT * 16, NW_ = WM * WN, BUF_ = (BM + BN) * TKB;
   // + the epilogue scratch of the waves that do not fit the free K-slice buffer (8 KiB each; 192-row tiles: one wave)
   constexpr int EXTRA = (sizeof(T) == 2 && NW_ == 8 && BUF_ / 8192 < NW_) ? (NW_ - BUF_ / 8192) * 8192 : 0;
-  constexpr int LDS = 2 * BUF_ + (SIDE ? 32 * 1024 : 0) + EXTRA;
+  constexpr int LDS = 2 * BUF_ + (SIDE ? 32 * 1024 : 0) + EXTRA + (QUEUE ? 16 : 0);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, TO, WM, WN, MT, NT, SIDE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, TO, WM, WN, MT, NT, SIDE, QUEUE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_done = true;
   }
@@ -1534,7 +1591,17 @@ void launch_nt_cfg(NtArgs a, const lako_tuning_t& tu, hipStream_t s) {
   // --dephase 0,100,…): [64000,768]×[2304,768] 287 → 250 µs, o+res 140 → 134, wi 374 → 366, long launches unchanged; the size of
   // the delay (1…16 µs) and the number of phases (2, 4, 8) do not matter — the lockstep start is what costs.
   a.dephase = (tu.nt_dephase > 0 && a.tiles_m * a.tiles_n > grid) ? ((tu.nt_dephase_n << 16) | (tu.nt_dephase & 0xffff)) : 0;
-  hipLaunchKernelGGL((gemm_nt_kernel<T, TO, WM, WN, MT, NT, SIDE>), dim3(grid), dim3(WM * WN * 64), LDS, s, a);
+  if constexpr (QUEUE) {
+    a.queue = nt_queue_counters(s);
+    // (needs two K-steps per tile to hand the ticket over, several tiles per workgroup to be of any use, and a persistent grid)
+    if (!a.queue || a.K * (int)sizeof(T) <= TKB || a.tiles_m * a.tiles_n <= grid || !tu.nt_persistent) {
+      launch_nt_cfg<T, TO, WM, WN, MT, NT, SIDE, false>(a, tu, s);
+      return;
+    }
+  } else {
+    a.queue = nullptr;
+  }
+  hipLaunchKernelGGL((gemm_nt_kernel<T, TO, WM, WN, MT, NT, SIDE, QUEUE>), dim3(grid), dim3(WM * WN * 64), LDS, s, a);
 }
 
 // the 256² kernel, with the LDS-staged side operand where the epilogue has exactly one (bf16 in and out, 16-B aligned rows)
@@ -1547,7 +1614,12 @@ void launch_nt_256(const NtArgs& a, const lako_tuning_t& tu, hipStream_t s) {
     if (tu.nt_side_lds && (side == LAKO_EPI_RESID || side == LAKO_EPI_AUXMASK) && !(a.flags & LAKO_EPI_ATOMIC) && a.N % 8 == 0 &&
         a.ldc % 8 == 0 && ld % 8 == 0 && reinterpret_cast<uintptr_t>(a.C) % 16 == 0 && reinterpret_cast<uintptr_t>(sp) % 16 == 0 &&
         (int64_t)256 * a.ldc * 2 < (1ll << 31) && (int64_t)256 * ld * 2 < (1ll << 31)) {
-      launch_nt_cfg<T, TO, 2, 4, MT, 4, true>(a, tu, s);
+      if (MT == 8 && tu.nt_queue) launch_nt_cfg<T, TO, 2, 4, 8, 4, true, true>(a, tu, s);
+      else launch_nt_cfg<T, TO, 2, 4, MT, 4, true>(a, tu, s);
+      return;
+    }
+    if (MT == 8 && tu.nt_queue) {
+      launch_nt_cfg<T, TO, 2, 4, 8, 4, false, true>(a, tu, s);
       return;
     }
   }

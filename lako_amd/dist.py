@@ -12,7 +12,9 @@ reports finished ranges through `Engine.grad_hook`.  Two modes:
                         stretch every such kernel by a whole scheduling round.
   "overlap"             one asynchronous all-reduce per finished range (decoder + cross-K/V first, then per
                         encoder layer, coalesced to `bucket_bytes`), issued while backward is still running;
-                        `LAKO_DP_MODE=overlap`.  Correct (2-rank gloo test) — to be measured on 8 GPUs.
+                        `LAKO_DP_MODE=overlap`.  The persistent GEMM launches then draw their tiles from per-XCD ticket
+                        counters (`gemm_nt_queue`), so the CUs the RCCL kernels hold cost a share of the tiles, not a whole
+                        extra pass.  Correct (2-rank gloo test, world-1 RCCL test) — to be measured on 8 GPUs (tools/scale.sh).
 
 `LAKO_DP_GRAD_DTYPE=bf16` (or `grad_dtype=torch.bfloat16`): the gradients travel as bf16 — half the bytes over the xGMI links (446 MB
 instead of 892 MB at T5-base; it is the 2- and 4-GPU runs, with one link per peer, that pay most for the collective) — through a
@@ -51,6 +53,11 @@ class GradSync:
         eng = model._get_engine()
         eng.grad_hook = self._on_ready
         model._grad_sync = self
+        if self.mode == "overlap" and hasattr(eng.ops, "set_tuning"):
+            # the collectives' kernels hold CUs while backward's GEMMs run: the persistent GEMM launches pull their tiles from
+            # per-XCD ticket counters instead of striding by the grid size (include/lako_hip.h: lako_tuning_t.nt_queue), so a
+            # workgroup that becomes resident late finds the queue drained instead of a whole list of tiles to do
+            eng.ops.set_tuning("gemm_nt_queue", 1)
 
     @property
     def active(self):

@@ -177,6 +177,42 @@ def test_gemm_nt_tail_split(ops, ref):
         ops.set_tuning("gemm_nt_tail_split", 1)
 
 
+def test_gemm_nt_tile_queue(ops, ref):
+    """`gemm_nt_queue` (data-parallel overlap mode): the persistent 256² kernel pulls every tile after a workgroup's first from
+    per-XCD ticket counters.  Every tile must be computed exactly once — results bit-identical to the strided walk — with every
+    epilogue, on multi-round launches (banded and row-major tile order), back to back (the last workgroup leaves the counters zero
+    for the next launch), on a second stream (its own counters), and on shapes where the queue does not apply (one round; K of
+    one K-step) and the launch falls back to the strided kernel."""
+    T = torch.bfloat16
+    try:
+        for (M, N, K) in [(70000, 768, 768), (40000, 2304, 192), (5000, 768, 64), (1000, 768, 768)]:
+            A, B = rnd(M, K, dtype=T, seed=95), rnd(N, K, dtype=T, seed=96)
+            R, X = rnd(M, N, dtype=T, seed=97), rnd(M, N, dtype=T, seed=98)
+            for kw in (dict(), dict(relu=True, drop=(0.1, 5, 6)), dict(resid=R, drop=(0.1, 7, 8), alpha=0.5), dict(aux=X, aux_scale=1.1)):
+                got = []
+                for q in (0, 1, 1):
+                    ops.set_tuning("gemm_nt_queue", q)
+                    C = torch.empty(M, N, dtype=T, device=dev())
+                    ops.gemm_nt(A, B, C, **kw)
+                    got.append(C)
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    C2 = torch.empty(M, N, dtype=T, device=dev())
+                    ops.gemm_nt(A, B, C2, **kw)
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                assert torch.equal(got[0], got[1]) and torch.equal(got[0], got[2]) and torch.equal(got[0], C2), (M, N, K, list(kw))
+            Cr = torch.zeros(M, N, device=dev())
+            ref.gemm_nt(A, B, Cr)
+            ops.set_tuning("gemm_nt_queue", 1)
+            C = torch.empty(M, N, dtype=T, device=dev())
+            ops.gemm_nt(A, B, C)
+            close(C, Cr, T, f"gemm_nt tile queue {M}x{N}x{K}")
+    finally:
+        ops.set_tuning("gemm_nt_queue", 0)
+
+
 def test_gemm_nt_tile_height_plan(ops, ref):
     """With `gemm_nt_tile192` on, launch_nt prices 256-row and 192-row tiles per call: 47 757 rows x 768 columns — the benchmark's
     encoder shape — take 192-row tiles in three full rounds and no tail launch; with it off (the default: measured no faster,
