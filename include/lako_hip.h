@@ -364,6 +364,31 @@ int lako_bi_score(const float* q, const float* p, float* out, int B, int n, int 
 /* loss[0] = torch.nn.KLDivLoss()(log_softmax(score, -1), gold) over fp32 [B, n] (src/model.py:480-483); value only */
 int lako_kldiv_fwd(const float* score, const float* gold, float* loss, int B, int n, lako_stream_t stream);
 
+/* ---- retriever TRAINING (the autograd of src/model.py:413-483 under train_retriever.py:37-71 — KL distillation
+ * of the reader's per-fact cross-attention scores into the bi-encoder).  The matrix products of the backward are lako_gemm_nt
+ * (dX, with its residual epilogue for the skip connections) and lako_gemm_tn (dW), the attention backward lako_attn_bwd; these are
+ * the row-wise pieces between them (csrc/bertbwd.hip).  Parameter gradients (fp32) are ACCUMULATED (+=).
+ * lako_layernorm_bwd: backward of lako_layernorm_fwd, y = LayerNorm(z)*gamma + beta with z = x + lin_bias + resid (z and its
+ *   statistics are recomputed from the forward's inputs): dz [rows, d] = the gradient of x and of resid; dgamma += sum_rows dy*zhat,
+ *   dbeta += sum_rows dy, dbias (may be NULL) += sum_rows dz.
+ * lako_bias_act_bwd: backward of y = act(x + bias) on a [rows, n] column block with row stride ld: dx (may be NULL, may alias dy)
+ *   = dy * act'(x + bias), dbias += dbias_scale * sum_rows dx.  act 0 identity (x unused), 1 exact GELU.
+ * lako_seq_mean_bwd: dx[b, l, :] = dout[b, :] / count_b on the rows that took part in lako_seq_mean, 0 elsewhere.
+ * lako_bi_score_bwd: dp[b][i] = scale*dscore[b][i]*q[b], dq[b] = scale*sum_i dscore[b][i]*p[b][i] (overwritten).
+ * lako_kldiv_bwd: dscore = upstream/(B*n) * (softmax(score)*sum_j gold - gold)  (upstream: device scalar or NULL = 1).
+ * lako_bert_embed_bwd: backward of lako_bert_embed: dword / dpos rows by float atomics, dtype0, dgamma, dbeta column sums. */
+int lako_layernorm_bwd(const void* dy, const void* x, const float* lin_bias, const void* resid, const float* gamma, void* dz,
+                       float* dgamma, float* dbeta, float* dbias, int64_t rows, int d, float eps, int dtype, lako_stream_t stream);
+int lako_bias_act_bwd(const void* dy, const void* x, const float* bias, void* dx, float* dbias, int64_t rows, int n, int64_t ld,
+                      int act, float dbias_scale, int dtype, lako_stream_t stream);
+int lako_seq_mean_bwd(const float* dout, const uint8_t* mask, void* dx, int B, int L, int d, int dtype, lako_stream_t stream);
+int lako_bi_score_bwd(const float* dscore, const float* q, const float* p, float* dq, float* dp, int B, int n, int d, float scale,
+                      lako_stream_t stream);
+int lako_kldiv_bwd(const float* score, const float* gold, float* dscore, const float* upstream, int B, int n, lako_stream_t stream);
+int lako_bert_embed_bwd(const int64_t* ids, const float* word, const float* pos, const float* type0, const float* gamma,
+                        const void* dy, float* dword, float* dpos, float* dtype0, float* dgamma, float* dbeta, int64_t n_tok, int L,
+                        int d, int64_t vocab, float eps, int dtype, lako_stream_t stream);
+
 
 #ifdef __cplusplus
 }

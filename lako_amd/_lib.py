@@ -118,6 +118,12 @@ SIGNATURES = {
     "lako_seq_mean": [vp, vp, vp, i32, i32, i32, i32, vp],
     "lako_bi_score": [vp, vp, vp, i32, i32, i32, f32, vp],
     "lako_kldiv_fwd": [vp, vp, vp, i32, i32, vp],
+    "lako_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, vp],
+    "lako_bias_act_bwd": [vp, vp, vp, vp, vp, i64, i32, i64, i32, f32, i32, vp],
+    "lako_seq_mean_bwd": [vp, vp, vp, i32, i32, i32, i32, vp],
+    "lako_bi_score_bwd": [vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
+    "lako_kldiv_bwd": [vp, vp, vp, vp, i32, i32, vp],
+    "lako_bert_embed_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i64, f32, i32, vp],
     "lako_tuning_init": [C.POINTER(Tuning)],
     "lako_tuning_set": [C.POINTER(Tuning), C.c_char_p, i32],
 }

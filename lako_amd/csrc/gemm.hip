@@ -338,8 +338,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
     // resident at once).  With tiles strided by the grid size a workgroup that starts late still owes its whole list and the launch
     // ends a full pass later; here only a workgroup's FIRST tile is static, the rest of an XCD's share — the same tile ids the
     // striding gives that XCD, so the operand panels stay in its L2 — is handed out by a ticket counter per XCD: late workgroups
-    // find the counter exhausted.  The ticket (one returning atomic by thread 0) is requested at the tile's start and consumed two
-    // K-steps before its end (a word in LDS, published by that K-step's barrier), in time for the next tile's first prefetch.
+    // find the counter exhausted.  The ticket (one returning atomic by thread 0) is requested at the tile's start and consumed at the
+    // top of its last K-step, in time for the next tile's first prefetch.
     int ticket = 0;
     if constexpr (QUEUE) {
       if (threadIdx.x == 0) ticket = atomicAdd(&a.queue[blockIdx.x & 7], 1);
@@ -358,15 +358,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
       const char* As = smem + cur * BUF;
       const char* Bs = As + A_BYTES;
       char* An = smem + (cur ^ 1) * BUF;
-      if constexpr (QUEUE) {       // (host: nk >= 2)
-        int* sh_next = reinterpret_cast<int*>(smem + 2 * BUF + (SIDE ? 32 * 1024 : 0) + (NW - SCR_IN_BUF) * 8192);
-        if (t == nk - 2 && threadIdx.x == 0) {
-          const int G = gridDim.x, x = blockIdx.x & 7, q = G >> 3, r = G & 7;
-          const int qx = q + (x < r ? 1 : 0), base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
-          *sh_next = base + ticket % qx + (ticket / qx + 1) * G;       // the XCD's share in the order the striding walks it
-        }
+      if constexpr (QUEUE) {
+        // the ticket becomes the next tile id at the top of the tile's LAST K-step, handed to the other waves through the first word
+        // of the K-slice buffer that this step is about to refill (free since the barrier that ended the previous step; the SIDE
+        // instantiation has no other byte of its 160 KiB to spare): write → barrier → read → barrier → the prefetch may overwrite it
         if (t == nk - 1) {
+          int* sh_next = reinterpret_cast<int*>(An);
+          if (threadIdx.x == 0) {
+            const int G = gridDim.x, x = blockIdx.x & 7, q = G >> 3, r = G & 7;
+            const int qx = q + (x < r ? 1 : 0), base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+            *sh_next = base + ticket % qx + (ticket / qx + 1) * G;       // the XCD's share in the order the striding walks it
+          }
+          __syncthreads();
           next_tile = *sh_next;
+          __syncthreads();
           has_next = next_tile < nwg;
           tile_coords(has_next ? next_tile : 0, a.tiles_m, a.tiles_n, a.group_m, tm_, tn_);
           nm0 = tm_ * BM;
@@ -1559,7 +1564,7 @@ void launch_nt_cfg(NtArgs a, const lako_tuning_t& tu, hipStream_t s) {
   constexpr int BM = WM * MT * 16, BN = WN * NT * 16, NW_ = WM * WN, BUF_ = (BM + BN) * TKB;
   // + the epilogue scratch of the waves that do not fit the free K-slice buffer (8 KiB each; 192-row tiles: one wave)
   constexpr int EXTRA = (sizeof(T) == 2 && NW_ == 8 && BUF_ / 8192 < NW_) ? (NW_ - BUF_ / 8192) * 8192 : 0;
-  constexpr int LDS = 2 * BUF_ + (SIDE ? 32 * 1024 : 0) + EXTRA + (QUEUE ? 16 : 0);
+  constexpr int LDS = 2 * BUF_ + (SIDE ? 32 * 1024 : 0) + EXTRA;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, TO, WM, WN, MT, NT, SIDE, QUEUE>),
@@ -1593,7 +1598,7 @@ void launch_nt_cfg(NtArgs a, const lako_tuning_t& tu, hipStream_t s) {
   a.dephase = (tu.nt_dephase > 0 && a.tiles_m * a.tiles_n > grid) ? ((tu.nt_dephase_n << 16) | (tu.nt_dephase & 0xffff)) : 0;
   if constexpr (QUEUE) {
     a.queue = nt_queue_counters(s);
-    // (needs two K-steps per tile to hand the ticket over, several tiles per workgroup to be of any use, and a persistent grid)
+    // (several K-steps per tile to cover the ticket's round trip, several tiles per workgroup to be of any use, a persistent grid)
     if (!a.queue || a.K * (int)sizeof(T) <= TKB || a.tiles_m * a.tiles_n <= grid || !tu.nt_persistent) {
       launch_nt_cfg<T, TO, WM, WN, MT, NT, SIDE, false>(a, tu, s);
       return;

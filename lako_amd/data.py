@@ -110,3 +110,22 @@ class Collator:
         passages = [p + [""] * (n - len(p)) for p in passages]          # ragged "separate" batches: empty passages
         passage_ids, passage_masks = encode_passages(passages, self.tokenizer, self.text_maxlength)
         return index, target_ids, target_mask, passage_ids, passage_masks
+
+
+class RetrieverCollator:
+    """src/data.py:178-211: question + caption → question ids / mask; the example's fact sentences → passage ids / masks [B, n, L];
+    the reader's per-fact scores as gold scores.  (index, question_ids, question_mask, passage_ids, passage_masks, scores) —
+    the batch train_retriever.py:57-66 feeds to `Retriever.forward`."""
+
+    def __init__(self, tokenizer, passage_maxlength=140, question_maxlength=140):
+        self.tokenizer, self.passage_maxlength, self.question_maxlength = tokenizer, passage_maxlength, question_maxlength
+
+    def __call__(self, batch):
+        index = torch.tensor([ex["index"] for ex in batch])
+        q = _encode(self.tokenizer, [ex["question"] + " " + ex["caption"] for ex in batch], self.question_maxlength, True)
+        question_ids, question_mask = q["input_ids"], q["attention_mask"].bool()
+        if batch[0]["score"] is None or batch[0]["fact"] is None:
+            return index, question_ids, question_mask, None, None, None
+        scores = torch.stack([ex["score"] for ex in batch], dim=0)
+        passage_ids, passage_masks = encode_passages([ex["fact"] for ex in batch], self.tokenizer, self.passage_maxlength)
+        return index, question_ids, question_mask, passage_ids, passage_masks, scores

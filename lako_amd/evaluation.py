@@ -61,3 +61,28 @@ def stem_ems(prediction, ground_truths, tokenizer, stemmer, dele_sw=False, stop_
         if any(stemmer.stem(t) in stem_ans for t in tokenizer.tokenize(normalize_answer(ground_truth))):
             return value
     return 0
+
+
+# ---- ranking metrics of the retriever's evaluation (src/evaluation.py:200-232, train_retriever.py:142) ----------------------
+def count_inversions(arr):
+    return sum(1 for i in range(len(arr)) for j in range(i + 1, len(arr)) if arr[i] > arr[j])
+
+
+def score(x, inversions, avg_topk, idx_topk):
+    """x: the gold ranks in predicted order.  inversions; per k: the share of the predicted top-k that is in the gold top-k, and the
+    number of predicted passages needed to cover the gold top-k."""
+    x = list(x)
+    inversions.append(count_inversions(x))
+    for k in avg_topk:
+        avg_topk[k].append(sum(1 for v in x[:k] if v < k) / float(len(x[:k])))
+    for k in idx_topk:
+        below = [v < k for v in x]
+        last = max((i for i, b in enumerate(below) if b), default=len(x) - 1)       # numpy: len − argmax(reversed) = last True + 1
+        idx_topk[k].append(last + 1 if any(below) else len(x))
+
+
+def eval_batch(scores, inversions, avg_topk, idx_topk):
+    for s in scores:
+        s = [float(v) for v in s]
+        order = sorted(range(len(s)), key=lambda i: -s[i])
+        score(order, inversions, avg_topk, idx_topk)

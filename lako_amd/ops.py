@@ -518,6 +518,53 @@ class HipOps:
             raise LakoError("kldiv_fwd: fp32 contiguous [B, n] score and gold")
         self._timed("kldiv_fwd", 0.0, lambda: check(self.lib.lako_kldiv_fwd(_p(score), _p(gold), _p(loss), B, n, self._stream()), "lako_kldiv_fwd"))
 
+    # ---- retriever training (csrc/bertbwd.hip) ------------------------------------------------
+    def layernorm_bwd(self, dy, x, gamma, dz, dgamma, dbeta, *, lin_bias=None, resid=None, dbias=None, eps=1e-12):
+        """backward of layernorm_fwd (z = x + lin_bias + resid recomputed): dz; dgamma / dbeta / dbias (fp32) accumulated"""
+        rows, d = x.shape
+        if not (dy.is_contiguous() and x.is_contiguous() and dz.is_contiguous()) or (resid is not None and not resid.is_contiguous()):
+            raise LakoError("layernorm_bwd: contiguous [rows, d] tensors")
+        self._timed("layernorm_bwd", 0.0, lambda: check(self.lib.lako_layernorm_bwd(
+            _p(dy), _p(x), _p(lin_bias), _p(resid), _p(gamma), _p(dz), _p(dgamma), _p(dbeta), _p(dbias), rows, d, float(eps), _dt(x),
+            self._stream()), "lako_layernorm_bwd"))
+
+    def bias_act_bwd(self, dy, x, bias, dx, dbias, gelu=False, dbias_scale=1.0):
+        """dx (None: skip) = dy·act'(x + bias) on a [rows, n] column block (unit inner stride, shared row stride); dbias += scale·Σ_rows dx"""
+        rows, n = dy.shape
+        ld = dy.stride(0)
+        if dy.stride(1) != 1 or (x is not None and (x.stride() != dy.stride() or x.shape != dy.shape)) or \
+                (dx is not None and (dx.stride() != dy.stride() or dx.shape != dy.shape)):
+            raise LakoError("bias_act_bwd: dy, x and dx must share shape and strides (unit inner stride)")
+        self._timed("bias_act_bwd", 0.0, lambda: check(self.lib.lako_bias_act_bwd(
+            _p(dy), _p(x), _p(bias), _p(dx), _p(dbias), rows, n, ld, 1 if gelu else 0, float(dbias_scale), _dt(dy), self._stream()),
+            "lako_bias_act_bwd"))
+
+    def seq_mean_bwd(self, dout, mask, dx):
+        B, L, d = dx.shape
+        if dout.dtype != torch.float32 or not dout.is_contiguous() or not dx.is_contiguous():
+            raise LakoError("seq_mean_bwd: dout fp32 [B, d], dx contiguous [B, L, d]")
+        self._timed("seq_mean_bwd", 0.0, lambda: check(self.lib.lako_seq_mean_bwd(_p(dout), _p(mask), _p(dx), B, L, d, _dt(dx), self._stream()),
+                                                       "lako_seq_mean_bwd"))
+
+    def bi_score_bwd(self, dscore, q, p, dq, dp, scale):
+        B, n, d = p.shape
+        for t in (dscore, q, p, dq, dp):
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise LakoError("bi_score_bwd: fp32 contiguous tensors")
+        self._timed("bi_score_bwd", 0.0, lambda: check(self.lib.lako_bi_score_bwd(_p(dscore), _p(q), _p(p), _p(dq), _p(dp), B, n, d, float(scale),
+                                                                                 self._stream()), "lako_bi_score_bwd"))
+
+    def kldiv_bwd(self, score, gold, dscore, upstream=None):
+        B, n = score.shape
+        self._timed("kldiv_bwd", 0.0, lambda: check(self.lib.lako_kldiv_bwd(_p(score), _p(gold), _p(dscore), _p(upstream), B, n, self._stream()),
+                                                    "lako_kldiv_bwd"))
+
+    def bert_embed_bwd(self, ids, word, pos, type0, gamma, dy, dword, dpos, dtype0, dgamma, dbeta, L, eps=1e-12):
+        n_tok, d = dy.shape
+        self._timed("bert_embed_bwd", 0.0, lambda: check(self.lib.lako_bert_embed_bwd(
+            _p(ids), _p(word), _p(pos), _p(type0), _p(gamma), _p(dy), _p(dword), _p(dpos), _p(dtype0), _p(dgamma), _p(dbeta), n_tok, int(L), d,
+            word.shape[0], float(eps), _dt(dy), self._stream()), "lako_bert_embed_bwd"))
+
     # ---- integer helpers ------------------------------------------------------------------------
     def shift_right(self, labels, dec_ids):
         B, T = labels.shape

@@ -1,7 +1,7 @@
 """Flag system of the reader drivers — same flag names, types and defaults as the reference's
 `src/options.py` (base :90-112, optim :20-48, reader :55-66, eval :50-53) so that the argument lists of
-run_okvqa_train.sh / run_okvqa_test.sh parse unchanged.  Retriever-only flags are out of scope
-(SURVEY.md §2.1 #10-14).  Added flags (all optional): --synthetic, --dtype, --steps."""
+run_okvqa_train.sh / run_okvqa_test.sh parse unchanged; `add_retriever_options` carries the flags train_retriever.py reads
+(src/options.py:68-86; the index-building ones are parsed and unused).  Added flags (all optional): --synthetic, --dtype, --steps."""
 from __future__ import annotations
 
 import argparse
@@ -76,6 +76,27 @@ class Options:
         p.add_argument("--answer_maxlength", type=int, default=-1)
         p.add_argument("--no_title", action="store_true")
         p.add_argument("--n_context", type=int, default=1)
+        return self
+
+    def add_retriever_options(self):
+        p = self.parser
+        p.add_argument("--indexing_batch_size", type=int, default=50000)
+        p.add_argument("--n-subquantizers", type=int, default=0)
+        p.add_argument("--n-bits", type=int, default=8)
+        p.add_argument("--passages_embeddings", type=str, default="fact_embedding_dim256_at_11-07-13.pkl")
+        p.add_argument("--save_or_load_index", action="store_true")
+        p.add_argument("--train_data", type=str, default="none")
+        p.add_argument("--eval_data", type=str, default="none")
+        p.add_argument("--indexing_dimension", type=int, default=256)
+        p.add_argument("--no_projection", action="store_true")
+        p.add_argument("--question_maxlength", type=int, default=130)
+        p.add_argument("--passage_maxlength", type=int, default=130)
+        p.add_argument("--no_question_mask", action="store_true")
+        p.add_argument("--no_passage_mask", action="store_true")
+        p.add_argument("--extract_cls", action="store_true")
+        p.add_argument("--no_title", action="store_true")
+        p.add_argument("--n_context", type=int, default=1)
+        p.add_argument("--retriever_layers", type=int, default=12, help="(addition) BERT layers of a randomly initialised retriever")
         return self
 
     def parse(self, argv=None):

@@ -6,8 +6,11 @@ What runs: HF `BertModel` (absolute positions, token type 0, post-LN blocks, bia
 dropout) → optional projection + LayerNorm (`proj`/`norm`, or `proj_iq`/`proj_fact` for the asymmetric variant) → CLS
 row or (masked) mean → `einsum('bd,bid->bi') / sqrt(d)`.  Every FLOP is a gfx950 kernel behind the C-ABI: the reader's
 `lako_gemm_nt` and `lako_attn_fwd` (the 1/sqrt(d_head) scale is folded into the query weights here) plus the row-wise
-kernels of `csrc/bertops.hip`.  Training the retriever (KL distillation backward, train_retriever.py) is NOT built:
-`forward(gold_score=…)` returns the KLDivLoss *value* only, and `.backward()` does not exist on it.
+kernels of `csrc/bertops.hip`.  TRAINING (round 3): with autograd enabled, `forward(..., gold_score=…)` runs the training
+schedule of `lako_amd/retriever_train.py` (activations kept, dropout in `.train()` mode) and returns a loss whose `.backward()`
+runs the hand-written backward (csrc/bertbwd.hip + the reader's GEMM / attention-backward kernels) into `.grad`; the parameters
+are views of one flat fp32 buffer, so `util.set_optim` / `util.clip_grad_norm_` (the reader's fused AdamW) apply unchanged —
+train_retriever.py:37-71.  Under `torch.no_grad()` the forward is the inference schedule below.
 
 Parameters carry the reference's state-dict key names (`model.embeddings.…`, `model.encoder.layer.i.…`, `proj.weight`, …),
 so a checkpoint written by the reference's `Retriever.save_pretrained` loads with `load_state_dict`.
@@ -45,6 +48,9 @@ class RetrieverConfig:
     question_maxlength: int = 130
     projection: bool = True
     asymmetric_retri: object = False       # the reference compares with the string "yes" (src/model.py:395,462)
+    pad_token_id: int = 0                  # BertConfig default: the word-embedding row that never receives a gradient
+    hidden_dropout_prob: float = 0.1       # BertConfig defaults; train_retriever.py:237 overrides both through
+    attention_probs_dropout_prob: float = 0.1   # src.util.set_dropout(model, opt.dropout) → Retriever.set_dropout
 
     @classmethod
     def from_hf(cls, cfg):
@@ -113,25 +119,96 @@ class Retriever(nn.Module):
         self._ops = _ops
         self._pack = None
         self._pack_key = None
+        self._seed = int(seed)
+        self._engine = None
+        self._trainer = None
+        self._master_version = 0
         g = torch.Generator().manual_seed(seed)
+        # one flat fp32 master buffer (64-element aligned blocks); every nn.Parameter is a view of it — the fused optimizer and the
+        # gradient-norm kernel walk P / G as flat arrays (util.AdamW, util.clip_grad_norm_), like the reader's engine
+        shapes = _param_shapes(c)
+        # (the pooler — in the checkpoints, never on the path: embed_text takes BertModel's output [0] — sits behind the trained range:
+        #  the reference's optimizer skips parameters without a gradient, decay included, so the fused step must not see it)
+        order = [k for k in shapes if not k.startswith("model.pooler.")] + [k for k in shapes if k.startswith("model.pooler.")]
+        self._layout, off, self._n_train = {}, 0, None
+        for name in order:
+            shape = shapes[name]
+            if name.startswith("model.pooler.") and self._n_train is None:
+                self._n_train = off
+            n = 1
+            for k in shape:
+                n *= k
+            self._layout[name] = (off, n, tuple(shape))
+            off += -(-n // 64) * 64
+        self._n_train = off if self._n_train is None else self._n_train
+        self._master = torch.zeros(off, dtype=torch.float32)
         self._by_name = {}
-        for name, shape in _param_shapes(c).items():
+        for name in shapes:                       # (draw in the state-dict order: the initialisation does not depend on the layout)
+            o, n, shape = self._layout[name]
+            v = self._master[o:o + n].view(shape)
             if name.endswith("LayerNorm.weight") or name.startswith("norm") and name.endswith(".weight"):
-                t = torch.ones(shape)
-            elif name.endswith(".bias"):
-                t = torch.zeros(shape)
-            else:
-                t = torch.randn(shape, generator=g) * 0.02      # BertPreTrainedModel._init_weights std
+                v.fill_(1.0)
+            elif not name.endswith(".bias"):
+                v.copy_(torch.randn(shape, generator=g) * 0.02)      # BertPreTrainedModel._init_weights std
             mod = self
             parts = name.split(".")
             for part in parts[:-1]:
                 if part not in mod._modules:
                     mod.add_module(part, nn.Module())
                 mod = mod._modules[part]
-            prm = nn.Parameter(t, requires_grad=False)
+            prm = nn.Parameter(v, requires_grad=True)
             mod.register_parameter(parts[-1], prm)
             self._by_name[name] = prm
         self.eval()
+
+    # ------------------------------------------------------------------------------------------
+    # flat storage: moving the model moves ONE buffer and re-points the parameter views (nn.Module._apply would give every
+    # parameter a storage of its own)
+    def _views(self, flat):
+        return {name: flat[o:o + n].view(shape) for name, (o, n, shape) in self._layout.items()}
+
+    def _rebind(self):
+        views = self._views(self._master)
+        gviews = self._views(self._engine.G_all) if self._engine is not None else None
+        for name, prm in self._by_name.items():
+            prm.data = views[name]
+            prm.grad = gviews[name] if gviews is not None else None
+
+    def _apply(self, fn, recurse=True):
+        new = fn(self._master)
+        if self._engine is not None and new.device == self._master.device:
+            if new.data_ptr() != self._master.data_ptr():
+                self._master.copy_(new)
+                self._pack = None
+            return self
+        self._master = new if new.dtype == torch.float32 else new.float()
+        self._engine = None
+        self._pack = None
+        self._rebind()
+        return self
+
+    def _get_engine(self):
+        """flat P / G / AdamW moments for util.set_optim / util.clip_grad_norm_ (retriever_train.RetrieverEngine)"""
+        if self._engine is None:
+            from .retriever_train import RetrieverEngine
+            self._engine = RetrieverEngine(self, self._get_ops(), self._master.device)
+            self._rebind()
+        return self._engine
+
+    def _grad_views(self):
+        eng = self._get_engine()
+        if getattr(self, "_gv", None) is None or self._gv[0] is not eng.G_all:
+            self._gv = (eng.G_all, self._views(eng.G_all))
+        return self._gv[1]
+
+    def zero_grad(self, set_to_none: bool = False):
+        if self._engine is not None:
+            self._engine.zero_grad()
+
+    def set_dropout(self, p: float):
+        """src/util.py set_dropout(model, p) (train_retriever.py:237): every nn.Dropout of the BERT tower gets probability p"""
+        self.config.hidden_dropout_prob = float(p)
+        self.config.attention_probs_dropout_prob = float(p)
 
     # ------------------------------------------------------------------------------------------
     def load_state_dict(self, state_dict, strict=True, **kw):
@@ -148,6 +225,7 @@ class Retriever(nn.Module):
                         raise ValueError(f"{k}: shape {tuple(v.shape)} != {tuple(p.shape)}")
                     p.copy_(torch.as_tensor(v).to(p.device, torch.float32))
         self._pack = None
+        self._master_version += 1
         return missing
 
     def save_pretrained(self, path):
@@ -179,12 +257,13 @@ class Retriever(nn.Module):
             self._ops = HipOps()            # raises without a GPU / the HIP library: there is no CPU fallback
         return self._ops
 
-    def _packed(self):
+    def _packed(self, train: bool = False):
         """Compute-layout weights: fused [3d, d] QKV with the 1/sqrt(d_head) score scale folded into the query rows,
-        matrices in the compute dtype, biases / LayerNorm / embedding tables in fp32."""
+        matrices in the compute dtype, biases / LayerNorm / embedding tables in fp32.  train: also the transposed copies the
+        backward's dX products read (dX = dY·W as an NT product against Wᵀ)."""
         dev = self._by_name["model.embeddings.word_embeddings.weight"].device
-        key = (str(dev), self.compute_dtype, tuple(p._version for p in self._by_name.values()))
-        if self._pack is not None and self._pack_key == key:
+        key = (str(dev), self.compute_dtype, self._master_version, tuple(p._version for p in self._by_name.values()))
+        if self._pack is not None and self._pack_key == key and (not train or self._pack.get("train")):
             return self._pack
         c, P, cd = self.config, self._by_name, self.compute_dtype
         qs = 1.0 / math.sqrt(c.hidden_size // c.num_attention_heads)
@@ -207,6 +286,13 @@ class Retriever(nn.Module):
         for pj, nm in (("proj", "norm"), ("proj_iq", "norm_iq"), ("proj_fact", "norm_fact")):
             if pj + ".weight" in P:
                 pk[pj] = (w(pj + ".weight"), f32(pj + ".bias"), f32(nm + ".weight"), f32(nm + ".bias"))
+                if train:
+                    pk[pj + "_t"] = pk[pj][0].t().contiguous()
+        if train:
+            for ly in pk["layers"]:
+                for n in ("wqkv", "wo", "wi", "wo2"):
+                    ly[n + "_t"] = ly[n].t().contiguous()
+            pk["train"] = True
         self._pack, self._pack_key = pk, key
         return pk
 
@@ -270,8 +356,14 @@ class Retriever(nn.Module):
         return out
 
     def forward(self, question_ids, question_mask, passage_ids, passage_mask, gold_score=None):
-        """src/model.py:413-449 → (question_output, passage_output, score, loss)."""
+        """src/model.py:413-449 → (question_output, passage_output, score, loss).  With a gold score and autograd enabled the
+        loss carries the hand-written backward (train_retriever.py:57-66); otherwise this is the inference schedule."""
         c = self.config
+        if gold_score is not None and torch.is_grad_enabled():
+            if self._trainer is None:
+                from .retriever_train import RetrieverTrainer
+                self._trainer = RetrieverTrainer(self)
+            return self._trainer.forward(question_ids, question_mask, passage_ids, passage_mask, gold_score)
         bsz, n_passages, plen = passage_ids.shape
         q = self.embed_text(question_ids, question_mask, "q", c.apply_question_mask, c.extract_cls)
         p = self.embed_text(passage_ids.reshape(bsz * n_passages, plen), passage_mask.reshape(bsz * n_passages, plen), "f",

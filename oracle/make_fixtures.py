@@ -417,11 +417,89 @@ def make_retriever():
     print("retriever.npz", {k: v.shape for k, v in out.items() if k.startswith("proj_mean")})
 
 
+RANK_SCORES = [[0.9, 0.1, 0.5, 0.3, 0.2, 0.05, 0.7], [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7], [3.0, 2.0, 1.0, 0.5, 0.4, 0.3, 0.2],
+               [0.0, 5.0, -1.0, 4.0, 4.5, 2.0, 1.0], [1.0, 0.5]]
+
+
+def make_rank_metrics():
+    """Golden values of the retriever evaluation's ranking metrics (src/evaluation.py:200-232: eval_batch → inversions, share of the
+    predicted top-k in the gold top-k, predicted passages needed to cover the gold top-k) on fixed score rows → tests/golden/rank_metrics.json"""
+    import json
+    import src.evaluation as rev
+    rows = []
+    for sc in RANK_SCORES:
+        ks = [k for k in (1, 2, 5) if k <= len(sc)]
+        inv, avg, idx = [], {k: [] for k in ks}, {k: [] for k in ks}
+        rev.eval_batch(torch.tensor([sc]), inv, avg, idx)
+        rows.append({"scores": sc, "inversions": [int(v) for v in inv], "avg_topk": {str(k): [float(x) for x in v] for k, v in avg.items()},
+                     "idx_topk": {str(k): [int(x) for x in v] for k, v in idx.items()}})
+    with open(os.path.join(ROOT, "tests", "golden", "rank_metrics.json"), "w") as f:
+        json.dump(rows, f, indent=1)
+    print("wrote rank_metrics.json", len(rows))
+
+
+def make_retriever_train():
+    """Gradients of the reference's own Retriever (src/model.py:413-483: KLDivLoss of log_softmax(q·p/√d) against the gold
+    scores, train_retriever.py:57-66) for every parameter, plus the weights after TWO steps of the reference's optimizer
+    (src/util.set_optim → the HF<=4 AdamW stub of this harness + WarmupLinearScheduler, clip_grad_norm_ 1.0 as in
+    train_retriever.py:68-71) → tests/golden/retriever_train.npz.  eval() mode (dropout off), same weights / batches as
+    make_retriever."""
+    import types
+    import src.model as rm
+    import src.util as ru
+    from lako_amd.retriever import RetrieverConfig
+    from oracle import retriever_oracle as RO
+    out = {}
+    for ci, (name, over) in enumerate(RETRIEVER_CASES.items()):
+        if name == "proj_mean":              # (covered by proj_mask / raw_mean)
+            continue
+        kw = dict(RETRIEVER_TINY, **over)
+        ref_cfg = rm.RetrieverConfig(**kw)
+        cfg = RetrieverConfig.from_hf(ref_cfg)
+        w = RO.init_weights(cfg, seed=40 + ci)
+        ref = rm.Retriever(ref_cfg)
+        ref.load_state_dict(w, strict=False)
+        ref.eval()
+        qi, qm, pi, pm, gold = RO.synthetic_batch(cfg, 3, 4, 9, 14, seed=70 + ci)
+        _, _, _, loss = ref(qi, qm, pi, pm, gold_score=gold)
+        loss.backward()
+        out[f"{name}.loss"] = loss.detach().double().numpy()
+        for k, prm in ref.named_parameters():
+            if k in w:
+                g = prm.grad if prm.grad is not None else torch.zeros_like(prm)
+                out[f"{name}.g/{k}"] = g.detach().numpy().astype(np.float32)
+        ref.zero_grad()
+        if name != "asym_mask":              # (fixture size: the optimizer steps of one configuration, gradients of all)
+            continue
+        opt = types.SimpleNamespace(optim="adamw", lr=1e-3, weight_decay=0.01, scheduler="linear", scheduler_steps=None, total_steps=10,
+                                    warmup_steps=1, fixed_lr=False)
+        optimizer, scheduler = ru.set_optim(opt, ref)
+        for step in range(2):
+            _, _, _, loss = ref(qi, qm, pi, pm, gold_score=gold)
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(ref.parameters(), 1.0)
+            optimizer.step()
+            scheduler.step()
+            ref.zero_grad()
+            out[f"{name}.loss_step{step}"] = loss.detach().double().numpy()
+        for k, prm in ref.named_parameters():
+            if k in w:
+                out[f"{name}.w2/{k}"] = prm.detach().numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "retriever_train.npz"), **out)
+    print("retriever_train.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "retriever_train":
+        make_retriever_train()
+        make_rank_metrics()
+        sys.exit(0)
     tiny = O.T5Dims.named("tiny")
     make_tables()
     make_collate()
     make_retriever()
+    make_retriever_train()
+    make_rank_metrics()
     make_evaluation()
     make_case("tiny_a", tiny, B=3, N=3, L=12, T=5, seed=1, full_pad=(1, 2))
     make_case("tiny_fact", tiny, B=3, N=2, L=24, T=4, seed=2, fact_case=True)

@@ -46,7 +46,8 @@ def bert_encode(c, w, ids, mask=None, dtype=torch.float64):
     B, L = ids.shape
     d, H = c.hidden_size, c.num_attention_heads
     dk = d // H
-    x = W["model.embeddings.word_embeddings.weight"][ids] + W["model.embeddings.position_embeddings.weight"][:L][None] \
+    # (nn.Embedding(vocab, hidden, padding_idx=pad_token_id = 0) in HF BertEmbeddings: the pad row receives NO gradient)
+    x = F.embedding(ids, W["model.embeddings.word_embeddings.weight"], padding_idx=0) + W["model.embeddings.position_embeddings.weight"][:L][None] \
         + W["model.embeddings.token_type_embeddings.weight"][0]
     x = F.layer_norm(x, (d,), W["model.embeddings.LayerNorm.weight"], W["model.embeddings.LayerNorm.bias"], c.layer_norm_eps)
     add = None

@@ -461,6 +461,71 @@ class RefOps:
     def kldiv_fwd(self, score, gold, loss):
         loss[0] = torch.nn.KLDivLoss()(torch.log_softmax(score, -1), gold)
 
+    # ---- retriever training (test doubles of csrc/bertbwd.hip: torch autograd of the forward doubles above) -------------------
+    @torch.enable_grad()
+    def layernorm_bwd(self, dy, x, gamma, dz, dgamma, dbeta, *, lin_bias=None, resid=None, dbias=None, eps=1e-12):
+        z = x.float()
+        if lin_bias is not None:
+            z = z + lin_bias.float()
+        if resid is not None:
+            z = z + resid.float()
+        z = z.detach().requires_grad_(True)
+        g = gamma.float().detach().requires_grad_(True)
+        b = torch.zeros_like(g).requires_grad_(True)
+        y = torch.nn.functional.layer_norm(z, (z.shape[-1],), g, b, eps)
+        gz, gg, gb = torch.autograd.grad(y, [z, g, b], dy.float())
+        dz.copy_(gz)
+        dgamma += gg
+        dbeta += gb
+        if dbias is not None:
+            dbias += gz.sum(0)
+
+    @torch.enable_grad()
+    def bias_act_bwd(self, dy, x, bias, dx, dbias, gelu=False, dbias_scale=1.0):
+        g = dy.float()
+        if gelu:
+            v = (x.float() + bias.float()).detach().requires_grad_(True)
+            g, = torch.autograd.grad(torch.nn.functional.gelu(v), v, g)
+        if dx is not None:
+            dx.copy_(g)
+        dbias += g.sum(0) * dbias_scale
+
+    def seq_mean_bwd(self, dout, mask, dx):
+        B, L, d = dx.shape
+        if mask is None:
+            dx.copy_((dout[:, None, :] / L).expand(B, L, d))
+        else:
+            m = mask.bool()
+            dx.copy_(torch.where(m[:, :, None], dout[:, None, :] / m.sum(1).float()[:, None, None], torch.zeros((), dtype=dout.dtype)))
+
+    def bi_score_bwd(self, dscore, q, p, dq, dp, scale):
+        dp.copy_(dscore[:, :, None] * q[:, None, :] * scale)
+        dq.copy_(torch.einsum("bi,bid->bd", dscore, p) * scale)
+
+    @torch.enable_grad()
+    def kldiv_bwd(self, score, gold, dscore, upstream=None):
+        sc = score.detach().clone().requires_grad_(True)
+        loss = torch.nn.KLDivLoss()(torch.log_softmax(sc, -1), gold)
+        g, = torch.autograd.grad(loss, sc)
+        dscore.copy_(g * (upstream[0] if upstream is not None else 1.0))
+
+    @torch.enable_grad()
+    def bert_embed_bwd(self, ids, word, pos, type0, gamma, dy, dword, dpos, dtype0, dgamma, dbeta, L, eps=1e-12):
+        n_tok, d = dy.shape
+        ids = ids.reshape(-1)
+        ids = torch.where((ids < 0) | (ids >= word.shape[0]), torch.zeros_like(ids), ids)
+        p_idx = torch.arange(n_tok, device=ids.device) % L
+        z = (word[ids].float() + pos[p_idx].float() + type0.float()).detach().requires_grad_(True)
+        g = gamma.float().detach().requires_grad_(True)
+        b = torch.zeros_like(g).requires_grad_(True)
+        y = torch.nn.functional.layer_norm(z, (d,), g, b, eps)
+        gz, gg, gb = torch.autograd.grad(y, [z, g, b], dy.float())
+        dword.index_add_(0, ids, gz)
+        dpos.index_add_(0, p_idx, gz)
+        dtype0 += gz.sum(0)
+        dgamma += gg
+        dbeta += gb
+
     # ---- integer helpers ------------------------------------------------------------------------
     def shift_right(self, labels, dec_ids):
         dec_ids[:, 0] = 0

@@ -161,3 +161,17 @@ def test_test_reader_evaluate_writes_scores_and_results(tmp_path):
     rows = json.load(open(tmp_path / "test_results" / res[0]))
     assert len(rows) == 3 and {"question", "answer", "real answers", "score", "include_score", "stem_score"} <= set(rows[0])
     assert tr.scores_file_name(opt) == "dev_full_attention_of_tiny_with_max_v1.json"
+
+
+def test_rank_metrics_match_reference():
+    """the retriever evaluation's ranking metrics (src/evaluation.py:200-232) against values of the reference's own functions"""
+    import json
+    from lako_amd.evaluation import eval_batch
+    rows = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "rank_metrics.json")))
+    for r in rows:
+        ks = [k for k in (1, 2, 5) if k <= len(r["scores"])]
+        inv, avg, idx = [], {k: [] for k in ks}, {k: [] for k in ks}
+        eval_batch([r["scores"]], inv, avg, idx)
+        assert inv == r["inversions"]
+        assert {str(k): v for k, v in avg.items()} == r["avg_topk"]
+        assert {str(k): v for k, v in idx.items()} == r["idx_topk"]

@@ -127,3 +127,28 @@ def test_collated_batches_through_the_hip_reader_vs_oracle(tmp_path):
             facts = ds.data[int(bidx[k])]["fact"]
             for j in range(min(opt.n_context, len(facts))):
                 assert abs(facts[j]["score"] - ref_p[k, j].item()) < 1e-4, (int(bidx[k]), j)
+
+
+@pytest.mark.gpu
+def test_train_retriever_driver_end_to_end(tmp_path):
+    """train_retriever.py (the reference driver's flags: src/options.py base + retriever + optim) on synthetic batches: BERT-base
+    width, 2 layers, 6 optimizer steps with dropout on, evaluation (KL loss, inversions, top-k overlap), checkpoint in the
+    reference's directory format; the loss must fall on the (fixed) training batches, and a second run resumes from the checkpoint."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, "train_retriever.py"), "--synthetic", "4,6,24,40", "--retriever_layers", "2", "--optim", "adamw",
+            "--scheduler", "linear", "--lr", "1e-3", "--weight_decay", "0.01", "--dropout", "0.1", "--epochs", "3", "--checkpoint_dir",
+            str(tmp_path), "--name", "ret", "--per_gpu_batch_size", "4"]
+    r = subprocess.run(base + ["--steps", "40"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    evals = [float(ln.split("eval: ")[1].split(",")[0]) for ln in r.stderr.splitlines() if "eval: " in ln]
+    trains = [float(ln.split("train: ")[1].split(",")[0]) for ln in r.stderr.splitlines() if "train: " in ln]
+    assert len(evals) >= 2 and all(np.isfinite(evals)) and trains[1] < trains[0], (trains, evals)      # second full epoch below the first
+    assert "avg top1" in r.stderr and "questions/s" in r.stderr
+    ck = tmp_path / "ret" / "checkpoint" / "best_dev"
+    assert (ck / "optimizer.pth.tar").exists() and (ck / "model.safetensors").exists()
+    r2 = subprocess.run(base + ["--steps", "4", "--model_path", str(tmp_path / "ret" / "checkpoint" / "latest")], capture_output=True,
+                        text=True, timeout=900)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    assert "model loaded from" in r2.stderr
