@@ -109,3 +109,19 @@ def test_chunked_oracle_evaluation_equals_direct():
     torch.testing.assert_close(logits_c, logits.detach(), atol=1e-5, rtol=1e-5)
     for k, v in leaves.items():
         torch.testing.assert_close(grads_c[k], v.grad, atol=1e-6, rtol=1e-4, msg=lambda m, k=k: f"{k}: {m}")
+
+
+def test_per_sample_oracle_evaluation_equals_batch():
+    """tests/test_real_size_gpu.py evaluates the oracle on the benchmark's 16-sample batch one sample at a time; that must give the
+    batch's own loss / logits / gradients (mean over all valid label tokens of the batch)."""
+    from tests.test_real_size_gpu import oracle_fwd_bwd_per_sample
+    z, dims, w = load_case("mid_a")
+    ids, mask, labels = O.synthetic_batch(3, 4, 16, 5, dims.vocab_size, seed=18)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+    loss, logits = O.fid_forward(leaves, dims, ids, mask, labels, training=False)
+    loss.backward()
+    loss_s, logits_s, grads_s = oracle_fwd_bwd_per_sample(w, dims, ids, mask, labels)
+    assert abs(loss_s - loss.item()) < 1e-6
+    torch.testing.assert_close(logits_s, logits.detach(), atol=1e-5, rtol=1e-5)
+    for k, v in leaves.items():
+        torch.testing.assert_close(grads_s[k], v.grad, atol=1e-6, rtol=1e-4, msg=lambda m, k=k: f"{k}: {m}")

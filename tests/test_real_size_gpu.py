@@ -63,6 +63,24 @@ def oracle_fwd_bwd_chunked(w, dims, ids, mask, labels, chunk):
     return loss.item(), logits.detach(), {k: v.grad for k, v in leaves.items()}
 
 
+def oracle_fwd_bwd_per_sample(w, dims, ids, mask, labels):
+    """The oracle's loss, logits and gradients of a BATCH, one sample at a time (host memory of one sample's graph): the batch loss is
+    Σ_b Σ_t CE / (number of valid label tokens of the whole batch) (HF5:1051-1054 mean over labels != -100), so sample b contributes
+    its summed CE over that count — the same numbers as O.fid_forward on the batch, gradients accumulated over the samples."""
+    import torch.nn.functional as F
+    B = ids.shape[0]
+    n_valid = int((labels != -100).sum())
+    leaves = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+    total, logits = 0.0, []
+    for b in range(B):
+        _, lg = O.fid_forward(leaves, dims, ids[b:b + 1], mask[b:b + 1], labels[b:b + 1], training=False)
+        ce = F.cross_entropy(lg.view(-1, lg.size(-1)), labels[b].view(-1), ignore_index=-100, reduction="sum") / n_valid
+        ce.backward()
+        total += float(ce)
+        logits.append(lg.detach())
+    return total, torch.cat(logits), {k: v.grad for k, v in leaves.items()}
+
+
 def _oracle_case(size, N, seed, chunk=None):
     dims = O.T5Dims.named(size)
     dims.dropout = 0.0
@@ -189,6 +207,34 @@ def test_c2_batch1_fp32_vs_oracle(base_case, variant):
 @pytest.mark.parametrize("variant", [None, 2], ids=["auto", "256x256"])
 def test_c2_batch1_bf16_vs_oracle(base_case, variant):
     _check_bf16(base_case, _run_hip(base_case, torch.bfloat16, variant), f"c2_b1_bf16_{'auto' if variant is None else 'v2'}")
+
+
+def test_c2_batch16_bf16_vs_oracle():
+    """The benchmark's own step against the ORACLE (the batch-16 tests were self-comparisons): config 2 at the
+    per-GPU batch of the bench line — 16 samples x 20 passages x 200 tokens, ≈48 k valid tokens: the 256² NT kernel with its row-tail
+    split and both fast epilogues, the 256² TN kernel, the persistent dQ pass, cross-attention in the encoder-state space over 16
+    ragged samples — loss, logits and every parameter gradient with the bf16 bounds of the batch-1 tests.  The oracle walks the
+    batch one sample at a time (oracle_fwd_bwd_per_sample: ≈2-3 minutes on the host)."""
+    from bench import synthetic_batch
+    dims = O.T5Dims.named("base")
+    dims.dropout = 0.0
+    w = O.init_weights(dims, seed=404, shared_std=0.05)
+    ids, mask, labels, lens = synthetic_batch(16, 20, 200, 8, dims.vocab_size, seed=9, device="cpu", with_lengths=True)
+    loss, logits, grads = oracle_fwd_bwd_per_sample(w, dims, ids, mask, labels)
+    case = dict(dims=dims, w=w, loss=loss, logits=logits, grads=grads)
+    model = FiDT5(cfg_of(dims), dtype=torch.bfloat16)
+    model.load_t5(w)
+    model = model.cuda().train()
+    ops = model._get_engine().ops
+    ops.probe = []
+    out = model(input_ids=ids.to(DEV), attention_mask=mask.to(DEV), labels=labels.to(DEV), passage_lengths=lens)
+    assert model._engine.ctx.rag is not None and model._engine.xattn_active
+    out[0].backward()
+    torch.cuda.synchronize()
+    ops.probe = None
+    got = dict(loss=out[0].item(), logits=out.logits.float().cpu().clone(),
+               grads={plain_name(n): p.grad.detach().cpu().clone() for n, p in model.named_parameters()})
+    _check_bf16(case, got, "c2_b16_bf16_vs_oracle")
 
 
 def test_c2_batch16_benchmark_kernels_equal_pinned_kernels():
