@@ -76,7 +76,7 @@ def oracle_fwd_bwd_per_sample(w, dims, ids, mask, labels):
         _, lg = O.fid_forward(leaves, dims, ids[b:b + 1], mask[b:b + 1], labels[b:b + 1], training=False)
         ce = F.cross_entropy(lg.view(-1, lg.size(-1)), labels[b].view(-1), ignore_index=-100, reduction="sum") / n_valid
         ce.backward()
-        total += float(ce)
+        total += float(ce.detach())
         logits.append(lg.detach())
     return total, torch.cat(logits), {k: v.grad for k, v in leaves.items()}
 
