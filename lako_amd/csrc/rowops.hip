@@ -116,9 +116,141 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const T* __restrict__ 
   }
 }
 
-// dx = dres + rstd*(w∘dy − x·rstd²·mean(w∘dy∘x));  dw += Σ_rows dy∘x·rstd.   d <= 1024.
+// 8 consecutive elements as they sit in memory (a prefetched row costs 4 registers per 8 bf16, converted when it is used)
 template <typename T>
-__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+struct Raw8;
+template <>
+struct Raw8<bf16_t> {
+  bf16x8 v;
+  __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const bf16x8*>(p); }
+  __device__ __forceinline__ void get(float (&o)[8]) const {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+  }
+};
+template <>
+struct Raw8<float> {
+  f32x4 a, b;
+  __device__ __forceinline__ void load(const float* p) {
+    a = *reinterpret_cast<const f32x4*>(p);
+    b = *reinterpret_cast<const f32x4*>(p + 4);
+  }
+  __device__ __forceinline__ void get(float (&o)[8]) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[i] = a[i]; o[4 + i] = b[i]; }
+  }
+};
+
+// dx = dres + rstd*(w∘dy − x·rstd²·mean(w∘dy∘x));  dw += Σ_rows dy∘x·rstd.   d <= 1024.
+// A wave walks its rows one at a time; all three operands of the NEXT row (dy, x, dres) are requested before the current row's
+// reduction, so a row costs one memory round trip that overlaps the previous row's arithmetic instead of two exposed ones (the first
+// version fetched dres only after the wave reduction: 3.6-4.6 TB/s).  dx may alias dres: a row is read and written by one wave only.
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* dy, const T* x, const float* __restrict__ w,
+                                                          const float* __restrict__ rstd, const T* dres, T* dx,
+                                                          float* __restrict__ dw, int64_t rows, int d, DropDev dr,
+                                                          T* __restrict__ dx_drop, DropDev dr_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  float dwacc[2][8];
+  float wv[2][8];
+  const int c0 = lane * 8, c1 = 512 + lane * 8;
+  const bool has1 = c1 < d, has0 = c0 < d;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    int c = it * 512 + lane * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { dwacc[it][i] = 0.f; wv[it][i] = 0.f; }
+    if (c < d) load8(w + c, wv[it]);
+  }
+  Raw8<T> ng[2], nx[2], nr[2];
+  float nrs = 0.f;
+  auto fetch = [&](int64_t row) {
+    if (row < rows) {
+      nrs = rstd[row];
+      const int64_t base = row * d;
+      if (has0) {
+        ng[0].load(dy + base + c0);
+        nx[0].load(x + base + c0);
+        if (dres) nr[0].load(dres + base + c0);
+      }
+      if (has1) {
+        ng[1].load(dy + base + c1);
+        nx[1].load(x + base + c1);
+        if (dres) nr[1].load(dres + base + c1);
+      }
+    }
+  };
+  fetch(wid);
+  for (int64_t row = wid; row < rows; row += nw) {
+    const float rs = nrs;
+    float g[2][8], xv[2][8], o[2][8];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) g[it][i] = xv[it][i] = o[it][i] = 0.f;
+      if (it == 0 ? has0 : has1) {
+        ng[it].get(g[it]);
+        nx[it].get(xv[it]);
+        if (dres) nr[it].get(o[it]);
+      }
+    }
+    fetch(row + nw);
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      int c = it * 512 + lane * 8;
+      if (c < d) {
+        bool kp[8];
+        if (dr.thresh) keep8(dr.key, (uint64_t)row * d + c, dr.thresh, kp);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          if (dr.thresh) g[it][i] = kp[i] ? g[it][i] * dr.scale : 0.f;
+          s += wv[it][i] * g[it][i] * xv[it][i];
+          dwacc[it][i] += g[it][i] * xv[it][i] * rs;
+        }
+      }
+    }
+    s = wave_sum(s);
+    const float k = rs * rs * rs * s / (float)d;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      int c = it * 512 + lane * 8;
+      if (c < d) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[it][i] += rs * wv[it][i] * g[it][i] - xv[it][i] * k;
+        store8(dx + row * d + c, o[it]);
+        if (dx_drop) {   // the consumer's dropout_bwd(dx) in the same pass: exactly lako_dropout_apply of the ROUNDED dx
+          bool kp[8];
+          keep8(dr_out.key, (uint64_t)row * d + c, dr_out.thresh, kp);
+          float od[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) od[i] = kp[i] ? (float)(T)o[it][i] * dr_out.scale : 0.f;
+          store8(dx_drop + row * d + c, od);
+        }
+      }
+    }
+  }
+  // block-level reduction of the 4 waves' partial dw in LDS, then ONE atomic per column per block (all
+  // blocks add into the same d addresses, so the number of adders per address is what costs)
+  __shared__ float red[4][1024];
+  const int wave_id = threadIdx.x >> 6;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    int c = it * 512 + lane * 8;
+    if (c < d) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) red[wave_id][c + i] = dwacc[it][i];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += 256) atomicAdd(dw + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+}
+
+#ifdef LAKO_EXPERIMENTS   // round 2's kernel (dres fetched after the reduction, no prefetch) for A/B timing: LAKO_RMS_OLD=1
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_old_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                           const float* __restrict__ w,
                                                           const float* __restrict__ rstd, const T* __restrict__ dres,
                                                           T* __restrict__ dx, float* __restrict__ dw, int64_t rows,
@@ -195,6 +327,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* __restrict__ 
   __syncthreads();
   for (int c = threadIdx.x; c < d; c += 256) atomicAdd(dw + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
 }
+#endif
 
 // ---- embedding ----------------------------------------------------------------------------------
 template <typename T>
@@ -806,8 +939,21 @@ extern "C" int lako_rmsnorm_bwd(const void* dy, const void* x, const float* w, c
   LAKO_CHECK_ALIGN(dx_drop, 16);
   DropDev dr = make_drop(drop), dr_out = make_drop(drop_out);
   int grid = rows_grid(rows);
-  if (grid > 1024) grid = 1024;   // 4 blocks per CU: enough waves to stream (measured: 512 → 4.0, 1024 → 5.1, 2048 → 4.6 TB/s at
-                                  // 64 k rows), still few adders per dw address
+  // 3 blocks per CU = the 12 waves the kernel's 148 registers allow: every wave resident from the start, each keeping its next row
+  // in flight.  Measured at 64 k rows × 768, in place + dropout_bwd(dx) (run r03j, 491 MB per launch): round 2's kernel 101 µs; this
+  // one with 512 / 768 / 1024 / 1536 / 2048 blocks 90 / 85 / 95 / 89 / 90 µs (5.8 TB/s at 768); without the second output 77 → 64.5 µs
+  // (6.1 TB/s — the float4-copy rate of the chip is 6.3).  Few adders per dw address as a side effect.
+  if (grid > 768) grid = 768;
+#ifdef LAKO_EXPERIMENTS
+  if (const char* e = getenv("LAKO_RMS_GRID")) grid = std::min(rows_grid(rows), atoi(e));
+  if (const char* e = getenv("LAKO_RMS_OLD"); e && e[0] == '1') {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((rmsnorm_bwd_old_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                         (const T*)dy, (const T*)x, w, rstd, (const T*)dres, (T*)dx, dw, rows, d, dr, (T*)dx_drop,
+                                         dr_out));
+    LAKO_LAUNCH_CHECK();
+    return LAKO_OK;
+  }
+#endif
   DISPATCH_T(dtype, hipLaunchKernelGGL((rmsnorm_bwd_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
                                        (const T*)dy, (const T*)x, w, rstd, (const T*)dres, (T*)dx, dw, rows, d, dr, (T*)dx_drop,
                                        dr_out));

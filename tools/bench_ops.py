@@ -216,6 +216,9 @@ if "norm" in only:
     timeit("rmsnorm_fwd [Me,768]", lambda: ops.rmsnorm_fwd(x, w, y, rs, 1e-6), bytes_=2.0 * Me * d * ES)
     dy, dx, dw = rnd(Me, d), torch.empty_like(x), torch.zeros(d, device=dev)
     timeit("rmsnorm_bwd [Me,768] +dres", lambda: ops.rmsnorm_bwd(dy, x, w, rs, dy, dx, dw), bytes_=4.0 * Me * d * ES)
+    dh, dyd = rnd(Me, d), torch.empty_like(x)
+    timeit("rmsnorm_bwd [Me,768] in place + dropout_bwd(dx) (the step's form)",
+           lambda: ops.rmsnorm_bwd(dy, x, w, rs, dh, dh, dw, dx_drop=dyd, drop_out=drop), bytes_=5.0 * Me * d * ES)
     timeit("dropout_apply [Me,768]", lambda: ops.dropout_apply(x, y, drop), bytes_=2.0 * Me * d * ES)
 
 if "misc" in only:
