@@ -344,6 +344,20 @@ int lako_fact_scores(const float* scores, const uint8_t* mask, const int64_t* id
 int lako_topk(const float* scores, int64_t rows, int64_t n, int64_t ld, int k, float* out_vals, int64_t* out_idx,
               lako_stream_t stream);
 
+/* ---- product-quantised index: faiss.IndexPQ(d, M, nbits, METRIC_INNER_PRODUCT) behind src/index.py:21-23 (Indexer with
+ * n_subquantizers > 0; round 3).  A vector is M sub-vectors of dsub floats; centroids [M][ksub][dsub] fp32, ksub = 2^nbits <= 256.
+ * lako_pq_assign: per (vector, m) the nearest centroid in L2, lowest index on ties -> codes [n][M] (may be NULL); with sums
+ *   [M][ksub][dsub] / counts [M][ksub] (both or neither; caller zeroes them) the sub-vector is also added to its centroid's running
+ *   sum (the k-means update), and *err (may be NULL; caller zeroes) receives the summed squared distances.  x [n][ldx], ldx >= M*dsub.
+ * lako_pq_lut:  lut [nq][M][ksub] = <q_m, centroid[m][c]>.      q [nq][ldq].
+ * lako_pq_scan: scores[q][i] = sum over m (ascending, fp32) of lut[q][m][codes[i][m]]; scores [nq][ld], ld >= n; top-k: lako_topk. */
+int lako_pq_assign(const float* x, int64_t n, int64_t ldx, const float* centroids, int M, int ksub, int dsub, uint8_t* codes,
+                   float* sums, int32_t* counts, float* err, lako_stream_t stream);
+int lako_pq_lut(const float* q, int64_t nq, int64_t ldq, const float* centroids, int M, int ksub, int dsub, float* lut,
+                lako_stream_t stream);
+int lako_pq_scan(const float* lut, const uint8_t* codes, int64_t n, int64_t nq, int M, int ksub, float* scores, int64_t ld,
+                 lako_stream_t stream);
+
 /* ---- retriever bi-encoder, FORWARD only (src/model.py:375-483 over HF BertModel); the matrix products and
  * the attention are lako_gemm_nt / lako_attn_fwd --------------------------------------------------------------------------
  * y = LayerNorm(x + lin_bias + resid)·gamma + beta (torch.nn.LayerNorm); lin_bias (fp32 [d]) and resid may be NULL */

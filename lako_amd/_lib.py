@@ -112,6 +112,9 @@ SIGNATURES = {
     "lako_greedy_step": [vp, i64, i32, vp, i64, i32, vp, vp, vp, i64, i64, vp],
     "lako_fact_scores": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "lako_topk": [vp, i64, i64, i64, i32, vp, vp, vp],
+    "lako_pq_assign": [vp, i64, i64, vp, i32, i32, i32, vp, vp, vp, vp, vp],
+    "lako_pq_lut": [vp, i64, i64, vp, i32, i32, i32, vp, vp],
+    "lako_pq_scan": [vp, vp, i64, i64, i32, i32, vp, i64, vp],
     "lako_layernorm_fwd": [vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, vp],
     "lako_bert_embed": [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i64, f32, i32, vp],
     "lako_bias_act": [vp, vp, vp, i64, i32, i32, i32, vp],

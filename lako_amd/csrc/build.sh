@@ -28,7 +28,7 @@ if [ "${LAKO_ASAN:-0}" = "1" ]; then
 fi
 objs=()
 pids=()
-for f in gemm rowops attn attn_enc xattn index bertops bertbwd; do
+for f in gemm rowops attn attn_enc xattn index pq bertops bertbwd; do
   [ -f $f.hip ] || continue
   o=$f.$SFX
   if [ $FORCE = 1 ] || [ ! -f $o ] || [ $f.hip -nt $o ] || [ common.h -nt $o ] || [ attn_shared.h -nt $o ] || [ lds_image.h -nt $o ] || [ ../../include/lako_hip.h -nt $o ] || [ build.sh -nt $o ]; then

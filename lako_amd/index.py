@@ -5,9 +5,14 @@
 Same surface as the reference class: `Indexer(vector_sz)`, `index_data(ids, embeddings)`, `search_knn(query_vectors,
 top_docs, index_batch_size)` → `[(db_ids as str, scores), …]`, `serialize(dir)` / `deserialize_from(dir)`.  The scores are
 one fp32 `lako_gemm_nt` (exact-fp32 MFMA) of a query batch against the resident embeddings, the selection is `lako_topk`
-(descending; equal scores in ascending insertion order — faiss leaves that order unspecified).  Product quantisation
-(`n_subquantizers > 0`, unused by LaKo's scripts) is not implemented.  On-disk format: `index.pt` (embeddings + ids), not
-faiss' binary format.  The BERT bi-encoder that produces the embeddings (src/model.py:375-483) is the remaining part of f4."""
+(descending; equal scores in ascending insertion order — faiss leaves that order unspecified).  With `n_subquantizers > 0`
+(`faiss.IndexPQ(d, M, n_bits, METRIC_INNER_PRODUCT)`, src/index.py:21-23; LaKo's own scripts construct the flat index) the vectors
+are stored as M one-byte codes each: `ProductQuantizer` below trains the M codebooks by k-means (`lako_pq_assign` = assignment +
+accumulation, the loop around it is host logic), `index_data` encodes, and a search is a per-query lookup table (`lako_pq_lut`), a
+scan of the codes (`lako_pq_scan`) and the same `lako_topk`.  faiss is absent from the image: the definition followed is the
+published one (csrc/pq.hip header), the random choices (training subsample, initial centroids) come from numpy's RandomState(1234)
+rather than faiss' generator, so codebooks are comparable in quality, not in bits — parity unpinned by reference outputs, like the
+flat index.  On-disk format: `index.pt` (embeddings or codebooks + codes, ids), not faiss' binary format."""
 from __future__ import annotations
 
 import os
@@ -17,10 +22,77 @@ import numpy as np
 import torch
 
 
+PQ_SUBVECTOR_LENGTHS = (1, 2, 4, 6, 8, 12, 16, 24, 32, 48, 64)      # instantiations of pq_assign_kernel (csrc/pq.hip)
+
+
+class ProductQuantizer:
+    """faiss.ProductQuantizer(d, M, nbits) as IndexPQ uses it: M independent k-means codebooks of ksub = 2^nbits centroids over
+    the M sub-vectors of length d / M (faiss.Clustering defaults: 25 iterations, at most 256 training points per centroid —
+    a random subsample beyond that —, initial centroids = ksub random training points, an empty cluster re-seeded from the most
+    populated one with a ±1/1024 relative perturbation)."""
+    NITER, MAX_POINTS_PER_CENTROID, SEED, EPS = 25, 256, 1234, 1.0 / 1024.0
+
+    def __init__(self, d: int, M: int, nbits: int, ops, device):
+        if M <= 0 or d % M:
+            raise ValueError(f"the vector size {d} must be a multiple of n_subquantizers {M}")
+        if not 1 <= nbits <= 8:
+            raise ValueError("n_bits must be in 1..8 (one byte per sub-quantiser code)")
+        self.d, self.M, self.nbits, self.ksub, self.dsub = int(d), int(M), int(nbits), 1 << int(nbits), d // M
+        if self.dsub not in PQ_SUBVECTOR_LENGTHS:
+            raise ValueError(f"sub-vector length {self.dsub} (= vector_sz / n_subquantizers) must be one of {PQ_SUBVECTOR_LENGTHS}")
+        if self.M * self.ksub * 4 > 128 * 1024:
+            raise ValueError("n_subquantizers * 2^n_bits * 4 bytes (one query's lookup table) must fit 128 KiB of LDS")
+        self.ops, self.device = ops, torch.device(device)
+        self.centroids = None                    # [M, ksub, dsub] fp32
+        self.train_error = []                    # mean squared quantisation error per iteration (whole vectors)
+
+    @property
+    def is_trained(self) -> bool:
+        return self.centroids is not None
+
+    def train(self, x: torch.Tensor):
+        n = x.shape[0]
+        if n < self.ksub:
+            raise ValueError(f"{n} training vectors for {self.ksub} centroids per sub-quantiser")
+        rs = np.random.RandomState(self.SEED)
+        if n > self.ksub * self.MAX_POINTS_PER_CENTROID:
+            x = x[torch.from_numpy(rs.permutation(n)[:self.ksub * self.MAX_POINTS_PER_CENTROID]).to(x.device)].contiguous()
+            n = x.shape[0]
+        first = torch.from_numpy(rs.permutation(n)[:self.ksub]).to(x.device)
+        M, ksub, dsub = self.M, self.ksub, self.dsub
+        cent = x[first].view(ksub, M, dsub).transpose(0, 1).contiguous()
+        sums = torch.empty(M, ksub, dsub, dtype=torch.float32, device=self.device)
+        counts = torch.empty(M, ksub, dtype=torch.int32, device=self.device)
+        err = torch.empty(1, dtype=torch.float32, device=self.device)
+        self.train_error = []
+        for _ in range(self.NITER):
+            sums.zero_(); counts.zero_(); err.zero_()
+            self.ops.pq_assign(x, cent, None, sums, counts, err)
+            cent = torch.where(counts[..., None] > 0, sums / counts.clamp(min=1)[..., None].float(), cent)
+            cnt = counts.cpu().numpy().astype(np.int64)
+            self.train_error.append(float(err) / n)
+            for m, c in zip(*np.nonzero(cnt == 0)):           # empty clusters (host logic; rare)
+                big = int(cnt[m].argmax())
+                sign = torch.where(torch.arange(dsub, device=self.device) % 2 == 0, 1.0, -1.0) * self.EPS
+                cent[m, c] = cent[m, big] * (1.0 + sign)
+                cent[m, big] = cent[m, big] * (1.0 - sign)
+                cnt[m, c] = cnt[m, big] // 2
+                cnt[m, big] -= cnt[m, c]
+        self.centroids = cent.contiguous()
+
+    def compute_codes(self, x: torch.Tensor) -> torch.Tensor:
+        codes = torch.empty(x.shape[0], self.M, dtype=torch.uint8, device=self.device)
+        self.ops.pq_assign(x, self.centroids, codes)
+        return codes
+
+    def decode(self, codes: torch.Tensor) -> torch.Tensor:
+        """reconstruction (faiss `ProductQuantizer.decode`): host-side convenience for tests and inspection"""
+        m = torch.arange(self.M, device=codes.device)[None, :]
+        return self.centroids[m, codes.long()].reshape(codes.shape[0], self.d)
+
+
 class Indexer:
     def __init__(self, vector_sz: int, n_subquantizers: int = 0, n_bits: int = 8, device="cuda", ops=None):
-        if n_subquantizers > 0:
-            raise NotImplementedError("IndexPQ is not implemented (LaKo's scripts use the flat index)")
         if vector_sz % 4:
             raise ValueError("vector_sz must be a multiple of 4")
         self.vector_sz = int(vector_sz)
@@ -29,12 +101,14 @@ class Indexer:
             from .ops import HipOps
             ops = HipOps()          # raises when the HIP library is missing: there is no CPU search path
         self.ops = ops
-        self.embeddings = torch.empty(0, self.vector_sz, dtype=torch.float32, device=self.device)
+        self.pq = ProductQuantizer(self.vector_sz, n_subquantizers, n_bits, ops, self.device) if n_subquantizers > 0 else None
+        self.embeddings = torch.empty(0, self.vector_sz, dtype=torch.float32, device=self.device)       # flat index
+        self.codes = torch.empty(0, n_subquantizers, dtype=torch.uint8, device=self.device)              # PQ index
         self.index_id_to_db_id = np.empty((0,), dtype=np.int64)
 
     @property
     def ntotal(self) -> int:
-        return self.embeddings.shape[0]
+        return self.codes.shape[0] if self.pq is not None else self.embeddings.shape[0]
 
     def index_data(self, ids, embeddings):
         """src/index.py:28-35: append `embeddings` [m, vector_sz] under the external ids `ids`."""
@@ -43,6 +117,12 @@ class Indexer:
         if len(ids) != emb.shape[0]:
             raise ValueError("ids and embeddings disagree in length")
         self.index_id_to_db_id = np.concatenate((self.index_id_to_db_id, np.array(ids, dtype=np.int64)), axis=0)
+        if self.pq is not None:                  # src/index.py:31-33: `if not self.index.is_trained: self.index.train(embeddings)`, then add
+            emb = emb.contiguous()
+            if not self.pq.is_trained:
+                self.pq.train(emb)
+            self.codes = torch.cat([self.codes, self.pq.compute_codes(emb)], 0).contiguous()
+            return
         self.embeddings = torch.cat([self.embeddings, emb], 0).contiguous()
 
     def search_scores(self, query_vectors) -> torch.Tensor:
@@ -52,6 +132,11 @@ class Indexer:
         n = self.ntotal
         ld = (n + 3) // 4 * 4                                 # 16-byte rows for the store epilogue / the top-k loads
         buf = torch.empty(q.shape[0], ld, dtype=torch.float32, device=self.device)
+        if self.pq is not None:                  # asymmetric distance computation: table per query, then one pass over the codes
+            lut = torch.empty(q.shape[0], self.pq.M, self.pq.ksub, dtype=torch.float32, device=self.device)
+            self.ops.pq_lut(q, self.pq.centroids, lut)
+            self.ops.pq_scan(lut, self.codes, buf[:, :n])
+            return buf[:, :n]
         if ld != n:                                           # pad the embedding rows seen by the GEMM, never the result
             emb = torch.zeros(ld, self.vector_sz, dtype=torch.float32, device=self.device)
             emb[:n] = self.embeddings
@@ -78,14 +163,24 @@ class Indexer:
 
     def serialize(self, dir_path):
         os.makedirs(str(dir_path), exist_ok=True)
-        torch.save({"embeddings": self.embeddings.cpu(), "index_id_to_db_id": self.index_id_to_db_id, "vector_sz": self.vector_sz},
-                   os.path.join(str(dir_path), "index.pt"))
+        d = {"embeddings": self.embeddings.cpu(), "index_id_to_db_id": self.index_id_to_db_id, "vector_sz": self.vector_sz}
+        if self.pq is not None:
+            d.update(codes=self.codes.cpu(), centroids=None if self.pq.centroids is None else self.pq.centroids.cpu(),
+                     n_subquantizers=self.pq.M, n_bits=self.pq.nbits)
+        torch.save(d, os.path.join(str(dir_path), "index.pt"))
 
     def deserialize_from(self, dir_path):
         d = torch.load(os.path.join(str(dir_path), "index.pt"), map_location="cpu", weights_only=False)
-        assert d["vector_sz"] == self.vector_sz and len(d["index_id_to_db_id"]) == d["embeddings"].shape[0]
-        self.embeddings = d["embeddings"].to(self.device)
+        assert d["vector_sz"] == self.vector_sz
+        if "codes" in d:                         # (like faiss.read_index: the file decides the index type)
+            self.pq = ProductQuantizer(self.vector_sz, d["n_subquantizers"], d["n_bits"], self.ops, self.device)
+            self.pq.centroids = None if d["centroids"] is None else d["centroids"].to(self.device)
+            self.codes = d["codes"].to(self.device)
+        else:
+            self.pq = None
+            self.embeddings = d["embeddings"].to(self.device)
         self.index_id_to_db_id = d["index_id_to_db_id"]
+        assert len(self.index_id_to_db_id) == self.ntotal, "Deserialized index_id_to_db_id should match the index size"
 
 
 def resort_facts(examples, all_id_to_facts_dic, questions_embedding, allembeddings, ops=None, device="cuda"):

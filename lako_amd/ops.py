@@ -479,6 +479,37 @@ class HipOps:
                                                                  self._stream()), "lako_topk"))
 
     # ---- retriever bi-encoder forward ---------------------------------------------------
+
+    # ---- product quantiser (faiss.IndexPQ, src/index.py:21-23) ------------------------------------------------------------
+    def pq_assign(self, x, centroids, codes=None, sums=None, counts=None, err=None):
+        """x [n, >= M·dsub] fp32 (row stride free), centroids [M, ksub, dsub] fp32 → codes [n, M] uint8 (nearest centroid per
+        sub-quantiser) and / or the k-means accumulators sums [M, ksub, dsub] / counts [M, ksub] int32 (+ err [1])."""
+        M, ksub, dsub = centroids.shape
+        if x.dtype != torch.float32 or centroids.dtype != torch.float32 or x.stride(1) != 1 or not centroids.is_contiguous():
+            raise LakoError("pq_assign: x / centroids fp32, x rows contiguous, centroids contiguous")
+        if codes is not None and (codes.dtype != torch.uint8 or not codes.is_contiguous() or tuple(codes.shape) != (x.shape[0], M)):
+            raise LakoError("pq_assign: codes must be contiguous uint8 [n, M]")
+        if (sums is None) != (counts is None) or (sums is not None and (tuple(sums.shape) != (M, ksub, dsub) or counts.dtype != torch.int32)):
+            raise LakoError("pq_assign: sums [M, ksub, dsub] fp32 and counts [M, ksub] int32 go together")
+        self._timed("pq_assign", 0.0, lambda: check(self.lib.lako_pq_assign(_p(x), x.shape[0], x.stride(0), _p(centroids), M, ksub, dsub, _p(codes),
+                                                                            _p(sums), _p(counts), _p(err), self._stream()), "lako_pq_assign"))
+
+    def pq_lut(self, q, centroids, lut):
+        M, ksub, dsub = centroids.shape
+        if q.dtype != torch.float32 or q.stride(1) != 1 or not lut.is_contiguous() or tuple(lut.shape) != (q.shape[0], M, ksub):
+            raise LakoError("pq_lut: q fp32 rows contiguous, lut contiguous fp32 [nq, M, ksub]")
+        self._timed("pq_lut", 0.0, lambda: check(self.lib.lako_pq_lut(_p(q), q.shape[0], q.stride(0), _p(centroids), M, ksub, dsub, _p(lut),
+                                                                      self._stream()), "lako_pq_lut"))
+
+    def pq_scan(self, lut, codes, scores):
+        nq, M, ksub = lut.shape
+        n = codes.shape[0]
+        if not lut.is_contiguous() or codes.dtype != torch.uint8 or not codes.is_contiguous() or codes.shape[1] != M or \
+                scores.dtype != torch.float32 or scores.stride(1) != 1 or scores.shape[0] != nq or scores.shape[1] != n:
+            raise LakoError("pq_scan: lut [nq, M, ksub] fp32, codes [n, M] uint8, scores [nq, n] fp32 (row stride free)")
+        self._timed("pq_scan", 0.0, lambda: check(self.lib.lako_pq_scan(_p(lut), _p(codes), n, nq, M, ksub, _p(scores), scores.stride(0),
+                                                                        self._stream()), "lako_pq_scan"))
+
     def layernorm_fwd(self, x, gamma, beta, y, *, lin_bias=None, resid=None, eps=1e-12):
         """y = LayerNorm(x + lin_bias + resid)·gamma + beta over the rows of [rows, d]"""
         rows, d = x.shape

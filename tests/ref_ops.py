@@ -427,6 +427,31 @@ class RefOps:
         out_idx.copy_(order)
         out_vals.copy_(torch.gather(scores, 1, order))
 
+    # ---- product quantiser (csrc/pq.hip) ------------------------------------------------------------------
+    def pq_assign(self, x, centroids, codes=None, sums=None, counts=None, err=None):
+        M, ksub, dsub = centroids.shape
+        xs = x[:, :M * dsub].reshape(x.shape[0], M, dsub)
+        d2 = ((xs[:, :, None, :] - centroids[None]) ** 2).sum(-1)             # [n, M, ksub]
+        best = d2.argmin(-1)                                                  # lowest index on ties
+        if codes is not None:
+            codes.copy_(best.to(torch.uint8))
+        if sums is not None:
+            for m in range(M):
+                sums[m].index_add_(0, best[:, m], xs[:, m])
+                counts[m] += torch.bincount(best[:, m], minlength=ksub).to(torch.int32)
+        if err is not None:
+            err += d2.gather(-1, best[..., None]).sum()
+
+    def pq_lut(self, q, centroids, lut):
+        M, ksub, dsub = centroids.shape
+        lut.copy_(torch.einsum("qmj,mcj->qmc", q[:, :M * dsub].reshape(q.shape[0], M, dsub), centroids))
+
+    def pq_scan(self, lut, codes, scores):
+        acc = torch.zeros(lut.shape[0], codes.shape[0], dtype=torch.float32)
+        for m in range(lut.shape[1]):                                         # ascending m, fp32: the kernel's order
+            acc += lut[:, m, :][:, codes[:, m].long()]
+        scores.copy_(acc)
+
     # ---- retriever bi-encoder forward ------------------------------------------------------------------
     def layernorm_fwd(self, x, gamma, beta, y, *, lin_bias=None, resid=None, eps=1e-12):
         v = x.float()
