@@ -243,6 +243,17 @@ if "index" in only:
     vals, idx = torch.empty(nq, k, device=dev), torch.empty(nq, k, dtype=torch.int64, device=dev)
     timeit("index scores [1024,256]x[300600,256] fp32", lambda: ops.gemm_nt(q, e, sc), flops=2.0 * nq * nf * dim)
     timeit("index top-500 of [1024,300600]", lambda: ops.topk(sc, k, vals, idx), bytes_=5.0 * nq * nf * 4)
+    # the product-quantised variant (faiss.IndexPQ): 16 / 32 / 64 one-byte sub-quantisers over the same facts
+    for M in (16, 32, 64):
+        ksub, dsub = 256, dim // M
+        cent = torch.randn(M, ksub, dsub, device=dev)
+        codes = torch.empty(nf, M, dtype=torch.uint8, device=dev)
+        sums, counts, err = torch.zeros(M, ksub, dsub, device=dev), torch.zeros(M, ksub, dtype=torch.int32, device=dev), torch.zeros(1, device=dev)
+        lut = torch.empty(nq, M, ksub, device=dev)
+        timeit(f"pq M={M}: encode 300600 x 256 (nearest of 256 centroids per sub-vector)", lambda: ops.pq_assign(e, cent, codes), flops=3.0 * nf * dim * ksub)
+        timeit(f"pq M={M}: one k-means iteration on 65536 vectors (assign + accumulate)", lambda: ops.pq_assign(e[:65536], cent, None, sums, counts, err))
+        timeit(f"pq M={M}: lookup tables of 1024 queries", lambda: ops.pq_lut(q, cent, lut))
+        timeit(f"pq M={M}: scan [1024 queries] x [300600 codes] ({1024 * 300600 * M / 1e9:.1f} G lookups)", lambda: ops.pq_scan(lut, codes, sc), bytes_=4.0 * nq * nf)
 
 if "retriever" in only:
     # BERT-base bi-encoder forward (src/model.py:451-478) at passage_maxlength 130 — embedding throughput
