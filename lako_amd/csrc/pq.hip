@@ -6,7 +6,7 @@
 //   * search (asymmetric distance computation): per query a table LUT[m][c] = <q_m, centroid[m][c]>, the score of a stored
 //     vector is Σ_m LUT[m][code_m] summed in ascending m in fp32, the result the k largest scores.
 // HBM / LDS-gather bound byte work, no MFMA: the codes are streamed once per group of queries (16 B per lane per load), the
-// tables of QT queries sit in LDS and every lookup is a `ds_read_b32` at a data-dependent bank.  The k-means loop around
+// tables of QT queries sit in LDS, interleaved by query, and a lookup of four queries is one `ds_read_b128` at a data-dependent bank.  The k-means loop around
 // lako_pq_assign (initialisation, empty clusters, convergence) is host logic in lako_amd/index.py.
 #include "common.h"
 
@@ -14,6 +14,7 @@ namespace {
 
 constexpr int PQ_MAX_DSUB = 64;
 constexpr int PQ_LDS_BYTES = 128 * 1024;
+constexpr int PQ_SCAN_THREADS = 1024;      // one workgroup per CU (its tables fill the LDS): 16 waves to cover the gathers' latency
 
 // One thread per (vector, sub-quantiser): the centroids of sub-quantiser m in LDS (every lane reads the same address: broadcast),
 // the sub-vector in registers.  Optionally adds the sub-vector to its centroid's running sum (the k-means update) and the squared
@@ -76,45 +77,53 @@ __global__ __launch_bounds__(256) void pq_lut_kernel(const float* __restrict__ q
   }
 }
 
-// scores[q][i] = Σ_m LUT[q][m][codes[i][m]] (ascending m, fp32).  The tables of QT queries in LDS; a thread per stored vector,
-// whose M code bytes are consecutive (16-byte loads when M % 16 == 0); a wave writes 256 consecutive bytes of one score row.
+// scores[q][i] = Σ_m LUT[q][m][codes[i][m]] (ascending m, fp32).  The tables of QT queries in LDS, INTERLEAVED by query
+// (ls[(m·ksub + c)·QT + q]): the QT entries one code selects are adjacent, so a lane fetches four queries' entries with one
+// ds_read_b128 — the scan is bound by LDS gathers at data-dependent banks, and this quarters their number (measured, 1024 queries ×
+// 300 600 codes, with 1024-thread workgroups instead of 256: M = 16 1 675 → 653 µs, M = 32 2 340 → 943, M = 64 4 250 → 1 993;
+// profiles/r03m_bench_ops_index.txt; the exact fp32 GEMM of the flat index takes 1 540 µs).  A thread per stored vector, whose M code bytes are
+// consecutive (16-byte loads when M % 16 == 0); a wave writes 256 consecutive bytes of one score row.
 template <int QT>
-__global__ __launch_bounds__(256) void pq_scan_kernel(const float* __restrict__ lut, const uint8_t* __restrict__ codes, int64_t n,
+__global__ __launch_bounds__(PQ_SCAN_THREADS) void pq_scan_kernel(const float* __restrict__ lut, const uint8_t* __restrict__ codes, int64_t n,
                                                       int64_t nq, int M, int ksub, float* __restrict__ scores, int64_t ld,
                                                       int per_block) {
-  extern __shared__ __attribute__((aligned(16))) float ls[];     // [QT][M][ksub]
+  extern __shared__ __attribute__((aligned(16))) float ls[];     // [M·ksub][QT]
   const int64_t q0 = (int64_t)blockIdx.y * QT;
   const int tab = M * ksub;
-  for (int t = threadIdx.x; t < QT * tab; t += 256) {
-    const int64_t qq = q0 + t / tab;
-    ls[t] = qq < nq ? lut[qq * tab + t % tab] : 0.f;
+  for (int t = threadIdx.x; t < QT * tab; t += PQ_SCAN_THREADS) {            // (coalesced reads of each query's table, strided LDS writes)
+    const int qi = t / tab, o = t % tab;
+    ls[o * QT + qi] = q0 + qi < nq ? lut[(q0 + qi) * tab + o] : 0.f;
   }
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * per_block;
   const int64_t end = base + per_block < n ? base + per_block : n;
-  for (int64_t i = base + threadIdx.x; i < end; i += 256) {
+  for (int64_t i = base + threadIdx.x; i < end; i += PQ_SCAN_THREADS) {
     const uint8_t* c = codes + i * M;
     float acc[QT];
 #pragma unroll
     for (int qi = 0; qi < QT; ++qi) acc[qi] = 0.f;
+    auto add = [&](int o) {
+      if constexpr (QT >= 4) {
+#pragma unroll
+        for (int h = 0; h < QT / 4; ++h) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(ls + o * QT + 4 * h);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[4 * h + r] += t[r];
+        }
+      } else {
+#pragma unroll
+        for (int qi = 0; qi < QT; ++qi) acc[qi] += ls[o * QT + qi];
+      }
+    };
     int m = 0;
     if ((M & 15) == 0) {
       for (; m < M; m += 16) {
         const u32x4 w = *reinterpret_cast<const u32x4*>(c + m);
 #pragma unroll
-        for (int b = 0; b < 16; ++b) {
-          const int code = (w[b >> 2] >> (8 * (b & 3))) & 0xff;
-          const int o = (m + b) * ksub + code;
-#pragma unroll
-          for (int qi = 0; qi < QT; ++qi) acc[qi] += ls[qi * tab + o];
-        }
+        for (int b = 0; b < 16; ++b) add((m + b) * ksub + (int)((w[b >> 2] >> (8 * (b & 3))) & 0xff));
       }
     } else {
-      for (; m < M; ++m) {
-        const int o = m * ksub + c[m];
-#pragma unroll
-        for (int qi = 0; qi < QT; ++qi) acc[qi] += ls[qi * tab + o];
-      }
+      for (; m < M; ++m) add(m * ksub + c[m]);
     }
 #pragma unroll
     for (int qi = 0; qi < QT; ++qi)
@@ -148,7 +157,7 @@ void launch_scan(const float* lut, const uint8_t* codes, int64_t n, int64_t nq, 
   if (blocks > want) blocks = want;
   const int64_t per_block = ((n + blocks - 1) / blocks + 255) / 256 * 256;
   blocks = (n + per_block - 1) / per_block;
-  hipLaunchKernelGGL((pq_scan_kernel<QT>), dim3((unsigned)blocks, (unsigned)qgroups), dim3(256), (size_t)QT * M * ksub * 4, s, lut, codes, n, nq,
+  hipLaunchKernelGGL((pq_scan_kernel<QT>), dim3((unsigned)blocks, (unsigned)qgroups), dim3(PQ_SCAN_THREADS), (size_t)QT * M * ksub * 4, s, lut, codes, n, nq,
                      M, ksub, scores, ld, (int)per_block);
 }
 

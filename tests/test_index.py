@@ -191,7 +191,7 @@ def test_pq_indexer_host_logic_on_double(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,d,M,nbits,nq", [(20000, 256, 16, 8, 9), (3000, 64, 16, 4, 3), (70000, 256, 32, 8, 5), (2500, 768, 12, 6, 4)])
+@pytest.mark.parametrize("n,d,M,nbits,nq", [(8000, 256, 16, 8, 9), (3000, 64, 16, 4, 3), (70000, 256, 32, 8, 5), (2500, 768, 12, 6, 4)])
 def test_pq_indexer_on_gpu(tmp_path, n, d, M, nbits, nq):
     """lako_pq_assign / lako_pq_lut / lako_pq_scan + lako_topk behind Indexer(d, M, nbits): the reference's vector size (256) with 16
     and 32 one-byte sub-quantisers (the second case trains on a 65 536-vector subsample), a 4-bit case with sub-vectors of 4, and
@@ -202,7 +202,7 @@ def test_pq_indexer_on_gpu(tmp_path, n, d, M, nbits, nq):
     ix.index_data(ids[:half], emb[:half])
     ix.index_data(ids[half:], emb[half:])
     assert ix.ntotal == n
-    if n <= 20000:
+    if n <= 8000:
         # the oracle's codebook comparison trains on everything; the class trained on the first batch: re-train for the comparison
         ix = Indexer(d, n_subquantizers=M, n_bits=nbits)
         ix.index_data(ids, emb)
