@@ -96,6 +96,16 @@ def test_bad_arguments_return_error_codes(lib):
     assert L.lako_xattn_decode(x, 8, 8, x, 768, x, x, x, 17, 768, 16, 16, None) == -1                          # R > 16
     assert L.lako_xattn_decode_combine(x, x, x, 768, x, 768, 12, 640, 16, 16, None) == -1                      # D not in {512, 768, 1024}
     assert L.lako_xattn_softmax_fwd(x, 255, x, x, 256, x, x, 16, 8, 12, 4000, _lib.NO_DROP, None) == -1        # s_ld % 4
+    # the product-quantised index and the retriever's backward (round 3)
+    assert L.lako_pq_assign(x, 100, 256, x, 16, 256, 5, x, None, None, None, None) == -1       # sub-vector length 5: no instantiation
+    assert L.lako_pq_assign(x, 100, 256, x, 16, 256, 16, None, None, None, None, None) == -1   # neither codes nor sums
+    assert L.lako_pq_assign(x, 100, 256, x, 16, 256, 16, x, x, None, None, None) == -1         # sums without counts
+    assert L.lako_pq_assign(x, 100, 128, x, 16, 256, 16, x, None, None, None, None) == -1      # row stride < M * dsub
+    assert L.lako_pq_lut(x, 8, 256, x, 16, 256, 128, x, None) == -1                            # sub-vector longer than 64
+    assert L.lako_pq_scan(x, x, 1000, 8, 256, 256, x, 1000, None) == -1                        # one query's table > 128 KiB of LDS
+    assert L.lako_pq_scan(x, x, 1000, 8, 16, 256, x, 999, None) == -1                          # ld < n
+    assert L.lako_kldiv_bwd(x, x, x, None, 0, 8, None) == -1
+    assert L.lako_layernorm_bwd(x, x, None, None, x, x, x, x, None, 16, 2000, 1e-5, 1, None) == -1   # d > the kernel's register budget
 
 
 def test_product_fails_loudly_without_library(monkeypatch, tmp_path):
