@@ -358,7 +358,7 @@ int lako_pq_lut(const float* q, int64_t nq, int64_t ldq, const float* centroids,
 int lako_pq_scan(const float* lut, const uint8_t* codes, int64_t n, int64_t nq, int M, int ksub, float* scores, int64_t ld,
                  lako_stream_t stream);
 
-/* ---- retriever bi-encoder, FORWARD only (src/model.py:375-483 over HF BertModel); the matrix products and
+/* ---- retriever bi-encoder, forward (the backward follows below; SURVEY.md §8 f4: src/model.py:375-483 over HF BertModel); the matrix products and
  * the attention are lako_gemm_nt / lako_attn_fwd --------------------------------------------------------------------------
  * y = LayerNorm(x + lin_bias + resid)·gamma + beta (torch.nn.LayerNorm); lin_bias (fp32 [d]) and resid may be NULL */
 int lako_layernorm_fwd(const void* x, const float* lin_bias, const void* resid, const float* gamma, const float* beta, void* y,
