@@ -115,7 +115,8 @@ if args.vendor:
         timeit("vendor " + nm, lambda: torch.matmul(A.t(), Bm, out=C), flops=2.0 * M * Nn * K)
         del A, Bm, C
 
-for big in ([1, 2, 0] if "tn" in only else []):
+# (gemm_tn_big = 2, the accumulation switched off, exists in the experiments build only: LAKO_LIB=…/liblako_hip_exp.so)
+for big in (([1, 2, 0] if os.environ.get("LAKO_LIB") else [1, 0]) if "tn" in only else []):
     ops.set_tuning("gemm_tn_big", big)
     print(f"--- gemm_tn 256x256 kernel {['off (128x128)', 'on', 'on, accumulation atomics skipped (timing experiment)'][big]}", flush=True)
     for nm, (K, M, Nn) in [
