@@ -420,7 +420,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) bf[nt] = read_frag_rows(Bs, (wc * NT + nt) * 16 + r16, kh * 4 + g);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) af[mt] = read_frag_rows(As, (wr * MT + mt) * 16 + r16, kh * 4 + g);
+        for (int mt = 0; mt < MT; ++mt) {
+          // debug bit 5 (timing experiment, wrong results): every second A fragment is a copy of its neighbour — a third fewer LDS
+          // reads at unchanged DMA and MFMA work: does the fragment-read traffic slow the DMA's LDS writes?
+          if (NT_DBG(a, 32) && (mt & 1)) af[mt] = af[mt - 1];
+          else af[mt] = read_frag_rows(As, (wr * MT + mt) * 16 + r16, kh * 4 + g);
+        }
         // all fragment reads of the K-half go out back to back; left alone, the machine scheduler folds every
         // A fragment into ONE register quad (read → s_waitcnt lgkmcnt(0) → 4 MFMAs, MT times per K-half),
         // exposing a full LDS round trip per 64 MFMA cycles
