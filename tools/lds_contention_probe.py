@@ -33,7 +33,9 @@ for (M, N, K) in [(8192, 8192, 8192), (64000, 2304, 768), (64000, 768, 3072)]:
     B = (torch.randn(N, K, device=dev) * 0.1).bfloat16()
     Cm = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
     row = []
-    for dbg, what in [(0, "as shipped"), (32, "1/3 fewer LDS fragment reads"), (1, "no K-loop DMA"), (33, "no DMA + fewer reads"), (0, "as shipped")]:
+    # bit 2 (4): the K-loop never waits for its DMA — nor, through the in-order counter, for the previous tile's stores; bit 3 (8): no stores
+    for dbg, what in [(0, "as shipped"), (32, "1/3 fewer LDS fragment reads"), (1, "no K-loop DMA"), (33, "no DMA + fewer reads"),
+                      (4, "no vmcnt waits in the K-loop"), (8, "no stores"), (12, "no waits, no stores"), (0, "as shipped")]:
         ops.set_tuning("gemm_nt_debug", dbg)
         us = timeit(lambda: ops.gemm_nt(A, B, Cm))
         row.append(f"{what}: {us:8.1f} us ({2.0 * M * N * K / us / 1e6:7.1f} TF/s)")
