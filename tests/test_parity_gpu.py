@@ -419,28 +419,35 @@ def test_bf16_generate_encoder_space_decode_vs_oracle_tokens():
     cfg = FiDConfig.named("small", dropout_rate=0.0)
     dims = O.T5Dims.named("small")
     dims.dropout = 0.0
-    torch.manual_seed(0)
-    m = FiDT5(cfg, dtype=torch.bfloat16, seed=1)         # (embeddings at their N(0, 1) init: with the 0.05 scale of the throughput runs
-    m = m.cuda().train()                                 #  the passages hardly tell the samples apart and the loss stalls near 0.5)
     B, N, L, T, ML = 4, 10, 200, 6, 9
     ids_c, mask_c, labels_c = O.synthetic_batch(B, N, L, T, cfg.vocab_size, seed=91)
     ids, mask, labels = dev(ids_c, mask_c, labels_c)
     opt = types.SimpleNamespace(optim="adamw", lr=1e-3, weight_decay=0.0, scheduler="fixed", fixed_lr=True,
                                 scheduler_steps=None, total_steps=4000, warmup_steps=0)
-    optimizer, scheduler = U.set_optim(opt, m)
-    last = None
-    for k in range(600):           # (the oracle on the CPU reaches 1.5e-3 after 50 such steps at 2 x 32-token passages)
-        loss = m(input_ids=ids, attention_mask=mask, labels=labels)[0]
-        loss.backward()
-        U.clip_grad_norm_(m, 1.0)
-        optimizer.step()
-        scheduler.step()
-        m.zero_grad()
-        if k % 20 == 19:
-            last = loss.item()
-            if last < 0.005:
-                break
-    assert last is not None and last < 0.05, last
+    # The fit usually takes 100-200 steps, but a run can settle on a plateau (observed once: loss 0.37 after 600 steps — the fp32
+    # atomics of the weight gradients make trajectories differ from run to run); the test is about DECODING trained weights, so a
+    # stalled fit is restarted from another initialisation instead of failing the comparison that follows.
+    last, tried = None, []
+    for attempt in range(4):
+        torch.manual_seed(attempt)
+        m = FiDT5(cfg, dtype=torch.bfloat16, seed=1 + attempt)   # (embeddings at their N(0, 1) init: with the 0.05 scale of the throughput
+        m = m.cuda().train()                                     #  runs the passages hardly tell the samples apart and the loss stalls near 0.5)
+        optimizer, scheduler = U.set_optim(opt, m)
+        for k in range(600):           # (the oracle on the CPU reaches 1.5e-3 after 50 such steps at 2 x 32-token passages)
+            loss = m(input_ids=ids, attention_mask=mask, labels=labels)[0]
+            loss.backward()
+            U.clip_grad_norm_(m, 1.0)
+            optimizer.step()
+            scheduler.step()
+            m.zero_grad()
+            if k % 20 == 19:
+                last = loss.item()
+                if last < 0.005:
+                    break
+        tried.append(last)
+        if last < 0.05:
+            break
+    assert last is not None and last < 0.05, tried
     w = {plain_name(n): p.detach().float().cpu().clone() for n, p in m.named_parameters()}
     want = O.fid_generate(w, dims, ids_c, mask_c, ML)
     # the oracle reproduces the training answers (so the comparison below is about trained margins, not about noise)
