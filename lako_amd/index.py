@@ -163,14 +163,17 @@ class Indexer:
 
     def serialize(self, dir_path):
         os.makedirs(str(dir_path), exist_ok=True)
-        d = {"embeddings": self.embeddings.cpu(), "index_id_to_db_id": self.index_id_to_db_id, "vector_sz": self.vector_sz}
+        # tensors and plain numbers only: the file loads with torch.load(weights_only=True) (the reference pickles its id map,
+        # src/index.py:58-59 — an index file from an untrusted source must not be able to run code here)
+        d = {"embeddings": self.embeddings.cpu(), "index_id_to_db_id": torch.from_numpy(np.ascontiguousarray(self.index_id_to_db_id)),
+             "vector_sz": self.vector_sz}
         if self.pq is not None:
             d.update(codes=self.codes.cpu(), centroids=None if self.pq.centroids is None else self.pq.centroids.cpu(),
                      n_subquantizers=self.pq.M, n_bits=self.pq.nbits)
         torch.save(d, os.path.join(str(dir_path), "index.pt"))
 
     def deserialize_from(self, dir_path):
-        d = torch.load(os.path.join(str(dir_path), "index.pt"), map_location="cpu", weights_only=False)
+        d = torch.load(os.path.join(str(dir_path), "index.pt"), map_location="cpu", weights_only=True)
         assert d["vector_sz"] == self.vector_sz
         if "codes" in d:                         # (like faiss.read_index: the file decides the index type)
             self.pq = ProductQuantizer(self.vector_sz, d["n_subquantizers"], d["n_bits"], self.ops, self.device)
@@ -179,7 +182,8 @@ class Indexer:
         else:
             self.pq = None
             self.embeddings = d["embeddings"].to(self.device)
-        self.index_id_to_db_id = d["index_id_to_db_id"]
+        ids = d["index_id_to_db_id"]
+        self.index_id_to_db_id = ids.numpy().astype(np.int64) if torch.is_tensor(ids) else np.asarray(ids, dtype=np.int64)
         assert len(self.index_id_to_db_id) == self.ntotal, "Deserialized index_id_to_db_id should match the index size"
 
 

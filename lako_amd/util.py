@@ -236,6 +236,8 @@ def load(model_class, dir_path, opt, reset_params=False, **model_kw):
     if device is not None and torch.device(device).type == "cuda":
         model = model.to(device)
     logger.info("loading checkpoint %s", optimizer_path)
+    # (the reference's format: `opt` is the pickled argparse Namespace, src/util.py:113-118 — a checkpoint directory is as trusted
+    # as the code that reads it, exactly as with the reference; the model weights themselves are safetensors)
     checkpoint = torch.load(optimizer_path, map_location="cpu", weights_only=False)
     opt_checkpoint = checkpoint["opt"]
     step = checkpoint["step"]
