@@ -209,3 +209,12 @@ def test_host_side_validation_under_address_sanitizer():
                         "bad_arguments or rejects_timing or caller_owned"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0 and "AddressSanitizer" not in r.stderr and "AddressSanitizer" not in r.stdout, r.stdout[-2500:] + r.stderr[-2500:]
     assert "3 passed" in r.stdout, r.stdout[-500:]
+
+
+def test_documents_state_the_current_number_of_entry_points():
+    """README.md / DESIGN.md / INTEGRATION.md quote the size of the C-ABI; keep the quote equal to what include/lako_hip.h declares."""
+    n = len(header_functions())
+    for doc in ("README.md", "DESIGN.md", "INTEGRATION.md"):
+        text = open(os.path.join(ROOT, doc)).read()
+        quoted = {int(m) for m in re.findall(r"(\d+)\s+(?:`extern \"C\"`\s+|extern \"C\"\s+)?(?:entry points|functions taking raw device pointers)", text)}
+        assert quoted and quoted == {n}, (doc, quoted, n)
