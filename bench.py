@@ -192,6 +192,42 @@ def cpu_baseline(args):
                       f"the leg is cut off after {args.cpu_seconds:.0f} s), {cores} threads"}
 
 
+def visible_gpus() -> int:
+    """Devices this process could use (torch.cuda.device_count() counts without initialising the GPU on this image)."""
+    return int(torch.cuda.device_count())
+
+
+def rank_launch_cmd(n: int, argv: list, port: int | None = None) -> list:
+    """The command the driver itself uses for N > 1: one process per GPU started by torch.distributed.run, RCCL rendezvous on
+    127.0.0.1, bench.py's own arguments relayed unchanged."""
+    port = port or int(os.environ.get("LAKO_BENCH_PORT", 29500 + os.getpid() % 2000))
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args, argv) -> int:
+    """`python bench.py --gpus N` (N > 1) WITHOUT torchrun around it: start the N rank processes as a CHILD (subprocess, never exec; this
+    parent has not touched a GPU — device_count() does not initialise HIP), relay its stdout (rank 0's JSON line) and return its exit
+    code.  Fewer than N visible devices is an error, never a silent 1-GPU line (the reference's scaffolding for this: src/slurm.py:157-160,
+    src/util.py:248-275)."""
+    import subprocess
+    have = visible_gpus()
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible; refusing to report a {have}-GPU run as {args.gpus}", file=sys.stderr)
+        return 3
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))   # dmabuf IPC (RCCL across processes)
+    proc = subprocess.run(rank_launch_cmd(args.gpus, argv), env=env)
+    return proc.returncode
+
+
+def check_world(args, env=os.environ):
+    """(world, rank, local_rank) from the launcher's environment; a world size that is not --gpus ends the run (exit code 4)."""
+    world = int(env.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to print a line for the wrong GPU count")
+    return world, int(env.get("RANK", "0")), int(env.get("LOCAL_RANK", "0"))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,16 +254,19 @@ def main():
     args = ap.parse_args()
     if args.cpu_worker:
         return cpu_worker(args)
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: become one (BEFORE anything here touches a GPU) instead of measuring one GPU under an N-GPU label
+        raise SystemExit(self_launch(args, sys.argv[1:]))
 
     import torch.distributed as dist
     from lako_amd import FiDConfig, FiDT5
     from lako_amd import util as U
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    world, rank, local_rank = check_world(args)
+    if visible_gpus() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} wants device {local_rank} but only {visible_gpus()} GPU(s) are visible")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     force_dist = os.environ.get("LAKO_FORCE_DIST") == "1"   # exercise the RCCL path even at world size 1
@@ -238,6 +277,8 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
+        if dist.get_world_size() != args.gpus and not (force_dist and args.gpus == 1):
+            raise SystemExit(f"bench.py: RCCL reports world size {dist.get_world_size()}, --gpus is {args.gpus}")
 
     cfg = FiDConfig.named(args.model, dropout_rate=args.dropout)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -256,7 +297,7 @@ def main():
     if use_dist:
         from lako_amd.dist import GradSync, broadcast_parameters
         broadcast_parameters(model)
-        GradSync(model, force=force_dist)
+        sync = GradSync(model, force=force_dist)
     ops = model._get_engine().ops
 
     B, N, L, T = args.batch, args.n_passages, args.seq_len, args.target_len
@@ -362,9 +403,12 @@ def main():
                                    f"(fwd+bwd+clip+AdamW), T5-{args.model} random-init, synthetic OKVQA-shaped batches resident in HBM",
                        "per_gpu_batch": B, "global_batch": B * world, "n_passages": N, "text_maxlength": L,
                        "answer_len": T, "dropout": args.dropout, "parallelism": f"dp{world}",
-                       "rccl_world_size": dist.get_world_size() if use_dist else None,
-                       "dp_mode": os.environ.get("LAKO_DP_MODE", "deferred") if use_dist else None,
-                       "dp_grad_dtype": os.environ.get("LAKO_DP_GRAD_DTYPE", "fp32") if use_dist else None,
+                       "rccl_world_size": dist.get_world_size() if use_dist else None,      # None: one GPU, RCCL not initialised
+                       "dp_mode": sync.mode if use_dist else "none (one GPU: no collective)",
+                       "dp_grad_dtype": ("bf16" if sync.grad_dtype is not None else "fp32") if use_dist else None,
+                       "dp_estimated_allreduce_ms": {k: round(v, 2) for k, v in sync.cost_table_ms.items()} if use_dist else None,
+                       "gemm_dephase": {"ticks_10ns": int(ops.tuning.nt_dephase), "phases": int(ops.tuning.nt_dephase_n),
+                                        "note": "every other workgroup of an XCD starts late (s_memrealtime spin) in multi-round persistent GEMM launches; tuned on one box"},
                        "host_enqueue_ms_per_step": None if r["host_ms"] is None else round(r["host_ms"], 2),
                        "master_weights": "fp32", "final_mean_loss": round(final_loss, 4),
                        "passage_lengths": "all text_maxlength" if args.all_valid else "U{L/2..L} (SURVEY.md §8d)",

@@ -16,10 +16,13 @@ reports finished ranges through `Engine.grad_hook`.  Two modes:
                         counters (`gemm_nt_queue`), so the CUs the RCCL kernels hold cost a share of the tiles, not a whole
                         extra pass.  Correct (2-rank gloo test, world-1 RCCL test) — to be measured on 8 GPUs (tools/scale.sh).
 
+Which of the two transports is the default depends on the world size and the gradient bytes — `choose_dp` below, a stated cost table
+(bf16 at N = 2 and 4 for T5-base, fp32 at N = 8); `LAKO_DP_MODE`, `LAKO_DP_GRAD_DTYPE` and the constructor arguments override it.
+
 `LAKO_DP_GRAD_DTYPE=bf16` (or `grad_dtype=torch.bfloat16`): the gradients travel as bf16 — half the bytes over the xGMI links (446 MB
 instead of 892 MB at T5-base; it is the 2- and 4-GPU runs, with one link per peer, that pay most for the collective) — through a
 bf16 staging buffer: cast → all-reduce → cast back, two extra passes over the flat buffer (≈0.5 ms).  The sum of world-size bf16
-gradients carries one more rounding than the single-GPU path has; the default stays fp32.
+gradients carries one more rounding than the single-GPU path has.
 
 `finish()` makes the compute stream wait for the collectives; the 1/world factor is folded into the fused
 optimizer step (lako_adamw_step grad_scale) and into the clip norm, so gradients are never rescaled in a
@@ -32,25 +35,66 @@ import os
 import torch.distributed as dist
 
 
+# ---- the default per world size, by arithmetic (UNMEASURED ON HARDWARE: no multi-GPU node was available to any round) ------------
+# One MI355X has 7 xGMI links, one per peer of an 8-GPU node (≈153 GB/s each, both directions together; DESIGN.md §7 prices a
+# direction at ≈64 GB/s after protocol overhead).  xGMI is point to point: an all-reduce among N GPUs can use the N − 1 links a GPU
+# has to the other participants and nothing else, so with reduce-scatter + all-gather over the full mesh every GPU sends and
+# receives bytes/N per peer link, twice.  The fewer the ranks, the fewer the links: it is the 2- and 4-GPU runs that pay most.
+XGMI_GBPS_PER_DIRECTION = 64.0
+STAGING_TBPS = 5.0            # the two cast passes of the bf16 transport stream the flat buffer at about the chip's copy rate
+BF16_MIN_GAIN_MS = 2.0        # the bf16 transport adds a rounding the single-GPU path does not have: only for a gain worth having
+
+
+def allreduce_ms(nbytes: int, world: int) -> float:
+    """Estimated time of one SUM all-reduce of `nbytes` per rank among `world` GPUs of one xGMI mesh."""
+    if world <= 1:
+        return 0.0
+    return 2.0 * (nbytes / world) / (XGMI_GBPS_PER_DIRECTION * 1e9) * 1e3
+
+
+def dp_cost_table(n_grad: int, world: int) -> dict:
+    """ms per step each gradient transport adds, for `n_grad` fp32 gradient elements: fp32 in place, or bf16 through a staging buffer
+    (cast → all-reduce → cast back: 12 B of HBM traffic per element on top of half the link bytes)."""
+    stage = n_grad * 12 / (STAGING_TBPS * 1e12) * 1e3
+    return {"fp32": allreduce_ms(4 * n_grad, world), "bf16": allreduce_ms(2 * n_grad, world) + stage}
+
+
+def choose_dp(n_grad: int, world: int) -> tuple:
+    """(mode, gradient transport) GradSync uses when neither the caller nor LAKO_DP_MODE / LAKO_DP_GRAD_DTYPE say otherwise.
+    Mode: "deferred" — the one mode that cannot slow the step's kernels down (the persistent GEMMs hold every CU; "overlap" stays an
+    opt-in until it has been measured on a node).  Transport: bf16 where the table says it saves ≥ BF16_MIN_GAIN_MS — at T5-base
+    (892 MB of fp32 gradients) that is N = 2 (13.9 → 7.5 ms) and N = 4 (7.0 → 4.0 ms), not N = 8 (3.5 → 2.3 ms)."""
+    t = dp_cost_table(n_grad, world)
+    return "deferred", ("bf16" if t["fp32"] - t["bf16"] >= BF16_MIN_GAIN_MS else "fp32")
+
+
 class GradSync:
     def __init__(self, model, group=None, bucket_bytes: int = 64 << 20, force: bool = False, mode: str | None = None,
                  grad_dtype=None):
+        import torch
         self.force = force          # issue the collectives even at world size 1 (single-GPU test of the RCCL path)
         self.model = model
         self.group = group
         self.world_size = dist.get_world_size(group)
         self.bucket_bytes = bucket_bytes
-        self.mode = mode or os.environ.get("LAKO_DP_MODE", "deferred")
+        eng = model._get_engine()
+        auto_mode, auto_dtype = choose_dp(eng.G.numel(), self.world_size)
+        self.cost_table_ms = dp_cost_table(eng.G.numel(), self.world_size)
+        self.mode = mode or os.environ.get("LAKO_DP_MODE") or auto_mode
         if self.mode not in ("deferred", "overlap"):
             raise ValueError(f"unknown DP mode {self.mode!r}")
         self.handles = []
         self._pending = None
         self._dirty = False
-        if grad_dtype is None:
-            grad_dtype = {"bf16": __import__("torch").bfloat16, "fp32": None, "f32": None}[os.environ.get("LAKO_DP_GRAD_DTYPE", "fp32")]
-        self.grad_dtype = grad_dtype      # None: all-reduce the fp32 buffer in place
+        if grad_dtype is None:      # the caller did not say: the environment, else the cost table
+            name = os.environ.get("LAKO_DP_GRAD_DTYPE") or auto_dtype
+            if name not in ("bf16", "fp32", "f32"):
+                raise ValueError(f"unknown LAKO_DP_GRAD_DTYPE {name!r}")
+            grad_dtype = torch.bfloat16 if name == "bf16" else torch.float32
+        if grad_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError(f"gradient transport dtype {grad_dtype} unsupported (fp32 or bf16)")
+        self.grad_dtype = None if grad_dtype == torch.float32 else grad_dtype      # None: all-reduce the fp32 buffer in place
         self._stage = None                # low-precision staging buffer, same layout as G
-        eng = model._get_engine()
         eng.grad_hook = self._on_ready
         model._grad_sync = self
         if self.mode == "overlap" and hasattr(eng.ops, "set_tuning"):

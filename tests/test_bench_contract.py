@@ -50,6 +50,47 @@ def test_synthetic_batch_recipe():
     assert torch.equal(i4, ids) and torch.equal(m4, mask) and torch.equal(lens4.long(), mask.sum(-1)) and not lens4.is_cuda
 
 
+def _run_bench(argv, env_extra=None, timeout=120):
+    env = dict(os.environ, **(env_extra or {}))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        if env_extra is None or k not in env_extra:
+            env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, timeout=timeout, env=env)
+
+
+def test_bench_gpus_n_cannot_report_the_wrong_gpu_count():
+    """`python bench.py --gpus N` the way the driver calls `--gpus 1` (no torchrun around it) must start N ranks itself or fail —
+    never print a 1-GPU line under an N-GPU request.  Here: fewer than N devices visible ⇒ non-zero exit, no JSON line."""
+    hide = {"HIP_VISIBLE_DEVICES": "", "CUDA_VISIBLE_DEVICES": "", "ROCR_VISIBLE_DEVICES": ""}
+    r = _run_bench(["--gpus", "8", "--steps", "1", "--warmup", "0"], hide)
+    assert r.returncode != 0 and "only 0 GPU(s) visible" in r.stderr
+    assert not any(ln.lstrip().startswith("{") for ln in r.stdout.splitlines())
+    # a launcher environment whose world size is not --gpus (torchrun --nproc-per-node 2 … --gpus 4, or --gpus 1 under a 2-rank launch)
+    for gpus, world in (("4", "2"), ("1", "2"), ("2", "1")):
+        r = _run_bench(["--gpus", gpus, "--steps", "1", "--warmup", "0"], dict(hide, WORLD_SIZE=world, RANK="0", LOCAL_RANK="0"))
+        assert r.returncode != 0 and f"WORLD_SIZE={world}" in r.stderr, (gpus, world, r.stderr[-300:])
+        assert not any(ln.lstrip().startswith("{") for ln in r.stdout.splitlines())
+    r = _run_bench(["--gpus", "0"], hide)
+    assert r.returncode != 0
+
+
+def test_bench_self_launch_relays_its_arguments():
+    cmd = bench.rank_launch_cmd(4, ["--gpus", "4", "--steps", "7", "--warmup", "2", "--no-cpu-baseline"], port=29999)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2", "--no-cpu-baseline"]
+
+    class A:
+        gpus = 2
+    assert bench.check_world(A, {"WORLD_SIZE": "2", "RANK": "1", "LOCAL_RANK": "1"}) == (2, 1, 1)
+    with pytest.raises(SystemExit):
+        bench.check_world(A, {})                      # not under a launcher and not self-launched: refuse
+    with pytest.raises(SystemExit):
+        bench.check_world(A, {"WORLD_SIZE": "8"})
+
+
 @pytest.mark.gpu
 def test_bench_prints_one_json_line_last(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--model", "small", "--batch", "2", "--n-passages", "3",
@@ -65,6 +106,9 @@ def test_bench_prints_one_json_line_last(tmp_path):
     assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1 and out["vs_baseline"] is None
     assert out["unit"] == "samples/s" and out["scaling"] == "weak" and out["data"] == "synthetic" and out["dtype"] == "bf16"
     assert "workload" in out["config"] and "model" not in out["config"]
+    for k in ("dp_mode", "dp_grad_dtype", "rccl_world_size", "gemm_dephase"):      # on every line, also at one GPU
+        assert k in out["config"], k
+    assert out["config"]["rccl_world_size"] is None and out["config"]["dp_mode"].startswith("none")
     rf = out["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert {"value", "unit", "cores", "kind", "sample"} <= set(out["cpu_baseline"]) and out["cpu_baseline"]["kind"] == "port"

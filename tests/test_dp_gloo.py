@@ -39,7 +39,7 @@ def _batches():
     return dims, w, [O.synthetic_batch(4, N, L, T, dims.vocab_size, seed=900 + k) for k in range(2)]
 
 
-def _worker(rank, world, port, out_path, mode, grad_dtype=None):
+def _worker(rank, world, port, out_path, mode, grad_dtype=torch.float32):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -51,7 +51,11 @@ def _worker(rank, world, port, out_path, mode, grad_dtype=None):
         from lako_amd.dist import GradSync, broadcast_parameters
         model._get_engine()
         broadcast_parameters(model)             # … the broadcast must make the replicas identical
-        sync = GradSync(model, bucket_bytes=1 << 12, mode=mode, grad_dtype=grad_dtype)     # overlap: tiny buckets → several all-reduces
+        if grad_dtype == "auto":           # nobody chose: the cost table does, and for a model of a few kB that is fp32 in place
+            sync = GradSync(model, bucket_bytes=1 << 12)
+            assert (sync.mode, sync.grad_dtype) == ("deferred", None) and sync.cost_table_ms["fp32"] < 1e-2
+        else:
+            sync = GradSync(model, bucket_bytes=1 << 12, mode=mode, grad_dtype=grad_dtype)     # overlap: tiny buckets → several all-reduces
         optimizer, scheduler = _opt(model)
         model.train()
         n_calls = 0
@@ -115,7 +119,7 @@ def test_two_rank_bf16_gradient_collective(tmp_path, mode):
     """LAKO_DP_GRAD_DTYPE=bf16: gradients travel as bf16 (half the xGMI bytes).  Both ranks end with identical weights (asserted in
     the worker) that equal the fp32-collective result up to the bf16 rounding of the summed gradients."""
     outs = []
-    for gd in (None, torch.bfloat16):
+    for gd in (torch.float32, torch.bfloat16):
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0))
             port = s.getsockname()[1]
@@ -125,3 +129,22 @@ def test_two_rank_bf16_gradient_collective(tmp_path, mode):
     d = (outs[0]["P"] - outs[1]["P"]).abs().max().item()
     assert 0 < d < 5e-3, d                     # different (the rounding is real) but close: two AdamW steps at lr 5e-3
     assert abs(outs[0]["gn"] - outs[1]["gn"]) < 2e-2 * max(1.0, outs[0]["gn"])
+
+
+def test_default_transport_follows_the_cost_table():
+    """GradSync's default per world size (lako_amd/dist.py::choose_dp): T5-base's 222.9 M gradients travel as bf16 at N = 2 and 4
+    (one xGMI link per peer: 13.9 / 7.0 ms in fp32) and as fp32 at N = 8; always the deferred single all-reduce."""
+    from lako_amd.dist import allreduce_ms, choose_dp, dp_cost_table
+    n = 222_903_552
+    assert [choose_dp(n, w) for w in (1, 2, 4, 8)] == [("deferred", "fp32"), ("deferred", "bf16"), ("deferred", "bf16"), ("deferred", "fp32")]
+    t2, t8 = dp_cost_table(n, 2), dp_cost_table(n, 8)
+    assert 13.0 < t2["fp32"] < 15.0 and 7.0 < t2["bf16"] < 8.0 and 3.0 < t8["fp32"] < 4.0
+    assert allreduce_ms(1 << 30, 1) == 0.0
+    assert choose_dp(737_000_000, 8) == ("deferred", "bf16")        # T5-large: 2.9 GB of gradients pay for the staging even at N = 8
+
+
+def test_two_rank_auto_choice_runs(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path / "dp.pt"), "deferred", "auto"), nprocs=2, join=True)

@@ -19,12 +19,9 @@ for n in $GPUS; do
   if [ "$n" -gt "$avail" ]; then echo "skip N=$n: only $avail GPU(s) visible"; continue; fi
   args="--gpus $n --steps $STEPS --warmup $WARMUP --all-valid-steps 0"
   [ "$n" != 1 ] && args="$args --no-cpu-baseline"
-  if [ "$n" = 1 ]; then
-    python bench.py $args --no-cpu-baseline > "$OUT/scale_n$n.json" 2> "$OUT/scale_n$n.err"
-  else
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node "$n" --master-addr 127.0.0.1 --master-port "$PORT" \
-      bench.py $args > "$OUT/scale_n$n.json" 2> "$OUT/scale_n$n.err"
-  fi
+  # `bench.py --gpus N` starts its own N ranks (torch.distributed.run as a child, before the parent touches a GPU) when no launcher
+  # is around it, exactly as the driver calls it; LAKO_BENCH_PORT keeps consecutive runs on different rendezvous ports
+  LAKO_BENCH_PORT=$PORT python bench.py $args --no-cpu-baseline > "$OUT/scale_n$n.json" 2> "$OUT/scale_n$n.err"
   echo "N=$n rc=$?"
   PORT=$((PORT + 1))
 done
@@ -37,9 +34,15 @@ for p in glob.glob(os.path.join(sys.argv[1], "scale_n*.json")):
         j = json.loads(lines[-1])
         rows[j["n_gpus"]] = j
 base = rows.get(1)
+bad = 0
 for n in sorted(rows):
     j = rows[n]
     eff = f"{j['value'] / (n * base['value']):.3f}" if base else "n/a"
-    print(f"N={n}: {j['value']:.1f} samples/s  {j['ms_per_step']:.2f} ms/step  rccl_world_size={j['config'].get('rccl_world_size')}  "
+    ws = j['config'].get('rccl_world_size')
+    print(f"N={n}: {j['value']:.1f} samples/s  {j['ms_per_step']:.2f} ms/step  rccl_world_size={ws}  "
           f"dp_mode={j['config'].get('dp_mode')} grad_dtype={j['config'].get('dp_grad_dtype')}  efficiency vs 1 GPU {eff}")
+    if n > 1 and ws != n:
+        print(f"  ERROR: the line for N={n} was produced by {ws} RCCL rank(s)")
+        bad = 1
+sys.exit(bad)
 PY
