@@ -25,7 +25,10 @@
 extern "C" {
 #endif
 
-#define LAKO_ABI_VERSION 1
+/* 2 (round 4): the struct and argument changes of round 3 (lako_gemm_nt_t.tuning, the tuning / alpha arguments of lako_gemm_tn*,
+ * lako_fact_scores, no lako_set_tuning) are incompatible with callers built against version 1 — such a caller must be rebuilt.
+ * lako_amd/_lib.py::load() refuses a library whose lako_version() is not the one it was written for. */
+#define LAKO_ABI_VERSION 2
 
 enum { LAKO_F32 = 0, LAKO_BF16 = 1, LAKO_FP8_E4M3 = 2 /* MX block-scaled operands of lako_gemm_nt_mx only */ };
 enum { LAKO_OK = 0, LAKO_E_BADARG = -1, LAKO_E_ALIGN = -2, LAKO_E_LAUNCH = -3, LAKO_E_UNSUPPORTED = -4 };
@@ -75,7 +78,11 @@ typedef struct lako_tuning {
   int32_t nt_tile192;    /* 1: 192-row tiles (variant 7) where the round count favours them (default 0: measured no faster) */
   int32_t nt_queue;      /* 1: the persistent 256x256 kernel pulls its tiles from per-XCD ticket counters (a launch that shares the chip
                             with RCCL kernels — LAKO_DP_MODE=overlap — ends when the tiles do, not when the last-started workgroup does) */
-  int32_t reserved[15];  /* zero */
+  int32_t nt_pp;         /* main-loop schedule of the 256x256 / 8-wave kernel (round 4, A/B only): 0 (default) the two waves of a SIMD in
+                            phase; 1 "ping-pong": waves 4-7 half a K-step behind waves 0-3 (one in its MFMA segment while the other issues
+                            LDS-DMA and reads fragments); 2 / 3 every wave in the early / late role; 4 = 2 from K = 2048 up.  Same results
+                            bit for bit; measured no faster on the training step (profiles/r04c_gemm_ping_pong.txt) */
+  int32_t reserved[14];  /* zero */
 } lako_tuning_t;
 int lako_tuning_init(lako_tuning_t* t);
 int lako_tuning_set(lako_tuning_t* t, const char* key, int value);

@@ -11,6 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LAKO_LIB") or os.path.join(_HERE, "liblako_hip.so")   # LAKO_LIB: A/B measurements of two builds
 
+ABI_VERSION = 2          # include/lako_hip.h LAKO_ABI_VERSION this binding was written for
 LAKO_F32, LAKO_BF16, LAKO_FP8_E4M3 = 0, 1, 2
 EPI_RELU, EPI_RESID, EPI_AUXMASK, EPI_ATOMIC = 1, 2, 4, 8
 
@@ -32,7 +33,7 @@ class Tuning(C.Structure):
     """lako_tuning_t: kernel-selection knobs, owned by the caller (one per HipOps — the library keeps no tuning state)"""
     _fields_ = [(n, i32) for n in ("nt_variant", "nt_tail_split", "nt_ring", "nt_skinny", "nt_side_lds", "nt_wide_epi", "nt_group_m",
                                    "nt_persistent", "nt_stagger", "nt_dephase", "nt_dephase_n", "tn_big", "tn_split", "nt_debug",
-                                   "nt_store_aux", "nt_tile192", "nt_queue")] + [("reserved", i32 * 15)]
+                                   "nt_store_aux", "nt_tile192", "nt_queue", "nt_pp")] + [("reserved", i32 * 14)]
 
 
 class GemmNT(C.Structure):
@@ -149,6 +150,9 @@ def load(path: str | None = None):
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = C.c_int
+    if lib.lako_version() != ABI_VERSION:     # structs and argument lists differ between versions: a mismatch reads garbage pointers
+        raise LakoError(f"{path} implements C-ABI version {lib.lako_version()}, this package binds version {ABI_VERSION} "
+                        f"(include/lako_hip.h LAKO_ABI_VERSION): rebuild with lako_amd/csrc/build.sh")
     _lib = lib
     return lib
 

@@ -24,6 +24,11 @@
 // redirected, cache-policy bits on the stores, atomics skipped — exist only in a build with -DLAKO_EXPERIMENTS
 // (csrc/build.sh LAKO_EXPERIMENTS=1 → liblako_hip_exp.so, never loaded by the product).  In the release library the
 // tests below are compile-time zero and lako_set_tuning rejects the keys that would set them.
+// cache-policy bits of the NT kernels' LDS-DMA loads (gfx940 encoding of the builtin's aux operand: 1 = sc0, 2 = nt, 16 = sc1): 0 in the
+// product; other values only in throw-away A/B builds (-DLAKO_LOAD_AUX=…, tools/gemm_pp_probe.py)
+#ifndef LAKO_LOAD_AUX
+#define LAKO_LOAD_AUX 0
+#endif
 #ifdef LAKO_EXPERIMENTS
 #define NT_DBG(a, bits) ((a).debug & (bits))
 #else
@@ -115,7 +120,7 @@ __device__ __forceinline__ void stage_rows(char* lds_tile, const char* base, int
     int c = cp ^ ((row >> 1) & 7);
     bool ok = (row < rows_valid) && (c * 16 < kbytes_left);
     uint32_t voff = ok ? (uint32_t)(row * ld_bytes + c * 16) : 0xFFFFFFF0u;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + inst * 1024), 16, (int)voff, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + inst * 1024), 16, (int)voff, 0, 0, LAKO_LOAD_AUX);
   }
 }
 
@@ -138,12 +143,12 @@ __device__ __forceinline__ void stage_piece(char* lds_tile, __amdgpu_buffer_rsrc
   int c = cp ^ ((row >> 1) & 7);
   bool ok = (row < rows_valid) && (c * 16 < kbytes_left);
   uint32_t voff = ok ? (uint32_t)(row * ld_bytes + c * 16) : 0xFFFFFFF0u;
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + inst * 1024), 16, (int)voff, 0, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + inst * 1024), 16, (int)voff, 0, 0, LAKO_LOAD_AUX);
 }
 // SIDE kernel: ONE per-lane offset (piece_base) serves all pieces of a wave, each piece with its own descriptor
 template <int NWAVES>
 __device__ __forceinline__ void stage_piece_at(char* lds_tile, __amdgpu_buffer_rsrc_t rsrc, uint32_t vbase, int wave, int i) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + (wave + i * NWAVES) * 1024), 16, (int)vbase, 0, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + (wave + i * NWAVES) * 1024), 16, (int)vbase, 0, 0, LAKO_LOAD_AUX);
 }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t slice_rsrc(const char* base, int rows_valid, int64_t ld_bytes, int kbytes_left) {
   uint32_t nrec = (rows_valid > 0 && kbytes_left > 0)
@@ -266,8 +271,11 @@ __device__ __forceinline__ void nt_store_tile(const NtArgs& a, f32x4 (&acc)[NT][
 //   <2,4,8,4> 256×256, 8 waves, 128 KiB LDS (1 workgroup / CU)      — half the LDS+L2 bytes per FLOP
 //   SIDE (256² bf16 only): the residual / aux operand of the epilogue is LDS-DMA'd in four 32-row passes (see the epilogue)
 //   QUEUE: the tiles after a workgroup's first are PULLED from per-XCD ticket counters instead of strided by the grid size (below)
-template <typename T, typename TO, int WM, int WN, int MT, int NT, bool SIDE = false, bool QUEUE = false>
+//   PP ("ping-pong", round 4; 8 waves only): the two waves that share a SIMD (w and w + 4) run the K-step half a step apart — see the
+//       PP main loop below
+template <typename T, typename TO, int WM, int WN, int MT, int NT, bool SIDE = false, bool QUEUE = false, bool PP = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
+  static_assert(!PP || (WM * WN == 8 && !QUEUE), "PP: 8 waves, static tile order");
   constexpr int NW = WM * WN, BM = WM * MT * 16, BN = WN * NT * 16;
   constexpr int A_BYTES = BM * TKB, B_BYTES = BN * TKB, BUF = A_BYTES + B_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -354,6 +362,116 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
 #pragma unroll
       for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    if constexpr (PP) {
+      // PING-PONG main loop.  In the loop below (the round 1–3 schedule) the two waves of a SIMD run the same program in phase: both
+      // issue their LDS-DMA pieces (≈100 cycles of issue each while the other wave does the same), both read fragments, both queue
+      // MFMAs — a wave's K-step is DMA issue + fragment reads + the MFMA time of BOTH waves (≈800 + 260 + 2 048 cycles; measured
+      // ≈3 200 per K-step, ≈2 400 with the DMA switched off), and the matrix pipe idles while both are in their memory segments.
+      // Here waves 4–7 ("late") lag waves 0–3 ("early") by one K-half: their MFMAs of K-half 1 run at the START of the next K-step,
+      // from fragments held in registers across the barrier, so that at every point one wave of a SIMD is in a matrix segment
+      // (32 MFMAs, ≈512 cycles alone on the pipe) while its partner is in a memory segment (DMA issue + 12 fragment reads):
+      //     early:  [DMA a, R0] [M0] [DMA b, R1] [M1 … wait, barrier … M1]
+      //     late :  [M1(t−1)]  [R0, DMA a + b] [M0] [R1, wait, barrier]
+      // One barrier per K-step as before (slice t + 1 has landed, slice t is no longer read), two K-slice buffers as before.  The
+      // late waves issue all their pieces in their FIRST memory segment: pieces issued in the second one (just before the barrier)
+      // would have no time to land.  MI355X_MICROARCH.md § "Two waves per SIMD" (items 1, 7, 9) is the model this follows.
+      const bool late = a.stagger == 2 ? false : a.stagger == 3 ? true : wave >= NW / 2;   // (2 / 3: every wave early / late — A/B of the schedule itself)
+      u32x4 af[MT], bf[NT];
+      auto mma_rows = [&](int lo, int hi) {
+#pragma unroll
+        for (int mt = lo; mt < hi; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[nt][mt] = Mma<T>::run(bf[nt], af[mt], acc[nt][mt]);
+      };
+      // one K-step of one role; the loop is written out per role so that the accumulators never meet at a control-flow merge inside it
+      auto kstep = [&](int t, auto role) {
+        constexpr int ROLE = decltype(role)::value;      // 0 early, 1 late (first K-step of a tile: no held fragments), 2 late
+        const char* As = smem + cur * BUF;
+        const char* Bs = As + A_BYTES;
+        char* An = smem + (cur ^ 1) * BUF;
+        const bool more_k = t + 1 < nk;
+        const bool pf = more_k || has_next;
+        const int koff = more_k ? (t + 1) * TKB : 0;
+        const int pf_rows_a = more_k ? rows_a : min(BM, a.M - nm0), pf_rows_b = more_k ? rows_b : min(BN, a.N - nn0);
+        const char* pf_a = more_k ? Abase + koff : a.A + (int64_t)nm0 * lda_b;
+        const char* pf_b = more_k ? Bbase + koff : a.B + (int64_t)nn0 * ldb_b;
+        constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;
+        const auto rsrc_a = slice_rsrc(pf_a, pf_rows_a, lda_b, kbytes - koff);
+        const auto rsrc_b = slice_rsrc(pf_b, pf_rows_b, ldb_b, kbytes - koff);
+        auto pieces = [&](int lo, int hi) {
+          if (!pf) return;
+          if constexpr (SIDE) {
+            const uint32_t vb_a = piece_base(lda_b, kbytes - koff, wave, lane), vb_b = piece_base(ldb_b, kbytes - koff, wave, lane);
+#pragma unroll
+            for (int j = lo; j < hi; ++j) {
+              if (j < PA)
+                stage_piece_at<NW>(An, slice_rsrc(pf_a + (int64_t)j * NW * 8 * lda_b, pf_rows_a - j * NW * 8, lda_b, kbytes - koff), vb_a, wave, j);
+              else
+                stage_piece_at<NW>(An + A_BYTES, slice_rsrc(pf_b + (int64_t)(j - PA) * NW * 8 * ldb_b, pf_rows_b - (j - PA) * NW * 8, ldb_b, kbytes - koff),
+                                   vb_b, wave, j - PA);
+            }
+          } else {
+#pragma unroll
+            for (int j = lo; j < hi; ++j) {
+              if (j < PA) stage_piece<NW>(An, rsrc_a, pf_rows_a, lda_b, kbytes - koff, wave, lane, j);
+              else stage_piece<NW>(An + A_BYTES, rsrc_b, pf_rows_b, ldb_b, kbytes - koff, wave, lane, j - PA);
+            }
+          }
+        };
+        auto read_half = [&](int kh) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) bf[nt] = read_frag_rows(Bs, (wc * NT + nt) * 16 + r16, kh * 4 + g);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) af[mt] = read_frag_rows(As, (wr * MT + mt) * 16 + r16, kh * 4 + g);
+        };
+        auto wait_landed = [&]() {
+          if (SIDE && t == 0 && nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // the side pass may land during the next K-step
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        constexpr int E1 = (PA + PB) / 2;      // pieces an early wave issues in its first memory segment
+        if constexpr (ROLE == 0) {
+          pieces(0, E1);
+          read_half(0);
+          __builtin_amdgcn_sched_barrier(0);
+          mma_rows(0, MT);
+          __builtin_amdgcn_sched_barrier(0);
+          pieces(E1, PA + PB);
+          if (SIDE && t == 0) side_issue(0, smem + 2 * BUF + wave * 4096, m0, n0);
+          read_half(1);
+          __builtin_amdgcn_sched_barrier(0);
+          mma_rows(0, MT - MT / 4);
+          __builtin_amdgcn_sched_barrier(0);
+          wait_landed();
+          __syncthreads();
+          __builtin_amdgcn_sched_barrier(0);
+          mma_rows(MT - MT / 4, MT);
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+          if constexpr (ROLE == 2) mma_rows(0, MT);          // K-half 1 of the previous slice: its fragments were read before the barrier
+          __builtin_amdgcn_sched_barrier(0);
+          read_half(0);
+          pieces(0, PA + PB);
+          if (SIDE && t == 0) side_issue(0, smem + 2 * BUF + wave * 4096, m0, n0);
+          __builtin_amdgcn_sched_barrier(0);
+          mma_rows(0, MT);
+          __builtin_amdgcn_sched_barrier(0);
+          read_half(1);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the buffer is refilled right after the barrier
+          wait_landed();
+          __syncthreads();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        cur ^= 1;
+      };
+      if (!late) {
+        for (int t = 0; t < nk; ++t) kstep(t, std::integral_constant<int, 0>{});
+      } else {
+        kstep(0, std::integral_constant<int, 1>{});
+        for (int t = 1; t < nk; ++t) kstep(t, std::integral_constant<int, 2>{});
+        mma_rows(0, MT);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    } else
     for (int t = 0; t < nk; ++t) {
       const char* As = smem + cur * BUF;
       const char* Bs = As + A_BYTES;
@@ -1469,7 +1587,7 @@ const TuneKey TUNE_KEYS[] = {
     {"gemm_nt_dephase_n", &lako_tuning_t::nt_dephase_n, false},   {"gemm_tn_big", &lako_tuning_t::tn_big, false},
     {"gemm_tn_split", &lako_tuning_t::tn_split, false},           {"gemm_nt_debug", &lako_tuning_t::nt_debug, true},
     {"gemm_nt_store_aux", &lako_tuning_t::nt_store_aux, true},    {"gemm_nt_tile192", &lako_tuning_t::nt_tile192, false},
-    {"gemm_nt_queue", &lako_tuning_t::nt_queue, false},
+    {"gemm_nt_queue", &lako_tuning_t::nt_queue, false},           {"gemm_nt_pp", &lako_tuning_t::nt_pp, false},
 };
 
 void tuning_defaults(lako_tuning_t* t) {
@@ -1487,6 +1605,7 @@ void tuning_defaults(lako_tuning_t* t) {
   t->nt_dephase_n = 2;     // phases
   t->tn_big = 1;
   t->tn_split = 0;         // > 0: force the number of K-splits of the 256x256 TN kernel (A/B measurements)
+  t->nt_pp = 0;            // main-loop schedule of the 256² / 8-wave kernel: 0 in phase (default), 1 ping-pong, 2 / 3 all early / late, 4 = 2 from K = 2048 up (round 4: measured no gain on the step)
   t->nt_tile192 = 0;       // 1: 192-row tiles where the round count favours them (launch_nt) — measured no faster, off
 }
 
@@ -1564,7 +1683,12 @@ static int* nt_queue_counters(hipStream_t stream) {
   return p;
 }
 
-template <typename T, typename TO, int WM, int WN, int MT, int NT, bool SIDE = false, bool QUEUE = false>
+// which main-loop schedule the 256² / 8-wave kernel runs: 0 the in-phase loop of rounds 1–3, 1 ping-pong, 2 / 3 every wave in the early / late
+// role; tuning value 4 = by shape (measured, tools/gemm_pp_probe.py: the early role on every wave is 3–6 % faster from K = 2304 up and
+// 10 % slower on the K = 768 QKV projection)
+inline int nt_pp_mode(const lako_tuning_t& tu, const NtArgs& a) { return tu.nt_pp == 4 ? (a.K >= 2048 ? 2 : 0) : tu.nt_pp; }
+
+template <typename T, typename TO, int WM, int WN, int MT, int NT, bool SIDE = false, bool QUEUE = false, bool PP = false>
 void launch_nt_cfg(NtArgs a, const lako_tuning_t& tu, hipStream_t s) {
   constexpr int BM = WM * MT * 16, BN = WN * NT * 16, NW_ = WM * WN, BUF_ = (BM + BN) * TKB;
   // + the epilogue scratch of the waves that do not fit the free K-slice buffer (8 KiB each; 192-row tiles: one wave)
@@ -1572,13 +1696,13 @@ void launch_nt_cfg(NtArgs a, const lako_tuning_t& tu, hipStream_t s) {
   constexpr int LDS = 2 * BUF_ + (SIDE ? 32 * 1024 : 0) + EXTRA;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, TO, WM, WN, MT, NT, SIDE, QUEUE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, TO, WM, WN, MT, NT, SIDE, QUEUE, PP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_done = true;
   }
   a.tiles_m = cdiv(a.M, BM);
   a.tiles_n = cdiv(a.N, BN);
-  a.stagger = tu.nt_stagger;
+  a.stagger = PP ? nt_pp_mode(tu, a) : tu.nt_stagger;
   a.store_aux = (int64_t)256 * a.ldc * 2 < (1ll << 31) ? tu.nt_store_aux : 0;   // tile-relative 32-bit store offsets
   a.debug = tu.nt_debug;
   // narrow outputs (≤ 7 tile columns) already give an XCD a compact block; a negative knob forces |value| on every shape (tests).
@@ -1611,7 +1735,7 @@ void launch_nt_cfg(NtArgs a, const lako_tuning_t& tu, hipStream_t s) {
   } else {
     a.queue = nullptr;
   }
-  hipLaunchKernelGGL((gemm_nt_kernel<T, TO, WM, WN, MT, NT, SIDE, QUEUE>), dim3(grid), dim3(WM * WN * 64), LDS, s, a);
+  hipLaunchKernelGGL((gemm_nt_kernel<T, TO, WM, WN, MT, NT, SIDE, QUEUE, PP>), dim3(grid), dim3(WM * WN * 64), LDS, s, a);
 }
 
 // the 256² kernel, with the LDS-staged side operand where the epilogue has exactly one (bf16 in and out, 16-B aligned rows)
@@ -1625,11 +1749,16 @@ void launch_nt_256(const NtArgs& a, const lako_tuning_t& tu, hipStream_t s) {
         a.ldc % 8 == 0 && ld % 8 == 0 && reinterpret_cast<uintptr_t>(a.C) % 16 == 0 && reinterpret_cast<uintptr_t>(sp) % 16 == 0 &&
         (int64_t)256 * a.ldc * 2 < (1ll << 31) && (int64_t)256 * ld * 2 < (1ll << 31)) {
       if (MT == 8 && tu.nt_queue) launch_nt_cfg<T, TO, 2, 4, 8, 4, true, true>(a, tu, s);
+      else if (MT == 8 && nt_pp_mode(tu, a)) launch_nt_cfg<T, TO, 2, 4, 8, 4, true, false, true>(a, tu, s);
       else launch_nt_cfg<T, TO, 2, 4, MT, 4, true>(a, tu, s);
       return;
     }
     if (MT == 8 && tu.nt_queue) {
       launch_nt_cfg<T, TO, 2, 4, 8, 4, false, true>(a, tu, s);
+      return;
+    }
+    if (MT == 8 && nt_pp_mode(tu, a)) {
+      launch_nt_cfg<T, TO, 2, 4, 8, 4, false, false, true>(a, tu, s);
       return;
     }
   }

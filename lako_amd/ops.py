@@ -66,7 +66,7 @@ class HipOps:
         if not torch.cuda.is_available():
             raise LakoError("HipOps needs a ROCm device (torch.cuda.is_available() is False); no CPU fallback exists")
         self.lib = _lib.load()
-        assert self.lib.lako_version() == 1
+        assert self.lib.lako_version() == _lib.ABI_VERSION
         self.probe = None   # list → every op records (name, algorithmic flops, start event, end event)
         # kernel-selection knobs are THIS object's (the library keeps no tuning state): defaults + the LAKO_TUNING environment
         # string ("key=value,key=value": A/B measurements), changed by set_tuning, handed to every GEMM call
