@@ -44,6 +44,40 @@ __device__ __forceinline__ void lds_dma16(const void* lds_dst, lako_u32x4_t rsrc
       : "memory");
 }
 
+// the same transfer as `global_load_lds_dwordx4` (saddr form: wave-uniform 64-bit base + one 32-bit byte offset per lane): no descriptor, no
+// range check — every lane's address must be valid (clamp it), nothing is zero-filled.  Measured cheaper to issue than the buffer form
+// inside the GEMM main loops (round 4: 4–14 % per launch, profiles/r04g_gemm_eight_phase.txt).
+__device__ __forceinline__ void lds_dma16_g(const void* lds_dst, const void* base, uint32_t voff) {
+  const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)LDS_PTR(lds_dst));
+  const uint64_t b = reinterpret_cast<uint64_t>(base);
+  const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)b), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+  const uint64_t sb = ((uint64_t)bhi << 32) | blo;
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(dst), "s"(sb)
+      : "memory");
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: set it once per (kernel instantiation, device) —
+// a process-wide "done" flag would leave the kernel without its LDS on the second GPU of a process (launch failure).  One call site
+// per instantiation (the static array belongs to the call site); 64 devices; relaxed atomics: setting it twice is harmless.
+#ifdef __cplusplus
+#include <atomic>
+#define LAKO_SET_MAX_LDS(kernel_ptr, bytes)                                                                              \
+  do {                                                                                                                    \
+    static std::atomic<bool> lako_lds_done_[64];                                                                          \
+    int lako_dev_ = 0;                                                                                                    \
+    (void)hipGetDevice(&lako_dev_);                                                                                       \
+    if (lako_dev_ < 0 || lako_dev_ >= 64 || !lako_lds_done_[lako_dev_].load(std::memory_order_relaxed)) {                 \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_ptr), hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                (int)(bytes));                                                                            \
+      if (lako_dev_ >= 0 && lako_dev_ < 64) lako_lds_done_[lako_dev_].store(true, std::memory_order_relaxed);             \
+    }                                                                                                                     \
+  } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // error plumbing (never throws, never exits; see include/lako_hip.h)
 // ---------------------------------------------------------------------------------------------

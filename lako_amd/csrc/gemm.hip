@@ -61,6 +61,7 @@ struct NtArgs {
   int store_aux;  // cache-policy bits for the 256² kernel's 16-byte output stores (store_b128_policy)
   int dephase;    // (phases << 16) | ticks: workgroup w of an XCD starts (w mod phases)·ticks·10 ns late (breaks the lockstep of main loops / epilogues)
   int wide_epi;   // 256² bf16 tile: LDS-transposed epilogue with 16-B row-major stores (needs N, ldc, ldr, ldaux % 8 == 0)
+  int glds;       // 1: K-slice pieces by global_load_lds where the slice is whole (tuning nt_glds)
   int* queue;     // QUEUE instantiation: [0..7] per-XCD tile tickets, [8] workgroups finished (all zero between launches)
 };
 
@@ -144,6 +145,25 @@ __device__ __forceinline__ void stage_piece(char* lds_tile, __amdgpu_buffer_rsrc
   bool ok = (row < rows_valid) && (c * 16 < kbytes_left);
   uint32_t voff = ok ? (uint32_t)(row * ld_bytes + c * 16) : 0xFFFFFFF0u;
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + inst * 1024), 16, (int)voff, 0, 0, LAKO_LOAD_AUX);
+}
+// the same piece by `global_load_lds` where the whole 128-byte K-slice exists (`full`): rows past the edge are clamped to the last valid
+// row (they feed accumulator rows that are never stored), nothing needs the buffer form's zero fill — measured 4–14 % faster per
+// launch than `buffer_load … lds` in the same loop (round 4, profiles/r04g_gemm_eight_phase.txt); a partial K-slice (K % 64 != 0: its
+// missing chunks must read as zeros) keeps the buffer form
+template <int NWAVES>
+__device__ __forceinline__ void stage_piece_g(char* lds_tile, const char* base, __amdgpu_buffer_rsrc_t rsrc, int rows_valid, int64_t ld_bytes,
+                                              int kbytes_left, int wave, int lane, int i, bool full) {
+  const int inst = wave + i * NWAVES;
+  const int row = inst * 8 + (lane >> 3);
+  const int c = (lane & 7) ^ ((row >> 1) & 7);
+  if (full) {
+    const uint32_t voff = (uint32_t)(min(row, rows_valid - 1) * ld_bytes + c * 16);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + voff), LDS_PTR(lds_tile + inst * 1024), 16, 0, LAKO_LOAD_AUX);
+  } else {
+    const bool ok = (row < rows_valid) && (c * 16 < kbytes_left);
+    const uint32_t voff = ok ? (uint32_t)(row * ld_bytes + c * 16) : 0xFFFFFFF0u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + inst * 1024), 16, (int)voff, 0, 0, LAKO_LOAD_AUX);
+  }
 }
 // SIDE kernel: ONE per-lane offset (piece_base) serves all pieces of a wave, each piece with its own descriptor
 template <int NWAVES>
@@ -271,8 +291,8 @@ __device__ __forceinline__ void nt_store_tile(const NtArgs& a, f32x4 (&acc)[NT][
 //   <2,4,8,4> 256×256, 8 waves, 128 KiB LDS (1 workgroup / CU)      — half the LDS+L2 bytes per FLOP
 //   SIDE (256² bf16 only): the residual / aux operand of the epilogue is LDS-DMA'd in four 32-row passes (see the epilogue)
 //   QUEUE: the tiles after a workgroup's first are PULLED from per-XCD ticket counters instead of strided by the grid size (below)
-//   PP ("ping-pong", round 4; 8 waves only): the two waves that share a SIMD (w and w + 4) run the K-step half a step apart — see the
-//       PP main loop below
+//   PP (round 4; 8 waves, bf16, K >= 128): the 8-phase main loop — the two waves of a SIMD (w and w + 4) alternate 16-MFMA clusters and
+//       memory segments across barriers, counted waits keep three half-tiles of LDS-DMA in flight (see the loop below)
 template <typename T, typename TO, int WM, int WN, int MT, int NT, bool SIDE = false, bool QUEUE = false, bool PP = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
   static_assert(!PP || (WM * WN == 8 && !QUEUE), "PP: 8 waves, static tile order");
@@ -363,114 +383,143 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
       for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     if constexpr (PP) {
-      // PING-PONG main loop.  In the loop below (the round 1–3 schedule) the two waves of a SIMD run the same program in phase: both
-      // issue their LDS-DMA pieces (≈100 cycles of issue each while the other wave does the same), both read fragments, both queue
-      // MFMAs — a wave's K-step is DMA issue + fragment reads + the MFMA time of BOTH waves (≈800 + 260 + 2 048 cycles; measured
-      // ≈3 200 per K-step, ≈2 400 with the DMA switched off), and the matrix pipe idles while both are in their memory segments.
-      // Here waves 4–7 ("late") lag waves 0–3 ("early") by one K-half: their MFMAs of K-half 1 run at the START of the next K-step,
-      // from fragments held in registers across the barrier, so that at every point one wave of a SIMD is in a matrix segment
-      // (32 MFMAs, ≈512 cycles alone on the pipe) while its partner is in a memory segment (DMA issue + 12 fragment reads):
-      //     early:  [DMA a, R0] [M0] [DMA b, R1] [M1 … wait, barrier … M1]
-      //     late :  [M1(t−1)]  [R0, DMA a + b] [M0] [R1, wait, barrier]
-      // One barrier per K-step as before (slice t + 1 has landed, slice t is no longer read), two K-slice buffers as before.  The
-      // late waves issue all their pieces in their FIRST memory segment: pieces issued in the second one (just before the barrier)
-      // would have no time to land.  MI355X_MICROARCH.md § "Two waves per SIMD" (items 1, 7, 9) is the model this follows.
-      const bool late = a.stagger == 2 ? false : a.stagger == 3 ? true : wave >= NW / 2;   // (2 / 3: every wave early / late — A/B of the schedule itself)
-      u32x4 af[MT], bf[NT];
-      auto mma_rows = [&](int lo, int hi) {
+      // 8-PHASE main loop (round 4; the schedule of cdna_hip_programming.md § "The 256² 8-phase template", rebuilt on this kernel's
+      // LDS image, accumulator layout and epilogues).  A K-step (64 k) is four phases; in each a wave
+      //     reads the fragments of ONE quadrant of its 128 × 64 tile  →  issues 2 LDS-DMA pieces (ONE half-tile per workgroup and
+      //     phase)  →  s_barrier  →  16 MFMAs (the quadrant × both K-halves)  →  s_barrier
+      // and waves 4–7 — the SIMD partners of waves 0–3 — run ONE BARRIER behind, so that on every SIMD one wave is inside its MFMA
+      // cluster while the other reads fragments and issues DMA (16-MFMA granularity, enforced by the barriers: the coarse
+      // half-K-step stagger without them measured no gain, profiles/r04c_gemm_ping_pong.txt).  The DMA stream runs 1¾ K-steps
+      // ahead and is retired by ONE counted wait per K-step (vmcnt(6): three half-tiles stay in flight across the barriers).
+      //   quadrants of a wave (mh: m-tiles 4mh…4mh+3, nh: n-tiles 2nh, 2nh+1):  phase 0 (0,0) · 1 (0,1) · 2 (1,1) · 3 (1,0)
+      //   fragment reads:  phase 0: B-half 0 (4, issued first, retired by lgkmcnt(8) before the barrier) + A-half 0 (8) · 1: B-half 1 (4)
+      //                    · 2: A-half 1 (8) · 3: none (B-half 0 is still in registers)
+      //   half-tiles (128 rows of the A or B image each = the rows ALL waves read for that half):
+      //     phase 0 of K-step k stages A-half 1 of k + 1;  phases 1, 2, 3 stage B-half 0, A-half 0, B-half 1 of k + 2
+      //     (each into a slot whose last fragment reads are at least two phases old, or one phase and retired before the barrier)
+      //   phase 3 of k waits vmcnt(6): everything but the three half-tiles staged in phases 1–3 has landed — all of K-step k + 1,
+      //     which is read from the next phase on (a staged buffer is read one phase AFTER the wait that retires it, never in it)
+      // At the end of a tile the stream continues with the next tile's first K-step (staged during this tile's last two K-steps);
+      // the three half-tiles of its second K-step are staged after the epilogue, whose scratch is the buffer they go to.
+      const bool late = wave >= NW / 2;
+      u32x4 af[4][2], b0f[2][2], b1f[2][2];       // [tile in the half][K-half]
+      // rows a wave stages: piece i (0, 1) of a half-tile, 8 image rows each (see the half-tile definition above)
+      auto a_row = [&](int mh, int i) { return i * 128 + mh * 64 + wave * 8; };
+      auto b_row = [&](int nh, int i) { const int j = wave + i * 8; return (j >> 2) * 64 + nh * 32 + (j & 3) * 8; };
+      // stage half-tile `which` (0 B0, 1 A0, 2 B1, 3 A1) of K-step kk of this tile — or, when kk == nk and the workgroup has another
+      // tile, of that tile's first K-step — into the buffer of parity (cur + kk); returns false when there is nothing to stage
+      auto stage_half = [&](int k, int d, int which) -> bool {
+        const int kk = k + d;                 // K-step of this tile (kk == nk: the next tile's first)
+        const bool nxt = kk >= nk;
+        if (nxt && !(has_next && kk == nk)) return false;
+        const int koff = nxt ? 0 : kk * TKB;
+        const int rows_v = (which & 1) ? (nxt ? min(BM, a.M - nm0) : rows_a) : (nxt ? min(BN, a.N - nn0) : rows_b);
+        const int64_t ld = (which & 1) ? lda_b : ldb_b;
+        const char* base = (which & 1) ? (nxt ? a.A + (int64_t)nm0 * lda_b : Abase) : (nxt ? a.B + (int64_t)nn0 * ldb_b : Bbase);
+        char* img = smem + (cur ^ (d & 1)) * BUF + ((which & 1) ? 0 : A_BYTES);
+        const auto rs = slice_rsrc(base + koff, rows_v, ld, kbytes - koff);
+        const bool full = a.glds && kbytes - koff >= TKB && rows_v > 0;
 #pragma unroll
-        for (int mt = lo; mt < hi; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) acc[nt][mt] = Mma<T>::run(bf[nt], af[mt], acc[nt][mt]);
+        for (int i = 0; i < 2; ++i) {
+          const int row0 = (which & 1) ? a_row(which >> 1, i) : b_row(which >> 1, i);
+          const int row = row0 + (lane >> 3);
+          const int c = (lane & 7) ^ ((row >> 1) & 7);
+          if (full) {      // (global_load_lds: see stage_piece_g)
+            const uint32_t voff = (uint32_t)(min(row, rows_v - 1) * ld + c * 16);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + koff + voff), LDS_PTR(img + row0 * TKB), 16, 0, LAKO_LOAD_AUX);
+          } else {
+            const bool ok = (row < rows_v) && (c * 16 < kbytes - koff);
+            const uint32_t voff = ok ? (uint32_t)(row * ld + c * 16) : 0xFFFFFFF0u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(img + row0 * TKB), 16, (int)voff, 0, 0, LAKO_LOAD_AUX);
+          }
+        }
+        return true;
       };
-      // one K-step of one role; the loop is written out per role so that the accumulators never meet at a control-flow merge inside it
-      auto kstep = [&](int t, auto role) {
-        constexpr int ROLE = decltype(role)::value;      // 0 early, 1 late (first K-step of a tile: no held fragments), 2 late
+      auto mma_quad = [&](int mh, u32x4 (&bq)[2][2], int nh) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc[nh * 2 + nt][mh * 4 + mt] = Mma<T>::run(bq[nt][kh], af[mt][kh], acc[nh * 2 + nt][mh * 4 + mt]);
+        __builtin_amdgcn_s_setprio(0);
+      };
+      auto read_a = [&](const char* As, int mh) {
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) af[mt][kh] = read_frag_rows(As, (wr * MT + mh * 4 + mt) * 16 + r16, kh * 4 + g);
+      };
+      auto read_b = [&](const char* Bs, int nh, u32x4 (&bq)[2][2]) {
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) bq[nt][kh] = read_frag_rows(Bs, (wc * NT + nh * 2 + nt) * 16 + r16, kh * 4 + g);
+      };
+      auto bar = [&]() { __builtin_amdgcn_s_barrier(); };
+      auto fence = [&]() { __builtin_amdgcn_sched_barrier(0); };
+      // the second K-step's first three half-tiles (first tile: behind the prologue; later tiles: behind the epilogue, whose scratch
+      // this buffer was)
+      stage_half(0, 1, 0);
+      stage_half(0, 1, 1);
+      stage_half(0, 1, 2);
+      fence();
+      if (late) bar();                       // waves 4–7 run one barrier behind from here to the end of the tile's K loop
+      for (int k = 0; k < nk; ++k) {
         const char* As = smem + cur * BUF;
         const char* Bs = As + A_BYTES;
-        char* An = smem + (cur ^ 1) * BUF;
-        const bool more_k = t + 1 < nk;
-        const bool pf = more_k || has_next;
-        const int koff = more_k ? (t + 1) * TKB : 0;
-        const int pf_rows_a = more_k ? rows_a : min(BM, a.M - nm0), pf_rows_b = more_k ? rows_b : min(BN, a.N - nn0);
-        const char* pf_a = more_k ? Abase + koff : a.A + (int64_t)nm0 * lda_b;
-        const char* pf_b = more_k ? Bbase + koff : a.B + (int64_t)nn0 * ldb_b;
-        constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;
-        const auto rsrc_a = slice_rsrc(pf_a, pf_rows_a, lda_b, kbytes - koff);
-        const auto rsrc_b = slice_rsrc(pf_b, pf_rows_b, ldb_b, kbytes - koff);
-        auto pieces = [&](int lo, int hi) {
-          if (!pf) return;
-          if constexpr (SIDE) {
-            const uint32_t vb_a = piece_base(lda_b, kbytes - koff, wave, lane), vb_b = piece_base(ldb_b, kbytes - koff, wave, lane);
-#pragma unroll
-            for (int j = lo; j < hi; ++j) {
-              if (j < PA)
-                stage_piece_at<NW>(An, slice_rsrc(pf_a + (int64_t)j * NW * 8 * lda_b, pf_rows_a - j * NW * 8, lda_b, kbytes - koff), vb_a, wave, j);
-              else
-                stage_piece_at<NW>(An + A_BYTES, slice_rsrc(pf_b + (int64_t)(j - PA) * NW * 8 * ldb_b, pf_rows_b - (j - PA) * NW * 8, ldb_b, kbytes - koff),
-                                   vb_b, wave, j - PA);
-            }
-          } else {
-#pragma unroll
-            for (int j = lo; j < hi; ++j) {
-              if (j < PA) stage_piece<NW>(An, rsrc_a, pf_rows_a, lda_b, kbytes - koff, wave, lane, j);
-              else stage_piece<NW>(An + A_BYTES, rsrc_b, pf_rows_b, ldb_b, kbytes - koff, wave, lane, j - PA);
-            }
-          }
-        };
-        auto read_half = [&](int kh) {
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) bf[nt] = read_frag_rows(Bs, (wc * NT + nt) * 16 + r16, kh * 4 + g);
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) af[mt] = read_frag_rows(As, (wr * MT + mt) * 16 + r16, kh * 4 + g);
-        };
-        auto wait_landed = [&]() {
-          if (SIDE && t == 0 && nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // the side pass may land during the next K-step
-          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        };
-        constexpr int E1 = (PA + PB) / 2;      // pieces an early wave issues in its first memory segment
-        if constexpr (ROLE == 0) {
-          pieces(0, E1);
-          read_half(0);
-          __builtin_amdgcn_sched_barrier(0);
-          mma_rows(0, MT);
-          __builtin_amdgcn_sched_barrier(0);
-          pieces(E1, PA + PB);
-          if (SIDE && t == 0) side_issue(0, smem + 2 * BUF + wave * 4096, m0, n0);
-          read_half(1);
-          __builtin_amdgcn_sched_barrier(0);
-          mma_rows(0, MT - MT / 4);
-          __builtin_amdgcn_sched_barrier(0);
-          wait_landed();
-          __syncthreads();
-          __builtin_amdgcn_sched_barrier(0);
-          mma_rows(MT - MT / 4, MT);
-          __builtin_amdgcn_sched_barrier(0);
-        } else {
-          if constexpr (ROLE == 2) mma_rows(0, MT);          // K-half 1 of the previous slice: its fragments were read before the barrier
-          __builtin_amdgcn_sched_barrier(0);
-          read_half(0);
-          pieces(0, PA + PB);
-          if (SIDE && t == 0) side_issue(0, smem + 2 * BUF + wave * 4096, m0, n0);
-          __builtin_amdgcn_sched_barrier(0);
-          mma_rows(0, MT);
-          __builtin_amdgcn_sched_barrier(0);
-          read_half(1);
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the buffer is refilled right after the barrier
-          wait_landed();
-          __syncthreads();
-          __builtin_amdgcn_sched_barrier(0);
-        }
+        // ---- phase 0: quadrant (0, 0) ----
+        read_b(Bs, 0, b0f);
+        fence();
+        read_a(As, 0);
+        fence();
+        stage_half(k, 1, 3);
+        fence();
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");      // the B-half-0 reads are done: its slot is restaged in the next phase
+        bar();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        fence();
+        mma_quad(0, b0f, 0);
+        fence();
+        bar();
+        // ---- phase 1: quadrant (0, 1) ----
+        read_b(Bs, 1, b1f);
+        fence();
+        const bool s1 = stage_half(k, 2, 0);
+        fence();
+        bar();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        fence();
+        mma_quad(0, b1f, 1);
+        fence();
+        bar();
+        // ---- phase 2: quadrant (1, 1) ----
+        read_a(As, 1);
+        fence();
+        stage_half(k, 2, 1);
+        fence();
+        bar();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        fence();
+        mma_quad(1, b1f, 1);
+        fence();
+        bar();
+        // ---- phase 3: quadrant (1, 0) ----
+        stage_half(k, 2, 2);
+        fence();
+        if (s1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // all but the three half-tiles of phases 1–3 have landed
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (SIDE && k == 0) side_issue(0, smem + 2 * BUF + wave * 4096, m0, n0);   // retired by the next K-step's wait (nk >= 2)
+        fence();
+        bar();
+        mma_quad(1, b0f, 0);
+        fence();
+        bar();
         cur ^= 1;
-      };
-      if (!late) {
-        for (int t = 0; t < nk; ++t) kstep(t, std::integral_constant<int, 0>{});
-      } else {
-        kstep(0, std::integral_constant<int, 1>{});
-        for (int t = 1; t < nk; ++t) kstep(t, std::integral_constant<int, 2>{});
-        mma_rows(0, MT);
       }
-      __builtin_amdgcn_sched_barrier(0);
+      if (!late) bar();                      // the two halves of the workgroup are in step again
+      fence();
     } else
     for (int t = 0; t < nk; ++t) {
       const char* As = smem + cur * BUF;
@@ -519,8 +568,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
             stage_piece_at<NW>(An + A_BYTES, slice_rsrc(pf_b + (int64_t)(j - PA) * NW * 8 * ldb_b, pf_rows_b - (j - PA) * NW * 8, ldb_b, kbytes - koff),
                                vb_b, wave, j - PA);
         } else {
-          if (j < PA) stage_piece<NW>(An, rsrc_a, pf_rows_a, lda_b, kbytes - koff, wave, lane, j);
-          else if (j < PA + PB) stage_piece<NW>(An + A_BYTES, rsrc_b, pf_rows_b, ldb_b, kbytes - koff, wave, lane, j - PA);
+          const bool full = a.glds && kbytes - koff >= TKB && pf_rows_a > 0 && pf_rows_b > 0;
+          if (j < PA) stage_piece_g<NW>(An, pf_a, rsrc_a, pf_rows_a, lda_b, kbytes - koff, wave, lane, j, full);
+          else if (j < PA + PB) stage_piece_g<NW>(An + A_BYTES, pf_b, rsrc_b, pf_rows_b, ldb_b, kbytes - koff, wave, lane, j - PA, full);
         }
       };
       auto prefetch = [&]() {
@@ -988,6 +1038,7 @@ struct TnArgs {
   float alpha;
   int tiles_m, tiles_n, split_k, k_chunk;  // k_chunk: rows of K per split (multiple of 64)
   int no_atomics;   // timing experiment (gemm_tn_big = 2): skip the accumulation
+  int glds;         // 1: whole K-steps staged by global_load_lds (tuning nt_glds)
   // grouped launch (gemm_tn256_kernel): n_items > 0 → tile id t belongs to the last item with tile_start <= t
   int n_items;
   struct Item {
@@ -1151,21 +1202,35 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs a) {
 // ---------------------------------------------------------------------------------------------
 constexpr int TN2_ROWB = 512, TN2_IMG = 64 * TN2_ROWB;  // 64 k-rows × 256 columns of bf16 = 32 KiB
 
+// GLDS: every k-row of the step exists (the host picks this instantiation only when K % 64 == 0 and every split is a multiple of 64):
+// global_load_lds, no descriptor (see lds_dma16_g) — k-rows past the end of K would have to read as zeros, which only the buffer form's
+// range check provides.  Columns past the edge are clamped to the last valid 16 bytes (they feed outputs that are never added).
+template <bool GLDS>
 __device__ __forceinline__ void stage_cols256(char* img, const char* base, int krows_valid, int64_t ld_bytes,
                                               int colbytes_valid, int wave, int lane) {
-  uint32_t nrec = (krows_valid > 0 && colbytes_valid > 0)
-                      ? (uint32_t)((int64_t)(krows_valid - 1) * ld_bytes + min(colbytes_valid, TN2_ROWB))
-                      : 0u;
-  const auto rsrc = lds_dma_rsrc(base, nrec);
+  if constexpr (GLDS) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int inst = wave + i * 8;            // 32 wave-instructions of 2 rows each
-    const int row = inst * 2 + (lane >> 5);
-    const int cp = lane & 31;
-    const int cb = (cp ^ (tn_key(row) << 1)) * 16;
-    const bool ok = (row < krows_valid) && (cb < colbytes_valid);
-    const uint32_t voff = ok ? (uint32_t)(row * ld_bytes + cb) : 0xFFFFFFF0u;
-    lds_dma16(img + inst * 1024, rsrc, voff);
+    for (int i = 0; i < 4; ++i) {
+      const int inst = wave + i * 8;
+      const int row = inst * 2 + (lane >> 5);
+      const int cb = min(((lane & 31) ^ (tn_key(row) << 1)) * 16, colbytes_valid - 16);
+      lds_dma16_g(img + inst * 1024, base, (uint32_t)(row * ld_bytes + cb));
+    }
+  } else {
+    uint32_t nrec = (krows_valid > 0 && colbytes_valid > 0)
+                        ? (uint32_t)((int64_t)(krows_valid - 1) * ld_bytes + min(colbytes_valid, TN2_ROWB))
+                        : 0u;
+    const auto rsrc = lds_dma_rsrc(base, nrec);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int inst = wave + i * 8;            // 32 wave-instructions of 2 rows each
+      const int row = inst * 2 + (lane >> 5);
+      const int cp = lane & 31;
+      const int cb = (cp ^ (tn_key(row) << 1)) * 16;
+      const bool ok = (row < krows_valid) && (cb < colbytes_valid);
+      const uint32_t voff = ok ? (uint32_t)(row * ld_bytes + cb) : 0xFFFFFFF0u;
+      lds_dma16(img + inst * 1024, rsrc, voff);
+    }
   }
 }
 
@@ -1185,6 +1250,7 @@ __device__ __forceinline__ u32x4 read_frag_tr256(const char* img, int kk, int c0
   return out;
 }
 
+template <bool GLDS>
 __global__ __launch_bounds__(512) void gemm_tn256_kernel(TnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -1226,8 +1292,8 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(TnArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  stage_cols256(smem, Abase, krows, lda_b, acols_b, wave, lane);
-  stage_cols256(smem + TN2_IMG, Bbase, krows, ldb_b, bcols_b, wave, lane);
+  stage_cols256<GLDS>(smem, Abase, krows, lda_b, acols_b, wave, lane);
+  stage_cols256<GLDS>(smem + TN2_IMG, Bbase, krows, ldb_b, bcols_b, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -1239,8 +1305,8 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(TnArgs a) {
       if (t + 1 < nk) {
         char* An = smem + (cur ^ 1) * 2 * TN2_IMG;
         const int kr = (t + 1) * 64;
-        stage_cols256(An, Abase + (int64_t)kr * lda_b, krows - kr, lda_b, acols_b, wave, lane);
-        stage_cols256(An + TN2_IMG, Bbase + (int64_t)kr * ldb_b, krows - kr, ldb_b, bcols_b, wave, lane);
+        stage_cols256<GLDS>(An, Abase + (int64_t)kr * lda_b, krows - kr, lda_b, acols_b, wave, lane);
+        stage_cols256<GLDS>(An + TN2_IMG, Bbase + (int64_t)kr * ldb_b, krows - kr, ldb_b, bcols_b, wave, lane);
       }
     };
     // K-step schedule as in gemm_nt_kernel: fragment reads of a K-half back to back (sched_barrier: the machine
@@ -1588,6 +1654,7 @@ const TuneKey TUNE_KEYS[] = {
     {"gemm_tn_split", &lako_tuning_t::tn_split, false},           {"gemm_nt_debug", &lako_tuning_t::nt_debug, true},
     {"gemm_nt_store_aux", &lako_tuning_t::nt_store_aux, true},    {"gemm_nt_tile192", &lako_tuning_t::nt_tile192, false},
     {"gemm_nt_queue", &lako_tuning_t::nt_queue, false},           {"gemm_nt_pp", &lako_tuning_t::nt_pp, false},
+    {"gemm_nt_glds", &lako_tuning_t::nt_glds, false},
 };
 
 void tuning_defaults(lako_tuning_t* t) {
@@ -1605,7 +1672,8 @@ void tuning_defaults(lako_tuning_t* t) {
   t->nt_dephase_n = 2;     // phases
   t->tn_big = 1;
   t->tn_split = 0;         // > 0: force the number of K-splits of the 256x256 TN kernel (A/B measurements)
-  t->nt_pp = 0;            // main-loop schedule of the 256² / 8-wave kernel: 0 in phase (default), 1 ping-pong, 2 / 3 all early / late, 4 = 2 from K = 2048 up (round 4: measured no gain on the step)
+  t->nt_glds = 1;          // K-slice staging of the 256² kernels by global_load_lds (0: buffer_load … lds everywhere)
+  t->nt_pp = 0;            // 1: the 8-phase main loop of the 256² / 8-wave bf16 kernel (measured slower, A/B only); 0: the two-phase loop
   t->nt_tile192 = 0;       // 1: 192-row tiles where the round count favours them (launch_nt) — measured no faster, off
 }
 
@@ -1683,10 +1751,8 @@ static int* nt_queue_counters(hipStream_t stream) {
   return p;
 }
 
-// which main-loop schedule the 256² / 8-wave kernel runs: 0 the in-phase loop of rounds 1–3, 1 ping-pong, 2 / 3 every wave in the early / late
-// role; tuning value 4 = by shape (measured, tools/gemm_pp_probe.py: the early role on every wave is 3–6 % faster from K = 2304 up and
-// 10 % slower on the K = 768 QKV projection)
-inline int nt_pp_mode(const lako_tuning_t& tu, const NtArgs& a) { return tu.nt_pp == 4 ? (a.K >= 2048 ? 2 : 0) : tu.nt_pp; }
+// the 8-phase main loop of the 256² / 8-wave kernel (tuning nt_pp) needs two K-steps per tile
+inline int nt_pp_mode(const lako_tuning_t& tu, const NtArgs& a) { return tu.nt_pp && a.K >= 128 ? 1 : 0; }
 
 template <typename T, typename TO, int WM, int WN, int MT, int NT, bool SIDE = false, bool QUEUE = false, bool PP = false>
 void launch_nt_cfg(NtArgs a, const lako_tuning_t& tu, hipStream_t s) {
@@ -1694,15 +1760,11 @@ void launch_nt_cfg(NtArgs a, const lako_tuning_t& tu, hipStream_t s) {
   // + the epilogue scratch of the waves that do not fit the free K-slice buffer (8 KiB each; 192-row tiles: one wave)
   constexpr int EXTRA = (sizeof(T) == 2 && NW_ == 8 && BUF_ / 8192 < NW_) ? (NW_ - BUF_ / 8192) * 8192 : 0;
   constexpr int LDS = 2 * BUF_ + (SIDE ? 32 * 1024 : 0) + EXTRA;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, TO, WM, WN, MT, NT, SIDE, QUEUE, PP>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_done = true;
-  }
+  LAKO_SET_MAX_LDS((&gemm_nt_kernel<T, TO, WM, WN, MT, NT, SIDE, QUEUE, PP>), LDS);
   a.tiles_m = cdiv(a.M, BM);
   a.tiles_n = cdiv(a.N, BN);
-  a.stagger = PP ? nt_pp_mode(tu, a) : tu.nt_stagger;
+  a.stagger = tu.nt_stagger;
+  a.glds = tu.nt_glds && (int64_t)256 * std::max(a.lda, a.ldb) * (int64_t)sizeof(T) < (1ll << 31);   // 32-bit row offsets inside a tile
   a.store_aux = (int64_t)256 * a.ldc * 2 < (1ll << 31) ? tu.nt_store_aux : 0;   // tile-relative 32-bit store offsets
   a.debug = tu.nt_debug;
   // narrow outputs (≤ 7 tile columns) already give an XCD a compact block; a negative knob forces |value| on every shape (tests).
@@ -1838,13 +1900,9 @@ int launch_nt(const NtArgs& a_in, const lako_tuning_t& tu, hipStream_t s) {
                       reinterpret_cast<uintptr_t>(a.A) % 16 == 0 && reinterpret_cast<uintptr_t>(a.B) % 16 == 0 &&
                       reinterpret_cast<uintptr_t>(a.C) % 16 == 0;
     if (fits && (v == 5 || (tu.nt_variant < 0 && tu.nt_skinny && a.M <= 256 && a.N <= 4096))) {
-      static bool attr_done = false;
-      if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_skinny_kernel<TO, 8, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_skinny_kernel<TO, 8, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_skinny_kernel<TO, 8, 16, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384);
-        attr_done = true;
-      }
+      LAKO_SET_MAX_LDS((&gemm_nt_skinny_kernel<TO, 8, 4, 4>), 8 * 16384);
+LAKO_SET_MAX_LDS((&gemm_nt_skinny_kernel<TO, 8, 8, 4>), 8 * 16384);
+LAKO_SET_MAX_LDS((&gemm_nt_skinny_kernel<TO, 8, 16, 4>), 8 * 16384);
       // a CU pulls ≈45 GB/s through its L1 whatever the other CUs do, so the bytes have to be spread over many CUs: 32² tiles
       // (4 × the workgroups of 64² tiles, half the operand bytes each) — measured on the whole training step: 64² 50.4 ms,
       // 32² 49.4 ms, 16² 49.3 ms ("gemm_nt_skinny" 2 / 3 / 4 force them)
@@ -1872,12 +1930,7 @@ int launch_nt(const NtArgs& a_in, const lako_tuning_t& tu, hipStream_t s) {
   }
   if (v == 4 || (tu.nt_variant < 0 && tu.nt_ring && (int64_t)cdiv(a.M, RING_BM) * cdiv(a.N, RING_BM) <= 256)) {
     // skinny: at most one 128² tile per CU → the 4-slot ring hides the global→LDS latency inside the workgroup
-    static bool attr_done = false;
-    if (!attr_done) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_ring_kernel<T, TO>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, RING_NST * RING_STAGE);
-      attr_done = true;
-    }
+    LAKO_SET_MAX_LDS((&gemm_nt_ring_kernel<T, TO>), RING_NST * RING_STAGE);
     NtArgs b = a;
     b.tiles_m = cdiv(a.M, RING_BM);
     b.tiles_n = cdiv(a.N, RING_BM);
@@ -1905,12 +1958,7 @@ int launch_nt(const NtArgs& a_in, const lako_tuning_t& tu, hipStream_t s) {
 
 template <typename T>
 int launch_tn(const TnArgs& a, hipStream_t s) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<T>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-    attr_done = true;
-  }
+  LAKO_SET_MAX_LDS((&gemm_tn_kernel<T>), GEMM_LDS);
   hipLaunchKernelGGL((gemm_tn_kernel<T>), dim3(a.tiles_m * a.tiles_n * a.split_k), dim3(256), GEMM_LDS, s, a);
   return 0;
 }
@@ -2038,15 +2086,17 @@ extern "C" int lako_gemm_tn(const void* A, const void* B, float* C, int64_t M, i
     a.split_k = cdiv(K, chunk);
     a.k_chunk = chunk;
     a.no_atomics = tu.tn_big == 2;
+  a.glds = tu.nt_glds;
+    a.glds = tu.nt_glds;
     LAKO_CHECK_ARG((int64_t)64 * lda * 2 < (1ll << 31) && (int64_t)64 * ldb * 2 < (1ll << 31),
                    "lako_gemm_tn: leading dimension too large");
-    static bool attr_done = false;
-    if (!attr_done) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn256_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TN2_IMG);
-      attr_done = true;
+    if (a.glds && K % 64 == 0) {
+      LAKO_SET_MAX_LDS((&gemm_tn256_kernel<true>), 4 * TN2_IMG);
+      hipLaunchKernelGGL(gemm_tn256_kernel<true>, dim3(tiles * a.split_k), dim3(512), 4 * TN2_IMG, s, a);
+    } else {
+      LAKO_SET_MAX_LDS((&gemm_tn256_kernel<false>), 4 * TN2_IMG);
+      hipLaunchKernelGGL(gemm_tn256_kernel<false>, dim3(tiles * a.split_k), dim3(512), 4 * TN2_IMG, s, a);
     }
-    hipLaunchKernelGGL(gemm_tn256_kernel, dim3(tiles * a.split_k), dim3(512), 4 * TN2_IMG, s, a);
     LAKO_LAUNCH_CHECK();
     return LAKO_OK;
   }
@@ -2090,6 +2140,7 @@ extern "C" int lako_gemm_tn_grouped(const lako_gemm_tn_item_t* items, int n_item
   a.n_items = n_items;
   a.K = (int)K;
   a.no_atomics = tu.tn_big == 2;
+  a.glds = tu.nt_glds;
   int tiles = 0;
   for (int i = 0; i < n_items; ++i) {
     const lako_gemm_tn_item_t& p = items[i];
@@ -2119,13 +2170,13 @@ extern "C" int lako_gemm_tn_grouped(const lako_gemm_tn_item_t* items, int n_item
   const int chunk = cdiv(cdiv(K, sk), 64) * 64;
   a.split_k = cdiv(K, chunk);
   a.k_chunk = chunk;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              4 * TN2_IMG);
-    attr_done = true;
+  if (a.glds && K % 64 == 0) {
+    LAKO_SET_MAX_LDS((&gemm_tn256_kernel<true>), 4 * TN2_IMG);
+    hipLaunchKernelGGL(gemm_tn256_kernel<true>, dim3(tiles * a.split_k), dim3(512), 4 * TN2_IMG, (hipStream_t)stream, a);
+  } else {
+    LAKO_SET_MAX_LDS((&gemm_tn256_kernel<false>), 4 * TN2_IMG);
+    hipLaunchKernelGGL(gemm_tn256_kernel<false>, dim3(tiles * a.split_k), dim3(512), 4 * TN2_IMG, (hipStream_t)stream, a);
   }
-  hipLaunchKernelGGL(gemm_tn256_kernel, dim3(tiles * a.split_k), dim3(512), 4 * TN2_IMG, (hipStream_t)stream, a);
   LAKO_LAUNCH_CHECK();
   return LAKO_OK;
 }
@@ -2194,11 +2245,7 @@ extern "C" int lako_gemm_nt_mx(const lako_gemm_nt_t* p, const uint8_t* a_scales,
   if (grid > 256) grid = 256;
   a.dephase = (tu.nt_dephase > 0 && a.tiles_m * a.tiles_n > grid) ? ((tu.nt_dephase_n << 16) | (tu.nt_dephase & 0xffff)) : 0;
   constexpr int LDS = 2 * (256 + 256) * TKB;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_mx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_done = true;
-  }
+  LAKO_SET_MAX_LDS((&gemm_nt_mx_kernel), LDS);
   hipLaunchKernelGGL(gemm_nt_mx_kernel, dim3(grid), dim3(512), LDS, (hipStream_t)stream, m);
   LAKO_LAUNCH_CHECK();
   return LAKO_OK;

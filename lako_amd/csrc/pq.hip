@@ -134,22 +134,14 @@ __global__ __launch_bounds__(PQ_SCAN_THREADS) void pq_scan_kernel(const float* _
 template <int DS>
 void launch_assign(const float* x, int64_t n, int64_t ldx, const float* cent, int M, int ksub, uint8_t* codes, float* sums,
                    int32_t* counts, float* err, hipStream_t s) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pq_assign_kernel<DS>), hipFuncAttributeMaxDynamicSharedMemorySize, 256 * DS * 4);
-    attr_done = true;
-  }
+  LAKO_SET_MAX_LDS((&pq_assign_kernel<DS>), 256 * DS * 4);
   hipLaunchKernelGGL((pq_assign_kernel<DS>), dim3((unsigned)((n + 255) / 256), (unsigned)M), dim3(256), (size_t)ksub * DS * 4, s, x, n, ldx,
                      cent, M, ksub, codes, sums, counts, err);
 }
 
 template <int QT>
 void launch_scan(const float* lut, const uint8_t* codes, int64_t n, int64_t nq, int M, int ksub, float* scores, int64_t ld, hipStream_t s) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pq_scan_kernel<QT>), hipFuncAttributeMaxDynamicSharedMemorySize, PQ_LDS_BYTES);
-    attr_done = true;
-  }
+  LAKO_SET_MAX_LDS((&pq_scan_kernel<QT>), PQ_LDS_BYTES);
   // ≥ 4 blocks per CU along the stored vectors when there are few query groups, whole multiples of 256 vectors per block
   const int64_t qgroups = (nq + QT - 1) / QT;
   int64_t blocks = (n + 255) / 256;

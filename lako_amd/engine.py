@@ -143,6 +143,8 @@ class _XPlan:
     p_h: list = None
     ptot: int = 0
     splits: int = 1         # workgroups sharing the keys of a sample in xattn_context
+    p0: int = 0             # first score column of this plan inside the batch's [·, cap] matrices (a chain of samples: its window)
+    sub: dict = None        # {n chains: [per-chain _XPlan]} (column offsets relative to the chain's window)
 
 
 @dataclass
@@ -161,6 +163,7 @@ class _Ctx:
     ckpt: bool = False
     rag: object = None      # _Ragged: the encoder ran on the valid tokens only
     xa: object = None       # _XPlan: cross-attention ran in the encoder-state space
+    chains: list = None     # the decoder's sample chains (_dec_chains)
     enc_ids: torch.Tensor = None   # the encoder's token ids: all [B·N·L], or the valid ones when rag is set
     ws: dict = field(default_factory=dict)
 
@@ -531,6 +534,27 @@ class Engine:
         self._xplan_cache[key] = plan
         return plan
 
+    def _xattn_subplans(self, xa, n, B):
+        """The plan cut into n chains of samples: chain c owns the score columns [p_h[b0], p_h[b1]) — its kernels get views of that
+        window and column offsets relative to it (the kernels launch one workgroup per 256 columns from column 0 of what they are
+        given) — and the absolute key offsets of its samples.  Cached with the plan."""
+        if xa.sub is None:
+            xa.sub = {}
+        if n not in xa.sub:
+            bounds = [(c * B // n, (c + 1) * B // n) for c in range(n)]
+            rel = [[p - xa.p_h[b0] for p in xa.p_h[b0:b1 + 1]] for b0, b1 in bounds]
+            host = torch.tensor([v for r in rel for v in r], dtype=torch.int32)
+            if self.device.type == "cuda":
+                host = host.pin_memory()
+            dev = host.to(self.device, non_blocking=True)
+            plans, at = [], 0
+            for (b0, b1), r in zip(bounds, rel):
+                plans.append(_XPlan(k_off=xa.k_off[b0:b1 + 1], p_off=dev[at:at + len(r)], k_h=xa.k_h[b0:b1 + 1], p_h=r, ptot=r[-1],
+                                    splits=xa.splits, p0=xa.p_h[b0]))
+                at += len(r)
+            xa.sub[n] = plans
+        return xa.sub[n]
+
     def _xw(self, i, which, transposed=False):
         """Per-head views of decoder layer i's cross-attention K ("k") or V ("v") projection inside the kv_all block:
         [H, dk, d] of the weight, or (transposed) [H, d, dk] of its transposed shadow — the B operands of headbatch_nt."""
@@ -566,14 +590,14 @@ class Engine:
         ops, H, dk, R = self.ops, self.cfg.num_heads, self.cfg.d_kv, xb["R"]
         qp = xb["dq"][:, (2 * i + 1) * R:(2 * i + 2) * R]
         ops.headbatch_nt(qc.view(B, T, H, dk), self._xw(i, "k", transposed=True), qp.unflatten(1, (T, H)))
-        s = xb["s"][i][:, :xa.ptot]
+        s = xb["s"][i][:, xa.p0:xa.p0 + xa.ptot]
         ops.xattn_scores(qp, enc_out, xa.k_off, xa.p_off, xa.ptot, s)
-        pr = xb["ps"][2 * i * R:(2 * i + 1) * R, :xa.ptot]
+        pr = xb["ps"][2 * i * R:(2 * i + 1) * R, xa.p0:xa.p0 + xa.ptot]
         ops.xattn_softmax_fwd(s, xb["st"][i], pr, xa.k_off, xa.p_off, T, H, max_keys, drop)
         ops.xattn_context(pr, enc_out, xa.k_off, xa.p_off, xb["c"][i])
         ops.headbatch_nt(xb["c"][i].unflatten(2, (T, H)), self._xw(i, "v"), c2.view(B, T, H, dk))
 
-    def _xattn_bwd(self, xb, xa, tmp, i, qc, enc_out, dctx, dqc, B, T, max_keys, drop):
+    def _xattn_bwd(self, xb, xa, tmp, i, qc, enc_out, dctx, dqc, B, T, max_keys, drop, b0=0, B_all=None):
         """Backward of _xattn_fwd: dctx [B·T, inner] → dqc [B·T, inner], the layer's Wk / Wv gradients, and the rows (dC', dS) the
         encoder-state gradient is assembled from after the last layer (_xattn_denc)."""
         ops, H, dk, R, d = self.ops, self.cfg.num_heads, self.cfg.d_kv, xb["R"], self.cfg.d_model
@@ -581,11 +605,11 @@ class Engine:
         d4 = dctx.view(B, T, H, dk)
         ops.headbatch_nt(d4, self._xw(i, "v", transposed=True), dcp.unflatten(1, (T, H)))
         ops.headbatch_tn(d4, xb["c"][i].unflatten(2, (T, H)), self._xg(i, "v"))
-        dp = self._buf(tmp, "x.dp", (R, xb["cap"]), torch.float32)[:, :xa.ptot]
+        dp = self._buf(tmp, "x.dp", (R, xb["cap"]), torch.float32)[:, xa.p0:xa.p0 + xa.ptot]
         ops.xattn_scores(dcp, enc_out, xa.k_off, xa.p_off, xa.ptot, dp)
-        ds = xb["ps"][(2 * i + 1) * R:(2 * i + 2) * R, :xa.ptot]
-        ops.xattn_softmax_bwd(xb["s"][i][:, :xa.ptot], dp, xb["st"][i], ds, xa.k_off, xa.p_off, T, H, max_keys, drop)
-        dqp = self._buf(tmp, "x.dqp", (xa.splits, B, R, d), torch.float32)
+        ds = xb["ps"][(2 * i + 1) * R:(2 * i + 2) * R, xa.p0:xa.p0 + xa.ptot]
+        ops.xattn_softmax_bwd(xb["s"][i][:, xa.p0:xa.p0 + xa.ptot], dp, xb["st"][i], ds, xa.k_off, xa.p_off, T, H, max_keys, drop)
+        dqp = self._buf(tmp, "x.dqp", (xa.splits, B_all or B, R, d), torch.float32)[:, b0:b0 + B]      # (a chain: its samples' slabs)
         ops.xattn_context(ds, enc_out, xa.k_off, xa.p_off, dqp)
         ops.headbatch_nt(dqp.unflatten(2, (T, H)), self._xw(i, "k"), dqc.view(B, T, H, dk))
         ops.headbatch_tn(qc.view(B, T, H, dk), dqp.unflatten(2, (T, H)), self._xg(i, "k"))
@@ -605,6 +629,206 @@ class Engine:
             dxe.copy_(de[:Me])
         else:
             ops.cast(de[:Me].view(-1), dxe.view(-1))
+
+    # ------------------------------------------------------------------------------------------
+    # the decoder as independent chains of samples
+    # ------------------------------------------------------------------------------------------
+    def _dec_chains(self, B, T, p, seed, xa, xb, rag, kb, kt, ckw):
+        """The decoder of a training step is ≈400 launches on B·T ≈ 128 rows: each kernel is a few µs of launch ramp, dependent
+        round trips and drain, and on one stream they run strictly one after the other.  Nothing in the decoder couples two samples
+        (self- and cross-attention are per sample, everything else per row), so the batch can be cut into `LAKO_DEC_CHAINS` runs of
+        samples whose layer-by-layer chains are enqueued on separate HIP streams; the weight gradients — the one place where the samples
+        meet — are summed over ALL rows in grouped launches after the last layer.  MEASURED NEGATIVE (round 4, profiles/r04e_decoder_chains.txt):
+        1 chain 40.95 ms per step, 2 chains 42.0, 4 chains 47.8 — kernels of two queues do overlap (each takes 1.5 × as long) but the
+        pair is no faster than the two in sequence, and every extra launch costs its boundary.  Default 1 = the single-stream schedule;
+        the split stays selectable and tested (results: forward values unchanged bit for bit — row-wise kernels; each chain draws its
+        dropout masks from its own seed)."""
+        n = max(1, min(int(os.environ.get("LAKO_DEC_CHAINS", "1")), B // 2)) if B >= 4 else 1
+        chains = []
+        for c in range(n):
+            b0, b1 = c * B // n, (c + 1) * B // n
+            seed_c = (seed ^ (0x9E3779B9 * c)) & 0xFFFFFFFF
+            ch = dict(c=c, b0=b0, b1=b1, B=b1 - b0, r0=b0 * T, r1=b1 * T, xa=None, xb=None, kv_b=kb, kv_t=kt, kv_r=None, ckw=ckw,
+                      dr=(lambda site, sd=seed_c: (p, sd, site)) if p > 0 else (lambda site: None))
+            if xa is not None:
+                ch["xa"] = self._xattn_subplans(xa, n, B)[c] if n > 1 else xa
+                ch["xb"] = dict(xb, dq=xb["dq"][b0:b1], st=xb["st"][:, b0:b1], c=xb["c"][:, :, b0:b1]) if n > 1 else xb
+            elif n > 1:
+                if rag is None:        # padded keys: the chain's samples are rows [b0·S, b1·S) of the projected K / V
+                    ch.update(kv_b=b1 - b0, kv_r=(b0 * kt, b1 * kt), ckw=dict(key_mask=ckw["key_mask"][b0:b1]))
+                else:                  # packed keys: the whole buffer, the chain's sample offsets
+                    ch["ckw"] = dict(k_off=ckw["k_off"][b0:b1 + 1], max_k=ckw["max_k"])
+            chains.append(ch)
+        return chains
+
+    def _run_chains(self, chains, n_layers, layer_fn, reverse=False):
+        """layer_fn(i, chain) for every layer and chain — on one stream when there is one chain (or no GPU: the CPU test double), else
+        chain c on its own side stream: forked from the current stream before the first layer, joined after the last."""
+        order = range(n_layers - 1, -1, -1) if reverse else range(n_layers)
+        if len(chains) == 1 or self.device.type != "cuda":
+            for i in order:
+                for ch in chains:
+                    layer_fn(i, ch)
+            return
+        if getattr(self, "_chain_streams", None) is None or len(self._chain_streams) < len(chains):
+            self._chain_streams = [torch.cuda.Stream(self.device) for _ in chains]
+            self._chain_events = [torch.cuda.Event() for _ in range(len(chains) + 1)]
+        main = torch.cuda.current_stream(self.device)
+        fork = self._chain_events[-1]
+        fork.record(main)
+        for st in self._chain_streams[:len(chains)]:
+            st.wait_event(fork)
+        for i in order:
+            for ch in chains:
+                with torch.cuda.stream(self._chain_streams[ch["c"]]):
+                    layer_fn(i, ch)
+        for ch in chains:
+            ev = self._chain_events[ch["c"]]
+            ev.record(self._chain_streams[ch["c"]])
+            main.wait_event(ev)
+
+    def _rows(self, ws, name, ch, shape, dtype=None):
+        """rows [r0, r1) of the [B·T, …] workspace tensor `name` (allocated at full size)"""
+        return self._buf(ws, name, shape, dtype)[ch["r0"]:ch["r1"]]
+
+    def _cross_kv(self, kv, ch, col0):
+        """[kb, kt, H, dk] head view of the projected cross-attention K or V (columns col0 …) for the chain's samples"""
+        if ch["kv_r"] is not None:
+            kv = kv[ch["kv_r"][0]:ch["kv_r"][1]]
+        return self._heads(kv, ch["kv_b"], ch["kv_t"] if ch["kv_r"] is None else kv.shape[0] // ch["kv_b"], col0)
+
+    def _dec_layer_fwd(self, ws, i, ch, enc_out, kv, rel, T, S):
+        """One decoder block (HF5:448-509) on the rows of one chain: RMSNorm → QKV → causal self-attention → O + residual → RMSNorm →
+        cross-attention query → cross-attention → O + residual → RMSNorm → FFN + residual."""
+        cfg, ops, lw, dr = self.cfg, self.ops, self.dec[i], ch["dr"]
+        d, f, inner, H, eps = cfg.d_model, cfg.d_ff, cfg.inner_dim, cfg.num_heads, cfg.layer_norm_epsilon
+        Bc, Ld = ch["B"], cfg.num_decoder_layers
+        Md = ws[f"d.h{i}"].shape[0]
+        R = lambda name, cols, dt=None: self._rows(ws, name, ch, (Md, cols) if cols else (Md,), dt)       # noqa: E731
+        h = ws[f"d.h{i}"][ch["r0"]:ch["r1"]]
+        if i == 0:
+            ops.embed_fwd(ws["d.ids"].view(-1)[ch["r0"]:ch["r1"]], self.shared.w, h, dr(S_DEC_EMBED))
+        xn1 = R(f"d.xn1.{i}", d)
+        ops.rmsnorm_fwd(h, lw["ln1"].p, xn1, R(f"d.rs1.{i}", 0, torch.float32), eps)
+        qkv = R(f"d.qkv.{i}", 3 * inner)
+        ops.gemm_nt(xn1, lw["qkv"].w, qkv)
+        c1 = R(f"d.ctx.{i}", inner)
+        st = self._buf(ws, f"d.st.{i}", (Md // T, H, T, 4), torch.float32)[ch["b0"]:ch["b1"]]
+        ops.attn_fwd(self._heads(qkv, Bc, T, 0), self._heads(qkv, Bc, T, inner), self._heads(qkv, Bc, T, 2 * inner),
+                     self._heads(c1, Bc, T, 0), st, rel_bias=rel, rel_off=T - 1, causal=True, drop=dr(_dec_site(i, 0)))
+        h1 = R(f"d.h1.{i}", d)
+        ops.gemm_nt(c1, lw["o"].w, h1, resid=h, drop=dr(_dec_site(i, 1)))
+        xn2 = R(f"d.xn2.{i}", d)
+        ops.rmsnorm_fwd(h1, lw["ln2"].p, xn2, R(f"d.rs2.{i}", 0, torch.float32), eps)
+        qc = R(f"d.qc.{i}", inner)
+        ops.gemm_nt(xn2, lw["cq"].w, qc)
+        c2 = R(f"d.cctx.{i}", inner)
+        if ch["xa"] is not None:
+            self._xattn_fwd(ch["xb"], ch["xa"], i, qc, enc_out, c2, Bc, T, S, dr(_dec_site(i, 2)))
+        else:
+            cst = self._buf(ws, f"d.cst.{i}", (Md // T, H, T, 4), torch.float32)[ch["b0"]:ch["b1"]]
+            ops.attn_fwd(self._heads(qc, Bc, T, 0), self._cross_kv(kv, ch, 2 * i * inner), self._cross_kv(kv, ch, (2 * i + 1) * inner),
+                         self._heads(c2, Bc, T, 0), cst, drop=dr(_dec_site(i, 2)), **ch["ckw"])
+        h2 = R(f"d.h2.{i}", d)
+        ops.gemm_nt(c2, lw["co"].w, h2, resid=h1, drop=dr(_dec_site(i, 3)))
+        xn3 = R(f"d.xn3.{i}", d)
+        ops.rmsnorm_fwd(h2, lw["ln3"].p, xn3, R(f"d.rs3.{i}", 0, torch.float32), eps)
+        a1 = R(f"d.a1.{i}", f)
+        ops.gemm_nt(xn3, lw["wi"].w, a1, relu=True, drop=dr(_dec_site(i, 4)))
+        h_out = ws[f"d.h{i + 1}"][ch["r0"]:ch["r1"]]
+        ops.gemm_nt(a1, lw["wo"].w, h_out, resid=h2, drop=dr(_dec_site(i, 5)))
+        if i == Ld - 1:
+            ops.rmsnorm_fwd(h_out, self.dec_final.p, ws["d.out"][ch["r0"]:ch["r1"]], ws["d.rsf"][ch["r0"]:ch["r1"]], eps, dr(S_DEC_FINAL))
+
+    def _dec_layer_bwd(self, ws, tmp, i, ch, dh_all, drel, kv, dkv, fused, T, S, dw_all):
+        """Backward of _dec_layer_fwd on the rows of one chain; dh_all [B·T, d] holds the gradient wrt the block's output on entry and
+        wrt its input on exit.  With dropout on, the six weight-gradient problems of the block are NOT launched here: their operands
+        (the dropped residual-branch gradients, dpre, dqc, dqkv) live in per-layer scratch, and the chain that handles the batch's last
+        rows appends the FULL-batch problems to `dw_all` — one grouped launch over all rows and layers after the chains have joined."""
+        cfg, ops, lw, dr = self.cfg, self.ops, self.dec[i], ch["dr"]
+        d, f, inner, H = cfg.d_model, cfg.d_ff, cfg.inner_dim, cfg.num_heads
+        Bc, r0, r1 = ch["B"], ch["r0"], ch["r1"]
+        Md, p, Ld = dh_all.shape[0], (0.0 if dr(0) is None else dr(0)[0]), cfg.num_decoder_layers
+        sl = lambda t: t[r0:r1]                                                                   # noqa: E731
+        R = lambda name, cols: self._rows(tmp, name, ch, (Md, cols))                              # noqa: E731
+        dh = sl(dh_all)
+        defer = p > 0 and os.environ.get("LAKO_DEC_DEFER_DW", "1") != "0"      # 0: launch them inside the chain, on its rows (A/B)
+        last = r1 == Md          # (this chain's call is the one that registers the full-batch weight-gradient problems)
+        if i == Ld - 1:          # final norm of the decoder: dout (gradient wrt the normed, dropped output) → dh
+            ops.rmsnorm_bwd(sl(tmp["d.dxn"]), sl(ws[f"d.h{Ld}"]), self.dec_final.p, sl(ws["d.rsf"]), None, dh, self.dec_final.g, dr(S_DEC_FINAL),
+                            **self._nxt((R(f"d.dy.ffn.{i}", d), dr(_dec_site(i, 5))) if fused else None))
+
+        def wgrad(name, dy_name, dy_c, x_all, g):
+            """dW += dyᵀ·x: deferred to the grouped launch (full-batch operands) or launched on the chain's rows"""
+            if defer:
+                if last:
+                    dw_all.append((tmp[dy_name], x_all, g, 1.0))
+            else:
+                ops.gemm_tn(dy_c, sl(x_all), g)
+
+        # ---- FFN ------------------------------------------------------------------------------
+        if p > 0:
+            dy = R(f"d.dy.ffn.{i}", d)
+            if not fused:
+                ops.dropout_apply(dh, dy, dr(_dec_site(i, 5)))
+        else:
+            dy = dh
+        wgrad("wo", f"d.dy.ffn.{i}", dy, ws[f"d.a1.{i}"], lw["wo"].g)
+        dpre = R(f"d.dpre.{i}" if defer else "d.dpre", f)
+        ops.gemm_nt(dy, lw["wo"].wt, dpre, aux=sl(ws[f"d.a1.{i}"]), aux_scale=1.0 / (1.0 - p))
+        wgrad("wi", f"d.dpre.{i}", dpre, ws[f"d.xn3.{i}"], lw["wi"].g)
+        dxn = R("d.dxn", d)
+        ops.gemm_nt(dpre, lw["wi"].wt, dxn)
+        dy_c = R(f"d.dy.c.{i}", d) if p > 0 else None
+        ops.rmsnorm_bwd(dxn, sl(ws[f"d.h2.{i}"]), lw["ln3"].p, sl(ws[f"d.rs3.{i}"]), dh, dh, lw["ln3"].g,
+                        **self._nxt((dy_c, dr(_dec_site(i, 3))) if fused else None))
+        # ---- cross-attention ---------------------------------------------------------------------
+        dy = dh
+        if p > 0:
+            dy = dy_c
+            if not fused:
+                ops.dropout_apply(dh, dy, dr(_dec_site(i, 3)))
+        wgrad("co", f"d.dy.c.{i}", dy, ws[f"d.cctx.{i}"], lw["co"].g)
+        dctx = R("d.dctx", inner)
+        ops.gemm_nt(dy, lw["co"].wt, dctx)
+        dqc = R(f"d.dqc.{i}" if defer else "d.dqc", inner)
+        qc = sl(ws[f"d.qc.{i}"])
+        if ch["xa"] is not None:
+            self._xattn_bwd(ch["xb"], ch["xa"], tmp, i, qc, ws["e.out"], dctx, dqc, Bc, T, S, dr(_dec_site(i, 2)), b0=ch["b0"],
+                            B_all=Md // T)
+        else:
+            c2 = sl(ws[f"d.cctx.{i}"])
+            ops.attn_bwd(self._heads(qc, Bc, T, 0), self._cross_kv(kv, ch, 2 * i * inner), self._cross_kv(kv, ch, (2 * i + 1) * inner),
+                         self._heads(c2, Bc, T, 0), self._heads(dctx, Bc, T, 0), ws[f"d.cst.{i}"][ch["b0"]:ch["b1"]],
+                         self._heads(dqc, Bc, T, 0), self._cross_kv(dkv, ch, 2 * i * inner), self._cross_kv(dkv, ch, (2 * i + 1) * inner),
+                         drop=dr(_dec_site(i, 2)), **ch["ckw"])
+        wgrad("cq", f"d.dqc.{i}", dqc, ws[f"d.xn2.{i}"], lw["cq"].g)
+        ops.gemm_nt(dqc, lw["cq"].wt, dxn)
+        dy_s = R(f"d.dy.{i}", d) if p > 0 else None
+        ops.rmsnorm_bwd(dxn, sl(ws[f"d.h1.{i}"]), lw["ln2"].p, sl(ws[f"d.rs2.{i}"]), dh, dh, lw["ln2"].g,
+                        **self._nxt((dy_s, dr(_dec_site(i, 1))) if fused else None))
+        # ---- causal self-attention ---------------------------------------------------------------
+        dy = dh
+        if p > 0:
+            dy = dy_s
+            if not fused:
+                ops.dropout_apply(dh, dy, dr(_dec_site(i, 1)))
+        wgrad("o", f"d.dy.{i}", dy, ws[f"d.ctx.{i}"], lw["o"].g)
+        ops.gemm_nt(dy, lw["o"].wt, dctx)
+        qkv, c1 = sl(ws[f"d.qkv.{i}"]), sl(ws[f"d.ctx.{i}"])
+        dqkv = R(f"d.dqkv.{i}" if defer else "d.dqkv", 3 * inner)
+        ops.attn_bwd(self._heads(qkv, Bc, T, 0), self._heads(qkv, Bc, T, inner), self._heads(qkv, Bc, T, 2 * inner),
+                     self._heads(c1, Bc, T, 0), self._heads(dctx, Bc, T, 0), ws[f"d.st.{i}"][ch["b0"]:ch["b1"]],
+                     self._heads(dqkv, Bc, T, 0), self._heads(dqkv, Bc, T, inner), self._heads(dqkv, Bc, T, 2 * inner),
+                     rel_bias=ws["d.rel"], drel=drel, rel_off=T - 1, causal=True, drop=dr(_dec_site(i, 0)))
+        wgrad("qkv", f"d.dqkv.{i}", dqkv, ws[f"d.xn1.{i}"], lw["qkv"].g)
+        ops.gemm_nt(dqkv, lw["qkv"].wt, dxn)
+        nxt = None
+        if fused and i > 0:
+            nxt = (R(f"d.dy.ffn.{i - 1}", d), dr(_dec_site(i - 1, 5)))
+        ops.rmsnorm_bwd(dxn, sl(ws[f"d.h{i}"]), lw["ln1"].p, sl(ws[f"d.rs1.{i}"]), dh, dh, lw["ln1"].g, **self._nxt(nxt))
+        if i == 0:
+            ops.embed_bwd(ws["d.ids"].view(-1)[r0:r1], dh, self.shared.g, dr(S_DEC_EMBED))
 
     def forward_loss(self, input_ids, attention_mask, labels, training: bool, lengths=None):
         """input_ids/attention_mask [B,N,L], labels [B,T] (−100 = ignore) → (loss 0-d fp32, logits [B,T,V] fp32).
@@ -642,45 +866,16 @@ class Engine:
         dec_ids = self._buf(ws, "d.ids", (B, T), torch.int64)
         ops.shift_right(labels.contiguous(), dec_ids)
         ctx.dec_ids = dec_ids
-        ops.embed_fwd(dec_ids.view(-1), self.shared.w, self._buf(ws, "d.h0", (Md, d)), dr(S_DEC_EMBED))
         rel = self._buf(ws, "d.rel", (H, 2 * T - 1), torch.float32)
         ops.relpos_expand(self.dec_rel.p, self._lut(T, T, False), rel)
-        if xa is not None:
-            xb = self._xattn_buffers(ws, B, N, L, T, Ld, xa.splits)
-        for i in range(Ld):
-            lw = self.dec[i]
-            h = ws[f"d.h{i}"]
-            xn1 = self._buf(ws, f"d.xn1.{i}", (Md, d))
-            ops.rmsnorm_fwd(h, lw["ln1"].p, xn1, self._buf(ws, f"d.rs1.{i}", (Md,), torch.float32), eps)
-            qkv = self._buf(ws, f"d.qkv.{i}", (Md, 3 * inner))
-            ops.gemm_nt(xn1, lw["qkv"].w, qkv)
-            c1 = self._buf(ws, f"d.ctx.{i}", (Md, inner))
-            ops.attn_fwd(self._heads(qkv, B, T, 0), self._heads(qkv, B, T, inner), self._heads(qkv, B, T, 2 * inner),
-                         self._heads(c1, B, T, 0), self._buf(ws, f"d.st.{i}", (B, H, T, 4), torch.float32),
-                         rel_bias=rel, rel_off=T - 1, causal=True, drop=dr(_dec_site(i, 0)))
-            h1 = self._buf(ws, f"d.h1.{i}", (Md, d))
-            ops.gemm_nt(c1, lw["o"].w, h1, resid=h, drop=dr(_dec_site(i, 1)))
-            xn2 = self._buf(ws, f"d.xn2.{i}", (Md, d))
-            ops.rmsnorm_fwd(h1, lw["ln2"].p, xn2, self._buf(ws, f"d.rs2.{i}", (Md,), torch.float32), eps)
-            qc = self._buf(ws, f"d.qc.{i}", (Md, inner))
-            ops.gemm_nt(xn2, lw["cq"].w, qc)
-            c2 = self._buf(ws, f"d.cctx.{i}", (Md, inner))
-            if xa is not None:
-                self._xattn_fwd(xb, xa, i, qc, enc_out, c2, B, T, S, dr(_dec_site(i, 2)))
-            else:
-                ops.attn_fwd(self._heads(qc, B, T, 0), self._heads(kv, kb, kt, 2 * i * inner),
-                             self._heads(kv, kb, kt, (2 * i + 1) * inner), self._heads(c2, B, T, 0),
-                             self._buf(ws, f"d.cst.{i}", (B, H, T, 4), torch.float32), drop=dr(_dec_site(i, 2)), **ckw)
-            h2 = self._buf(ws, f"d.h2.{i}", (Md, d))
-            ops.gemm_nt(c2, lw["co"].w, h2, resid=h1, drop=dr(_dec_site(i, 3)))
-            xn3 = self._buf(ws, f"d.xn3.{i}", (Md, d))
-            ops.rmsnorm_fwd(h2, lw["ln3"].p, xn3, self._buf(ws, f"d.rs3.{i}", (Md,), torch.float32), eps)
-            a1 = self._buf(ws, f"d.a1.{i}", (Md, f))
-            ops.gemm_nt(xn3, lw["wi"].w, a1, relu=True, drop=dr(_dec_site(i, 4)))
-            ops.gemm_nt(a1, lw["wo"].w, self._buf(ws, f"d.h{i + 1}", (Md, d)), resid=h2, drop=dr(_dec_site(i, 5)))
+        xb = self._xattn_buffers(ws, B, N, L, T, Ld, xa.splits) if xa is not None else None
+        for i in range(Ld + 1):
+            self._buf(ws, f"d.h{i}", (Md, d))
         dec_out = self._buf(ws, "d.out", (Md, d))
-        ops.rmsnorm_fwd(ws[f"d.h{Ld}"], self.dec_final.p, dec_out, self._buf(ws, "d.rsf", (Md,), torch.float32), eps,
-                        dr(S_DEC_FINAL))
+        self._buf(ws, "d.rsf", (Md,), torch.float32)
+        chains = ctx.chains = self._dec_chains(B, T, p, seed, xa, xb, rag, kb, kt, ckw)
+        # (embedding → blocks → final norm per chain of samples; the LM head and the loss see all rows again)
+        self._run_chains(chains, Ld, lambda i, ch: self._dec_layer_fwd(ws, i, ch, enc_out, kv, rel, T, S))
         logits = self._buf(ws, "d.logits", (Md, V), torch.float32)
         ops.gemm_nt(dec_out, self.shared.w, logits, alpha=d ** -0.5)       # tied LM head × d_model^-0.5
         loss_buf = self._buf(ws, "d.loss", (2,), torch.float32)
@@ -764,72 +959,19 @@ class Engine:
         ops.gemm_tn(dlog, ws["d.out"], self.shared.g, alpha=alpha)
         # every RMSNorm backward also writes dropout_bwd(dx) for the residual branch that consumes dx next (fused=True)
         fused = p > 0 and os.environ.get("LAKO_FUSE_DROP", "1") != "0"   # 0: separate dropout_apply launches (A/B)
-        dy_f = self._buf(tmp, "d.dy.ffn", (Md, d)) if fused else None
-        dy_c = self._buf(tmp, "d.dy.c", (Md, d)) if fused else None
-        dy_s = self._buf(tmp, "d.dy", (Md, d)) if fused else None
-        ops.rmsnorm_bwd(dout, ws[f"d.h{Ld}"], self.dec_final.p, ws["d.rsf"], None, dh, self.dec_final.g, dr(S_DEC_FINAL),
-                        **self._nxt((dy_f, dr(_dec_site(Ld - 1, 5))) if fused else None))
         xa = ctx.xa
-        if xa is not None:
-            xb = self._xattn_buffers(ws, B, N, L, T, Ld, xa.splits)
-        else:
+        xb = self._xattn_buffers(ws, B, N, L, T, Ld, xa.splits) if xa is not None else None
+        dkv = kv = None
+        if xa is None:
             dkv = self._buf(tmp, "dkv", (Me, self.kv_all.w.shape[0]))
             kv = ws["e.kv"]
         drel = self._buf(tmp, "d.drel", (H, 2 * T - 1), torch.float32)
         ops.zero_(drel)
-        for i in reversed(range(Ld)):
-            lw = self.dec[i]
-            # the layer's six weight gradients (K = B·T rows: two K-steps each) as one grouped launch at the end of the layer
-            dw = []
-            self._ffn_bwd(lw, dh, ws[f"d.a1.{i}"], ws[f"d.xn3.{i}"], ws[f"d.h2.{i}"], ws[f"d.rs3.{i}"], lw["ln3"], p,
-                          dr(_dec_site(i, 5)), tmp, dw, dy_pre=dy_f, nxt=(dy_c, dr(_dec_site(i, 3))) if fused else None)
-            # cross-attention
-            dy = dh
-            if p > 0:
-                dy = dy_c if fused else self._buf(tmp, "d.dy.c", (Md, d))
-                if not fused:
-                    ops.dropout_apply(dh, dy, dr(_dec_site(i, 3)))
-                dw.append((dy, ws[f"d.cctx.{i}"], lw["co"].g, 1.0))
-            else:
-                ops.gemm_tn(dy, ws[f"d.cctx.{i}"], lw["co"].g)
-            dctx = self._buf(tmp, "d.dctx", (Md, inner))
-            ops.gemm_nt(dy, lw["co"].wt, dctx)
-            dqc = self._buf(tmp, "d.dqc", (Md, inner))
-            if xa is not None:
-                self._xattn_bwd(xb, xa, tmp, i, ws[f"d.qc.{i}"], ws["e.out"], dctx, dqc, B, T, S, dr(_dec_site(i, 2)))
-            else:
-                ops.attn_bwd(self._heads(ws[f"d.qc.{i}"], B, T, 0), self._heads(kv, kb, kt, 2 * i * inner),
-                             self._heads(kv, kb, kt, (2 * i + 1) * inner), self._heads(ws[f"d.cctx.{i}"], B, T, 0),
-                             self._heads(dctx, B, T, 0), ws[f"d.cst.{i}"], self._heads(dqc, B, T, 0),
-                             self._heads(dkv, kb, kt, 2 * i * inner), self._heads(dkv, kb, kt, (2 * i + 1) * inner),
-                             drop=dr(_dec_site(i, 2)), **ckw)
-            dw.append((dqc, ws[f"d.xn2.{i}"], lw["cq"].g, 1.0))
-            dxn = self._buf(tmp, "d.dxn", (Md, d))
-            ops.gemm_nt(dqc, lw["cq"].wt, dxn)
-            ops.rmsnorm_bwd(dxn, ws[f"d.h1.{i}"], lw["ln2"].p, ws[f"d.rs2.{i}"], dh, dh, lw["ln2"].g,
-                            **self._nxt((dy_s, dr(_dec_site(i, 1))) if fused else None))
-            # causal self-attention
-            dy = dh
-            if p > 0:
-                dy = dy_s if fused else self._buf(tmp, "d.dy", (Md, d))
-                if not fused:
-                    ops.dropout_apply(dh, dy, dr(_dec_site(i, 1)))
-                dw.append((dy, ws[f"d.ctx.{i}"], lw["o"].g, 1.0))
-            else:
-                ops.gemm_tn(dy, ws[f"d.ctx.{i}"], lw["o"].g)
-            ops.gemm_nt(dy, lw["o"].wt, dctx)
-            qkv = ws[f"d.qkv.{i}"]
-            dqkv = self._buf(tmp, "d.dqkv", (Md, 3 * inner))
-            ops.attn_bwd(self._heads(qkv, B, T, 0), self._heads(qkv, B, T, inner), self._heads(qkv, B, T, 2 * inner),
-                         self._heads(ws[f"d.ctx.{i}"], B, T, 0), self._heads(dctx, B, T, 0), ws[f"d.st.{i}"],
-                         self._heads(dqkv, B, T, 0), self._heads(dqkv, B, T, inner), self._heads(dqkv, B, T, 2 * inner),
-                         rel_bias=ws["d.rel"], drel=drel, rel_off=T - 1, causal=True, drop=dr(_dec_site(i, 0)))
-            dw.append((dqkv, ws[f"d.xn1.{i}"], lw["qkv"].g, 1.0))
-            ops.gemm_nt(dqkv, lw["qkv"].wt, dxn)
-            ops.gemm_tn_grouped(dw)      # before the norm backward below overwrites dy_f for the next layer
-            ops.rmsnorm_bwd(dxn, ws[f"d.h{i}"], lw["ln1"].p, ws[f"d.rs1.{i}"], dh, dh, lw["ln1"].g,
-                            **self._nxt((dy_f, dr(_dec_site(i - 1, 5))) if fused and i > 0 else None))
-        ops.embed_bwd(ctx.dec_ids.view(-1), dh, self.shared.g, dr(S_DEC_EMBED))
+        dw_all = []      # every decoder weight gradient of the step (K = B·T rows): grouped launches after the last layer
+        self._run_chains(ctx.chains, Ld, lambda i, ch: self._dec_layer_bwd(ws, tmp, i, ch, dh, drel, kv, dkv, fused, T, S, dw_all),
+                         reverse=True)
+        if dw_all:
+            ops.gemm_tn_grouped(dw_all)
         ops.relpos_reduce(drel, self._lut(T, T, False), self.dec_rel.g)
         # ---- cross K/V projection of all decoder layers -----------------------------------------
         deh = self._buf(tmp, "e.dh", (Me, d))

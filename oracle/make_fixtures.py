@@ -489,7 +489,41 @@ def make_retriever_train():
     print("retriever_train.npz", len(out), "arrays")
 
 
+def make_rerank():
+    """Golden outputs of the reference's OWN re-rank, fact_retrieval_small_range.py:64-89 (`resort_facts`: every example's candidate facts
+    re-ordered by the inner product of their embeddings with the example's question embedding, `sorted(zip(score, id), reverse=True)`),
+    imported from /root/reference with `faiss` stubbed in sys.modules (the module imports src.index, which imports faiss at its top; the
+    function itself is plain torch — nothing of faiss runs) → tests/golden/rerank.json: seeded embeddings, the examples' candidate ids, the
+    order and scores the reference produced.  Includes exact score ties (duplicated embedding rows: descending id wins, the tuple sort) and
+    an example with one candidate."""
+    import copy
+    import json
+    sys.modules.setdefault("faiss", types.ModuleType("faiss"))
+    import fact_retrieval_small_range as frs
+    g = np.random.default_rng(11)
+    n, d, nq = 60, 16, 5
+    emb = (g.integers(-8, 9, size=(n, d)) / 8.0).astype(np.float32)      # multiples of 1/8: the products are exact in fp32 on any path
+    emb[7] = emb[3]
+    emb[41] = emb[3]                                                     # ties inside one candidate list
+    q = (g.integers(-8, 9, size=(nq, d)) / 8.0).astype(np.float32)
+    cand = [sorted(set([3, 7, 41] + g.choice(n, size=12, replace=False).tolist())), g.choice(n, size=20, replace=False).tolist(),
+            [5], g.permutation(n).tolist(), [41, 3, 7, 0]]
+    dic = {str(i): f"fact number {i}" for i in range(n)}
+    examples = [{"question": f"q{k}", "fact": [{"id": str(i), "sentence": dic[str(i)], "score": 0} for i in cand[k]]} for k in range(nq)]
+    ref = copy.deepcopy(examples)
+    frs.resort_facts(ref, dic, torch.from_numpy(q), torch.from_numpy(emb))
+    out = {"embeddings": emb.tolist(), "questions": q.tolist(), "candidates": cand,
+           "expected": [{"ids": [int(f["id"]) for f in ex["fact"]], "scores": [float(f["score"]) for f in ex["fact"]],
+                         "sentences": [f["sentence"] for f in ex["fact"]]} for ex in ref]}
+    with open(os.path.join(ROOT, "tests", "golden", "rerank.json"), "w") as f:
+        json.dump(out, f)
+    print("wrote rerank.json", [len(e["ids"]) for e in out["expected"]])
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "rerank":
+        make_rerank()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "retriever_train":
         make_retriever_train()
         make_rank_metrics()
@@ -500,6 +534,7 @@ if __name__ == "__main__":
     make_retriever()
     make_retriever_train()
     make_rank_metrics()
+    make_rerank()
     make_evaluation()
     make_case("tiny_a", tiny, B=3, N=3, L=12, T=5, seed=1, full_pad=(1, 2))
     make_case("tiny_fact", tiny, B=3, N=2, L=24, T=4, seed=2, fact_case=True)

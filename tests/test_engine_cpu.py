@@ -317,6 +317,52 @@ def test_encoder_space_cross_attention_equals_projected(name, dropout, monkeypat
     assert eng.xattn_active and torch.equal(t0, t1)
 
 
+@pytest.mark.parametrize("padded", [False, True])
+@pytest.mark.parametrize("xattn", ["1", "0"])
+def test_decoder_sample_chains_equal_one_chain(monkeypatch, padded, xattn):
+    """The decoder as independent chains of samples (Engine._dec_chains, round 4): cutting the batch into 2 or 3 runs of samples — every
+    row-wise kernel on row slices, the attention kernels on sample slices, the weight gradients of ALL rows in one grouped launch after the
+    last layer — must reproduce the one-chain schedule: loss, logits and every gradient (dropout off), on the packed and on the padded
+    encoder, with the cross-attention in either formulation.  With dropout on, the chains draw different masks (own seeds): two copies of
+    ONE sample placed in different chains get different logits, in the same chain with the same rows they would not; fwd / bwd stay consistent
+    (the deferred weight gradients use the masks the forward drew: same result as launching them inside the chain)."""
+    from oracle import fid_t5_oracle as O
+    z, dims, w = load_case("tiny_a")
+    N, L, T = z["input_ids"].shape[1], z["input_ids"].shape[2], z["labels"].shape[1]
+    ids, mask, labels = O.synthetic_batch(6, N, L, T, dims.vocab_size, seed=77)
+    if padded:
+        monkeypatch.setenv("LAKO_UNPAD", "0")
+    monkeypatch.setenv("LAKO_XATTN", xattn)
+    res = {}
+    for n in ("1", "2", "3"):
+        monkeypatch.setenv("LAKO_DEC_CHAINS", n)
+        m = FiDT5(cfg_of(dims, 0.0), dtype=torch.float32, _ops=RefOps())
+        m.load_t5(w)
+        m.train()
+        m(input_ids=ids, attention_mask=mask, labels=labels)
+        assert [(c["b0"], c["b1"]) for c in m._engine.ctx.chains] == {"1": [(0, 6)], "2": [(0, 3), (3, 6)], "3": [(0, 2), (2, 4), (4, 6)]}[n]
+        res[n] = _run_fb(m, ids, mask, labels)
+    for n in ("2", "3"):
+        assert abs(res[n][0] - res["1"][0]) < 1e-6
+        torch.testing.assert_close(res[n][1], res["1"][1], atol=2e-6, rtol=1e-5)
+        torch.testing.assert_close(res[n][2], res["1"][2], atol=2e-6, rtol=1e-4)
+    # dropout on: deferred grouped weight gradients == per-chain launches (LAKO_DEC_DEFER_DW=0), masks differ between chains
+    ids2 = torch.cat([ids[:1]] * 4)
+    mask2, labels2 = torch.cat([mask[:1]] * 4), torch.cat([labels[:1]] * 4)
+    monkeypatch.setenv("LAKO_DEC_CHAINS", "2")
+    got = []
+    for defer in ("1", "0"):
+        monkeypatch.setenv("LAKO_DEC_DEFER_DW", defer)
+        m = FiDT5(cfg_of(dims, 0.1), dtype=torch.float32, seed=5, _ops=RefOps())
+        m.load_t5(w)
+        m.train()
+        got.append(_run_fb(m, ids2, mask2, labels2))
+    assert got[0][0] == got[1][0]
+    torch.testing.assert_close(got[0][2], got[1][2], atol=2e-6, rtol=1e-4)
+    lg = got[0][1]
+    assert not torch.equal(lg[0], lg[2]) and not torch.equal(lg[1], lg[3])      # same sample, different chains: different masks
+
+
 def _ws_footprint(eng):
     n, nbytes = 0, 0
     for ws in eng._ws_cache.values():

@@ -66,6 +66,44 @@ def test_resort_facts_on_double():
         np.testing.assert_allclose([f["score"] for f in a["fact"]], [f["score"] for f in b["fact"]], rtol=1e-5, atol=1e-5)
 
 
+def _rerank_case():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "rerank.json")) as f:
+        z = json.load(f)
+    emb, q = np.asarray(z["embeddings"], np.float32), np.asarray(z["questions"], np.float32)
+    dic = {str(i): f"fact number {i}" for i in range(len(emb))}
+    ex = [{"question": f"q{k}", "fact": [{"id": str(i), "sentence": dic[str(i)], "score": 0} for i in c]} for k, c in enumerate(z["candidates"])]
+    return emb, q, dic, ex, z["expected"]
+
+
+def _check_rerank(examples, expected):
+    for ex, want in zip(examples, expected):
+        assert [f["id"] for f in ex["fact"]] == want["ids"]                      # the order, ties included (descending id)
+        assert [f["sentence"] for f in ex["fact"]] == want["sentences"]
+        assert [f["score"] for f in ex["fact"]] == want["scores"]                # exact: the fixture's products are exact in fp32
+
+
+def test_resort_facts_vs_reference_outputs():
+    """PIN of the re-rank: tests/golden/rerank.json holds what the reference's own `resort_facts`
+    (fact_retrieval_small_range.py:64-89, imported by oracle/make_fixtures.py::make_rerank with faiss stubbed) returned for seeded
+    embeddings; lako_amd.index.resort_facts (host logic on the test double) and the numpy restatement must reproduce ids, order — exact
+    ties included — sentences and scores.  (The faiss half of src/index.py stays unpinned: faiss is absent from the image.)"""
+    emb, q, dic, ex, want = _rerank_case()
+    ex_o = copy.deepcopy(ex)
+    resort_facts(ex, dic, q, emb, ops=RefOps(), device="cpu")
+    _check_rerank(ex, want)
+    IO.resort_facts(ex_o, dic, q, emb)
+    _check_rerank(ex_o, want)
+
+
+@pytest.mark.gpu
+def test_resort_facts_vs_reference_outputs_on_gpu():
+    emb, q, dic, ex, want = _rerank_case()
+    resort_facts(ex, dic, q, emb)
+    _check_rerank(ex, want)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("rows,n,k", [(3, 1000, 10), (2, 300600, 500), (5, 4099, 1024), (1, 7, 7), (4, 2048, 1)])
 def test_topk_kernel(rows, n, k):

@@ -127,13 +127,16 @@ def test_gemm_nt_side_operand_in_lds(ops, ref, M, N, K):
         ops.set_tuning("gemm_nt_side_lds", 1)
 
 
-@pytest.mark.parametrize("M,N,K", [(2048, 768, 768), (700, 520, 200), (515, 264, 64), (256, 256, 128), (16700, 1024, 192), (33300, 520, 72)])
-def test_gemm_nt_ping_pong_equals_in_phase(ops, ref, M, N, K):
-    """`gemm_nt_pp` (round 4): 1 = waves 4–7 of the 256² kernel run half a K-step behind waves 0–3, holding the fragments of K-half 1
-    across the barrier; 2 / 3 = every wave in the early / late role (2 is what the default, 4 = by shape, picks from K = 2048 up).  Every accumulator still sums its K-halves in the same order, so the result must equal the in-phase
-    schedule's BIT FOR BIT — one K-step (K = 64), two, many; ragged edges; persistent workgroups that walk several tiles (the last two
-    shapes: 264 and 393 tiles on 256 workgroups, the late waves' last MFMAs of a tile run after the tile's last barrier); plain, wide,
-    and LDS-staged side-operand epilogues."""
+@pytest.mark.parametrize("M,N,K", [(2048, 768, 768), (700, 520, 200), (515, 264, 64), (256, 256, 128), (16700, 1024, 192), (33300, 520, 72),
+                                   (47757, 768, 3072), (8192, 2304, 768)])
+def test_gemm_nt_eight_phase_equals_two_phase(ops, ref, M, N, K):
+    """`gemm_nt_pp` = 1 (round 4, the default): the 8-phase main loop of the 256² kernel — quadrant-wise fragment reads, half-tile LDS-DMA
+    stagings 1¾ K-steps ahead retired by counted waits, waves 4–7 one barrier behind waves 0–3.  Every accumulator still sums its K-halves
+    in the same order, so the result must equal the two-phase loop's BIT FOR BIT — two K-steps (K = 72: the second almost empty; K = 128),
+    three, many; K = 64 falls back to the two-phase loop; ragged edges; persistent workgroups that walk several tiles (264 … 560 tiles on
+    256 workgroups: the stream of stagings crosses tile boundaries, the epilogue's scratch is the buffer the next tile's second K-step
+    is staged into afterwards); plain, wide, and LDS-staged side-operand epilogues.  Repeated: a mis-placed wait or read shows up as a
+    rare wrong tile, not as a steady failure."""
     T = torch.bfloat16
     A, B = rnd(M, K, dtype=T, seed=71), rnd(N, K, dtype=T, seed=72)
     R = rnd(M, N, dtype=T, seed=73)
@@ -143,22 +146,28 @@ def test_gemm_nt_ping_pong_equals_in_phase(ops, ref, M, N, K):
         for wide in (1, 0):
             ops.set_tuning("gemm_nt_wide_epi", wide)
             for kw in cases:
-                got = {}
-                for pp in (0, 1, 2, 3):       # in phase; ping-pong; every wave in the early / in the late role
+                ops.set_tuning("gemm_nt_pp", 0)
+                ops.set_tuning("gemm_nt_glds", 0)
+                want = torch.full((M, N), 7.0, dtype=T, device=dev())
+                ops.gemm_nt(A, B, want, **kw)
+                for pp, glds in ((1, 1), (1, 0), (0, 1)):       # (global_load_lds staging: rows past the edge are clamped, not zero-filled)
                     ops.set_tuning("gemm_nt_pp", pp)
-                    C = torch.full((M, N), 7.0, dtype=T, device=dev())
-                    ops.gemm_nt(A, B, C, **kw)
-                    got[pp] = C
-                for pp in (1, 2, 3):
-                    assert torch.equal(got[0], got[pp]), f"schedule {pp} differs from the in-phase one {list(kw)} wide {wide} {M}x{N}x{K}"
+                    ops.set_tuning("gemm_nt_glds", glds)
+                    for rep in range(3 if M * N * K < 4e10 else 2):
+                        C = torch.full((M, N), 7.0, dtype=T, device=dev())
+                        ops.gemm_nt(A, B, C, **kw)
+                        bad = (C != want).any(dim=1).nonzero().flatten()
+                        assert bad.numel() == 0, (f"pp {pp} glds {glds} differs from the two-phase / buffer-load kernel {list(kw)} wide {wide} "
+                                                  f"{M}x{N}x{K} rep {rep}: {bad.numel()} rows, first {bad[:8].tolist()}")
                 if M * N <= 2048 * 768:
                     Cr = torch.zeros(M, N, device=dev())
                     ref.gemm_nt(A, B, Cr, **kw)
-                    close(got[1], Cr, T, f"gemm_nt ping-pong {list(kw)} {M}x{N}x{K}")
+                    close(want, Cr, T, f"gemm_nt {list(kw)} {M}x{N}x{K}")
     finally:
         ops.set_tuning("gemm_nt_variant", -1)
         ops.set_tuning("gemm_nt_wide_epi", 1)
         ops.set_tuning("gemm_nt_pp", 0)
+        ops.set_tuning("gemm_nt_glds", 1)
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 768, 768), (128, 768, 3072), (100, 200, 160), (256, 2304, 2304), (16, 3072, 4096), (130, 776, 1056)])

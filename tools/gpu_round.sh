@@ -19,7 +19,7 @@ TAG=${TAG:-round}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 QUICK="--no-cpu-baseline --all-valid-steps 0 --steps 20 --warmup 5"
-step_tests() { ( time timeout ${PYTEST_TIMEOUT:-2400} python -m pytest $1 -m gpu -x -q --durations=10 ) >> $OUT/pytest.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest.log; tail -4 $OUT/pytest.log; }
+step_tests() { ( time eval "timeout ${PYTEST_TIMEOUT:-2400} python -m pytest $1 -m gpu -x -q --durations=10" ) >> $OUT/pytest.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest.log; tail -4 $OUT/pytest.log; }
 step_smoke() { python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log; }
 step_bench() { ( time python bench.py ) > $OUT/bench.json 2> $OUT/bench.err; cut -c1-300 $OUT/bench.json; }
 step_quick() { python bench.py $QUICK --breakdown > $OUT/bench_quick.json 2> $OUT/breakdown.txt; cut -c1-220 $OUT/bench_quick.json; cat $OUT/breakdown.txt; }
