@@ -1732,21 +1732,37 @@ const lako_tuning_t& process_tuning() {
   return t;
 }
 
-// ticket counters of the QUEUE instantiation: 9 ints per (device, stream), allocated and zeroed once (a launch leaves them zero);
-// launches on one stream run one after the other, launches on different streams never share counters
+// ticket counters of the QUEUE instantiation: 9 ints per (device, stream); launches on one stream run one after the other, launches on
+// different streams never share counters.  Every QUEUE launch is preceded by its own hipMemsetAsync of the counters on the same stream
+// (checked): a launch that faulted or was aborted half-way cannot leave tickets behind for the next one (round 3 relied on each launch's
+// last workgroup to reset them).  The first use on a (device, stream) allocates — not possible while the stream is being captured:
+// then (or when the allocation or the memset fails) the caller falls back to the static tile order, which computes the same result.
 static int* nt_queue_counters(hipStream_t stream) {
   static std::mutex mu;
   static std::map<std::pair<int, hipStream_t>, int*> tab;
   int dev = 0;
   (void)hipGetDevice(&dev);
-  std::lock_guard<std::mutex> lock(mu);
-  int*& p = tab[{dev, stream}];
-  if (!p) {
-    if (hipMalloc(reinterpret_cast<void**>(&p), 16 * sizeof(int)) != hipSuccess) {
-      p = nullptr;
-      return nullptr;
+  int* p = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    int*& slot = tab[{dev, stream}];
+    if (!slot) {
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return nullptr;
+      }
+      if (hipMalloc(reinterpret_cast<void**>(&slot), 16 * sizeof(int)) != hipSuccess) {
+        (void)hipGetLastError();
+        slot = nullptr;
+        return nullptr;
+      }
     }
-    (void)hipMemsetAsync(p, 0, 16 * sizeof(int), stream);
+    p = slot;
+  }
+  if (hipMemsetAsync(p, 0, 16 * sizeof(int), stream) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
   }
   return p;
 }

@@ -116,14 +116,16 @@ class Indexer:
         emb = emb.to(self.device, torch.float32).reshape(-1, self.vector_sz)
         if len(ids) != emb.shape[0]:
             raise ValueError("ids and embeddings disagree in length")
-        self.index_id_to_db_id = np.concatenate((self.index_id_to_db_id, np.array(ids, dtype=np.int64)), axis=0)
+        new_ids = np.array(ids, dtype=np.int64)
         if self.pq is not None:                  # src/index.py:31-33: `if not self.index.is_trained: self.index.train(embeddings)`, then add
             emb = emb.contiguous()
             if not self.pq.is_trained:
-                self.pq.train(emb)
+                self.pq.train(emb)               # (may raise: too few vectors for 2^n_bits centroids, unsupported sub-vector width)
             self.codes = torch.cat([self.codes, self.pq.compute_codes(emb)], 0).contiguous()
-            return
-        self.embeddings = torch.cat([self.embeddings, emb], 0).contiguous()
+        else:
+            self.embeddings = torch.cat([self.embeddings, emb], 0).contiguous()
+        # the id map grows only AFTER the vectors are in: a failed train / encode must not leave ids without vectors behind them
+        self.index_id_to_db_id = np.concatenate((self.index_id_to_db_id, new_ids), axis=0)
 
     def search_scores(self, query_vectors) -> torch.Tensor:
         """fp32 inner products [nq, ntotal] of the queries with every stored vector (one GEMM)."""
@@ -173,7 +175,13 @@ class Indexer:
         torch.save(d, os.path.join(str(dir_path), "index.pt"))
 
     def deserialize_from(self, dir_path):
-        d = torch.load(os.path.join(str(dir_path), "index.pt"), map_location="cpu", weights_only=True)
+        path = os.path.join(str(dir_path), "index.pt")
+        try:
+            d = torch.load(path, map_location="cpu", weights_only=True)
+        except Exception as e:      # (pickle.UnpicklingError for anything but tensors / numbers: e.g. the numpy id map older files carried)
+            raise ValueError(f"{path} does not load as tensors and plain numbers only (torch.load(weights_only=True): {type(e).__name__}). "
+                             "Index files written before the id map became a tensor stored it as a pickled numpy array: rebuild the index "
+                             "(index_data + serialize) — such a file is not unpickled here, whatever its origin") from e
         assert d["vector_sz"] == self.vector_sz
         if "codes" in d:                         # (like faiss.read_index: the file decides the index type)
             self.pq = ProductQuantizer(self.vector_sz, d["n_subquantizers"], d["n_bits"], self.ops, self.device)
@@ -182,8 +190,7 @@ class Indexer:
         else:
             self.pq = None
             self.embeddings = d["embeddings"].to(self.device)
-        ids = d["index_id_to_db_id"]
-        self.index_id_to_db_id = ids.numpy().astype(np.int64) if torch.is_tensor(ids) else np.asarray(ids, dtype=np.int64)
+        self.index_id_to_db_id = d["index_id_to_db_id"].numpy().astype(np.int64)
         assert len(self.index_id_to_db_id) == self.ntotal, "Deserialized index_id_to_db_id should match the index size"
 
 

@@ -496,17 +496,24 @@ class HipOps:
         M, ksub, dsub = centroids.shape
         if x.dtype != torch.float32 or centroids.dtype != torch.float32 or x.stride(1) != 1 or not centroids.is_contiguous():
             raise LakoError("pq_assign: x / centroids fp32, x rows contiguous, centroids contiguous")
+        if x.dim() != 2 or x.shape[1] < M * dsub:
+            raise LakoError(f"pq_assign: x has {tuple(x.shape)} columns, the centroids split M·dsub = {M * dsub}")
         if codes is not None and (codes.dtype != torch.uint8 or not codes.is_contiguous() or tuple(codes.shape) != (x.shape[0], M)):
             raise LakoError("pq_assign: codes must be contiguous uint8 [n, M]")
-        if (sums is None) != (counts is None) or (sums is not None and (tuple(sums.shape) != (M, ksub, dsub) or counts.dtype != torch.int32)):
+        if (sums is None) != (counts is None) or (sums is not None and (tuple(sums.shape) != (M, ksub, dsub) or counts.dtype != torch.int32 or
+                                                                    sums.dtype != torch.float32 or not sums.is_contiguous() or
+                                                                    tuple(counts.shape) != (M, ksub) or not counts.is_contiguous())):
             raise LakoError("pq_assign: sums [M, ksub, dsub] fp32 and counts [M, ksub] int32 go together")
         self._timed("pq_assign", 0.0, lambda: check(self.lib.lako_pq_assign(_p(x), x.shape[0], x.stride(0), _p(centroids), M, ksub, dsub, _p(codes),
                                                                             _p(sums), _p(counts), _p(err), self._stream()), "lako_pq_assign"))
 
     def pq_lut(self, q, centroids, lut):
         M, ksub, dsub = centroids.shape
-        if q.dtype != torch.float32 or q.stride(1) != 1 or not lut.is_contiguous() or tuple(lut.shape) != (q.shape[0], M, ksub):
-            raise LakoError("pq_lut: q fp32 rows contiguous, lut contiguous fp32 [nq, M, ksub]")
+        if q.dtype != torch.float32 or q.stride(1) != 1 or not lut.is_contiguous() or tuple(lut.shape) != (q.shape[0], M, ksub) or \
+                lut.dtype != torch.float32 or centroids.dtype != torch.float32 or not centroids.is_contiguous():
+            raise LakoError("pq_lut: q fp32 rows contiguous, lut contiguous fp32 [nq, M, ksub], centroids contiguous fp32")
+        if q.dim() != 2 or q.shape[1] < M * dsub:
+            raise LakoError(f"pq_lut: q has {tuple(q.shape)} columns, the centroids split M·dsub = {M * dsub}")
         self._timed("pq_lut", 0.0, lambda: check(self.lib.lako_pq_lut(_p(q), q.shape[0], q.stride(0), _p(centroids), M, ksub, dsub, _p(lut),
                                                                       self._stream()), "lako_pq_lut"))
 

@@ -66,6 +66,28 @@ def test_resort_facts_on_double():
         np.testing.assert_allclose([f["score"] for f in a["fact"]], [f["score"] for f in b["fact"]], rtol=1e-5, atol=1e-5)
 
 
+def test_failed_add_leaves_the_id_map_alone_and_legacy_files_fail_clearly(tmp_path):
+    """ADVICE (round 3): (1) index_data appends the ids only after the vectors are in — a PQ train that raises (fewer vectors than
+    centroids) must not leave ids without codes behind them; (2) an index.pt whose id map is a pickled numpy array (files written before
+    the id map became a tensor) is refused with a message that says what to do, not unpickled."""
+    emb, _, ids = _data(n=40, d=32)
+    ix = Indexer(32, n_subquantizers=4, n_bits=8, device="cpu", ops=RefOps())
+    with pytest.raises(Exception):
+        ix.index_data(ids, emb)                       # 40 vectors cannot train 256 centroids per sub-quantiser
+    assert len(ix.index_id_to_db_id) == 0 and ix.ntotal == 0
+    flat = Indexer(32, device="cpu", ops=RefOps())
+    flat.index_data(ids, emb)
+    flat.serialize(tmp_path)
+    back = Indexer(32, device="cpu", ops=RefOps())
+    back.deserialize_from(tmp_path)
+    assert back.ntotal == 40 and list(back.index_id_to_db_id) == list(ids)
+    legacy = tmp_path / "legacy"
+    legacy.mkdir()
+    torch.save({"embeddings": torch.from_numpy(emb), "index_id_to_db_id": np.asarray(ids), "vector_sz": 32}, legacy / "index.pt")
+    with pytest.raises(ValueError, match="rebuild the index"):
+        Indexer(32, device="cpu", ops=RefOps()).deserialize_from(legacy)
+
+
 def _rerank_case():
     import json
     import os
