@@ -138,8 +138,10 @@ int lako_gemm_tn(const void* A, const void* B, float* C, int64_t M, int64_t N, i
  * each, and every split costs one fp32 atomic pass over the output (≈1.3 TB/s chip-wide).  Falls back to one lako_gemm_tn
  * per item for shapes the 256x256 kernel does not take (fp32 inputs, M or N < 256).  `items` is a HOST array.
  * split_k: 0 = choose; 1 = every output element has ONE contributor (into a zeroed C the result is then independent of the
- * order workgroups finish in — used where the product feeds further bf16 arithmetic, the encoder-state gradient of the
- * cross-attention, instead of being a final fp32 gradient). */
+ * order workgroups finish in); round 4, lako_gemm_tn too: -1 = one contributor AND the caller promises that nothing else adds to
+ * these outputs while the launch runs: C += v by plain loads and stores (the chip's copy rate instead of ≈1.3 TB/s of float
+ * atomics — the decoder's weight gradients, K = batch x answer length); -2 = the same, overwriting: C = v, no zeroed C needed (the
+ * encoder-state gradient of the cross-attention). */
 #define LAKO_TN_GROUP_MAX 8
 typedef struct {
   const void* a; /* [K, M] row-major, lda */
@@ -147,6 +149,9 @@ typedef struct {
   float* c;      /* [M, N] fp32, ldc */
   int64_t M, N, lda, ldb, ldc;
   float alpha;
+  int32_t rows_out; /* 0 = M; else only the first rows_out (<= M) rows of C are touched — M must be a multiple of 8 for the operand
+                       loads, a problem whose true row count is not (a sample's keys) says so here instead of spilling up to 7 rows
+                       into its neighbour's output (round 4: needed once C is overwritten rather than added to) */
 } lako_gemm_tn_item_t;
 int lako_gemm_tn_grouped(const lako_gemm_tn_item_t* items, int n_items, int64_t K, int in_dtype, int split_k,
                          const lako_tuning_t* tuning, lako_stream_t stream);
@@ -317,10 +322,11 @@ int lako_adamw_step(float* p, const float* g, float* m, float* v, void* shadow, 
 /* dst[c][r] = (dtype) src[r][c]  — transposed low-precision weight copies used by the dX GEMMs */
 int lako_transpose_cast(const float* src, void* dst, int64_t rows, int64_t cols, int dtype, lako_stream_t stream);
 /* the same for a whole table of matrices in one launch (all weights after an optimizer step): matrix i is
- * src_base + desc[4i] ([rows = desc[4i+2]][cols = desc[4i+3]], fp32) → dst_base + desc[4i+1] ([cols][rows], dtype);
+ * src_base + desc[4i] ([rows = desc[4i+2]][cols = desc[4i+3]], src_dtype) → dst_base + desc[4i+1] ([cols][rows], dtype);
  * tile_prefix[i] = number of 64×64 tiles of matrices 0..i-1, total_tiles = their sum over all n matrices.
- * desc / tile_prefix are DEVICE arrays; offsets in elements, multiples of 4 (16-byte aligned sources). */
-int lako_transpose_cast_batched(const float* src_base, void* dst_base, const int64_t* desc, const int32_t* tile_prefix,
+ * desc / tile_prefix are DEVICE arrays; offsets in elements, multiples of 4.  src_dtype LAKO_F32 (the master weights) or, for bf16
+ * copies, LAKO_BF16 (the bf16 shadow the optimizer step has just written: the same values from half the bytes — round 4). */
+int lako_transpose_cast_batched(const void* src_base, int src_dtype, void* dst_base, const int64_t* desc, const int32_t* tile_prefix,
                                 int n, int total_tiles, int dtype, lako_stream_t stream);
 int lako_cast(const float* src, void* dst, int64_t n, int dtype, lako_stream_t stream);
 

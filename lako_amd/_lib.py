@@ -44,7 +44,7 @@ class GemmNT(C.Structure):
 
 class GemmTNItem(C.Structure):
     _fields_ = [("a", vp), ("b", vp), ("c", vp), ("M", i64), ("N", i64), ("lda", i64), ("ldb", i64), ("ldc", i64),
-                ("alpha", f32)]
+                ("alpha", f32), ("rows_out", i32)]
 
 
 TN_GROUP_MAX = 8
@@ -106,7 +106,7 @@ SIGNATURES = {
     "lako_sumsq": [vp, i64, vp, vp],
     "lako_adamw_step": [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, f32, f32, i32, vp],
     "lako_transpose_cast": [vp, vp, i64, i64, i32, vp],
-    "lako_transpose_cast_batched": [vp, vp, vp, vp, i32, i32, i32, vp],
+    "lako_transpose_cast_batched": [vp, i32, vp, vp, vp, i32, i32, i32, vp],
     "lako_cast": [vp, vp, i64, i32, vp],
     "lako_dropout_apply": [vp, vp, i64, i32, Dropout, vp],
     "lako_shift_right": [vp, vp, i32, i32, vp],

@@ -1039,6 +1039,8 @@ struct TnArgs {
   int tiles_m, tiles_n, split_k, k_chunk;  // k_chunk: rows of K per split (multiple of 64)
   int no_atomics;   // timing experiment (gemm_tn_big = 2): skip the accumulation
   int glds;         // 1: whole K-steps staged by global_load_lds (tuning nt_glds)
+  int Mout;         // output rows actually written (<= M; single-problem launches)
+  int out_mode;     // 256² kernel with ONE K-split: 0 fp32 atomics, 1 plain read-modify-write (C += v), 2 overwrite (C = v)
   // grouped launch (gemm_tn256_kernel): n_items > 0 → tile id t belongs to the last item with tile_start <= t
   int n_items;
   struct Item {
@@ -1047,6 +1049,7 @@ struct TnArgs {
     int M, N, tiles_n, tile_start;
     int64_t lda, ldb, ldc;
     float alpha;
+    int Mout;     // output rows actually written (lako_gemm_tn_item_t.rows_out)
   } items[LAKO_TN_GROUP_MAX];
 };
 
@@ -1183,7 +1186,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int m = m0 + wr * 64 + mt * 16 + 4 * g + r;
-      if (m >= a.M) continue;
+      if (m >= a.Mout) continue;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         const int n = n0 + wc * 64 + nt * 16 + r16;
@@ -1202,9 +1205,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs a) {
 // ---------------------------------------------------------------------------------------------
 constexpr int TN2_ROWB = 512, TN2_IMG = 64 * TN2_ROWB;  // 64 k-rows × 256 columns of bf16 = 32 KiB
 
-// GLDS: every k-row of the step exists (the host picks this instantiation only when K % 64 == 0 and every split is a multiple of 64):
-// global_load_lds, no descriptor (see lds_dma16_g) — k-rows past the end of K would have to read as zeros, which only the buffer form's
-// range check provides.  Columns past the edge are clamped to the last valid 16 bytes (they feed outputs that are never added).
+// GLDS: every k-row of the step exists (the kernel stages a K range's incomplete step by the buffer form, see there; every split is a
+// multiple of 64 rows): global_load_lds, no descriptor (see lds_dma16_g) — k-rows past the end of K would have to read as zeros, which
+// only the buffer form's range check provides.  Columns past the edge are clamped to the last valid 16 bytes (they feed outputs that
+// are never added).
 template <bool GLDS>
 __device__ __forceinline__ void stage_cols256(char* img, const char* base, int krows_valid, int64_t ld_bytes,
                                               int colbytes_valid, int wave, int lane) {
@@ -1272,7 +1276,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(TnArgs a) {
     tid -= it.tile_start;
   } else {
     it.A = a.A; it.B = a.B; it.C = a.C; it.M = a.M; it.N = a.N; it.tiles_n = a.tiles_n;
-    it.lda = a.lda; it.ldb = a.ldb; it.ldc = a.ldc; it.alpha = a.alpha;
+    it.lda = a.lda; it.ldb = a.ldb; it.ldc = a.ldc; it.alpha = a.alpha; it.Mout = a.Mout;
   }
   const int tile_m = tid / it.tiles_n, tile_n = tid % it.tiles_n;
   const int m0 = tile_m * 256, n0 = tile_n * 256;
@@ -1292,8 +1296,17 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(TnArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  stage_cols256<GLDS>(smem, Abase, krows, lda_b, acols_b, wave, lane);
-  stage_cols256<GLDS>(smem + TN2_IMG, Bbase, krows, ldb_b, bcols_b, wave, lane);
+  // GLDS: the K range's incomplete last step (krows % 64 k-rows: they must be zero-filled, which only the buffer form does) is
+  // processed FIRST, staged here by the buffer form; every step staged inside the loop is then whole and goes by global_load_lds —
+  // both forms inside the loop cost 40 registers (spills).  The sum over k does not care about the order of the steps.
+  const int tail = GLDS ? (krows & 63) : 0;
+  if (tail) {
+    stage_cols256<false>(smem, Abase + (int64_t)(krows - tail) * lda_b, tail, lda_b, acols_b, wave, lane);
+    stage_cols256<false>(smem + TN2_IMG, Bbase + (int64_t)(krows - tail) * ldb_b, tail, ldb_b, bcols_b, wave, lane);
+  } else {
+    stage_cols256<GLDS>(smem, Abase, krows, lda_b, acols_b, wave, lane);
+    stage_cols256<GLDS>(smem + TN2_IMG, Bbase, krows, ldb_b, bcols_b, wave, lane);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -1304,7 +1317,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(TnArgs a) {
     auto prefetch = [&]() {
       if (t + 1 < nk) {
         char* An = smem + (cur ^ 1) * 2 * TN2_IMG;
-        const int kr = (t + 1) * 64;
+        const int kr = (t + 1 - (tail ? 1 : 0)) * 64;      // (with a tail step in front, loop step t + 1 is whole step t)
         stage_cols256<GLDS>(An, Abase + (int64_t)kr * lda_b, krows - kr, lda_b, acols_b, wave, lane);
         stage_cols256<GLDS>(An + TN2_IMG, Bbase + (int64_t)kr * ldb_b, krows - kr, ldb_b, bcols_b, wave, lane);
       }
@@ -1366,7 +1379,14 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(TnArgs a) {
       #ifdef LAKO_EXPERIMENTS
       if (a.no_atomics) continue;
 #endif
-      if (m < it.M && n < it.N) atomicAdd(it.C + (int64_t)m * it.ldc + n, v);
+      if (m < it.Mout && n < it.N) {
+        float* cp = it.C + (int64_t)m * it.ldc + n;
+        // one K-split and nobody else adding to C (the caller's promise, split_k < 0): 256 contiguous bytes per wave-instruction as
+        // plain loads / stores at the chip's copy rate instead of float atomics at ≈1.3 TB/s
+        if (a.out_mode == 2) *cp = v;
+        else if (a.out_mode == 1) *cp += v;
+        else atomicAdd(cp, v);
+      }
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -2058,11 +2078,23 @@ static int tn_pick_split(int tiles, int64_t K, int max_split) {
   return best;
 }
 
+static int tn_single(const void* A, const void* B, float* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                     int in_dtype, float alpha, int split_k, const lako_tuning_t* tuning, lako_stream_t stream, int rows_out);
+
 extern "C" int lako_gemm_tn(const void* A, const void* B, float* C, int64_t M, int64_t N, int64_t K, int64_t lda,
                             int64_t ldb, int64_t ldc, int in_dtype, float alpha, int split_k, const lako_tuning_t* tuning,
                             lako_stream_t stream) {
+  return tn_single(A, B, C, M, N, K, lda, ldb, ldc, in_dtype, alpha, split_k, tuning, stream, 0);
+}
+
+// rows_out: 0 = M, else only the first rows_out rows of C are written (lako_gemm_tn_item_t.rows_out)
+static int tn_single(const void* A, const void* B, float* C, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                     int in_dtype, float alpha, int split_k, const lako_tuning_t* tuning, lako_stream_t stream, int rows_out) {
   const lako_tuning_t& tu = tuning ? *tuning : process_tuning();
   LAKO_CHECK_ARG(M > 0 && N > 0 && K > 0, "lako_gemm_tn: bad dims");
+  LAKO_CHECK_ARG(split_k >= -2, "lako_gemm_tn: split_k %d", split_k);
+  const int out_mode = split_k < 0 ? -split_k : 0;      // -1: exclusive read-modify-write, -2: overwrite (one K-split either way)
+  if (split_k < 0) split_k = 1;
   LAKO_CHECK_ARG(in_dtype == LAKO_F32 || in_dtype == LAKO_BF16, "lako_gemm_tn: bad in_dtype");
   const int esz = in_dtype == LAKO_F32 ? 4 : 2;
   LAKO_CHECK_ARG((M * esz) % 16 == 0 && (N * esz) % 16 == 0 && (lda * esz) % 16 == 0 && (ldb * esz) % 16 == 0,
@@ -2083,6 +2115,8 @@ extern "C" int lako_gemm_tn(const void* A, const void* B, float* C, int64_t M, i
   a.ldb = ldb;
   a.ldc = ldc;
   a.alpha = alpha;
+  LAKO_CHECK_ARG(rows_out >= 0 && rows_out <= M, "lako_gemm_tn: rows_out");
+  a.Mout = rows_out > 0 ? rows_out : (int)M;
   a.tiles_m = cdiv(M, TM);
   a.tiles_n = cdiv(N, TN_);
   hipStream_t s = (hipStream_t)stream;
@@ -2102,11 +2136,11 @@ extern "C" int lako_gemm_tn(const void* A, const void* B, float* C, int64_t M, i
     a.split_k = cdiv(K, chunk);
     a.k_chunk = chunk;
     a.no_atomics = tu.tn_big == 2;
-  a.glds = tu.nt_glds;
     a.glds = tu.nt_glds;
+    a.out_mode = a.split_k == 1 ? out_mode : 0;
     LAKO_CHECK_ARG((int64_t)64 * lda * 2 < (1ll << 31) && (int64_t)64 * ldb * 2 < (1ll << 31),
                    "lako_gemm_tn: leading dimension too large");
-    if (a.glds && K % 64 == 0) {
+    if (a.glds && a.k_chunk % 64 == 0) {
       LAKO_SET_MAX_LDS((&gemm_tn256_kernel<true>), 4 * TN2_IMG);
       hipLaunchKernelGGL(gemm_tn256_kernel<true>, dim3(tiles * a.split_k), dim3(512), 4 * TN2_IMG, s, a);
     } else {
@@ -2115,6 +2149,12 @@ extern "C" int lako_gemm_tn(const void* A, const void* B, float* C, int64_t M, i
     }
     LAKO_LAUNCH_CHECK();
     return LAKO_OK;
+  }
+  if (out_mode == 2) {      // the small-tile kernel only adds: overwrite = zero, then add
+    if (hipMemset2DAsync(C, (size_t)ldc * 4, 0, (size_t)N * 4, (size_t)a.Mout, (hipStream_t)stream) != hipSuccess) {
+      lako_set_error("lako_gemm_tn: could not zero the output");
+      return LAKO_E_LAUNCH;
+    }
   }
   const int kr = in_dtype == LAKO_BF16 ? 64 : 32;
   if (split_k <= 0) {  // auto: aim at >= 2 workgroups per CU, at least 4 K-steps per split
@@ -2141,13 +2181,14 @@ extern "C" int lako_gemm_tn_grouped(const lako_gemm_tn_item_t* items, int n_item
                                     const lako_tuning_t* tuning, lako_stream_t stream) {
   const lako_tuning_t& tu = tuning ? *tuning : process_tuning();
   LAKO_CHECK_ARG(items && n_items >= 1 && n_items <= LAKO_TN_GROUP_MAX, "lako_gemm_tn_grouped: 1..%d items", LAKO_TN_GROUP_MAX);
+  LAKO_CHECK_ARG(split_k >= -2, "lako_gemm_tn_grouped: split_k %d", split_k);
   LAKO_CHECK_ARG(K > 0 && K < (1 << 30), "lako_gemm_tn_grouped: bad K");
   bool big = in_dtype == LAKO_BF16 && tu.tn_big;
   for (int i = 0; i < n_items; ++i) big = big && items[i].M >= 256 && items[i].N >= 256;
-  if (!big || n_items == 1) {   // shapes the 256×256 kernel does not take: one launch per problem
+  if (!big) {   // shapes the 256×256 kernel does not take: one launch per problem
     for (int i = 0; i < n_items; ++i) {
-      int rc = lako_gemm_tn(items[i].a, items[i].b, items[i].c, items[i].M, items[i].N, K, items[i].lda, items[i].ldb,
-                            items[i].ldc, in_dtype, items[i].alpha, split_k, tuning, stream);
+      int rc = tn_single(items[i].a, items[i].b, items[i].c, items[i].M, items[i].N, K, items[i].lda, items[i].ldb,
+                         items[i].ldc, in_dtype, items[i].alpha, split_k, tuning, stream, items[i].rows_out);
       if (rc != LAKO_OK) return rc;
     }
     return LAKO_OK;
@@ -2171,6 +2212,8 @@ extern "C" int lako_gemm_tn_grouped(const lako_gemm_tn_item_t* items, int n_item
     TnArgs::Item& d = a.items[i];
     d.A = (const char*)p.a; d.B = (const char*)p.b; d.C = p.c; d.M = (int)p.M; d.N = (int)p.N;
     d.lda = p.lda; d.ldb = p.ldb; d.ldc = p.ldc; d.alpha = p.alpha;
+    LAKO_CHECK_ARG(p.rows_out >= 0 && p.rows_out <= p.M, "lako_gemm_tn_grouped: item %d: rows_out", i);
+    d.Mout = p.rows_out > 0 ? p.rows_out : (int)p.M;
     d.tiles_n = cdiv((int)p.N, 256);
     d.tile_start = tiles;
     tiles += cdiv((int)p.M, 256) * d.tiles_n;
@@ -2181,12 +2224,14 @@ extern "C" int lako_gemm_tn_grouped(const lako_gemm_tn_item_t* items, int n_item
   int sk = tn_pick_split(tiles, K, max_split);
   if (tu.tn_split > 0) sk = tu.tn_split;
   if (split_k > 0) sk = split_k;
+  if (split_k < 0) sk = 1;
   if (sk > max_split) sk = max_split;
   if (sk < 1) sk = 1;
   const int chunk = cdiv(cdiv(K, sk), 64) * 64;
   a.split_k = cdiv(K, chunk);
   a.k_chunk = chunk;
-  if (a.glds && K % 64 == 0) {
+  a.out_mode = (split_k < 0 && a.split_k == 1) ? -split_k : 0;
+  if (a.glds && a.k_chunk % 64 == 0) {
     LAKO_SET_MAX_LDS((&gemm_tn256_kernel<true>), 4 * TN2_IMG);
     hipLaunchKernelGGL(gemm_tn256_kernel<true>, dim3(tiles * a.split_k), dim3(512), 4 * TN2_IMG, (hipStream_t)stream, a);
   } else {

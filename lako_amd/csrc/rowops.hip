@@ -427,8 +427,8 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __rest
 
 // All weight matrices of the model in ONE launch (122 matrices at T5-base: one launch instead of 122 of ≈8 µs each).
 // desc[i] = {src offset, dst offset (elements), rows, cols}; tile_prefix[i] = first 64×64 tile of matrix i.
-template <typename T>
-__global__ __launch_bounds__(256) void transpose_cast_batched_kernel(const float* __restrict__ src_base, T* __restrict__ dst_base,
+template <typename T, typename TS>
+__global__ __launch_bounds__(256) void transpose_cast_batched_kernel(const TS* __restrict__ src_base, T* __restrict__ dst_base,
                                                                      const int64_t* __restrict__ desc,
                                                                      const int32_t* __restrict__ tile_prefix, int n) {
   __shared__ float tile[64][65];
@@ -438,24 +438,24 @@ __global__ __launch_bounds__(256) void transpose_cast_batched_kernel(const float
     if (tile_prefix[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
   }
   const int64_t* dd = desc + 4 * lo;
-  const float* src = src_base + dd[0];
+  const TS* src = src_base + dd[0];
   T* dst = dst_base + dd[1];
   const int64_t rows = dd[2], cols = dd[3];
   const int t = blockIdx.x - tile_prefix[lo];
   const int tiles_c = (int)((cols + 63) >> 6);
   const int64_t r0 = (int64_t)(t / tiles_c) * 64, c0 = (int64_t)(t % tiles_c) * 64;
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;   // 16 × 16; a thread reads 4 consecutive floats
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;   // 16 × 16; a thread reads 4 consecutive elements
   const bool vec = (cols % 4 == 0) && (rows % 4 == 0);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int64_t r = r0 + ty + 16 * j, c = c0 + 4 * tx;
     if (vec && r < rows && c + 3 < cols) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(src + r * cols + c);
+      const f32x4 v = load4(src + r * cols + c);
 #pragma unroll
       for (int e = 0; e < 4; ++e) tile[ty + 16 * j][4 * tx + e] = v[e];
     } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) tile[ty + 16 * j][4 * tx + e] = (r < rows && c + e < cols) ? src[r * cols + c + e] : 0.f;
+      for (int e = 0; e < 4; ++e) tile[ty + 16 * j][4 * tx + e] = (r < rows && c + e < cols) ? to_f32(src[r * cols + c + e]) : 0.f;
     }
   }
   __syncthreads();
@@ -1021,15 +1021,22 @@ extern "C" int lako_transpose_cast(const float* src, void* dst, int64_t rows, in
   return LAKO_OK;
 }
 
-extern "C" int lako_transpose_cast_batched(const float* src_base, void* dst_base, const int64_t* desc,
+extern "C" int lako_transpose_cast_batched(const void* src_base, int src_dtype, void* dst_base, const int64_t* desc,
                                            const int32_t* tile_prefix, int n, int total_tiles, int dtype,
                                            lako_stream_t stream) {
   CHECK_DTYPE("lako_transpose_cast_batched", dtype);
+  CHECK_DTYPE("lako_transpose_cast_batched (source)", src_dtype);
+  LAKO_CHECK_ARG(src_dtype == LAKO_F32 || dtype == LAKO_BF16, "lako_transpose_cast_batched: a bf16 source has bf16 copies only");
   LAKO_CHECK_ARG(n > 0 && total_tiles > 0 && desc && tile_prefix, "lako_transpose_cast_batched: empty table");
-  LAKO_CHECK_ALIGN(src_base, 16);
+  LAKO_CHECK_ALIGN(src_base, 8);
   LAKO_CHECK_ALIGN(dst_base, 16);
-  DISPATCH_T(dtype, hipLaunchKernelGGL((transpose_cast_batched_kernel<T>), dim3((unsigned)total_tiles), dim3(256), 0,
-                                       (hipStream_t)stream, src_base, (T*)dst_base, desc, tile_prefix, n));
+  if (src_dtype == LAKO_BF16) {
+    hipLaunchKernelGGL((transpose_cast_batched_kernel<bf16_t, bf16_t>), dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)src_base, (bf16_t*)dst_base, desc, tile_prefix, n);
+  } else {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((transpose_cast_batched_kernel<T, float>), dim3((unsigned)total_tiles), dim3(256), 0,
+                                         (hipStream_t)stream, (const float*)src_base, (T*)dst_base, desc, tile_prefix, n));
+  }
   LAKO_LAUNCH_CHECK();
   return LAKO_OK;
 }

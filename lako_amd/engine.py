@@ -255,8 +255,10 @@ class Engine:
                 out[name] = v[r0:r0 + nr] if len(b.shape) == 2 else v
         return out
 
-    def refresh_transposed(self):
-        """WT ← transposed compute-dtype copies of every GEMM weight in P, one launch over a static table."""
+    def refresh_transposed(self, from_shadow=False):
+        """WT ← transposed compute-dtype copies of every GEMM weight in P, one launch over a static table.  from_shadow: the
+        compute-dtype shadow W is current (the fused optimizer step has just written it) — transpose IT: identical values
+        (W = bf16(P) element for element) from half the bytes (446 instead of 892 MB at T5-base)."""
         if self._tr_table is None:
             mats = [b for b in self.blocks if b.transpose]
             desc, prefix, total = [], [], 0
@@ -266,7 +268,8 @@ class Engine:
                 total += -(-b.shape[0] // 64) * -(-b.shape[1] // 64)
             self._tr_table = (torch.tensor(desc, dtype=torch.int64, device=self.device),
                               torch.tensor(prefix, dtype=torch.int32, device=self.device), len(mats), total)
-        self.ops.transpose_cast_batched(self.P, self.WT, *self._tr_table)
+        src = self.W if (from_shadow and self.W is not self.P and self.W.dtype == self.WT.dtype) else self.P
+        self.ops.transpose_cast_batched(src, self.WT, *self._tr_table)
 
     def refresh_shadows(self):
         """Re-derive the compute-dtype copies (W, WT) from the fp32 master after it changed."""
@@ -280,7 +283,7 @@ class Engine:
     def refresh_after_step(self):
         """After the fused optimizer step (which wrote P and the compute-dtype shadow W in one pass): every DERIVED copy of the
         weights — the transposed shadows and, in fp8 mode, the e4m3 + block-scale shadows the forward GEMMs multiply with."""
-        self.refresh_transposed()
+        self.refresh_transposed(from_shadow=True)
         if self.fp8:
             self.refresh_fp8()
         self.shadows_stale = False
@@ -619,13 +622,15 @@ class Engine:
         K = layers·2R (weight-gradient form: both operands K-major), fp32, then rounded once to the compute dtype."""
         ops, d = self.ops, self.cfg.d_model
         de = self._buf(tmp, "x.de", (xb["rows"] + 8, d), torch.float32)[:Me + 8]    # sized for the padded batch
-        ops.zero_(de)
         items = []
         for b in range(len(xa.k_h) - 1):
-            n8 = -(-(xa.k_h[b + 1] - xa.k_h[b]) // 8) * 8      # rows past the sample's keys add its zero padding columns
-            items.append((xb["ps"][:, xa.p_h[b]:xa.p_h[b] + n8], xb["dq"][b], de[xa.k_h[b]:xa.k_h[b] + n8], 1.0))
-        ops.gemm_tn_grouped(items, split_k=1)      # one contributor per element: dE feeds the encoder's bf16 backward, keep it
-        if dxe.dtype == torch.float32:                 # independent of the order workgroups finish in
+            nk = xa.k_h[b + 1] - xa.k_h[b]
+            n8 = -(-nk // 8) * 8      # the operand loads want a multiple of 8 columns (the score matrices' zero padding); only the
+            items.append((xb["ps"][:, xa.p_h[b]:xa.p_h[b] + n8], xb["dq"][b], de[xa.k_h[b]:xa.k_h[b] + n8], 1.0, nk))   # sample's nk rows are written
+        # one contributor per element, every element of dE written exactly once by plain stores (split_k −2: no zero fill, no atomics)
+        # — dE feeds the encoder's bf16 backward: independent of the order workgroups finish in
+        ops.gemm_tn_grouped(items, split_k=-2)
+        if dxe.dtype == torch.float32:
             dxe.copy_(de[:Me])
         else:
             ops.cast(de[:Me].view(-1), dxe.view(-1))
@@ -970,8 +975,8 @@ class Engine:
         dw_all = []      # every decoder weight gradient of the step (K = B·T rows): grouped launches after the last layer
         self._run_chains(ctx.chains, Ld, lambda i, ch: self._dec_layer_bwd(ws, tmp, i, ch, dh, drel, kv, dkv, fused, T, S, dw_all),
                          reverse=True)
-        if dw_all:
-            ops.gemm_tn_grouped(dw_all)
+        if dw_all:      # (K = B·T rows: one K-split; the chains have joined and nothing else touches these gradients: plain read-modify-write)
+            ops.gemm_tn_grouped(dw_all, split_k=-1)
         ops.relpos_reduce(drel, self._lut(T, T, False), self.dec_rel.g)
         # ---- cross K/V projection of all decoder layers -----------------------------------------
         deh = self._buf(tmp, "e.dh", (Me, d))

@@ -189,14 +189,17 @@ class HipOps:
                                     self._tuning_p, self._stream()), "lako_gemm_tn"))
 
     def gemm_tn_grouped(self, problems, split_k=0):
-        """[(A [K, M], B [K, N], C [M, N] fp32, alpha), …] with one K: every C += alpha·Aᵀ·B, one launch per
-        TN_GROUP_MAX problems (see lako_gemm_tn_grouped in include/lako_hip.h).  split_k=1: one contributor per output element."""
+        """[(A [K, M], B [K, N], C [M, N] fp32, alpha[, rows_out]), …] with one K: every C += alpha·Aᵀ·B, one launch per
+        TN_GROUP_MAX problems (see lako_gemm_tn_grouped in include/lako_hip.h).  split_k=1: one contributor per output element;
+        −1: the same and nothing else adds to C meanwhile (plain read-modify-write); −2: C is overwritten."""
         from ._lib import TN_GROUP_MAX, GemmTNItem
         for g0 in range(0, len(problems), TN_GROUP_MAX):
             grp = problems[g0:g0 + TN_GROUP_MAX]
             arr = (GemmTNItem * len(grp))()
             K0, flops = None, 0.0
-            for it, (A, B, Cm, alpha) in zip(arr, grp):
+            for it, prob in zip(arr, grp):
+                A, B, Cm, alpha = prob[:4]
+                it.rows_out = int(prob[4]) if len(prob) > 4 else 0       # (A, B, C, alpha[, rows of C actually written])
                 K, M, lda = _rowmajor2d(A, "gemm_tn_grouped A")
                 K2, N, ldb = _rowmajor2d(B, "gemm_tn_grouped B")
                 M2, N2, ldc = _rowmajor2d(Cm, "gemm_tn_grouped C")
@@ -448,10 +451,12 @@ class HipOps:
         self._timed("transpose_cast", 0.0, lambda: check(self.lib.lako_transpose_cast(_p(src), _p(dst), rows, cols, _dt(dst), self._stream()), "lako_transpose_cast"))
 
     def transpose_cast_batched(self, src_flat, dst_flat, desc, tile_prefix, n, total_tiles):
-        """every [rows, cols] fp32 matrix of the table → its [cols, rows] compute-dtype copy, one launch (desc and
-        tile_prefix are device tensors: see lako_transpose_cast_batched in include/lako_hip.h)"""
+        """every [rows, cols] matrix of the table (fp32, or bf16 for bf16 copies) → its [cols, rows] compute-dtype copy, one launch
+        (desc and tile_prefix are device tensors: see lako_transpose_cast_batched in include/lako_hip.h)"""
+        if src_flat.dtype not in (torch.float32, torch.bfloat16) or (src_flat.dtype == torch.bfloat16 and dst_flat.dtype != torch.bfloat16):
+            raise LakoError("transpose_cast_batched: fp32 source, or bf16 source with bf16 copies")
         self._timed("transpose_cast", 0.0, lambda: check(self.lib.lako_transpose_cast_batched(
-            _p(src_flat), _p(dst_flat), _p(desc), _p(tile_prefix), int(n), int(total_tiles), _dt(dst_flat), self._stream()),
+            _p(src_flat), _dt(src_flat), _p(dst_flat), _p(desc), _p(tile_prefix), int(n), int(total_tiles), _dt(dst_flat), self._stream()),
             "lako_transpose_cast_batched"))
 
     def cast(self, src, dst):

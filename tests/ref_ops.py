@@ -124,12 +124,18 @@ class RefOps:
         else:
             Cm.copy_(v)
 
-    def gemm_tn(self, A, B, Cm, *, alpha=1.0, split_k=0):
-        Cm += (f(A).t() @ f(B)) * alpha
+    def gemm_tn(self, A, B, Cm, *, alpha=1.0, split_k=0, rows_out=0):
+        v = (f(A).t() @ f(B)) * alpha
+        r = rows_out or Cm.shape[0]
+        if split_k == -2:       # overwrite
+            Cm[:r].copy_(v[:r])
+        else:
+            Cm[:r] += v[:r]
 
     def gemm_tn_grouped(self, problems, split_k=0):
-        for A, B, Cm, alpha in problems:
-            self.gemm_tn(A, B, Cm, alpha=alpha)
+        for prob in problems:
+            A, B, Cm, alpha = prob[:4]
+            self.gemm_tn(A, B, Cm, alpha=alpha, split_k=split_k, rows_out=prob[4] if len(prob) > 4 else 0)
 
     # ---- norm / embedding / dropout ------------------------------------------------------------
     def rmsnorm_fwd(self, x, w, y, rstd, eps, drop=None):

@@ -321,6 +321,43 @@ def test_gemm_tn_grouped(ops, ref, dt):
             close(Cg, Cr, T, f"gemm_tn_grouped {dt} {M}x{N}", tight=True)
 
 
+def test_gemm_tn_exclusive_and_overwrite(ops, ref):
+    """lako_gemm_tn_grouped with split_k −1 (one contributor, nothing else adds meanwhile: C += v by plain loads / stores) and −2 (C = v:
+    no zeroed C), and rows_out < M: a problem whose true row count is not a multiple of 8 touches only its own rows — two such problems
+    written side by side into one buffer (the encoder-state gradient of the cross-attention: one problem per sample) never overwrite
+    each other's rows, whatever order the workgroups finish in."""
+    T = torch.bfloat16
+    K = 2304
+    ks = [1003, 517, 2049]                       # "keys" per sample, none a multiple of 8
+    tot = sum(ks)
+    P = rnd(K, 3 * 2304, dtype=T, seed=81)
+    D = [rnd(K, 768, dtype=T, seed=82 + i) for i in range(3)]
+    off = [0, ks[0], ks[0] + ks[1]]
+    for mode in (-2, -1):
+        out = torch.full((tot + 8, 768), 3.0, device=dev())
+        want = out.clone()
+        items, items_r = [], []
+        p0 = 0
+        for i, nk in enumerate(ks):
+            n8 = -(-nk // 8) * 8
+            A = P[:, p0:p0 + n8].clone()
+            A[:, nk:] = 0                          # (the score matrices' zero padding columns)
+            items.append((A, D[i], out[off[i]:off[i] + n8], 0.5, nk))
+            items_r.append((A, D[i], want[off[i]:off[i] + n8], 0.5, nk))
+            p0 += 2304
+        ops.gemm_tn_grouped(items, split_k=mode)
+        ref.gemm_tn_grouped(items_r, split_k=mode)
+        close(out, want, T, f"gemm_tn_grouped split_k {mode}", tight=True)
+        assert torch.all(out[tot:] == 3.0)
+    # one problem, K = 128 (the decoder's deferred weight gradients): exclusive read-modify-write accumulates
+    A, B = rnd(128, 768, dtype=T, seed=91), rnd(128, 3072, dtype=T, seed=92)
+    C = torch.full((768, 3072), 1.0, device=dev())
+    Cr = C.clone()
+    ops.gemm_tn_grouped([(A, B, C, 1.0)] * 1 + [(B, A, torch.zeros(3072, 768, device=dev()), 1.0)], split_k=-1)
+    ref.gemm_tn_grouped([(A, B, Cr, 1.0)], split_k=-1)
+    close(C, Cr, T, "gemm_tn_grouped exclusive rmw", tight=True)
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("M,N,K", [(128, 768, 32128), (40, 264, 5000), (128, 132, 2048)])
 def test_gemm_nt_split_k_atomic(ops, ref, dt, M, N, K):
@@ -793,6 +830,11 @@ def test_optimizer(ops, ref):
                                    len(shapes), tiles)
         for (r, c), o in zip(shapes, offs):
             assert torch.equal(out[o:o + r * c].view(c, r), flat[o:o + r * c].view(r, c).t().to(T)), (r, c, T)
+    # from the bf16 shadow (what the training step does after the optimizer wrote it): the same copies from half the bytes
+    out2 = torch.full((total,), 7.0, dtype=torch.bfloat16, device=dev())
+    ops.transpose_cast_batched(flat.bfloat16(), out2, torch.tensor(desc, device=dev()), torch.tensor(prefix, dtype=torch.int32, device=dev()),
+                               len(shapes), tiles)
+    assert torch.equal(out2, out)
 
 
 def test_int_helpers(ops, ref):
