@@ -13,6 +13,8 @@
 #   c45                     BASELINE configs 4 and 5 (T5-large, 40 / 100 passages, batch 8)
 #   generate                tools/generate_probe.py
 #   pmcstep                 whole-step PMC totals (three separate --pmc passes)
+#   pmcgemm                 FETCH_SIZE / WRITE_SIZE of the encoder GEMM shapes at 48 000 and 64 000 rows → gemm_traffic*.json; MFMA-busy pass
+#   pmcattn                 SQ / MFMA counters of the encoder attention kernels (tools/attn_probe.py)
 #   full                    = tests "" smoke bench trace c45 generate
 set -x
 TAG=${TAG:-round}
@@ -56,6 +58,21 @@ step_pmcstep() {
   done
   python tools/pmc_step_totals.py /tmp/pmcstep 8 | tee $OUT/step_pmc_totals.txt
 }
+step_pmcgemm() {
+  cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+  LAKO_PROBE_TOKENS=48000 bash tools/run_pmc.sh /tmp/pmc_g48 tools/gemm_probe.py fetch write mfma
+  LAKO_PROBE_TOKENS=64000 bash tools/run_pmc.sh /tmp/pmc_g64 tools/gemm_probe.py fetch write
+  python tools/gemm_traffic.py /tmp/pmc_g48 48000 > $OUT/gemm_traffic.json
+  python tools/gemm_traffic.py /tmp/pmc_g64 64000 > $OUT/gemm_traffic_padded.json
+  python tools/pmc_summary.py /tmp/pmc_g48 --match gemm_ > $OUT/gemm_mfma_pmc.txt 2>&1
+  head -c 600 $OUT/gemm_traffic.json; tail -12 $OUT/gemm_mfma_pmc.txt
+}
+step_pmcattn() {
+  cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+  bash tools/run_pmc.sh /tmp/pmc_attn tools/attn_probe.py sq1 sq2 mfma
+  python tools/pmc_summary.py /tmp/pmc_attn --match enc_ > $OUT/attn_pmc.txt 2>&1
+  tail -30 $OUT/attn_pmc.txt
+}
 [ $# -eq 0 ] && set -- full
 while [ $# -gt 0 ]; do
   s=$1; shift
@@ -64,7 +81,7 @@ while [ $# -gt 0 ]; do
     ab) step_ab "$1"; shift;;
     ops) step_ops "$1"; shift;;
     full) step_tests ""; step_smoke; step_bench; step_trace; step_c45; step_generate;;
-    smoke|bench|quick|trace|c45|generate|pmcstep) step_$s;;
+    smoke|bench|quick|trace|c45|generate|pmcstep|pmcgemm|pmcattn) step_$s;;
     *) echo "unknown step $s"; exit 2;;
   esac
 done
