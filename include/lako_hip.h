@@ -154,7 +154,14 @@ typedef struct {
                        into its neighbour's output (round 4: needed once C is overwritten rather than added to) */
 } lako_gemm_tn_item_t;
 int lako_gemm_tn_grouped(const lako_gemm_tn_item_t* items, int n_items, int64_t K, int in_dtype, int split_k,
-                         const lako_tuning_t* tuning, lako_stream_t stream);
+                         const lako_tuning_t* tuning, void* workspace, int64_t workspace_bytes, lako_stream_t stream);
+/* workspace (round 4; optional — NULL keeps the float atomics): caller-owned scratch of at least
+ * lako_gemm_tn_grouped_workspace(...) bytes for the SAME arguments (0 = this launch needs none).  With it the K-splits of a tile meet
+ * through fp32 partial tiles and one arrival counter per tile: every split stores its partial, the split that arrives last sums them in
+ * split order and adds the tile to C by plain loads / stores — no atomics, and the result no longer depends on the order workgroups
+ * finish in.  The scratch may be reused by the next launch on the same stream; it holds nothing between launches. */
+int64_t lako_gemm_tn_grouped_workspace(const lako_gemm_tn_item_t* items, int n_items, int64_t K, int in_dtype, int split_k,
+                                       const lako_tuning_t* tuning);
 
 /* ---- T5LayerNorm (RMSNorm, HF5:59-72): y = dropout(x * rsqrt(mean(x²) + eps) * w) ----------------
  * rstd [rows] fp32 is written for the backward.  w is fp32 [d]. */

@@ -1040,6 +1040,8 @@ struct TnArgs {
   int no_atomics;   // timing experiment (gemm_tn_big = 2): skip the accumulation
   int glds;         // 1: whole K-steps staged by global_load_lds (tuning nt_glds)
   int Mout;         // output rows actually written (<= M; single-problem launches)
+  float* slabs;     // several K-splits WITHOUT atomics: [tile][split][64 Ki floats] partial tiles + tickets (below); nullptr = atomics
+  int* tickets;     // [tiles] arrival counters, zeroed before the launch
   int out_mode;     // 256² kernel with ONE K-split: 0 fp32 atomics, 1 plain read-modify-write (C += v), 2 overwrite (C = v)
   // grouped launch (gemm_tn256_kernel): n_items > 0 → tile id t belongs to the last item with tile_start <= t
   int n_items;
@@ -1264,6 +1266,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(TnArgs a) {
   const int flat = xcd_remap(blockIdx.x, gridDim.x);   // one XCD ← consecutive (split, tile) ids
   const int split = flat / ntile;
   int tid = flat % ntile;
+  const int gtile = tid;      // tile id over all problems of the launch (slab / ticket index)
   // the problem this tile belongs to (one problem, or up to LAKO_TN_GROUP_MAX weight gradients sharing K = tokens: with
   // more tiles per launch fewer K-splits fill the chip, and every split costs one fp32 atomic pass over the output)
   TnArgs::Item it;
@@ -1360,6 +1363,52 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(TnArgs a) {
     }
   }
 
+  // SLAB REDUCTION of the K-splits (round 4; cdna_hip_programming.md "in-launch split-K reduction", counter form): every split writes its
+  // fp32 partial tile with plain 16-byte stores (accumulator order: a wave-instruction writes 1 KiB), drains them, ONE lane issues an
+  // agent-scope release fence and draws a ticket; the workgroup that draws the last ticket acquires, sums ALL splits' slabs in split
+  // order (its own included: the sum does not depend on who arrived last — the gradients are bit-reproducible, which float atomics
+  // were not) and adds the tile to C by plain loads / stores.  Replaces two atomic passes over every tile (≈ 1.3 TB/s chip-wide).
+  if (a.slabs != nullptr && a.split_k > 1) {
+    float* mine = a.slabs + ((int64_t)gtile * a.split_k + split) * 65536 + (int64_t)wave * 8192;
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<f32x4*>(mine + ((mt * 4 + nt) * 64 + lane) * 4) = acc[mt][nt];
+      if (mt & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(smem);          // (the staging buffers are free after the K loop's last barrier)
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      *flag = __hip_atomic_fetch_add(a.tickets + gtile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const int ticket = *flag;
+    __syncthreads();                                    // (smem is reused as the transposition scratch below)
+    if (ticket != a.split_k - 1) return;
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      a.tickets[gtile] = 0;                             // (the host zeroes them before every launch as well)
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int sp = 0; sp < a.split_k; ++sp) {
+      const float* part = a.slabs + ((int64_t)gtile * a.split_k + sp) * 65536 + (int64_t)wave * 8192;
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt) {      // two rows of tiles' loads in flight at a time: all 32 at once cost 40 registers (spills)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] += *reinterpret_cast<const f32x4*>(part + ((mt * 4 + nt) * 64 + lane) * 4);
+        if (mt & 1) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  const int out_mode = (a.slabs != nullptr && a.split_k > 1) ? 1 : a.out_mode;
   // epilogue: per wave a private 16×64 fp32 slab in LDS (staging buffers are free after the last barrier)
   float* slab = reinterpret_cast<float*>(smem) + wave * 1024;
   const int r16 = lane & 15, g = lane >> 4;
@@ -1383,8 +1432,8 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(TnArgs a) {
         float* cp = it.C + (int64_t)m * it.ldc + n;
         // one K-split and nobody else adding to C (the caller's promise, split_k < 0): 256 contiguous bytes per wave-instruction as
         // plain loads / stores at the chip's copy rate instead of float atomics at ≈1.3 TB/s
-        if (a.out_mode == 2) *cp = v;
-        else if (a.out_mode == 1) *cp += v;
+        if (out_mode == 2) *cp = v;
+        else if (out_mode == 1) *cp += v;
         else atomicAdd(cp, v);
       }
     }
@@ -2139,6 +2188,8 @@ static int tn_single(const void* A, const void* B, float* C, int64_t M, int64_t 
     a.no_atomics = tu.tn_big == 2;
     a.glds = tu.nt_glds;
     a.out_mode = a.split_k == 1 ? out_mode : 0;
+    a.slabs = nullptr;
+    a.tickets = nullptr;
     LAKO_CHECK_ARG((int64_t)64 * lda * 2 < (1ll << 31) && (int64_t)64 * ldb * 2 < (1ll << 31),
                    "lako_gemm_tn: leading dimension too large");
     if (a.glds && a.k_chunk % 64 == 0) {
@@ -2178,8 +2229,36 @@ static int tn_single(const void* A, const void* B, float* C, int64_t M, int64_t 
   return LAKO_OK;
 }
 
+// K-splits the grouped launch would use (the same arithmetic as the launch itself)
+static int tn_grouped_plan(const lako_gemm_tn_item_t* items, int n_items, int64_t K, int split_k, const lako_tuning_t& tu, int* tiles_out) {
+  int tiles = 0;
+  for (int i = 0; i < n_items; ++i) tiles += cdiv((int)items[i].M, 256) * cdiv((int)items[i].N, 256);
+  const int max_split = cdiv(K, 64 * 4);
+  int sk = tn_pick_split(tiles, K, max_split);
+  if (tu.tn_split > 0) sk = tu.tn_split;
+  if (split_k > 0) sk = split_k;
+  if (split_k < 0) sk = 1;
+  if (sk > max_split) sk = max_split;
+  if (sk < 1) sk = 1;
+  const int chunk = cdiv(cdiv(K, sk), 64) * 64;
+  *tiles_out = tiles;
+  return cdiv(K, chunk);
+}
+
+extern "C" int64_t lako_gemm_tn_grouped_workspace(const lako_gemm_tn_item_t* items, int n_items, int64_t K, int in_dtype, int split_k,
+                                                  const lako_tuning_t* tuning) {
+  const lako_tuning_t& tu = tuning ? *tuning : process_tuning();
+  if (!items || n_items < 1 || n_items > LAKO_TN_GROUP_MAX || K <= 0 || in_dtype != LAKO_BF16 || !tu.tn_big) return 0;
+  for (int i = 0; i < n_items; ++i)
+    if (items[i].M < 256 || items[i].N < 256) return 0;
+  int tiles = 0;
+  const int sk = tn_grouped_plan(items, n_items, K, split_k, tu, &tiles);
+  if (sk <= 1) return 0;
+  return (int64_t)tiles * sk * 65536 * 4 + (int64_t)((tiles + 63) / 64) * 256;      // slabs + tickets (256-byte granules)
+}
+
 extern "C" int lako_gemm_tn_grouped(const lako_gemm_tn_item_t* items, int n_items, int64_t K, int in_dtype, int split_k,
-                                    const lako_tuning_t* tuning, lako_stream_t stream) {
+                                    const lako_tuning_t* tuning, void* workspace, int64_t workspace_bytes, lako_stream_t stream) {
   const lako_tuning_t& tu = tuning ? *tuning : process_tuning();
   LAKO_CHECK_ARG(items && n_items >= 1 && n_items <= LAKO_TN_GROUP_MAX, "lako_gemm_tn_grouped: 1..%d items", LAKO_TN_GROUP_MAX);
   LAKO_CHECK_ARG(split_k >= -2, "lako_gemm_tn_grouped: split_k %d", split_k);
@@ -2232,6 +2311,20 @@ extern "C" int lako_gemm_tn_grouped(const lako_gemm_tn_item_t* items, int n_item
   a.split_k = cdiv(K, chunk);
   a.k_chunk = chunk;
   a.out_mode = (split_k < 0 && a.split_k == 1) ? -split_k : 0;
+  a.slabs = nullptr;
+  a.tickets = nullptr;
+  if (a.split_k > 1 && workspace != nullptr) {      // K-splits meet through partial tiles in the caller's workspace instead of atomics
+    const int64_t slab_bytes = (int64_t)tiles * a.split_k * 65536 * 4, tick_bytes = (int64_t)((tiles + 63) / 64) * 256;
+    if (workspace_bytes >= slab_bytes + tick_bytes && reinterpret_cast<uintptr_t>(workspace) % 16 == 0) {
+      a.slabs = reinterpret_cast<float*>(workspace);
+      a.tickets = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + slab_bytes);
+      if (hipMemsetAsync(a.tickets, 0, (size_t)tick_bytes, (hipStream_t)stream) != hipSuccess) {
+        (void)hipGetLastError();
+        a.slabs = nullptr;
+        a.tickets = nullptr;
+      }
+    }
+  }
   if (a.glds && a.k_chunk % 64 == 0) {
     LAKO_SET_MAX_LDS((&gemm_tn256_kernel<true>), 4 * TN2_IMG);
     hipLaunchKernelGGL(gemm_tn256_kernel<true>, dim3(tiles * a.split_k), dim3(512), 4 * TN2_IMG, (hipStream_t)stream, a);

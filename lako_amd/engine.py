@@ -349,6 +349,18 @@ class Engine:
         ws[name] = t
         return t
 
+    def _tn_scratch(self, nbytes):
+        """grow-only device scratch for the weight-gradient launches whose K-splits meet through partial tiles (lako_gemm_tn_grouped).
+        OFF by default (LAKO_TN_SLABS=1 switches it on): measured +0.6 ms per step against the float atomics (round 4,
+        profiles/r04s_tn_slab_reduction.txt) — the atomics are fire-and-forget, the last arriver's slab reads and read-modify-write are
+        a serial tail.  What it buys is bit-reproducible encoder weight gradients."""
+        if os.environ.get("LAKO_TN_SLABS", "0") != "1":
+            return None
+        t = getattr(self, "_tn_ws", None)
+        if t is None or t.numel() < nbytes:
+            t = self._tn_ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return t
+
     def _workspace(self, key):
         return self._ws_cache.setdefault(key, {})
 
@@ -1027,7 +1039,7 @@ class Engine:
                          drop=dr(_enc_site(i, 0)), **akw)
             dw.append((dqkv, ws[f"e.xn1.{j}"], lw["qkv"].g, 1.0))
             ops.gemm_nt(dqkv, lw["qkv"].wt, dxe)
-            ops.gemm_tn_grouped(dw)      # before the norm backward below overwrites dy_f for the next layer
+            ops.gemm_tn_grouped(dw, workspace=self._tn_scratch)      # before the norm backward below overwrites dy_f for the next layer
             ops.rmsnorm_bwd(dxe, ws[f"e.h{i}"], lw["ln1"].p, ws[f"e.rs1.{j}"], deh, deh, lw["ln1"].g,
                             **self._nxt((dy_f, dr(_enc_site(i - 1, 3))) if fused and i > 0 else None))
             self._ready(f"enc.{i}.qkv", f"enc.{i}.ln2")

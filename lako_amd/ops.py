@@ -188,8 +188,9 @@ class HipOps:
         self._timed("gemm_tn", 2.0 * M * N * K, lambda: check(self.lib.lako_gemm_tn(_p(A), _p(B), _p(Cm), M, N, K, lda, ldb, ldc, _dt(A), float(alpha), int(split_k),
                                     self._tuning_p, self._stream()), "lako_gemm_tn"))
 
-    def gemm_tn_grouped(self, problems, split_k=0):
-        """[(A [K, M], B [K, N], C [M, N] fp32, alpha[, rows_out]), …] with one K: every C += alpha·Aᵀ·B, one launch per
+    def gemm_tn_grouped(self, problems, split_k=0, workspace=None):
+        """`workspace`: callable(nbytes) → a device uint8 tensor of at least that size (the engine's grow-only scratch), or None.
+        [(A [K, M], B [K, N], C [M, N] fp32, alpha[, rows_out]), …] with one K: every C += alpha·Aᵀ·B, one launch per
         TN_GROUP_MAX problems (see lako_gemm_tn_grouped in include/lako_hip.h).  split_k=1: one contributor per output element;
         −1: the same and nothing else adds to C meanwhile (plain read-modify-write); −2: C is overwritten."""
         from ._lib import TN_GROUP_MAX, GemmTNItem
@@ -212,8 +213,13 @@ class HipOps:
                 it.a, it.b, it.c = _p(A), _p(B), _p(Cm)
                 it.M, it.N, it.lda, it.ldb, it.ldc, it.alpha = M, N, lda, ldb, ldc, float(alpha)
                 flops += 2.0 * M * N * K
-            self._timed("gemm_tn", flops, lambda: check(self.lib.lako_gemm_tn_grouped(arr, len(grp), K0, _dt(grp[0][0]), int(split_k), self._tuning_p, self._stream()),
-                                                        "lako_gemm_tn_grouped"))
+            ws_p, ws_n = None, 0
+            if workspace is not None:      # K-splits through partial tiles in caller scratch instead of float atomics (see the header)
+                need = int(self.lib.lako_gemm_tn_grouped_workspace(arr, len(grp), K0, _dt(grp[0][0]), int(split_k), self._tuning_p))
+                if need > 0:
+                    ws_p, ws_n = _p(workspace(need)), need
+            self._timed("gemm_tn", flops, lambda: check(self.lib.lako_gemm_tn_grouped(arr, len(grp), K0, _dt(grp[0][0]), int(split_k), self._tuning_p,
+                                                                                      ws_p, ws_n, self._stream()), "lako_gemm_tn_grouped"))
 
     # ---- norm / embedding / dropout ---------------------------------------------------------------
     def rmsnorm_fwd(self, x, w, y, rstd, eps, drop=None):

@@ -132,7 +132,7 @@ class RefOps:
         else:
             Cm[:r] += v[:r]
 
-    def gemm_tn_grouped(self, problems, split_k=0):
+    def gemm_tn_grouped(self, problems, split_k=0, workspace=None):
         for prob in problems:
             A, B, Cm, alpha = prob[:4]
             self.gemm_tn(A, B, Cm, alpha=alpha, split_k=split_k, rows_out=prob[4] if len(prob) > 4 else 0)

@@ -16,7 +16,7 @@ LIB = os.path.join(ROOT, "lako_amd", "liblako_hip.so")
 def header_functions():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\bint\s+(lako_\w+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(?:int|int64_t)\s+(lako_\w+)\s*\(", src)))
 
 
 @pytest.fixture(scope="module")

@@ -321,6 +321,37 @@ def test_gemm_tn_grouped(ops, ref, dt):
             close(Cg, Cr, T, f"gemm_tn_grouped {dt} {M}x{N}", tight=True)
 
 
+def test_gemm_tn_grouped_slab_reduction(ops, ref):
+    """lako_gemm_tn_grouped with a workspace (round 4): the K-splits of a tile meet through fp32 partial tiles + one arrival ticket per
+    tile instead of float atomics; the workgroup that arrives last sums the slabs in split order.  Same result as the atomic path within
+    fp32 summation noise, BIT-IDENTICAL from run to run (atomics were not), C accumulated (not overwritten), 2 / 3 / 4 splits, a K
+    that is not a multiple of 64, ragged tile edges; the scratch may be dirty (it is reused across launches)."""
+    T = torch.bfloat16
+    scratch = {}
+
+    def ws(n):
+        if scratch.get("t") is None or scratch["t"].numel() < n:
+            scratch["t"] = torch.full((n,), 0x7F, dtype=torch.uint8, device=dev())      # garbage on purpose
+        return scratch["t"]
+    for K, split in ((47757, 0), (6400, 2), (9999, 3), (16384, 4)):
+        dy = {n: rnd(K, n, dtype=T, seed=11 + n) for n in (768, 2304, 3072, 520)}
+        x = {n: rnd(K, n, dtype=T, seed=13 + n) for n in (768, 3072, 264)}
+        shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768), (520, 264)]
+        runs = []
+        for rep in range(3):
+            G = [torch.full(sh, 0.25, device=dev()) for sh in shapes]
+            items = [(dy[m], x[n], g, 0.5) for (m, n), g in zip(shapes, G)]
+            ops.gemm_tn_grouped(items, split_k=split, workspace=ws if rep < 2 else None)
+            runs.append(G)
+        Gr = [torch.full(sh, 0.25, device=dev()) for sh in shapes]
+        ref.gemm_tn_grouped([(dy[m], x[n], g, 0.5) for (m, n), g in zip(shapes, Gr)])
+        for a, b, c, r, sh in zip(runs[0], runs[1], runs[2], Gr, shapes):
+            assert torch.equal(a, b), f"slab reduction not reproducible K={K} split={split} {sh}"
+            close(a, r, T, f"gemm_tn_grouped slabs K={K} split={split} {sh}", tight=True)
+            close(c, r, T, f"gemm_tn_grouped atomics K={K} split={split} {sh}", tight=True)
+    assert scratch["t"] is not None
+
+
 def test_gemm_tn_exclusive_and_overwrite(ops, ref):
     """lako_gemm_tn_grouped with split_k −1 (one contributor, nothing else adds meanwhile: C += v by plain loads / stores) and −2 (C = v:
     no zeroed C), and rows_out < M: a problem whose true row count is not a multiple of 8 touches only its own rows — two such problems
