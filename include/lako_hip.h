@@ -142,7 +142,7 @@ int lako_gemm_tn(const void* A, const void* B, float* C, int64_t M, int64_t N, i
  * these outputs while the launch runs: C += v by plain loads and stores (the chip's copy rate instead of ≈1.3 TB/s of float
  * atomics — the decoder's weight gradients, K = batch x answer length); -2 = the same, overwriting: C = v, no zeroed C needed (the
  * encoder-state gradient of the cross-attention). */
-#define LAKO_TN_GROUP_MAX 8
+#define LAKO_TN_GROUP_MAX 48
 typedef struct {
   const void* a; /* [K, M] row-major, lda */
   const void* b; /* [K, N] row-major, ldb */

@@ -47,7 +47,7 @@ class GemmTNItem(C.Structure):
                 ("alpha", f32), ("rows_out", i32)]
 
 
-TN_GROUP_MAX = 8
+TN_GROUP_MAX = 48
 
 
 class HeadBatch(C.Structure):

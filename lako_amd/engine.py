@@ -908,7 +908,7 @@ class Engine:
             a, b = self.by_name[first_block], self.by_name[last_block]
             self.grad_hook(a.off, b.off + -(-b.numel // ALIGN) * ALIGN)
 
-    def _ffn_bwd(self, lw, dh, a1, xn, h_in, rs, ln, p, drop_out, tmp, dw=None, dy_pre=None, nxt=None, role="d"):
+    def _ffn_bwd(self, lw, dh, a1, xn, h_in, rs, ln, p, drop_out, tmp, dw=None, dy_pre=None, nxt=None, role="d", slot=""):
         """residual FFN sublayer backward; dh is updated in place to the gradient wrt the sublayer input.
         `dw`: list collecting the weight-gradient problems for one grouped launch (encoder layers with dropout: their
         operands live in per-layer scratch that stays untouched until the layer's backward is complete).
@@ -923,13 +923,13 @@ class Engine:
         if p > 0 and dy_pre is not None:
             dy = dy_pre
         elif p > 0:
-            dy = self._buf(tmp, f"{role}.dy.ffn" if dw is not None else f"{role}.dy", (M, d))
+            dy = self._buf(tmp, f"{role}.dy.ffn{slot}" if dw is not None else f"{role}.dy", (M, d))
             ops.dropout_apply(dh, dy, drop_out)
         if dw is not None and p > 0:
             dw.append((dy, a1, lw["wo"].g, 1.0))
         else:
             ops.gemm_tn(dy, a1, lw["wo"].g)
-        dpre = self._buf(tmp, f"{role}.dpre", (M, f))
+        dpre = self._buf(tmp, f"{role}.dpre{slot}", (M, f))
         ops.gemm_nt(dy, lw["wo"].wt, dpre, aux=a1, aux_scale=1.0 / (1.0 - p))   # ∘ [relu'>0] ∘ dropout
         if dw is not None:
             dw.append((dpre, xn, lw["wi"].g, 1.0))
@@ -998,8 +998,23 @@ class Engine:
         else:
             ops.gemm_tn(dkv, ws["e.out"], self.kv_all.g)
             ops.gemm_nt(dkv, self.kv_all.wt, dxe)
-        dy_f = self._buf(tmp, "e.dy.ffn", (Me, d)) if fused else None
-        dy_s = self._buf(tmp, "e.dy", (Me, d)) if fused else None
+        # WEIGHT GRADIENTS OF SEVERAL ENCODER LAYERS IN ONE LAUNCH (round 4).  A layer's four dW are 108 tiles of 256²; with two K-splits
+        # that is 216 workgroups on 256 CUs — every layer's launch leaves 16 % of the chip idle, and nothing can fill it (one workgroup
+        # per CU: 128 KiB of LDS).  The products do not have to run where their operands are produced: with the operands of `grp`
+        # layers kept in per-slot scratch (dy, dpre, dqkv: 0.66 GB per layer at config 2) their 108·grp tiles × splits go out as ONE grid
+        # that the dispatcher deals over the CUs as they free up — 12 layers × 2 splits = 2 592 units = 10.1 rounds of half-K units
+        # instead of 12 rounds.  Not with set_checkpoint (the forward operands of a layer are recomputed into ONE slot), not when a
+        # data-parallel hook wants every layer's gradients as soon as they exist (overlap mode), not without dropout (dy aliases the
+        # residual gradient then).
+        grp = 1
+        if fused and not ctx.ckpt and self.grad_hook is None:
+            grp = max(1, min(int(os.environ.get("LAKO_ENC_DW_GROUP", "12")), Le, 12))
+        # K-splits of the grouped launch: 3 (1 296 tiles × 3 = 15.2 rounds of third-K units; measured per step, rocprofv3, 14 steps:
+        # one launch per layer 8.70 ms, 12 layers × 2 / 3 / 4 splits 8.35 / 8.32 / 8.30 ms, 6 layers × 3 splits 8.35 — the library's
+        # own cost model, built for one-round launches, would pick 1 split = 6 whole rounds: the slowest, 41.3 ms per step)
+        enc_split = int(os.environ.get("LAKO_ENC_DW_SPLIT", "3"))
+        slot_of = (lambda i: f".{i % grp}") if grp > 1 else (lambda i: "")
+        dy_f = self._buf(tmp, "e.dy.ffn" + slot_of(Le - 1), (Me, d)) if fused else None
         ops.rmsnorm_bwd(dxe, ws[f"e.h{Le}"], self.enc_final.p, ws["e.rsf"], None, deh, self.enc_final.g, dr(S_ENC_FINAL),
                         **self._nxt((dy_f, dr(_enc_site(Le - 1, 3))) if fused else None))
         self._ready("dec.final_ln", "enc.final_ln")
@@ -1007,18 +1022,19 @@ class Engine:
         BN = B * N
         drel_e = self._buf(tmp, "e.drel", (H, 2 * L - 1), torch.float32)
         ops.zero_(drel_e)
+        dw, dw_layers = [], []
         for i in reversed(range(Le)):
             lw = self.enc[i]
-            j = i
+            j, sl = i, slot_of(i)
             if ctx.ckpt:   # recompute this block's intermediates from its saved input (same seeds → same dropout masks)
                 j = 0
                 self._enc_layer_fwd(ws, i, 0, ws[f"e.h{i}"], None, BN, L, ctx.mask_u8, ws["e.rel"], dr, rag)
-            # the layer's four weight gradients (K = all tokens, small M×N) go out as ONE grouped launch at the end of the
-            # layer: 108 tiles fill the chip with ~2 K-splits, where four separate launches need 7–28 splits each and
-            # pay one fp32 atomic pass over the output per split
-            dw = []
+            # the layer's four weight gradients (K = all tokens, small M×N) go out in ONE grouped launch (with those of the other
+            # layers of its group): 108 tiles per layer fill the chip with ~2 K-splits, where four separate launches need 7–28 splits
+            # each and pay one fp32 atomic pass over the output per split
+            dy_s = self._buf(tmp, "e.dy" + sl, (Me, d)) if fused else None
             self._ffn_bwd(lw, deh, ws[f"e.a1.{j}"], ws[f"e.xn2.{j}"], ws[f"e.h1.{j}"], ws[f"e.rs2.{j}"], lw["ln2"], p,
-                          dr(_enc_site(i, 3)), tmp, dw, dy_pre=dy_f, nxt=(dy_s, dr(_enc_site(i, 1))) if fused else None, role="e")
+                          dr(_enc_site(i, 3)), tmp, dw, dy_pre=dy_f, nxt=(dy_s, dr(_enc_site(i, 1))) if fused else None, role="e", slot=sl)
             dy = deh
             if p > 0:
                 dy = dy_s if fused else self._buf(tmp, "e.dy", (Me, d))
@@ -1030,7 +1046,7 @@ class Engine:
             dctx = self._buf(tmp, "e.dctx", (Me, inner))
             ops.gemm_nt(dy, lw["o"].wt, dctx)
             qkv = ws[f"e.qkv.{j}"]
-            dqkv = self._buf(tmp, "e.dqkv", (Me, 3 * inner))
+            dqkv = self._buf(tmp, "e.dqkv" + sl, (Me, 3 * inner))
             hb, ht, akw = self._enc_attn_layout(rag, BN, L, ctx.mask_u8)
             ops.attn_bwd(self._heads(qkv, hb, ht, 0), self._heads(qkv, hb, ht, inner), self._heads(qkv, hb, ht, 2 * inner),
                          self._heads(ws[f"e.ctx.{j}"], hb, ht, 0), self._heads(dctx, hb, ht, 0), ws[f"e.st.{j}"],
@@ -1039,10 +1055,17 @@ class Engine:
                          drop=dr(_enc_site(i, 0)), **akw)
             dw.append((dqkv, ws[f"e.xn1.{j}"], lw["qkv"].g, 1.0))
             ops.gemm_nt(dqkv, lw["qkv"].wt, dxe)
-            ops.gemm_tn_grouped(dw, workspace=self._tn_scratch)      # before the norm backward below overwrites dy_f for the next layer
+            dw_layers.append(i)
+            if i % grp == 0:      # the group is complete: its launch goes out before the norm backward below rewrites the slot of layer i − 1
+                ops.gemm_tn_grouped(dw, split_k=enc_split if grp > 1 else 0, workspace=self._tn_scratch)
+                dw = []
+            dy_f = self._buf(tmp, "e.dy.ffn" + slot_of(i - 1), (Me, d)) if fused and i > 0 else None
             ops.rmsnorm_bwd(dxe, ws[f"e.h{i}"], lw["ln1"].p, ws[f"e.rs1.{j}"], deh, deh, lw["ln1"].g,
                             **self._nxt((dy_f, dr(_enc_site(i - 1, 3))) if fused and i > 0 else None))
-            self._ready(f"enc.{i}.qkv", f"enc.{i}.ln2")
+            if i % grp == 0:
+                for li in dw_layers:
+                    self._ready(f"enc.{li}.qkv", f"enc.{li}.ln2")
+                dw_layers = []
         ops.embed_bwd(ctx.enc_ids, deh, self.shared.g, dr(S_ENC_EMBED))
         ops.relpos_reduce(drel_e, self._lut(L, L, True), self.enc_rel.g)
         self._ready("enc.rel", "shared")
