@@ -224,6 +224,11 @@ typedef struct {
    * carry no padding in this form (key_mask must be NULL); score capture is not available. */
   const int32_t* q_off;
   const int32_t* k_off;
+  /* optional (round 4): device int32 [Bn], a PERMUTATION of 0 … Bn-1 — the order in which workgroups take the sequences.  Results do
+   * not depend on it (each sequence is computed as before, into its own rows); it exists for load balance: sequences sorted by
+   * descending length start the long ones first and give every persistent workgroup (which walks positions slot, slot + n, …)
+   * one sequence of every length class.  Honoured by the encoder fast path (bf16, d_head 64, <= 256 keys), ignored elsewhere. */
+  const int32_t* order;
 } lako_attn_fwd_t;
 int lako_attn_fwd(const lako_attn_fwd_t* p, lako_stream_t stream);
 
@@ -242,6 +247,7 @@ typedef struct {
   lako_dropout_t drop;
   const int32_t* q_off; /* ragged sequences, as in lako_attn_fwd_t (dq follows q_off; dk, dv follow k_off) */
   const int32_t* k_off;
+  const int32_t* order; /* as in lako_attn_fwd_t */
 } lako_attn_bwd_t;
 int lako_attn_bwd(const lako_attn_bwd_t* p, lako_stream_t stream);
 

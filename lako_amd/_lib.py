@@ -63,7 +63,7 @@ class AttnFwd(C.Structure):
                 ("v_stride_b", i64), ("v_stride_t", i64), ("o_stride_b", i64), ("o_stride_t", i64),
                 ("rel_bias", vp), ("R", i32), ("rel_off", i32), ("key_mask", vp), ("causal", i32),
                 ("causal_off", i32), ("Bn", i32), ("H", i32), ("Lq", i32), ("Lk", i32), ("d_head", i32),
-                ("dtype", i32), ("drop", Dropout), ("scores_out", vp), ("q_off", vp), ("k_off", vp)]
+                ("dtype", i32), ("drop", Dropout), ("scores_out", vp), ("q_off", vp), ("k_off", vp), ("order", vp)]
 
 
 class AttnBwd(C.Structure):
@@ -73,7 +73,7 @@ class AttnBwd(C.Structure):
                 ("v_stride_b", i64), ("v_stride_t", i64), ("o_stride_b", i64), ("o_stride_t", i64),
                 ("rel_bias", vp), ("drel", vp), ("R", i32), ("rel_off", i32), ("key_mask", vp), ("causal", i32),
                 ("causal_off", i32), ("Bn", i32), ("H", i32), ("Lq", i32), ("Lk", i32), ("d_head", i32),
-                ("dtype", i32), ("drop", Dropout), ("q_off", vp), ("k_off", vp)]
+                ("dtype", i32), ("drop", Dropout), ("q_off", vp), ("k_off", vp), ("order", vp)]
 
 
 # name -> argtypes (restype is always int).  Must list EVERY function include/lako_hip.h declares:

@@ -974,6 +974,7 @@ extern "C" int lako_attn_fwd(const lako_attn_fwd_t* p, lako_stream_t stream) {
   a.Bn = p->Bn; a.H = p->H; a.Lq = p->Lq; a.Lk = p->Lk;
   a.q_off = p->q_off;
   a.k_off = p->k_off;
+  a.order = p->order;
   LAKO_CHECK_ARG(!(p->scores_out && (p->q_off || p->k_off)), "lako_attn_fwd: score capture needs the padded layout");
   LAKO_CHECK_ARG(!(p->key_mask && p->k_off), "lako_attn_fwd: ragged keys carry no padding — pass key_mask = NULL");
   set_drop(a, p->drop);
@@ -1012,6 +1013,7 @@ extern "C" int lako_attn_bwd(const lako_attn_bwd_t* p, lako_stream_t stream) {
   a.Bn = p->Bn; a.H = p->H; a.Lq = p->Lq; a.Lk = p->Lk;
   a.q_off = p->q_off;
   a.k_off = p->k_off;
+  a.order = p->order;
   LAKO_CHECK_ARG(!(p->key_mask && p->k_off), "lako_attn_bwd: ragged keys carry no padding — pass key_mask = NULL");
   set_drop(a, p->drop);
   if (lako_attn_enc_supported(a, p->dtype, p->d_head)) lako_attn_enc_bwd(a, (hipStream_t)stream);

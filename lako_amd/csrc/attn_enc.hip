@@ -190,7 +190,7 @@ __global__ __launch_bounds__(FWD_NW * 64, FWD_NW / 2) void enc_fwd_kernel(AttnAr
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, l15 = lane & 15;
-  const int b = blockIdx.z, h = blockIdx.y;
+  const int b = attn_seq(a, blockIdx.z), h = blockIdx.y;
   const int q0 = a.q_off ? __builtin_amdgcn_readfirstlane(a.q_off[b]) : 0;
   const int k0 = a.k_off ? __builtin_amdgcn_readfirstlane(a.k_off[b]) : 0;
   const int Lq = a.q_off ? __builtin_amdgcn_readfirstlane(a.q_off[b + 1]) - q0 : a.Lq;
@@ -329,18 +329,19 @@ __global__ __launch_bounds__(PF_NW * 64) void enc_fwd_p_kernel(AttnArgs a) {
     const char* qbase = a.q + ((a.q_off ? (int64_t)q0 * a.qst : (int64_t)b * a.qsb) + hoff) * 2;
     eload_frags_buf(qf_next, qbase, (uint32_t)a.qst * 2u, wave * 16, Lq, (uint32_t)l15 * (uint32_t)a.qst * 2u + (uint32_t)g * 16u);
   };
-  issue(slot, smem);
-  request_q(slot);
+  issue(attn_seq(a, slot), smem);
+  request_q(attn_seq(a, slot));
   int cur = 0;
-  for (int b = slot; b < a.Bn; b += nslots) {
+  for (int bi = slot; bi < a.Bn; bi += nslots) {
+    const int b = attn_seq(a, bi);
     char* Kimg = smem + cur * 2 * R * EROW;
     char* Vimg = Kimg + R * EROW;
     u32x4 qf[2] = {qf_next[0], qf_next[1]};
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of item b (and its Q fragments) have landed
     __syncthreads();                                         // … everybody's; and every wave is done with the other image pair
-    if (b + nslots < a.Bn) {
-      issue(b + nslots, smem + (cur ^ 1) * 2 * R * EROW);
-      request_q(b + nslots);
+    if (bi + nslots < a.Bn) {
+      issue(attn_seq(a, bi + nslots), smem + (cur ^ 1) * 2 * R * EROW);
+      request_q(attn_seq(a, bi + nslots));
     }
     cur ^= 1;
     int q0, k0, Lq, Lk;
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(256, 2) void enc_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
   for (int t = 0; t < DQ_NACC; ++t) acc_lo[t] = acc_hi[t] = 0.f;
 
-  for (int b = b_begin; b < b_end; ++b) {
+  for (int b = b_begin; b < b_end; ++b) {      // (this kernel walks CONSECUTIVE sequences: a.order is not applied)
     const int q0 = a.q_off ? __builtin_amdgcn_readfirstlane(offs_l[b - b_begin]) : 0;
     const int k0 = a.k_off ? __builtin_amdgcn_readfirstlane(offs_l[OFFS_MAX + b - b_begin]) : 0;
     const int Lq = a.q_off ? __builtin_amdgcn_readfirstlane(offs_l[b - b_begin + 1]) - q0 : a.Lq;
@@ -618,9 +619,10 @@ __global__ __launch_bounds__(PF_NW * 64) void enc_bwd_dq_p_kernel(AttnArgs a) {
       lds_dma16(buf + (isv ? R * EROW : 0) + (row - pr) * EROW, isv ? vrs : krs, row < Lk ? voff : 0x80000000u);
     }
   };
-  issue(slot, smem);
+  issue(attn_seq(a, slot), smem);
   int cur = 0;
-  for (int b = slot; b < a.Bn; b += nslots) {
+  for (int bi = slot; bi < a.Bn; bi += nslots) {
+    const int b = attn_seq(a, bi);
     char* Kimg = smem + cur * 2 * R * EROW;
     char* Vimg = Kimg + R * EROW;
     int q0, k0, Lq, Lk;
@@ -644,7 +646,7 @@ __global__ __launch_bounds__(PF_NW * 64) void enc_bwd_dq_p_kernel(AttnArgs a) {
         st_il = stats[qi * 4 + 1];
       }
     }
-    if (b + nslots < a.Bn) issue(b + nslots, smem + (cur ^ 1) * 2 * R * EROW);
+    if (bi + nslots < a.Bn) issue(attn_seq(a, bi + nslots), smem + (cur ^ 1) * 2 * R * EROW);
     cur ^= 1;
     if (!mine) continue;
     char* dqbase = a.dq + ((a.q_off ? (int64_t)q0 * a.qst : (int64_t)b * a.qsb) + hoff) * 2;
@@ -757,7 +759,7 @@ __global__ __launch_bounds__(DKV_NW * 64, 2) void enc_bwd_dkv_kernel(AttnArgs a)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, l15 = lane & 15;
-  const int b = blockIdx.z, h = blockIdx.y;
+  const int b = attn_seq(a, blockIdx.z), h = blockIdx.y;
   const int q0 = a.q_off ? __builtin_amdgcn_readfirstlane(a.q_off[b]) : 0;
   const int k0 = a.k_off ? __builtin_amdgcn_readfirstlane(a.k_off[b]) : 0;
   const int Lq = a.q_off ? __builtin_amdgcn_readfirstlane(a.q_off[b + 1]) - q0 : a.Lq;
@@ -928,9 +930,10 @@ __global__ __launch_bounds__(PF_NW * 64) void enc_bwd_dkv_p_kernel(AttnArgs a) {
       lds_dma16(raw_l + (pair * RS + wave * 64) * 4, srs, (uint32_t)(wave * 64 + le) * 16u);
     }
   };
-  issue(slot, 0);
+  issue(attn_seq(a, slot), 0);
   int cur = 0;
-  for (int b = slot; b < a.Bn; b += nslots) {
+  for (int bi = slot; bi < a.Bn; bi += nslots) {
+    const int b = attn_seq(a, bi);
     char* Qimg = smem + cur * 2 * R * EROW;
     char* dOimg = Qimg + R * EROW;
     int q0, k0, Lq, Lk;
@@ -945,7 +948,7 @@ __global__ __launch_bounds__(PF_NW * 64) void enc_bwd_dkv_p_kernel(AttnArgs a) {
       eload_frags_buf(kf, kbase, (uint32_t)a.kst * 2u, wave * 16, Lk, (uint32_t)l15 * (uint32_t)a.kst * 2u + (uint32_t)g * 16u);
       eload_frags_buf(vf, vbase, (uint32_t)a.vst * 2u, wave * 16, Lk, (uint32_t)l15 * (uint32_t)a.vst * 2u + (uint32_t)g * 16u);
     }
-    if (b + nslots < a.Bn) issue(b + nslots, cur ^ 1);
+    if (bi + nslots < a.Bn) issue(attn_seq(a, bi + nslots), cur ^ 1);
     if ((int)threadIdx.x < R) {                              // rows past Lq arrive as zeros: p = exp2(−inf) = 0 there
       const f32x4 st4 = *reinterpret_cast<const f32x4*>(raw_l + (cur * RS + threadIdx.x) * 4);
       lse_l[threadIdx.x] = st4[1] > 0.f ? st4[0] * LOG2E - __builtin_amdgcn_logf(st4[1] * dscale) : INFINITY;

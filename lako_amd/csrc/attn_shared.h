@@ -36,6 +36,7 @@ struct AttnArgs {
   // ragged (unpadded) sequences: rows of sequence b are rows [off[b], off[b+1]) of ONE packed [rows, H·dk] buffer (the batch
   // stride is ignored); Lq / Lk are then the maxima (grid sizing, statistics and dropout indexing stay in padded coordinates)
   const int32_t *q_off, *k_off;
+  const int32_t* order;   // optional [Bn]: the sequence the i-th workgroup / item slot processes (longest first: see lako_attn_fwd_t.order); attn_enc.hip only
   int64_t qsb, qst, ksb, kst, vsb, vst, osb, ost;  // strides in elements
   int R, rel_off, causal, causal_off;
   int Bn, H, Lq, Lk;
@@ -47,6 +48,11 @@ struct AttnArgs {
   uint32_t drop_t16, drop_key;   // attention dropout: keep iff 16-bit half >= drop_t16 (0 = off)
   float drop_scale;
 };
+
+// i-th item in processing order → sequence id
+__device__ __forceinline__ int attn_seq(const AttnArgs& a, int i) {
+  return a.order ? __builtin_amdgcn_readfirstlane(a.order[i]) : i;
+}
 
 // f(integral_constant<int, 0>) … f(integral_constant<int, N-1>): a compile-time-indexed unrolled loop
 template <int N, typename F>

@@ -131,6 +131,7 @@ class _Ragged:
     soff: torch.Tensor      # int32 [B + 1]   row offset of each sample (its N passages are consecutive)
     idx: torch.Tensor       # int64 [M] position of each packed token in the flat [B·N·L] input
     soff_h: list = None     # the sample offsets on the host
+    order: torch.Tensor = None   # int32 [B·N] passages by descending length: the processing order of the attention kernels
 
 
 @dataclass
@@ -406,7 +407,7 @@ class Engine:
         [BN, L] with a key mask, or ONE packed run of rows with per-passage offsets."""
         if rag is None:
             return BN, L, dict(key_mask=mask_u8)
-        return 1, rag.M, dict(q_off=rag.off, k_off=rag.off, max_q=L, max_k=L)
+        return 1, rag.M, dict(q_off=rag.off, k_off=rag.off, max_q=L, max_k=L, order=rag.order)
 
     def _encode(self, ws, ids_flat, mask_u8, BN, L, p, seed, save, rag=None, want_kv=True):
         """save: True  — keep every intermediate of every layer (training; 288 GB of HBM make this the default);
@@ -470,7 +471,12 @@ class Engine:
             base = torch.arange(B * N, device=dev, dtype=torch.int64) * L - off_d[:-1].long()
             idx = torch.repeat_interleave(base, off_d[1:].long() - off_d[:-1].long(), output_size=M) + \
                 torch.arange(M, device=dev, dtype=torch.int64)
-            return _Ragged(M=M, off=off_d, soff=off_d[::N].contiguous(), idx=idx, soff_h=off[::N].tolist())
+            # passages sorted by descending length: the order the encoder-attention workgroups take them in (load balance only:
+            # long items first, every persistent workgroup one passage of each length class — measured with pre-sorted lengths:
+            # attention −0.24 ms per step)
+            order = torch.argsort(lens_h, descending=True, stable=True).to(torch.int32)
+            order_d = pin(order).to(dev, non_blocking=True) if os.environ.get("LAKO_ATTN_ORDER", "1") != "0" else None
+            return _Ragged(M=M, off=off_d, soff=off_d[::N].contiguous(), idx=idx, soff_h=off[::N].tolist(), order=order_d)
         key = (attention_mask.data_ptr(), attention_mask._version, B, N, L)
         hit = self._rag_cache.get(key)
         if hit is not None:
@@ -487,7 +493,9 @@ class Engine:
             off = torch.zeros(B * N + 1, dtype=torch.int32)
             off[1:] = torch.cumsum(lens_h, 0)
             rag = _Ragged(M=int(off[-1]), off=off.to(dev), soff=off[::N].contiguous().to(dev),
-                          idx=m.reshape(-1).nonzero().reshape(-1), soff_h=off[::N].tolist())
+                          idx=m.reshape(-1).nonzero().reshape(-1), soff_h=off[::N].tolist(),
+                          order=torch.argsort(lens_h, descending=True, stable=True).to(torch.int32).to(dev)
+                          if os.environ.get("LAKO_ATTN_ORDER", "1") != "0" else None)
         self._all_valid = ok and int(lens_h.sum()) == B * N * L
         if len(self._rag_cache) >= 16:
             self._rag_cache.clear()
@@ -973,7 +981,9 @@ class Engine:
         ops.gemm_nt(dlog, self.shared.wt, dout32, alpha=alpha, atomic=True)
         if dout32 is not dout:
             ops.cast(dout32.view(-1), dout.view(-1))
-        ops.gemm_tn(dlog, ws["d.out"], self.shared.g, alpha=alpha)
+        # (K = B·T rows, 378 tiles: one K-split; nothing else touches the embedding gradient until the embedding backward kernels later on
+        # this stream: plain read-modify-write instead of 99 MB of float atomics)
+        ops.gemm_tn(dlog, ws["d.out"], self.shared.g, alpha=alpha, split_k=-1)
         # every RMSNorm backward also writes dropout_bwd(dx) for the residual branch that consumes dx next (fused=True)
         fused = p > 0 and os.environ.get("LAKO_FUSE_DROP", "1") != "0"   # 0: separate dropout_apply launches (A/B)
         xa = ctx.xa

@@ -273,10 +273,20 @@ class HipOps:
                 raise LakoError("attention: k_off must have Bn + 1 entries")
         return Bn, Lq, Lk, H, dk
 
+    @staticmethod
+    def _order(order, Bn):
+        """lako_attn_*_t.order: a device int32 permutation of the Bn sequences (processing order; results do not depend on it)"""
+        if order is None:
+            return None
+        if order.dtype != torch.int32 or not order.is_contiguous() or order.numel() != Bn:
+            raise LakoError(f"attention: order must be a contiguous int32 permutation of the {Bn} sequences")
+        return order.data_ptr()
+
     def attn_fwd(self, q, k, v, out, stats, *, rel_bias=None, rel_off=0, key_mask=None, causal=False, causal_off=0,
-                 drop=None, scores_out=None, q_off=None, k_off=None, max_q=None, max_k=None):
+                 drop=None, scores_out=None, q_off=None, k_off=None, max_q=None, max_k=None, order=None):
         p = AttnFwd()
         Bn, Lq, Lk, H, dk = self._ragged(p, q, k, q_off, k_off, max_q, max_k)
+        p.order = self._order(order, Bn)
         p.q, p.k, p.v, p.out, p.lse = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), stats.data_ptr()
         p.q_stride_b, p.q_stride_t = _bthd(q, "attn q")
         p.k_stride_b, p.k_stride_t = _bthd(k, "attn k")
@@ -298,9 +308,10 @@ class HipOps:
         self._timed("attn_fwd", 4.0 * Bn * H * Lq * Lk * dk, lambda: check(self.lib.lako_attn_fwd(C.byref(p), self._stream()), "lako_attn_fwd"))
 
     def attn_bwd(self, q, k, v, out, dout, stats, dq, dk_, dv, *, rel_bias=None, drel=None, rel_off=0, key_mask=None,
-                 causal=False, causal_off=0, drop=None, q_off=None, k_off=None, max_q=None, max_k=None):
+                 causal=False, causal_off=0, drop=None, q_off=None, k_off=None, max_q=None, max_k=None, order=None):
         p = AttnBwd()
         Bn, Lq, Lk, H, dk = self._ragged(p, q, k, q_off, k_off, max_q, max_k)
+        p.order = self._order(order, Bn)
         p.q, p.k, p.v, p.out, p.dout, p.lse = (q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
                                                dout.data_ptr(), stats.data_ptr())
         p.dq_out, p.dk_out, p.dv_out = dq.data_ptr(), dk_.data_ptr(), dv.data_ptr()

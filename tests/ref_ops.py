@@ -238,7 +238,7 @@ class RefOps:
         return torch.arange(Lmax, device=off.device)[None, :] < lens[:, None]
 
     def attn_fwd(self, q, k, v, out, stats, *, rel_bias=None, rel_off=0, key_mask=None, causal=False, causal_off=0,
-                 drop=None, scores_out=None, q_off=None, k_off=None, max_q=None, max_k=None):
+                 drop=None, scores_out=None, q_off=None, k_off=None, max_q=None, max_k=None, order=None):
         qf, kf, vf = f(q), f(k), f(v)
         if q_off is not None:
             qf = self._pad(q, q_off, max_q)
@@ -256,7 +256,7 @@ class RefOps:
             scores_out.copy_(raw)
 
     def attn_bwd(self, q, k, v, out, dout, stats, dq, dk_, dv, *, rel_bias=None, drel=None, rel_off=0, key_mask=None,
-                 causal=False, causal_off=0, drop=None, q_off=None, k_off=None, max_q=None, max_k=None):
+                 causal=False, causal_off=0, drop=None, q_off=None, k_off=None, max_q=None, max_k=None, order=None):
         qp, kp, vp, dop = f(q), f(k), f(v), f(dout)
         if q_off is not None:
             qp, dop = self._pad(q, q_off, max_q), self._pad(dout, q_off, max_q)

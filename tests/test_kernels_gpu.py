@@ -698,6 +698,54 @@ def test_attention_persistent_kernels_equal_per_item_kernels(ops, drop, monkeypa
 
 
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("persist", ["2", "7", "0"])
+def test_attention_processing_order_does_not_change_results(ops, persist, monkeypatch):
+    """lako_attn_*_t.order (round 4): the order in which the encoder fast path's workgroups take the sequences — longest first for load
+    balance — is a pure scheduling choice: forward outputs, statistics, dq / dk / dv are BIT-identical for the natural order, the
+    descending-length order and a random permutation; the bias gradient (float atomics) agrees to summation noise.  Default kernels
+    (persistent dQ pass), all-persistent, and all per-item kernels (the non-persistent dQ kernel walks consecutive sequences and ignores
+    the order)."""
+    monkeypatch.setenv("LAKO_ATTN_PERSIST", persist)
+    T = torch.bfloat16
+    H, dk, Lmax = 12, 64, 200
+    inner = H * dk
+    g = torch.Generator().manual_seed(5)
+    lens = torch.randint(1, Lmax + 1, (45,), generator=g).tolist()
+    lens[7] = 0
+    Bn = len(lens)
+    off = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=dev())
+    rows = int(off[-1])
+    qkv = rnd(1, rows, 3 * inner, dtype=T, seed=48, scale=0.5)
+    dout = rnd(1, rows, inner, dtype=T, seed=49, scale=0.5)
+    rel = rnd(H, 2 * Lmax - 1, seed=50)
+    heads = lambda t, c0: t[:, :, c0:c0 + inner].unflatten(2, (H, dk))      # noqa: E731
+    args = tuple(heads(qkv, c) for c in (0, inner, 2 * inner))
+    kw = dict(rel_bias=rel, rel_off=Lmax - 1, drop=(0.1, 3, 4), q_off=off, k_off=off, max_q=Lmax, max_k=Lmax)
+    orders = [None, torch.argsort(torch.tensor(lens), descending=True, stable=True).to(torch.int32).to(dev()),
+              torch.randperm(Bn, generator=g).to(torch.int32).to(dev())]
+    res = []
+    for od in orders:
+        out = torch.zeros(1, rows, inner, dtype=T, device=dev())
+        st = torch.zeros(Bn, H, Lmax, 4, device=dev())
+        ops.attn_fwd(*args, out.unflatten(2, (H, dk)), st, order=od, **kw)
+        dqkv = torch.zeros_like(qkv)
+        drel = torch.zeros_like(rel)
+        ops.attn_bwd(*args, out.unflatten(2, (H, dk)), heads(dout, 0), st, *(heads(dqkv, c) for c in (0, inner, 2 * inner)),
+                     drel=drel, order=od, **{k: v for k, v in kw.items()})
+        res.append((out, st.clone(), dqkv, drel))
+    for r in res[1:]:
+        assert torch.equal(r[0], res[0][0]) and torch.equal(r[2], res[0][2])
+        valid = torch.zeros(Bn, Lmax, dtype=torch.bool, device=dev())
+        for b, n in enumerate(lens):
+            valid[b, :n] = True
+        assert torch.equal(r[1][valid[:, None].expand(-1, H, -1)], res[0][1][valid[:, None].expand(-1, H, -1)])
+        close(r[3], res[0][3], torch.float32, "bias gradient under a processing order", k=5)
+    with pytest.raises(Exception):
+        ops.attn_fwd(*args, torch.zeros(1, rows, inner, dtype=T, device=dev()).unflatten(2, (H, dk)), torch.zeros(Bn, H, Lmax, 4, device=dev()),
+                     order=orders[1][:-1].contiguous(), **kw)
+
+
+# ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("kind", ["self", "self_drop", "cross"])
 def test_attention_ragged_equals_padded(ops, dt, kind):
