@@ -445,15 +445,21 @@ def test_bf16_generate_encoder_space_decode_vs_oracle_tokens():
                 if last < 0.005:
                     break
         tried.append(last)
-        if last < 0.05:
+        if last >= 0.05:
+            continue
+        # the ORACLE (fp32, free-running greedy decode of the trained fp32 master weights) must reproduce the training answers — then the
+        # comparison below is about trained margins, not about noise.  A fit whose teacher-forced bf16 loss is small can still leave one
+        # token of the free-running fp32 decode on a thin margin (seen once in round 4: loss < 0.05, first token off): such a fit is
+        # a bad FIXTURE, not a decode error — take the next initialisation instead of failing
+        w = {plain_name(n): p.detach().float().cpu().clone() for n, p in m.named_parameters()}
+        want = O.fid_generate(w, dims, ids_c, mask_c, ML)
+        ok = all(want[b, 1:1 + int((labels_c[b] != -100).sum())].tolist() == labels_c[b, :int((labels_c[b] != -100).sum())].tolist()
+                 for b in range(B))
+        tried[-1] = (last, "oracle reproduces the answers" if ok else "oracle decode differs from the answers")
+        if ok:
             break
-    assert last is not None and last < 0.05, tried
-    w = {plain_name(n): p.detach().float().cpu().clone() for n, p in m.named_parameters()}
-    want = O.fid_generate(w, dims, ids_c, mask_c, ML)
-    # the oracle reproduces the training answers (so the comparison below is about trained margins, not about noise)
-    for b in range(B):
-        n_valid = int((labels_c[b] != -100).sum())
-        assert want[b, 1:1 + n_valid].tolist() == labels_c[b, :n_valid].tolist(), (b, want[b].tolist(), labels_c[b].tolist())
+    else:
+        pytest.fail(f"no usable fixture in 4 fits: {tried}")
     m.eval()
     for rnd in range(3):                                    # eager warm-up of the mode, graph capture, pure replay
         got = m.generate(input_ids=ids, attention_mask=mask, max_length=ML)
