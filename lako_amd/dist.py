@@ -96,6 +96,7 @@ class GradSync:
         self.grad_dtype = None if grad_dtype == torch.float32 else grad_dtype      # None: all-reduce the fp32 buffer in place
         self._stage = None                # low-precision staging buffer, same layout as G
         eng.grad_hook = self._on_ready
+        eng.grad_ranges_early = self.mode == "overlap"     # deferred: one all-reduce after backward — the engine may group weight gradients across layers
         model._grad_sync = self
         if self.mode == "overlap" and hasattr(eng.ops, "set_tuning"):
             # the collectives' kernels hold CUs while backward's GEMMs run: the persistent GEMM launches pull their tiles from

@@ -201,6 +201,7 @@ class Engine:
         self._lut_cache: dict = {}
         self.ctx: _Ctx | None = None
         self.grad_hook = None    # callable(lo, hi): gradients G[lo:hi] are final (data-parallel overlap)
+        self.grad_ranges_early = True   # the hook wants every range as early as possible (overlap mode); False: only that all are done
         self.shadows_stale = True
         # MX block-scaled fp8 forward GEMMs (BASELINE config 5): the encoder's QKV and FFN-in projections and the cross-K/V
         # projection — the GEMMs whose A operand is a norm output — multiply e4m3 operands with E8M0 block scales on
@@ -1014,10 +1015,10 @@ class Engine:
         # layers kept in per-slot scratch (dy, dpre, dqkv: 0.66 GB per layer at config 2) their 108·grp tiles × splits go out as ONE grid
         # that the dispatcher deals over the CUs as they free up — 12 layers × 2 splits = 2 592 units = 10.1 rounds of half-K units
         # instead of 12 rounds.  Not with set_checkpoint (the forward operands of a layer are recomputed into ONE slot), not when a
-        # data-parallel hook wants every layer's gradients as soon as they exist (overlap mode), not without dropout (dy aliases the
-        # residual gradient then).
+        # data-parallel hook wants every layer's gradients as soon as they exist (overlap mode; the deferred all-reduce does not), not
+        # without dropout (dy aliases the residual gradient then).
         grp = 1
-        if fused and not ctx.ckpt and self.grad_hook is None:
+        if fused and not ctx.ckpt and not (self.grad_hook is not None and self.grad_ranges_early):
             grp = max(1, min(int(os.environ.get("LAKO_ENC_DW_GROUP", "12")), Le, 12))
         # K-splits of the grouped launch: 3 (1 296 tiles × 3 = 15.2 rounds of third-K units; measured per step, rocprofv3, 14 steps:
         # one launch per layer 8.70 ms, 12 layers × 2 / 3 / 4 splits 8.35 / 8.32 / 8.30 ms, 6 layers × 3 splits 8.35 — the library's
