@@ -348,6 +348,9 @@ int lako_cast(const float* src, void* dst, int64_t n, int dtype, lako_stream_t s
 int lako_dropout_apply(const void* x, void* y, int64_t n, int dtype, lako_dropout_t drop, lako_stream_t stream);
 /* _shift_right (HF5:618-637): dec[b][0] = 0; dec[b][t] = labels[b][t-1] (−100 → 0) */
 int lako_shift_right(const int64_t* labels, int64_t* dec_ids, int B, int T, lako_stream_t stream);
+/* unpadded encoder input (round 4): the token ids of the valid positions of ids [BN, L], packed in (passage, position) order —
+ * out[off[j] + t] = ids[j*L + t] for t < off[j+1] - off[j]; off: device int32 [BN + 1] (the row offsets the attention kernels use). */
+int lako_pack_ids(const int64_t* ids, const int32_t* off, int64_t* out, int BN, int L, lako_stream_t stream);
 /* greedy step (HF generate, num_beams=1, do_sample=False): next = argmax(logits[b]); rows already
  * done emit pad(0); done |= next == eos.  seq[b*seq_ld + pos] = next; next_ids[b] = next.
  * n_done[0] = number of finished rows after the step. */

@@ -111,6 +111,7 @@ SIGNATURES = {
     "lako_cast": [vp, vp, i64, i32, vp],
     "lako_dropout_apply": [vp, vp, i64, i32, Dropout, vp],
     "lako_shift_right": [vp, vp, i32, i32, vp],
+    "lako_pack_ids": [vp, vp, vp, i32, i32, vp],
     "lako_greedy_step": [vp, i64, i32, vp, i64, i32, vp, vp, vp, i64, i64, vp],
     "lako_fact_scores": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "lako_topk": [vp, i64, i64, i64, i32, vp, vp, vp],

@@ -759,6 +759,15 @@ __global__ void shift_right_kernel(const int64_t* labels, int64_t* dec, int B, i
   dec[i] = v == -100 ? 0 : v;
 }
 
+// token ids of the VALID positions of a padded [BN, L] batch, packed in (passage, position) order: out[off[j] + t] = ids[j·L + t], t < len(j).
+// One launch instead of the arange / cumsum / repeat_interleave / gather chain that built and applied a packed-row index on the device.
+__global__ __launch_bounds__(256) void pack_ids_kernel(const int64_t* __restrict__ ids, const int32_t* __restrict__ off, int64_t* __restrict__ out,
+                                                       int BN, int L) {
+  const int j = blockIdx.x;
+  const int o0 = off[j], n = off[j + 1] - o0;
+  for (int t = threadIdx.x; t < n && t < L; t += 256) out[o0 + t] = ids[(int64_t)j * L + t];
+}
+
 __global__ __launch_bounds__(256) void greedy_step_kernel(const float* __restrict__ logits, int64_t V,
                                                           int64_t* seq, int64_t seq_ld, int pos, int64_t* next_ids,
                                                           uint8_t* done, int64_t eos, int64_t pad) {
@@ -1118,6 +1127,13 @@ extern "C" int lako_shift_right(const int64_t* labels, int64_t* dec_ids, int B, 
   LAKO_CHECK_ARG(B > 0 && T > 0, "lako_shift_right: bad dims");
   hipLaunchKernelGGL(shift_right_kernel, dim3((B * T + 255) / 256), dim3(256), 0, (hipStream_t)stream, labels, dec_ids,
                      B, T);
+  LAKO_LAUNCH_CHECK();
+  return LAKO_OK;
+}
+
+extern "C" int lako_pack_ids(const int64_t* ids, const int32_t* off, int64_t* out, int BN, int L, lako_stream_t stream) {
+  LAKO_CHECK_ARG(ids && off && out && BN > 0 && L > 0, "lako_pack_ids: bad arguments");
+  hipLaunchKernelGGL(pack_ids_kernel, dim3(BN), dim3(256), 0, (hipStream_t)stream, ids, off, out, BN, L);
   LAKO_LAUNCH_CHECK();
   return LAKO_OK;
 }

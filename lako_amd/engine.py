@@ -129,7 +129,7 @@ class _Ragged:
     M: int                  # number of valid tokens (rows of every encoder buffer)
     off: torch.Tensor       # int32 [B·N + 1] row offset of each passage
     soff: torch.Tensor      # int32 [B + 1]   row offset of each sample (its N passages are consecutive)
-    idx: torch.Tensor       # int64 [M] position of each packed token in the flat [B·N·L] input
+    idx: torch.Tensor       # int64 [M] position of each packed token in the flat [B·N·L] input (None: use pack(), lengths from the host)
     soff_h: list = None     # the sample offsets on the host
     order: torch.Tensor = None   # int32 [B·N] passages by descending length: the processing order of the attention kernels
 
@@ -468,10 +468,7 @@ class Engine:
             torch.cumsum(lens_h, 0, out=off[1:])
             pin = (lambda t: t.pin_memory()) if dev.type == "cuda" else (lambda t: t)
             off_d = pin(off).to(dev, non_blocking=True)
-            # packed row r of passage j is input position j·L + (r − off[j])
-            base = torch.arange(B * N, device=dev, dtype=torch.int64) * L - off_d[:-1].long()
-            idx = torch.repeat_interleave(base, off_d[1:].long() - off_d[:-1].long(), output_size=M) + \
-                torch.arange(M, device=dev, dtype=torch.int64)
+            idx = None      # (the packed token ids come from ONE lako_pack_ids launch over the offsets: no packed-row index on this path)
             # passages sorted by descending length: the order the encoder-attention workgroups take them in (load balance only:
             # long items first, every persistent workgroup one passage of each length class — measured with pre-sorted lengths:
             # attention −0.24 ms per step)
@@ -502,6 +499,14 @@ class Engine:
             self._rag_cache.clear()
         self._rag_cache[key] = (rag, attention_mask, self._all_valid)   # holding the tensor keeps (data_ptr, version) unambiguous
         return rag
+
+    def _packed_ids(self, ws, ids_flat, rag, L):
+        """token ids of the valid positions in packed order"""
+        if rag.idx is not None:
+            return ids_flat[rag.idx]
+        out = self._buf(ws, "e.ids", (rag.M,), torch.int64)
+        self.ops.pack_ids(ids_flat, rag.off, out, L)
+        return out
 
     def _check_lengths(self, attention_mask, lens_h, B, N, L):
         """`passage_lengths` is trusted (no device→host sync on the training path): lengths that do not describe the mask — not
@@ -877,7 +882,7 @@ class Engine:
         ctx.ckpt = bool(self.use_checkpoint and training)
         rag = ctx.rag = self._ragged_batch(attention_mask, B, N, L, lengths)
         self._row_cap = {rag.M: B * N * L} if rag is not None else {}
-        enc_ids = ctx.ids if rag is None else ctx.ids[rag.idx]
+        enc_ids = ctx.ids if rag is None else self._packed_ids(ws, ctx.ids, rag, L)
         ctx.enc_ids = enc_ids
         xa = ctx.xa = self._xattn_plan(rag, B, N, L, T * H)
         self.xattn_active = xa is not None         # (bench.py / tests: which formulation the last forward ran)
@@ -1108,7 +1113,7 @@ class Engine:
         else:
             koff = self._buf(ws, "g.koff", (B + 1,), torch.int32)
             koff.copy_(rag.soff)
-            ids, kb, kt, ckw, mode = ids[rag.idx], 1, rag.M, dict(k_off=koff, max_k=S), "r"
+            ids, kb, kt, ckw, mode = self._packed_ids(ws, ids, rag, L), 1, rag.M, dict(k_off=koff, max_k=S), "r"
         # cross-attention in the encoder-state space (R = H query rows per sample and step; no K/V projection of the N·L encoder
         # states): five launches per layer and step instead of one — slower while the host's launch rate bounds the loop (eager:
         # 113 ms against 93 ms for 50 tokens at config 2), faster once a step is one graph launch.  Never when the raw scores are

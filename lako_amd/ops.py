@@ -639,6 +639,13 @@ class HipOps:
         B, T = labels.shape
         self._timed("shift_right", 0.0, lambda: check(self.lib.lako_shift_right(_p(labels), _p(dec_ids), B, T, self._stream()), "lako_shift_right"))
 
+    def pack_ids(self, ids, off, out, L):
+        """out[off[j] + t] = ids[j·L + t] for the valid positions t of every passage j (ids int64 [BN·L], off int32 [BN + 1], out int64 [M])"""
+        if ids.dtype != torch.int64 or out.dtype != torch.int64 or off.dtype != torch.int32 or not ids.is_contiguous() or \
+                not out.is_contiguous() or not off.is_contiguous() or ids.numel() != (off.numel() - 1) * L:
+            raise LakoError("pack_ids: ids int64 [BN·L], off int32 [BN + 1], out int64 [M], all contiguous")
+        self._timed("pack_ids", 0.0, lambda: check(self.lib.lako_pack_ids(_p(ids), _p(off), _p(out), off.numel() - 1, int(L), self._stream()), "lako_pack_ids"))
+
     def greedy_step(self, logits, seq, pos, next_ids, done, n_done, eos_id=1, pad_id=0):
         B, V = logits.shape
         self._timed("greedy_step", 0.0, lambda: check(self.lib.lako_greedy_step(_p(logits), V, B, _p(seq), seq.stride(0), int(pos), _p(next_ids), _p(done),

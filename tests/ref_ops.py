@@ -563,6 +563,11 @@ class RefOps:
         dec_ids[:, 1:] = labels[:, :-1]
         dec_ids.masked_fill_(dec_ids == -100, 0)
 
+    def pack_ids(self, ids, off, out, L):
+        o = off.tolist()
+        for j in range(len(o) - 1):
+            out[o[j]:o[j + 1]] = ids[j * L:j * L + (o[j + 1] - o[j])]
+
     def greedy_step(self, logits, seq, pos, next_ids, done, n_done, eos_id=1, pad_id=0):
         nxt = logits.argmax(-1)
         nxt = torch.where(done.bool(), torch.full_like(nxt, pad_id), nxt)

@@ -410,7 +410,9 @@ def test_host_passage_lengths_equal_mask_readback(name):
     rag = eng.ctx.rag
     ref = eng._ragged_batch(mask, *ids.shape)
     assert rag is not None and rag.M == ref.M
-    assert torch.equal(rag.off, ref.off) and torch.equal(rag.soff, ref.soff) and torch.equal(rag.idx, ref.idx)
+    assert torch.equal(rag.off, ref.off) and torch.equal(rag.soff, ref.soff)
+    # (host lengths: no packed-row index is built — the ids are packed by one lako_pack_ids launch over the offsets; same tokens)
+    assert rag.idx is None and torch.equal(eng.ctx.enc_ids, ids.reshape(-1)[ref.idx])
     out[0].backward()
     assert abs(out[0].item() - l0) < 1e-7
     torch.testing.assert_close(eng.G, g0, atol=1e-7, rtol=1e-6)

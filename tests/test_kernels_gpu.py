@@ -916,6 +916,22 @@ def test_optimizer(ops, ref):
     assert torch.equal(out2, out)
 
 
+def test_pack_ids(ops, ref):
+    """lako_pack_ids: the valid positions of a padded [BN, L] id batch in packed (passage, position) order — empty and full passages"""
+    g = torch.Generator().manual_seed(3)
+    BN, L = 37, 50
+    lens = torch.randint(0, L + 1, (BN,), generator=g)
+    lens[0], lens[5] = L, 0
+    off = torch.zeros(BN + 1, dtype=torch.int32)
+    off[1:] = torch.cumsum(lens, 0)
+    ids = torch.randint(0, 32000, (BN * L,), generator=g)
+    out = torch.full((int(off[-1]),), -7, dtype=torch.int64, device=dev())
+    outr = torch.full_like(out, -7)
+    ops.pack_ids(ids.to(dev()), off.to(dev()), out, L)
+    ref.pack_ids(ids.to(dev()), off.to(dev()), outr, L)
+    assert torch.equal(out, outr) and int((out == -7).sum()) == 0
+
+
 def test_int_helpers(ops, ref):
     labels = torch.tensor([[5, 9, 1, -100], [7, 1, -100, -100]], device=dev())
     dec = torch.full_like(labels, 99)
