@@ -2074,7 +2074,7 @@ extern "C" int lako_gemm_nt(const lako_gemm_nt_t* p, lako_stream_t stream) {
   }
   if (p->flags & LAKO_EPI_ATOMIC) LAKO_CHECK_ARG(p->out_dtype == LAKO_F32, "lako_gemm_nt: ATOMIC needs fp32 C");
   LAKO_CHECK_ARG(p->drop.p >= 0.f && p->drop.p < 1.f, "lako_gemm_nt: dropout p out of range");
-  NtArgs a;
+  NtArgs a{};
   a.row0 = 0;
   a.A = (const char*)p->A;
   a.B = (const char*)p->B;

@@ -42,6 +42,7 @@ step_trace() {
   rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o b -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --all-valid-steps 0 > $OUT/bench_under_rocprof.json 2> $OUT/prof.log
   python tools/rocpd_stats.py /tmp/prof_$TAG/b_results.db > $OUT/bench_kernel_stats.csv
   python tools/rocpd_timeline.py /tmp/prof_$TAG/b_results.db 6 > $OUT/step_timeline.txt
+  python tools/rocpd_timeline.py /tmp/prof_$TAG/b_results.db 6 --all > $OUT/step_sequence.txt
   head -30 $OUT/step_timeline.txt
 }
 step_c45() {
