@@ -84,7 +84,8 @@ typedef struct lako_tuning {
                             bit for bit */
   int32_t nt_glds;       /* 1 (default): whole K-slices are staged by global_load_lds (rows past the edge clamped) instead of
                             buffer_load ... lds; partial K-slices (K % 64) keep the buffer form and its zero fill */
-  int32_t reserved[13];  /* zero */
+  int32_t nt_tile288;    /* 1 (default): 288-row tiles (variant 8) where they save a round or the tail launch — plain epilogues only */
+  int32_t reserved[12];  /* zero */
 } lako_tuning_t;
 int lako_tuning_init(lako_tuning_t* t);
 int lako_tuning_set(lako_tuning_t* t, const char* key, int value);

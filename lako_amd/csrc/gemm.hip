@@ -114,8 +114,9 @@ __device__ __forceinline__ void stage_rows(char* lds_tile, const char* base, int
                       : 0u;
   auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)nrec, 0x00020000);
 #pragma unroll
-  for (int i = 0; i < ROWS / 8 / NWAVES; ++i) {
+  for (int i = 0; i < (ROWS / 8 + NWAVES - 1) / NWAVES; ++i) {
     int inst = wave + i * NWAVES;
+    if ((ROWS / 8) % NWAVES != 0 && inst >= ROWS / 8) break;      // 288-row tiles: 36 pieces over 8 waves (wave-uniform)
     int row = inst * 8 + (lane >> 3);
     int cp = lane & 7;
     int c = cp ^ ((row >> 1) & 7);
@@ -552,12 +553,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
       const int pf_rows_a = more_k ? rows_a : min(BM, a.M - nm0), pf_rows_b = more_k ? rows_b : min(BN, a.N - nn0);
       const char* pf_a = more_k ? Abase + koff : a.A + (int64_t)nm0 * lda_b;
       const char* pf_b = more_k ? Bbase + koff : a.B + (int64_t)nn0 * ldb_b;
-      constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;    // 1-KiB DMA pieces per wave and K-step
+      constexpr int PA = (BM / 8 + NW - 1) / NW, PB = BN / 8 / NW;    // 1-KiB DMA pieces per wave and K-step (288-row tiles: the last A piece exists for waves 0–3 only)
       const auto rsrc_a = slice_rsrc(pf_a, pf_rows_a, lda_b, kbytes - koff);
       const auto rsrc_b = slice_rsrc(pf_b, pf_rows_b, ldb_b, kbytes - koff);
       auto piece = [&](int j) {
         if (!pf) return;
         if constexpr (SIDE) {
+          static_assert(!SIDE || (BM / 8) % NW == 0, "SIDE: whole pieces per wave");
           // one per-lane offset, a descriptor per piece (scalar arithmetic): the eight per-lane offsets the plain kernel keeps
           // in registers across the K-loop do not fit beside the SIDE epilogue's state (spills inside the K-loop); the plain
           // kernel keeps them — the scalar variant measured 2 % slower there (SGPR pressure spills into VGPR lanes)
@@ -569,7 +571,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
                                vb_b, wave, j - PA);
         } else {
           const bool full = a.glds && kbytes - koff >= TKB && pf_rows_a > 0 && pf_rows_b > 0;
-          if (j < PA) stage_piece_g<NW>(An, pf_a, rsrc_a, pf_rows_a, lda_b, kbytes - koff, wave, lane, j, full);
+          if (j < PA) { if ((BM / 8) % NW == 0 || wave + j * NW < BM / 8) stage_piece_g<NW>(An, pf_a, rsrc_a, pf_rows_a, lda_b, kbytes - koff, wave, lane, j, full); }
           else if (j < PA + PB) stage_piece_g<NW>(An + A_BYTES, pf_b, rsrc_b, pf_rows_b, ldb_b, kbytes - koff, wave, lane, j - PA, full);
         }
       };
@@ -743,7 +745,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
     rows_b = min(BN, a.N - n0);
     continue;
   }
-  if constexpr (sizeof(T) == 2 && sizeof(TO) == 2 && (MT == 8 || MT == 6) && NT == 4 && WM == 2 && WN == 4) {
+  if constexpr (sizeof(T) == 2 && sizeof(TO) == 2 && (MT == 8 || MT == 6 || MT == 9) && NT == 4 && WM == 2 && WN == 4) {
     if (a.wide_epi) {
       // WIDE epilogue (256² bf16 tile).  In the accumulator layout a lane owns 4 consecutive columns of 32
       // different sub-tiles: 32 eight-byte stores per lane that land as 32-B granules — store-ISSUE bound, ≈9 µs
@@ -754,10 +756,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
       char* ep = wave_scratch(cur ^ 1);
       const int cj = lane & 7, n = n0 + wc * 64 + cj * 8;
 #pragma unroll
-      for (int pass = 0; pass < MT / 2; ++pass) {
+      for (int pass = 0; pass < (MT + 1) / 2; ++pass) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
           const int mt = 2 * pass + mi, row_l = mi * 16 + r16;
+          if (mt >= MT) continue;            // odd MT (288-row tiles): the last pass is 16 rows
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt) {
             f32x4 v = acc[nt][mt] * a.alpha;
@@ -770,6 +773,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
         }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
+          if (2 * pass + it / 2 >= MT) continue;
           const int row_l = it * 8 + (lane >> 3);
           const f32x4 lo = *reinterpret_cast<const f32x4*>(ep + row_l * 256 + (((2 * cj) ^ (row_l & 15)) * 16));
           const f32x4 hi = *reinterpret_cast<const f32x4*>(ep + row_l * 256 + (((2 * cj + 1) ^ (row_l & 15)) * 16));
@@ -1722,13 +1726,14 @@ const TuneKey TUNE_KEYS[] = {
     {"gemm_nt_dephase_n", &lako_tuning_t::nt_dephase_n, false},   {"gemm_tn_big", &lako_tuning_t::tn_big, false},
     {"gemm_tn_split", &lako_tuning_t::tn_split, false},           {"gemm_nt_debug", &lako_tuning_t::nt_debug, true},
     {"gemm_nt_store_aux", &lako_tuning_t::nt_store_aux, true},    {"gemm_nt_tile192", &lako_tuning_t::nt_tile192, false},
+    {"gemm_nt_tile288", &lako_tuning_t::nt_tile288, false},
     {"gemm_nt_queue", &lako_tuning_t::nt_queue, false},           {"gemm_nt_pp", &lako_tuning_t::nt_pp, false},
     {"gemm_nt_glds", &lako_tuning_t::nt_glds, false},
 };
 
 void tuning_defaults(lako_tuning_t* t) {
   memset(t, 0, sizeof(*t));
-  t->nt_variant = -1;      // -1 auto; 0: 128x128 / 4 waves; 1: 256x128 / 8 waves; 2: 256x256 / 8 waves; 4: 128x128 ring; 5: split-K skinny; 6: 256x256 / 4 waves (experiment); 7: 192x256 / 8 waves
+  t->nt_variant = -1;      // -1 auto; 0: 128x128 / 4 waves; 1: 256x128 / 8 waves; 2: 256x256 / 8 waves; 4: 128x128 ring; 5: split-K skinny; 6: 256x256 / 4 waves (experiment); 7: 192x256 / 8 waves; 8: 288x256 / 8 waves (plain epilogues)
   t->nt_tail_split = 1;
   t->nt_ring = 1;          // skinny problems go to gemm_nt_ring_kernel (0 disables; variant 4 forces it)
   t->nt_skinny = 1;        // M <= 256 rows: gemm_nt_skinny_kernel (0 disables, 2 / 3 / 4 force 64² / 32² / 16² tiles; variant 5 forces the kernel)
@@ -1743,6 +1748,7 @@ void tuning_defaults(lako_tuning_t* t) {
   t->tn_split = 0;         // > 0: force the number of K-splits of the 256x256 TN kernel (A/B measurements)
   t->nt_glds = 1;          // K-slice staging of the 256² kernels by global_load_lds (0: buffer_load … lds everywhere)
   t->nt_pp = 0;            // 1: the 8-phase main loop of the 256² / 8-wave bf16 kernel (measured slower, A/B only); 0: the two-phase loop
+  t->nt_tile288 = 1;       // 1: 288-row tiles where the round count favours them (launch_nt; plain epilogues)
   t->nt_tile192 = 0;       // 1: 192-row tiles where the round count favours them (launch_nt) — measured no faster, off
 }
 
@@ -1849,7 +1855,7 @@ void launch_nt_cfg(NtArgs a, const lako_tuning_t& tu, hipStream_t s) {
   a.tiles_m = cdiv(a.M, BM);
   a.tiles_n = cdiv(a.N, BN);
   a.stagger = tu.nt_stagger;
-  a.glds = tu.nt_glds && (int64_t)256 * std::max(a.lda, a.ldb) * (int64_t)sizeof(T) < (1ll << 31);   // 32-bit row offsets inside a tile
+  a.glds = tu.nt_glds && (int64_t)BM * std::max(a.lda, a.ldb) * (int64_t)sizeof(T) < (1ll << 31);   // 32-bit row offsets inside a tile
   a.store_aux = (int64_t)256 * a.ldc * 2 < (1ll << 31) ? tu.nt_store_aux : 0;   // tile-relative 32-bit store offsets
   a.debug = tu.nt_debug;
   // narrow outputs (≤ 7 tile columns) already give an XCD a compact block; a negative knob forces |value| on every shape (tests).
@@ -1885,6 +1891,12 @@ void launch_nt_cfg(NtArgs a, const lako_tuning_t& tu, hipStream_t s) {
   hipLaunchKernelGGL((gemm_nt_kernel<T, TO, WM, WN, MT, NT, SIDE, QUEUE, PP>), dim3(grid), dim3(WM * WN * 64), LDS, s, a);
 }
 
+// 288-row tiles (MT = 9) exist for the plain epilogues (wide LDS-transposed stores); a side operand (residual / aux mask) or atomics keep 256 rows
+template <typename T, typename TO>
+bool nt288_ok(const NtArgs& a, const lako_tuning_t& tu) {
+  return sizeof(T) == 2 && sizeof(TO) == 2 && !(a.flags & (LAKO_EPI_RESID | LAKO_EPI_AUXMASK | LAKO_EPI_ATOMIC)) && !tu.nt_queue;
+}
+
 // the 256² kernel, with the LDS-staged side operand where the epilogue has exactly one (bf16 in and out, 16-B aligned rows)
 template <typename T, typename TO, int MT = 8>
 void launch_nt_256(const NtArgs& a, const lako_tuning_t& tu, hipStream_t s) {
@@ -1892,12 +1904,12 @@ void launch_nt_256(const NtArgs& a, const lako_tuning_t& tu, hipStream_t s) {
     const int side = a.flags & (LAKO_EPI_RESID | LAKO_EPI_AUXMASK);
     const char* sp = side == LAKO_EPI_RESID ? a.resid : a.aux;
     const int64_t ld = side == LAKO_EPI_RESID ? a.ldr : a.ldaux;
-    if (tu.nt_side_lds && (side == LAKO_EPI_RESID || side == LAKO_EPI_AUXMASK) && !(a.flags & LAKO_EPI_ATOMIC) && a.N % 8 == 0 &&
+    if (MT != 9 && tu.nt_side_lds && (side == LAKO_EPI_RESID || side == LAKO_EPI_AUXMASK) && !(a.flags & LAKO_EPI_ATOMIC) && a.N % 8 == 0 &&
         a.ldc % 8 == 0 && ld % 8 == 0 && reinterpret_cast<uintptr_t>(a.C) % 16 == 0 && reinterpret_cast<uintptr_t>(sp) % 16 == 0 &&
         (int64_t)256 * a.ldc * 2 < (1ll << 31) && (int64_t)256 * ld * 2 < (1ll << 31)) {
       if (MT == 8 && tu.nt_queue) launch_nt_cfg<T, TO, 2, 4, 8, 4, true, true>(a, tu, s);
       else if (MT == 8 && nt_pp_mode(tu, a)) launch_nt_cfg<T, TO, 2, 4, 8, 4, true, false, true>(a, tu, s);
-      else launch_nt_cfg<T, TO, 2, 4, MT, 4, true>(a, tu, s);
+      else if constexpr (MT != 9) launch_nt_cfg<T, TO, 2, 4, MT, 4, true>(a, tu, s);
       return;
     }
     if (MT == 8 && tu.nt_queue) {
@@ -1954,12 +1966,26 @@ int launch_nt(const NtArgs& a_in, const lako_tuning_t& tu, hipStream_t s) {
             bm = 192;
           }
         }
+        // 288-ROW TILES (round 4, MT = 9; profiles/r04h_gemm_tile_height.txt).  The other direction pays: a 288-row tile takes ≈1.13–1.16 of a
+        // 256-row tile's time for 1.125 of its work, and 47 757 rows × 768 columns are 498 of them — two rounds at 97 % instead of two rounds +
+        // a 128²-tile tail launch: −10…−12 % per call on the three N = 768 gradient products of a layer, −1…−3 % at N = 2304 / 3072 (one round
+        // fewer).  144 accumulator registers: 243 VGPRs with the plain epilogues; with a side operand 288-row tiles need the 16-row side passes
+        // (launch_nt_256<…, 9>).
+        if (tu.nt_tile288 && !(a.flags & LAKO_EPI_ATOMIC) && nt288_ok<T, TO>(a, tu)) {
+          const Plan p288 = plan(288, 1.13);
+          if (p288.cost < 0.99 * pl.cost) {
+            pl = p288;
+            bm = 288;
+          }
+        }
       }
       if (pl.tail) {
         NtArgs head = a;
         head.M = (int)(pl.full_rows * bm);
         if (bm == 192) {
           if constexpr (sizeof(T) == 2 && sizeof(TO) == 2) launch_nt_256<T, TO, 6>(head, tu, s);
+        } else if (bm == 288) {
+          if constexpr (sizeof(T) == 2 && sizeof(TO) == 2) launch_nt_256<T, TO, 9>(head, tu, s);
         } else {
           launch_nt_256<T, TO>(head, tu, s);
         }
@@ -1973,6 +1999,8 @@ int launch_nt(const NtArgs& a_in, const lako_tuning_t& tu, hipStream_t s) {
         v = 0;      // the tail: 128² tiles (round 4: 256 × 128 / 8-wave tiles for the tail measured +0.2 ms on the step)
       } else if (bm == 192) {
         v = 7;
+      } else if (bm == 288) {
+        v = 8;
       }
     }
   }
@@ -2032,10 +2060,15 @@ LAKO_SET_MAX_LDS((&gemm_nt_skinny_kernel<TO, 8, 16, 4>), 8 * 16384);
     hipLaunchKernelGGL((gemm_nt_ring_kernel<T, TO>), dim3(tiles * b.split_k), dim3(256), RING_NST * RING_STAGE, s, b);
     return 0;
   }
-  if (v == 7 && (sizeof(T) != 2 || sizeof(TO) != 2)) v = 2;
+  if ((v == 7 || v == 8) && (sizeof(T) != 2 || sizeof(TO) != 2)) v = 2;
   if (v == 2) launch_nt_256<T, TO>(a, tu, s);
   else if (v == 7) {
     if constexpr (sizeof(T) == 2 && sizeof(TO) == 2) launch_nt_256<T, TO, 6>(a, tu, s);     // 192 x 256 tiles
+  } else if (v == 8) {
+    if constexpr (sizeof(T) == 2 && sizeof(TO) == 2) {                                          // 288 x 256 tiles
+      if (nt288_ok<T, TO>(a, tu)) launch_nt_256<T, TO, 9>(a, tu, s);
+      else launch_nt_256<T, TO>(a, tu, s);
+    }
   } else if (v == 6 && sizeof(T) == 2) launch_nt_cfg<T, TO, 2, 2, 8, 8>(a, tu, s);   // EXPERIMENT: 256x256 on 4 waves of 128x128 (hipBLASLt's MT256x256x64 MIWT8_8 shape)
   else if (v == 1) launch_nt_cfg<T, TO, 4, 2, 4, 4>(a, tu, s);
   else launch_nt_cfg<T, TO, 2, 2, 4, 4>(a, tu, s);

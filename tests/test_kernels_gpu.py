@@ -77,14 +77,15 @@ def test_gemm_nt_plain(ops, ref, dt, M, N, K):
         close(C, Cr, T, f"gemm_nt {dt}->{out_t} {M}x{N}x{K}", tight=True)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 7])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 7, 8])
 @pytest.mark.parametrize("M,N,K", [(1024, 768, 768), (700, 520, 200), (256, 256, 32), (2048, 2304, 768), (300, 264, 3072), (128, 768, 72),
                                    (128, 768, 768), (100, 200, 160), (16, 3072, 768), (130, 776, 3072)])
 def test_gemm_nt_tile_variants(ops, ref, variant, M, N, K):
     """every tile variant of the bf16 NT kernel (0: 128², 1: 256×128, 2: 256² 2-buffer, 3: 256² 4-slot ring, 4: the 128²
     4-slot ring that skinny problems are dispatched to, 5: the 64² kernel whose four waves split K, for M <= 256 rows — it
     falls back to the ring when K is not a multiple of 32, 7: 192×256 tiles — the 256² kernel's MT = 6 instantiation, whose last
-    wave keeps its epilogue scratch behind the K-slice buffers),
+    wave keeps its epilogue scratch behind the K-slice buffers, 8: 288×256 tiles — MT = 9: the last A piece of a K-slice exists for
+    waves 0–3 only, the last epilogue pass is 16 rows; plain epilogues only, the others fall back to 256-row tiles),
     persistent and one-tile-per-workgroup grids, ragged edges, fused epilogues."""
     T = torch.bfloat16
     A, B = rnd(M, K, dtype=T, seed=41), rnd(N, K, dtype=T, seed=42)
@@ -272,7 +273,8 @@ def test_gemm_nt_tile_queue(ops, ref):
 
 
 def test_gemm_nt_tile_height_plan(ops, ref):
-    """With `gemm_nt_tile192` on, launch_nt prices 256-row and 192-row tiles per call: 47 757 rows x 768 columns — the benchmark's
+    """(`gemm_nt_tile288`, round 4, on by default: 288-row tiles where they save the tail launch or a round — two rounds of 498 tiles here.)
+    With `gemm_nt_tile192` on, launch_nt prices 256-row and 192-row tiles per call: 47 757 rows x 768 columns — the benchmark's
     encoder shape — take 192-row tiles in three full rounds and no tail launch; with it off (the default: measured no faster,
     profiles/r03e_gemm_tile192.txt) the call runs 256-row tiles + the tail launch.  Same result to bf16 rounding of identical fp32 sums (bit for bit: each output element's K-loop is the
     same sequence of MFMAs), with every fused epilogue; dropout draws by global row."""
@@ -283,20 +285,22 @@ def test_gemm_nt_tile_height_plan(ops, ref):
     try:
         for kw in (dict(), dict(relu=True, drop=(0.1, 5, 6)), dict(resid=R, drop=(0.1, 7, 8), alpha=0.5), dict(aux=X, aux_scale=1.1)):
             got = []
-            for t192 in (1, 0):
+            for t192, t288 in ((1, 0), (0, 0), (0, 1)):      # (0, 1) = the default: 288-row tiles for the plain epilogues of this shape
                 ops.set_tuning("gemm_nt_tile192", t192)
+                ops.set_tuning("gemm_nt_tile288", t288)
                 ops.probe = []
                 C = torch.empty(M, N, dtype=T, device=dev())
                 ops.gemm_nt(A, B, C, **kw)
                 torch.cuda.synchronize()
                 ops.probe = None
                 got.append(C)
-            assert torch.equal(got[0], got[1]), list(kw)
+            assert torch.equal(got[0], got[1]) and torch.equal(got[2], got[1]), list(kw)
             Cr = torch.zeros(M, N, device=dev())
             ref.gemm_nt(A, B, Cr, **kw)
             close(got[0], Cr, T, f"gemm_nt 192-row plan {list(kw)}", tight=True)
     finally:
         ops.set_tuning("gemm_nt_tile192", 0)
+        ops.set_tuning("gemm_nt_tile288", 1)
         ops.probe = None
 
 
