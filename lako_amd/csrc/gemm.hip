@@ -178,6 +178,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t slice_rsrc(const char* base, i
   return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)nrec, 0x00020000);
 }
 
+// the lane id, recomputed where it is needed (v_mbcnt of an opaque zero: cannot be hoisted, keeps no register alive across the K loop)
+__device__ __forceinline__ int fresh_lane() {
+  int z = 0;
+  asm volatile("" : "+v"(z));
+  return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)z));
+}
+
 __device__ __forceinline__ u32x4 read_frag_rows(const char* lds_tile, int row, int chunk) {
   int cp = chunk ^ ((row >> 1) & 7);
   return *reinterpret_cast<const u32x4*>(lds_tile + row * TKB + cp * 16);
@@ -299,6 +306,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
   static_assert(!PP || (WM * WN == 8 && !QUEUE), "PP: 8 waves, static tile order");
   constexpr int NW = WM * WN, BM = WM * MT * 16, BN = WN * NT * 16;
   constexpr int A_BYTES = BM * TKB, B_BYTES = BN * TKB, BUF = A_BYTES + B_BYTES;
+  // SIDE: rows of a side pass (32 = two m-tiles; odd MT — the 288-row tile — takes one m-tile per pass, which also halves the slots so that
+  // they fit behind the two 68-KiB K-slice buffers), its DMA pieces (= the 16-byte stores of a finished pass) and the bytes of one slot
+  constexpr int PH = MT % 2 == 0 ? 32 : 16, SP = PH / 8, SLOT = PH * 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -334,7 +344,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
   // 8 waves × 8 KiB (192-row tiles: 56 KiB) the last wave(s) use an extra region behind the buffers (and the SIDE slots)
   constexpr int SCR_IN_BUF = BUF / 8192 < NW ? BUF / 8192 : NW;
   auto wave_scratch = [&](int free_buf) -> char* {
-    return wave < SCR_IN_BUF ? smem + free_buf * BUF + wave * 8192 : smem + 2 * BUF + (SIDE ? 32 * 1024 : 0) + (wave - SCR_IN_BUF) * 8192;
+    return wave < SCR_IN_BUF ? smem + free_buf * BUF + wave * 8192 : smem + 2 * BUF + (SIDE ? NW * SLOT : 0) + (wave - SCR_IN_BUF) * 8192;
   };
 
   // SIDE: pass p = rows [32p, 32p + 32) of this wave's 128×64 region of the residual / aux tile → 4 KiB of LDS, 16-B chunk c of
@@ -349,12 +359,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
       const int ld_b = (int)(res ? a.ldr : a.ldaux) * 2;
       const int rows_v = min(BM, a.M - tm0), cols_v = min(BN, a.N - tn0);
       const auto rs = lds_dma_rsrc(sp + (int64_t)tm0 * ld_b + (int64_t)tn0 * 2, (uint32_t)((rows_v - 1) * ld_b + cols_v * 2));
-      int l = lane;
-      asm volatile("" : "+v"(l));
+      const int l = fresh_lane();
       const int col_t = wc * 64 + (((l & 7) ^ ((l >> 3) & 7)) * 8);
       const uint32_t vb = col_t < cols_v ? (uint32_t)((wr * (MT * 16) + (l >> 3)) * ld_b + col_t * 2) : 0x80000000u;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) lds_dma16(slot + j * 1024, rs, vb + (uint32_t)((pass * 32 + j * 8) * ld_b));
+      for (int j = 0; j < SP; ++j) lds_dma16(slot + j * 1024, rs, vb + (uint32_t)((pass * PH + j * 8) * ld_b));
     }
   };
 
@@ -556,17 +565,24 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
       constexpr int PA = (BM / 8 + NW - 1) / NW, PB = BN / 8 / NW;    // 1-KiB DMA pieces per wave and K-step (288-row tiles: the last A piece exists for waves 0–3 only)
       const auto rsrc_a = slice_rsrc(pf_a, pf_rows_a, lda_b, kbytes - koff);
       const auto rsrc_b = slice_rsrc(pf_b, pf_rows_b, ldb_b, kbytes - koff);
+      // (SIDE: the per-lane offset is rebuilt from an opaque copy of the lane id in every K-step — hoisted out of the K loop its parts
+      //  are four more live registers, which the 288-row instantiation spills and reloads, with a vmcnt(0) each, inside the loop)
+      uint32_t vb_a = 0, vb_b = 0;
+      if constexpr (SIDE) {
+        const int lo = fresh_lane();
+        vb_a = piece_base(lda_b, kbytes - koff, wave, lo);
+        vb_b = piece_base(ldb_b, kbytes - koff, wave, lo);
+      }
       auto piece = [&](int j) {
         if (!pf) return;
         if constexpr (SIDE) {
-          static_assert(!SIDE || (BM / 8) % NW == 0, "SIDE: whole pieces per wave");
           // one per-lane offset, a descriptor per piece (scalar arithmetic): the eight per-lane offsets the plain kernel keeps
           // in registers across the K-loop do not fit beside the SIDE epilogue's state (spills inside the K-loop); the plain
           // kernel keeps them — the scalar variant measured 2 % slower there (SGPR pressure spills into VGPR lanes)
-          const uint32_t vb_a = piece_base(lda_b, kbytes - koff, wave, lane), vb_b = piece_base(ldb_b, kbytes - koff, wave, lane);
-          if (j < PA)
-            stage_piece_at<NW>(An, slice_rsrc(pf_a + (int64_t)j * NW * 8 * lda_b, pf_rows_a - j * NW * 8, lda_b, kbytes - koff), vb_a, wave, j);
-          else if (j < PA + PB)
+          if (j < PA) {
+            if ((BM / 8) % NW == 0 || wave + j * NW < BM / 8)
+              stage_piece_at<NW>(An, slice_rsrc(pf_a + (int64_t)j * NW * 8 * lda_b, pf_rows_a - j * NW * 8, lda_b, kbytes - koff), vb_a, wave, j);
+          } else if (j < PA + PB)
             stage_piece_at<NW>(An + A_BYTES, slice_rsrc(pf_b + (int64_t)(j - PA) * NW * 8 * ldb_b, pf_rows_b - (j - PA) * NW * 8, ldb_b, kbytes - koff),
                                vb_b, wave, j - PA);
         } else {
@@ -584,17 +600,25 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
       // row of MFMAs instead measured equal to 3 % slower: the L2→LDS path, not the issue slot, is the limit.)
       const bool late = a.stagger && NW == 8 && wave >= NW / 2;
       if (!late) prefetch();
+      // (288-row tile with a side operand: 256 registers — the lane parts of the fragment addresses are rebuilt per K-step; kept across the
+      //  loop one of them is spilled and its reload sits, with a vmcnt(0), between the DMA issue and the fragment reads)
+      int r16k = r16, gk = g;
+      if constexpr (SIDE && MT > 8) {
+        const int lf = fresh_lane();
+        r16k = lf & 15;
+        gk = lf >> 4;
+      }
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh) {
         u32x4 af[MT], bf[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bf[nt] = read_frag_rows(Bs, (wc * NT + nt) * 16 + r16, kh * 4 + g);
+        for (int nt = 0; nt < NT; ++nt) bf[nt] = read_frag_rows(Bs, (wc * NT + nt) * 16 + r16k, kh * 4 + gk);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           // debug bit 5 (timing experiment, wrong results): every second A fragment is a copy of its neighbour — a third fewer LDS
           // reads at unchanged DMA and MFMA work: does the fragment-read traffic slow the DMA's LDS writes?
           if (NT_DBG(a, 32) && (mt & 1)) af[mt] = af[mt - 1];
-          else af[mt] = read_frag_rows(As, (wr * MT + mt) * 16 + r16, kh * 4 + g);
+          else af[mt] = read_frag_rows(As, (wr * MT + mt) * 16 + r16k, kh * 4 + gk);
         }
         // all fragment reads of the K-half go out back to back; left alone, the machine scheduler folds every
         // A fragment into ONE register quad (read → s_waitcnt lgkmcnt(0) → 4 MFMAs, MT times per K-half),
@@ -616,7 +640,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
           }
           if (SIDE && t == 0) {   // pass 0 of the side operand → the spare 32 KiB, behind this step's K-slice DMA
             __builtin_amdgcn_sched_barrier(0);
-            side_issue(0, smem + 2 * BUF + wave * 4096, m0, n0);
+            side_issue(0, smem + 2 * BUF + wave * SLOT, m0, n0);
             __builtin_amdgcn_sched_barrier(0);
           }
           mma_rows(Q, MT);
@@ -626,7 +650,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
           // enough that the barrier round trip is covered by MFMAs already queued
           mma_rows(0, MT - Q);
           __builtin_amdgcn_sched_barrier(0);
-          if (SIDE && t == 0 && nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // the side pass may land during the next K-step
+          if (SIDE && t == 0 && nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SP) : "memory");   // the side pass may land during the next K-step
           else if (!NT_DBG(a, 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __syncthreads();
           __builtin_amdgcn_sched_barrier(0);
@@ -653,13 +677,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
     // results); the finished 16 rows then go through 4 KiB of scratch and leave as row-major 16-B stores.
     // every lane-derived address below is rebuilt from an opaque copy of the lane id: as loop invariants of the persistent tile
     // loop they would be hoisted to the kernel prologue and stay live across the main loop (spills)
-    int le = lane;
-    asm volatile("" : "+v"(le));
+    const int le = fresh_lane();
     const int r16e = le & 15, ge = le >> 4;
-    char* slot_a = smem + 2 * BUF + wave * 4096;
+    char* slot_a = smem + 2 * BUF + wave * SLOT;
     char* fr = wave_scratch(cur ^ 1);
     char* slot_b = fr + 4096;
-    constexpr int NP = MT / 2;          // 32-row passes of the wave's rows
+    constexpr int NP = MT * 16 / PH;    // PH-row passes of the wave's rows
+    constexpr int MPP = PH / 16;        // m-tiles per pass
     const int rows_v = min(BM, a.M - m0), cols_v = min(BN, a.N - n0), ldc_b = (int)a.ldc * 2;
     // rows past the edge fall out of the descriptor's range by themselves; columns past it start from an out-of-range base
     const auto crs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(C + (int64_t)m0 * a.ldc + n0), 0,
@@ -670,18 +694,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
 #pragma unroll
     for (int pass = 0; pass < NP; ++pass) {
       char* slot = (pass & 1) ? slot_b : slot_a;
-      // in flight behind the side pass needed now (4 DMA pieces per side pass, 4 stores per finished pass) — pass 1: side 2 + stores 0;
+      // in flight behind the side pass needed now (SP DMA pieces per side pass, SP stores per finished pass) — pass 1: side 2 + stores 0;
       // pass p >= 2: stores p−2, side p+1 (if there is one), stores p−1
       if (pass == 1) {
-        if (NP > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (NP > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * SP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SP) : "memory");
       } else if (pass >= 2) {
-        if (pass + 1 < NP) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (pass + 1 < NP) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * SP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * SP) : "memory");
       }
-      bf16x4 sv[2][4];
+      bf16x4 sv[MPP][4];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < MPP; ++mi)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
           const int row_l = mi * 16 + r16e;
@@ -692,8 +716,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
         side_issue(pass + 2, slot, m0, n0);
       }
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        const int mt = 2 * pass + mi;
+      for (int mi = 0; mi < MPP; ++mi) {
+        const int mt = MPP * pass + mi;
         const int m = m0 + (wr * MT + mt) * 16 + r16e;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
@@ -1850,7 +1874,8 @@ void launch_nt_cfg(NtArgs a, const lako_tuning_t& tu, hipStream_t s) {
   constexpr int BM = WM * MT * 16, BN = WN * NT * 16, NW_ = WM * WN, BUF_ = (BM + BN) * TKB;
   // + the epilogue scratch of the waves that do not fit the free K-slice buffer (8 KiB each; 192-row tiles: one wave)
   constexpr int EXTRA = (sizeof(T) == 2 && NW_ == 8 && BUF_ / 8192 < NW_) ? (NW_ - BUF_ / 8192) * 8192 : 0;
-  constexpr int LDS = 2 * BUF_ + (SIDE ? 32 * 1024 : 0) + EXTRA;
+  constexpr int LDS = 2 * BUF_ + (SIDE ? NW_ * (MT % 2 == 0 ? 32 : 16) * 128 : 0) + EXTRA;
+  static_assert(LDS <= 160 * 1024, "LDS");
   LAKO_SET_MAX_LDS((&gemm_nt_kernel<T, TO, WM, WN, MT, NT, SIDE, QUEUE, PP>), LDS);
   a.tiles_m = cdiv(a.M, BM);
   a.tiles_n = cdiv(a.N, BN);
@@ -1891,10 +1916,10 @@ void launch_nt_cfg(NtArgs a, const lako_tuning_t& tu, hipStream_t s) {
   hipLaunchKernelGGL((gemm_nt_kernel<T, TO, WM, WN, MT, NT, SIDE, QUEUE, PP>), dim3(grid), dim3(WM * WN * 64), LDS, s, a);
 }
 
-// 288-row tiles (MT = 9) exist for the plain epilogues (wide LDS-transposed stores); a side operand (residual / aux mask) or atomics keep 256 rows
+// 288-row tiles (MT = 9): bf16 in and out, static tile order (the QUEUE instantiations are 256-row)
 template <typename T, typename TO>
 bool nt288_ok(const NtArgs& a, const lako_tuning_t& tu) {
-  return sizeof(T) == 2 && sizeof(TO) == 2 && !(a.flags & (LAKO_EPI_RESID | LAKO_EPI_AUXMASK | LAKO_EPI_ATOMIC)) && !tu.nt_queue;
+  return sizeof(T) == 2 && sizeof(TO) == 2 && !(a.flags & LAKO_EPI_ATOMIC) && !tu.nt_queue;
 }
 
 // the 256² kernel, with the LDS-staged side operand where the epilogue has exactly one (bf16 in and out, 16-B aligned rows)
@@ -1904,12 +1929,12 @@ void launch_nt_256(const NtArgs& a, const lako_tuning_t& tu, hipStream_t s) {
     const int side = a.flags & (LAKO_EPI_RESID | LAKO_EPI_AUXMASK);
     const char* sp = side == LAKO_EPI_RESID ? a.resid : a.aux;
     const int64_t ld = side == LAKO_EPI_RESID ? a.ldr : a.ldaux;
-    if (MT != 9 && tu.nt_side_lds && (side == LAKO_EPI_RESID || side == LAKO_EPI_AUXMASK) && !(a.flags & LAKO_EPI_ATOMIC) && a.N % 8 == 0 &&
+    if (tu.nt_side_lds && (side == LAKO_EPI_RESID || side == LAKO_EPI_AUXMASK) && !(a.flags & LAKO_EPI_ATOMIC) && a.N % 8 == 0 &&
         a.ldc % 8 == 0 && ld % 8 == 0 && reinterpret_cast<uintptr_t>(a.C) % 16 == 0 && reinterpret_cast<uintptr_t>(sp) % 16 == 0 &&
         (int64_t)256 * a.ldc * 2 < (1ll << 31) && (int64_t)256 * ld * 2 < (1ll << 31)) {
       if (MT == 8 && tu.nt_queue) launch_nt_cfg<T, TO, 2, 4, 8, 4, true, true>(a, tu, s);
       else if (MT == 8 && nt_pp_mode(tu, a)) launch_nt_cfg<T, TO, 2, 4, 8, 4, true, false, true>(a, tu, s);
-      else if constexpr (MT != 9) launch_nt_cfg<T, TO, 2, 4, MT, 4, true>(a, tu, s);
+      else launch_nt_cfg<T, TO, 2, 4, MT, 4, true>(a, tu, s);
       return;
     }
     if (MT == 8 && tu.nt_queue) {

@@ -123,7 +123,7 @@ def test_gemm_nt_side_operand_in_lds(ops, ref, M, N, K):
     cases = (dict(resid=R), dict(resid=R, drop=(0.1, 7, 8), alpha=0.5), dict(resid=R, relu=True), dict(aux=X, aux_scale=1.1),
              dict(aux=X, aux_scale=1.0 / 0.9, drop=(0.1, 3, 4)))
     try:
-        for variant in (2, 7):              # 256-row tiles (4 side passes per wave) and 192-row tiles (3)
+        for variant in (2, 7, 8):           # 256-row tiles (4 side passes per wave), 192-row tiles (3) and 288-row tiles (9 passes of 16 rows)
             ops.set_tuning("gemm_nt_variant", variant)
             for kw in cases:
                 got = {}

@@ -22,12 +22,22 @@ shapes = [("qkv   [M,768]x[2304,768]", 2304, 768, {}),
           ("dctx  [M,768]x[768,768]", 768, 768, {}),
           ("dxn   [M,2304]x[768,2304]", 768, 2304, {}),
           ("dxn   [M,3072]x[768,3072]", 768, 3072, {}),
+          ("o+res [M,768]x[768,768] res+drop", 768, 768, dict(resid=True, drop=drop)),
+          ("wo+res[M,3072]x[768,3072] res+drop", 768, 3072, dict(resid=True, drop=drop)),
+          ("dpre  [M,768]x[3072,768] auxmask", 3072, 768, dict(aux=True)),
           ("8192^3", 8192, 8192, {})]
+if os.environ.get("ONLY"):
+    shapes = [sh for sh in shapes if any(k in sh[0] for k in os.environ["ONLY"].split(","))]
 for nm, N, K, kw in shapes:
     M = 8192 if nm.startswith("8192") else ROWS
     A = torch.randn(M, K, device=dev).to(torch.bfloat16)
     B = torch.randn(N, K, device=dev).to(torch.bfloat16)
     C = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    kw = dict(kw)
+    if kw.pop("resid", False):
+        kw["resid"] = torch.randn(M, N, device=dev).to(torch.bfloat16)
+    if kw.pop("aux", False):
+        kw["aux"], kw["aux_scale"] = torch.randn(M, N, device=dev).to(torch.bfloat16), 1.1
     res = {v: [] for v in VARIANTS}
     for rep in range(REPS + 1):
         for v in VARIANTS:
