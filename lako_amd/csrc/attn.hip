@@ -812,13 +812,11 @@ inline int pick_chunk(int L) {
   return ch > CH_MAX ? CH_MAX : ch;
 }
 
-// raise the kernel's dynamic-LDS limit only when a launch needs more than any earlier one (`cur` is
-// a per-instantiation static owned by the caller)
+// raise the kernel's dynamic-LDS limit only when a launch needs more than any earlier one ON THIS DEVICE (`cur` is a per-instantiation
+// static owned by the caller; the attribute is per device: common.h)
 template <typename K>
-void set_lds_attr(K kern, int bytes, int& cur) {
-  if (bytes <= cur) return;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  cur = bytes;
+void set_lds_attr(K kern, int bytes, lako_lds_cur_t& cur) {
+  lako_raise_max_lds(reinterpret_cast<const void*>(kern), bytes, cur);
 }
 
 // choose register-side blocks per workgroup: all of them when there are already plenty of workgroups,
@@ -840,11 +838,11 @@ int run_fwd(AttnArgs& a, hipStream_t s) {
   const int lds = lds_bytes_fwd<T, DK>(a.chunk_rows, a.R, nqb == 1);
   dim3 grid((nqb + a.blocks_per_wg - 1) / a.blocks_per_wg, a.H, a.Bn);
   if (a.scores_out) {
-    static int curc = 0;
+    static lako_lds_cur_t curc;
     set_lds_attr(&attn_fwd_kernel<T, DK, true>, lds, curc);
     hipLaunchKernelGGL((attn_fwd_kernel<T, DK, true>), grid, dim3(256), lds, s, a);
   } else {
-    static int cur = 0;
+    static lako_lds_cur_t cur;
     set_lds_attr(&attn_fwd_kernel<T, DK, false>, lds, cur);
     hipLaunchKernelGGL((attn_fwd_kernel<T, DK, false>), grid, dim3(256), lds, s, a);
   }
@@ -873,7 +871,7 @@ int run_bwd(AttnArgs& a, hipStream_t s) {
       if (q.bn_per_wg > OFFS_MAX - 1) q.bn_per_wg = OFFS_MAX - 1;   // the kernel stages bn_per_wg + 1 row offsets in LDS
     }
     const int lds = lds_bytes_bwd<T, DK>(q.chunk_rows, a.R, nqb == 1);
-    static int cur0 = 0;
+    static lako_lds_cur_t cur0;
     set_lds_attr(&attn_bwd_kernel<T, DK, 0>, lds, cur0);
     dim3 grid((nqb + q.blocks_per_wg - 1) / q.blocks_per_wg, a.H, (a.Bn + q.bn_per_wg - 1) / q.bn_per_wg);
     q.grid_x = 0;
@@ -894,7 +892,7 @@ int run_bwd(AttnArgs& a, hipStream_t s) {
     const int nkb = (a.Lk + 15) / 16;
     k.blocks_per_wg = pick_blocks_per_wg(nkb, (int64_t)a.Bn * a.H);
     const int lds = lds_bytes_bwd<T, DK>(k.chunk_rows, a.R, false);
-    static int cur1 = 0;
+    static lako_lds_cur_t cur1;
     set_lds_attr(&attn_bwd_kernel<T, DK, 1>, lds, cur1);
     dim3 grid((nkb + k.blocks_per_wg - 1) / k.blocks_per_wg, a.H, a.Bn);
     hipLaunchKernelGGL((attn_bwd_kernel<T, DK, 1>), grid, dim3(256), lds, s, k);

@@ -1017,10 +1017,8 @@ __global__ __launch_bounds__(PF_NW * 64) void enc_bwd_dkv_p_kernel(AttnArgs a) {
 }
 
 template <typename K>
-void eset_lds(K kern, int bytes, int& cur) {
-  if (bytes <= cur) return;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  cur = bytes;
+void eset_lds(K kern, int bytes, lako_lds_cur_t& cur) {
+  lako_raise_max_lds(reinterpret_cast<const void*>(kern), bytes, cur);
 }
 
 // query / key blocks per workgroup: all of them when there are already plenty of workgroups, otherwise split so that the grid
@@ -1036,8 +1034,8 @@ inline int eblocks_per_wg(int nblocks, int64_t bh, int nw) {
 
 #define EDISPATCH(KERN, NTHR, drop, grid, lds, s, args)                                                                          \
   do {                                                                                                                           \
-    if (drop) { static int c = 0; eset_lds(&KERN<true>, lds, c); hipLaunchKernelGGL((KERN<true>), grid, dim3(NTHR), lds, s, args); }    \
-    else { static int c = 0; eset_lds(&KERN<false>, lds, c); hipLaunchKernelGGL((KERN<false>), grid, dim3(NTHR), lds, s, args); }       \
+    if (drop) { static lako_lds_cur_t c; eset_lds(&KERN<true>, lds, c); hipLaunchKernelGGL((KERN<true>), grid, dim3(NTHR), lds, s, args); }    \
+    else { static lako_lds_cur_t c; eset_lds(&KERN<false>, lds, c); hipLaunchKernelGGL((KERN<false>), grid, dim3(NTHR), lds, s, args); }       \
   } while (0)
 
 }  // namespace

@@ -76,6 +76,16 @@ __device__ __forceinline__ void lds_dma16_g(const void* lds_dst, const void* bas
       if (lako_dev_ >= 0 && lako_dev_ < 64) lako_lds_done_[lako_dev_].store(true, std::memory_order_relaxed);             \
     }                                                                                                                     \
   } while (0)
+// the same for kernels whose LDS need varies per launch: `cur` holds, PER DEVICE, the largest size set so far (a static array of the call site)
+struct lako_lds_cur_t { std::atomic<int> v[64]; };
+inline void lako_raise_max_lds(const void* kern, int bytes, lako_lds_cur_t& cur) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const bool ok = dev >= 0 && dev < 64;
+  if (ok && bytes <= cur.v[dev].load(std::memory_order_relaxed)) return;
+  (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (ok) cur.v[dev].store(bytes, std::memory_order_relaxed);
+}
 #endif
 
 // ---------------------------------------------------------------------------------------------

@@ -883,12 +883,7 @@ int xcheck_common(const char* fn, const void* e, int64_t e_ld, const int32_t* k_
   return LAKO_OK;
 }
 
-void xset_lds(const void* fn, int bytes, bool& done) {
-  if (!done) {
-    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    done = true;
-  }
-}
+void xset_lds(const void* fn, int bytes, lako_lds_cur_t& done) { lako_raise_max_lds(fn, bytes, done); }
 
 }  // namespace
 
@@ -909,7 +904,7 @@ extern "C" int lako_xattn_scores(const void* q, int64_t q_sb, int64_t q_ld, cons
   a.k_off = k_off; a.p_off = p_off;
   a.s = s; a.s_ld = s_ld;
   a.R = R; a.D = D; a.B = B; a.Z = 1;
-  static bool done = false;
+  static lako_lds_cur_t done;
   xset_lds(reinterpret_cast<const void*>(&xscores_kernel), XS_NSTG * XS_STAGE, done);
   hipLaunchKernelGGL(xscores_kernel, dim3((unsigned)(p_total / 256), (unsigned)((R + 127) / 128)), dim3(512), XS_NSTG * XS_STAGE,
                      (hipStream_t)stream, a);
@@ -934,7 +929,7 @@ extern "C" int lako_xattn_context(const void* p, int64_t p_ld, const void* e, in
   a.out = out; a.out_zs = out_zs; a.out_sb = out_sb; a.out_ld = out_ld;
   a.R = R; a.D = D; a.B = B; a.Z = key_splits;
   const int lds = XC_NSTG * XC_STAGE;
-  static bool done = false;
+  static lako_lds_cur_t done;
   xset_lds(reinterpret_cast<const void*>(&xcontext_kernel), lds, done);
   hipLaunchKernelGGL(xcontext_kernel, dim3((unsigned)(D / 128), (unsigned)(B * key_splits), (unsigned)((R + 127) / 128)),
                      dim3(512), lds, (hipStream_t)stream, a);
@@ -1096,7 +1091,7 @@ extern "C" int lako_xattn_decode(const void* q, int64_t q_sb, int64_t q_ld, cons
   hipStream_t s = (hipStream_t)stream;
 #define XD_GO(KSV)                                                                                                     \
   do {                                                                                                                 \
-    static bool done = false;                                                                                          \
+    static lako_lds_cur_t done;                                                                                          \
     xset_lds(reinterpret_cast<const void*>(&xdecode_kernel<KSV>), lds, done);                                          \
     hipLaunchKernelGGL((xdecode_kernel<KSV>), grid, dim3(512), lds, s, a);                                             \
   } while (0)
