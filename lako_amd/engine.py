@@ -181,6 +181,7 @@ class Engine:
         dev = self.device
         self.P = torch.zeros(self.n_param, dtype=torch.float32, device=dev)
         self.G = torch.zeros(self.n_param, dtype=torch.float32, device=dev)
+        self._g_fresh = True         # G is all zeros (construction / zero_grad) and no backward has added to it yet
         self.W = self.P if dtype == torch.float32 else torch.zeros(self.n_param, dtype=dtype, device=dev)
         self.WT = torch.zeros(self.n_trans, dtype=dtype, device=dev)
         self.opt_m = None   # AdamW moments, allocated by the optimizer on first use
@@ -321,6 +322,7 @@ class Engine:
 
     def zero_grad(self):
         self.ops.zero_(self.G)
+        self._g_fresh = True
 
     # ------------------------------------------------------------------------------------------
     # helpers
@@ -989,7 +991,11 @@ class Engine:
             ops.cast(dout32.view(-1), dout.view(-1))
         # (K = B·T rows, 378 tiles: one K-split; nothing else touches the embedding gradient until the embedding backward kernels later on
         # this stream: plain read-modify-write instead of 99 MB of float atomics)
-        ops.gemm_tn(dlog, ws["d.out"], self.shared.g, alpha=alpha, split_k=-1)
+        # (and the FIRST writer of a freshly zeroed gradient buffer overwrites: no read at all.  A second backward without zero_grad —
+        # gradient accumulation — adds)
+        one = -2 if self._g_fresh else -1
+        self._g_fresh = False
+        ops.gemm_tn(dlog, ws["d.out"], self.shared.g, alpha=alpha, split_k=one)
         # every RMSNorm backward also writes dropout_bwd(dx) for the residual branch that consumes dx next (fused=True)
         fused = p > 0 and os.environ.get("LAKO_FUSE_DROP", "1") != "0"   # 0: separate dropout_apply launches (A/B)
         xa = ctx.xa
@@ -1004,7 +1010,7 @@ class Engine:
         self._run_chains(ctx.chains, Ld, lambda i, ch: self._dec_layer_bwd(ws, tmp, i, ch, dh, drel, kv, dkv, fused, T, S, dw_all),
                          reverse=True)
         if dw_all:      # (K = B·T rows: one K-split; the chains have joined and nothing else touches these gradients: plain read-modify-write)
-            ops.gemm_tn_grouped(dw_all, split_k=-1)
+            ops.gemm_tn_grouped(dw_all, split_k=one)
         ops.relpos_reduce(drel, self._lut(T, T, False), self.dec_rel.g)
         # ---- cross K/V projection of all decoder layers -----------------------------------------
         deh = self._buf(tmp, "e.dh", (Me, d))

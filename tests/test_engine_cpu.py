@@ -204,6 +204,29 @@ def test_dropout_training_is_deterministic_and_unbiased():
     assert abs(m(input_ids=ids, attention_mask=mask, labels=labels)[0].item() - float(z["loss"])) < 2e-5
 
 
+def test_gradient_accumulation_adds_and_zero_grad_resets():
+    """The first backward after zero_grad (or construction) may OVERWRITE the gradients it is the only writer of (decoder weights, the
+    LM-head product: `Engine._g_fresh`); a second backward without zero_grad must ADD (the reference's accumulation_steps,
+    train_reader.py:62-84), and zero_grad must make the next one overwrite again — also over stale values."""
+    z, dims, w = load_case("tiny_a")
+    ids, mask, labels = (torch.from_numpy(z[k]) for k in ("input_ids", "attention_mask", "labels"))
+    m = FiDT5(cfg_of(dims, 0.0), dtype=torch.float32, seed=3, _ops=RefOps())
+    m.load_t5(w)
+    m.train()
+    m(input_ids=ids, attention_mask=mask, labels=labels)[0].backward()
+    g1 = m._engine.G.clone()
+    assert float(g1.abs().sum()) > 0
+    m(input_ids=ids, attention_mask=mask, labels=labels)[0].backward()          # no zero_grad: accumulate
+    torch.testing.assert_close(m._engine.G, 2 * g1, atol=1e-6, rtol=1e-5)
+    m.zero_grad()
+    m(input_ids=ids, attention_mask=mask, labels=labels)[0].backward()
+    torch.testing.assert_close(m._engine.G, g1, atol=1e-7, rtol=1e-6)
+    m._engine.G.fill_(123.0)                                                     # somebody else's values: not fresh
+    m._engine._g_fresh = False
+    m(input_ids=ids, attention_mask=mask, labels=labels)[0].backward()
+    torch.testing.assert_close(m._engine.G, g1 + 123.0, atol=1e-4, rtol=1e-5)
+
+
 def test_set_checkpoint_recompute_matches(tmp_path):
     """set_checkpoint(True): encoder blocks are recomputed in backward (src/model.py:84-90,237-283) — with and without
     dropout the loss and every gradient must equal the keep-everything schedule bit for bit (same seeds → same masks)."""
