@@ -777,14 +777,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
       // its private 8 KiB of the free LDS buffer, 32 rows at a time (XOR-swizzled 16-B chunks), and leaves with
       // row-major data: 8 consecutive columns per lane, 8 rows × 128 B per wave-instruction, 16-B stores (16 store
       // instructions per wave instead of 32).  Only for epilogues WITHOUT a residual / aux operand (host-selected).
+      // (round 4) the tile goes through the scratch as BF16: alpha, ReLU and dropout happen in the accumulator layout (a lane's four consecutive
+      // columns are one dropout quad — the generic epilogue's arithmetic), the four values are rounded and leave as ONE ds_write_b64 (6 cycles
+      // per wave-instruction against 13 for the 16-byte fp32 form, whose ≈ 79 B/clk made the transposition of a 288 × 256 tile 1.5 µs of LDS
+      // time); a finished row is then one ds_read_b128 per lane.  16-byte slot C of row r sits at C ^ (r & 7); a pass (32 rows × 128 B) is 4 KiB,
+      // so the wave's 8 KiB hold two passes: the next pass's writes do not wait for this pass's reads.
       char* ep = wave_scratch(cur ^ 1);
       const int cj = lane & 7, n = n0 + wc * 64 + cj * 8;
 #pragma unroll
       for (int pass = 0; pass < (MT + 1) / 2; ++pass) {
+        char* buf = ep + (pass & 1) * 4096;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
           const int mt = 2 * pass + mi, row_l = mi * 16 + r16;
           if (mt >= MT) continue;            // odd MT (288-row tiles): the last pass is 16 rows
+          const int m = m0 + (wr * MT + mt) * 16 + r16;
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt) {
             f32x4 v = acc[nt][mt] * a.alpha;
@@ -792,38 +799,34 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
             }
-            *reinterpret_cast<f32x4*>(ep + row_l * 256 + (((nt * 4 + g) ^ (row_l & 15)) * 16)) = v;
+            if (drop) {
+              const uint64_t idx = (uint64_t)(a.row0 + m) * (uint64_t)a.N + (uint64_t)(n0 + (wc * NT + nt) * 16 + 4 * g);
+              bool kp[4];
+              lako_keep4(a.drop_key, idx >> 2, a.drop_thresh, kp);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = kp[r] ? v[r] * a.drop_scale : 0.f;
+            }
+            const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+            const int c = nt * 4 + g;          // 8-byte chunk of the row
+            *reinterpret_cast<bf16x4*>(buf + row_l * 128 + (((c >> 1) ^ (row_l & 7)) * 16) + (c & 1) * 8) = o;
           }
         }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
           if (2 * pass + it / 2 >= MT) continue;
           const int row_l = it * 8 + (lane >> 3);
-          const f32x4 lo = *reinterpret_cast<const f32x4*>(ep + row_l * 256 + (((2 * cj) ^ (row_l & 15)) * 16));
-          const f32x4 hi = *reinterpret_cast<const f32x4*>(ep + row_l * 256 + (((2 * cj + 1) ^ (row_l & 15)) * 16));
+          const u32x4 o = *reinterpret_cast<const u32x4*>(buf + row_l * 128 + ((cj ^ (row_l & 7)) * 16));
           const int m = m0 + wr * (MT * 16) + pass * 32 + row_l;
           if (m < a.M && n < a.N) {
-            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            if (drop) {
-              const uint64_t idx = (uint64_t)(a.row0 + m) * (uint64_t)a.N + (uint64_t)n;
-              bool kp[2][4];
-              lako_keep4(a.drop_key, idx >> 2, a.drop_thresh, kp[0]);          // 8 consecutive columns = two quads
-              lako_keep4(a.drop_key, (idx >> 2) + 1, a.drop_thresh, kp[1]);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = kp[e >> 2][e & 3] ? v[e] * a.drop_scale : 0.f;
-            }
-            bf16x8 o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
 #ifdef LAKO_EXPERIMENTS
-            if (a.debug & 16) *reinterpret_cast<bf16x8*>(C + (int64_t)(m - m0) * a.ldc + (n - n0)) = o;   // timing experiment: every tile stores to tile (0, 0)
+            if (a.debug & 16) *reinterpret_cast<u32x4*>(C + (int64_t)(m - m0) * a.ldc + (n - n0)) = o;   // timing experiment: every tile stores to tile (0, 0)
             else if (a.store_aux) {   // streaming cache policy (see store_b128_policy)
               const auto crs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(C + (int64_t)m0 * a.ldc + n0), 0, 0x7fffffff, 0x00020000);
               if (!(a.debug & 8))
-                store_b128_policy(__builtin_bit_cast(u32x4, o), crs, (int)(((int64_t)(m - m0) * a.ldc + (n - n0)) * 2), a.store_aux);
+                store_b128_policy(o, crs, (int)(((int64_t)(m - m0) * a.ldc + (n - n0)) * 2), a.store_aux);
             } else if (!(a.debug & 8))
 #endif
-            *reinterpret_cast<bf16x8*>(C + (int64_t)m * a.ldc + n) = o;
+            *reinterpret_cast<u32x4*>(C + (int64_t)m * a.ldc + n) = o;
           }
         }
       }
