@@ -9,12 +9,13 @@ Units and corrections (MI355X_MICROARCH.md § HBM): both counters are in KiB; on
 coalesced reads (16 B per lane: LDS-DMA and global loads alike) and is DOUBLED here; WRITE_SIZE is exact for 16-byte stores and float
 atomics.  Infinity-Cache hits are counted, so these are fabric-side (L2-miss) bytes, an upper bound of the HBM bytes.  A call of the
 library may be two dispatches (the 256x256 kernel on the rows of the full rounds + a small-tile launch on the row tail): dispatches
-are grouped into calls by order — a call starts at a gemm_nt_kernel<…,2,4,8,4,…> / gemm_tn256_kernel dispatch."""
+are grouped into calls by order — a call starts at a gemm_nt_kernel<…,2,4,{6,8,9},4,…> / gemm_tn256_kernel dispatch."""
 import collections
 import csv
 import glob
 import json
 import os
+import re
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -40,7 +41,7 @@ def calls_of(disp):
     """[(kind, [kernel names], counter sum)] in dispatch order"""
     out = []
     for name, val in disp:
-        head = ("gemm_nt_kernel" in name and "Li2ELi4ELi8ELi4E" in name) or "gemm_tn256_kernel" in name
+        head = ("gemm_nt_kernel" in name and re.search(r"Li2ELi4ELi[689]ELi4E", name) is not None) or "gemm_tn256_kernel" in name   # 256- / 192- / 288-row tiles
         if head or not out:
             out.append(["tn" if "gemm_tn" in name else "nt", [name], val])
         else:
