@@ -1074,6 +1074,9 @@ struct TnArgs {
   float* slabs;     // several K-splits WITHOUT atomics: [tile][split][64 Ki floats] partial tiles + tickets (below); nullptr = atomics
   int* tickets;     // [tiles] arrival counters, zeroed before the launch
   int wide_out;     // out_mode 1 / 2 with 16-byte aligned rows (every item: C % 16 == 0, ldc % 4 == 0, N % 4 == 0): 16-byte epilogue accesses
+  int t_full;       // HYBRID schedule (grouped launch, split_k −3): the first t_full tiles (a multiple of 256: whole rounds of the chip) run their
+                    // WHOLE K in one workgroup each (plain C += v, no atomics), the remaining tiles are cut into split_k pieces of k_chunk that
+                    // add by atomics; 0 = uniform splits
   int out_mode;     // 256² kernel with ONE K-split: 0 fp32 atomics, 1 plain read-modify-write (C += v), 2 overwrite (C = v)
   // grouped launch (gemm_tn256_kernel): n_items > 0 → tile id t belongs to the last item with tile_start <= t
   int n_items;
@@ -1295,9 +1298,33 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(TnArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int ntile = a.tiles_m * a.tiles_n;               // grouped: the tiles of all items
-  const int flat = xcd_remap(blockIdx.x, gridDim.x);   // one XCD ← consecutive (split, tile) ids
-  const int split = flat / ntile;
-  int tid = flat % ntile;
+  int split, tid, k_begin, k_end, unit_mode = a.out_mode;
+  if (a.t_full > 0) {
+    // HYBRID: workgroup b belongs to XCD x = b mod 8 and is its i-th; every XCD first walks its eighth of the full-K tiles (consecutive
+    // tile ids: neighbours share operand panels in its L2), then its share of the short pieces — long units first, short ones fill the end
+    const int x = blockIdx.x & 7, i = blockIdx.x >> 3, fpx = a.t_full >> 3;
+    if (i < fpx) {
+      tid = x * fpx + i;
+      split = 0;
+      k_begin = 0;
+      k_end = a.K;
+      unit_mode = 1;
+    } else {
+      const int j = (i - fpx) * 8 + x;
+      if (j >= (ntile - a.t_full) * a.split_k) return;
+      tid = a.t_full + j / a.split_k;
+      split = j % a.split_k;
+      k_begin = split * a.k_chunk;
+      k_end = min(a.K, k_begin + a.k_chunk);
+      unit_mode = 0;
+    }
+  } else {
+    const int flat = xcd_remap(blockIdx.x, gridDim.x);   // one XCD ← consecutive (split, tile) ids
+    split = flat / ntile;
+    tid = flat % ntile;
+    k_begin = split * a.k_chunk;
+    k_end = min(a.K, k_begin + a.k_chunk);
+  }
   const int gtile = tid;      // tile id over all problems of the launch (slab / ticket index)
   // the problem this tile belongs to (one problem, or up to LAKO_TN_GROUP_MAX weight gradients sharing K = tokens: with
   // more tiles per launch fewer K-splits fill the chip, and every split costs one fp32 atomic pass over the output)
@@ -1315,8 +1342,6 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(TnArgs a) {
   }
   const int tile_m = tid / it.tiles_n, tile_n = tid % it.tiles_n;
   const int m0 = tile_m * 256, n0 = tile_n * 256;
-  const int k_begin = split * a.k_chunk;
-  const int k_end = min(a.K, k_begin + a.k_chunk);
   if (k_begin >= k_end) return;
   const int64_t lda_b = it.lda * 2, ldb_b = it.ldb * 2;
   const int acols_b = (it.M - m0) * 2, bcols_b = (it.N - n0) * 2;
@@ -1440,7 +1465,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(TnArgs a) {
       }
     }
   }
-  const int out_mode = (a.slabs != nullptr && a.split_k > 1) ? 1 : a.out_mode;
+  const int out_mode = (a.slabs != nullptr && a.split_k > 1) ? 1 : unit_mode;
   // epilogue: per wave a private 16×64 fp32 slab in LDS (staging buffers are free after the last barrier)
   float* slab = reinterpret_cast<float*>(smem) + wave * 1024;
   const int r16 = lane & 15, g = lane >> 4;
@@ -2345,14 +2370,14 @@ extern "C" int lako_gemm_tn_grouped(const lako_gemm_tn_item_t* items, int n_item
                                     const lako_tuning_t* tuning, void* workspace, int64_t workspace_bytes, lako_stream_t stream) {
   const lako_tuning_t& tu = tuning ? *tuning : process_tuning();
   LAKO_CHECK_ARG(items && n_items >= 1 && n_items <= LAKO_TN_GROUP_MAX, "lako_gemm_tn_grouped: 1..%d items", LAKO_TN_GROUP_MAX);
-  LAKO_CHECK_ARG(split_k >= -2, "lako_gemm_tn_grouped: split_k %d", split_k);
+  LAKO_CHECK_ARG(split_k >= -3, "lako_gemm_tn_grouped: split_k %d", split_k);
   LAKO_CHECK_ARG(K > 0 && K < (1 << 30), "lako_gemm_tn_grouped: bad K");
   bool big = in_dtype == LAKO_BF16 && tu.tn_big;
   for (int i = 0; i < n_items; ++i) big = big && items[i].M >= 256 && items[i].N >= 256;
   if (!big) {   // shapes the 256×256 kernel does not take: one launch per problem
     for (int i = 0; i < n_items; ++i) {
       int rc = tn_single(items[i].a, items[i].b, items[i].c, items[i].M, items[i].N, K, items[i].lda, items[i].ldb,
-                         items[i].ldc, in_dtype, items[i].alpha, split_k, tuning, stream, items[i].rows_out);
+                         items[i].ldc, in_dtype, items[i].alpha, split_k == -3 ? 0 : split_k, tuning, stream, items[i].rows_out);
       if (rc != LAKO_OK) return rc;
     }
     return LAKO_OK;
@@ -2391,16 +2416,36 @@ extern "C" int lako_gemm_tn_grouped(const lako_gemm_tn_item_t* items, int n_item
   int sk = tn_pick_split(tiles, K, max_split);
   if (tu.tn_split > 0) sk = tu.tn_split;
   if (split_k > 0) sk = split_k;
-  if (split_k < 0) sk = 1;
+  if (split_k == -1 || split_k == -2) sk = 1;
+  // HYBRID (split_k −3, round 4): ⌊tiles / 256⌋ whole rounds of full-K tiles (one contributor: plain adds, no atomic pass, a third of the
+  // prologues) + the remaining tiles cut finely enough to fill one or a few short rounds.  Uniform splits pay a last round of full-length
+  // units on a fraction of the chip (1 296 tiles × 3 = 15.19 rounds → 16) and one atomic pass of 256 KiB per unit — ≈ 50 µs of a 450 µs
+  // unit at the chip's ≈ 1.3 TB/s, during which the CU's only workgroup does nothing else.
+  a.t_full = 0;
+  if (split_k == -3) {
+    const int full = (tiles / 256) * 256, rem = tiles - full;
+    if (full > 0) {
+      int best = 1;
+      double best_cost = 1e30;
+      for (int c = 1; c <= 16 && c <= max_split; ++c) {      // remainder phase in full-unit times: rounds of 1/c-length units
+        const double cost = rem ? (double)cdiv((int64_t)rem * c, 256) / c + 0.004 * c : 0.0;
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = c; }
+      }
+      a.t_full = full;
+      sk = best;
+    } else {
+      sk = tn_pick_split(tiles, K, max_split);
+    }
+  }
   if (sk > max_split) sk = max_split;
   if (sk < 1) sk = 1;
   const int chunk = cdiv(cdiv(K, sk), 64) * 64;
   a.split_k = cdiv(K, chunk);
   a.k_chunk = chunk;
-  a.out_mode = (split_k < 0 && a.split_k == 1) ? -split_k : 0;
+  a.out_mode = ((split_k == -1 || split_k == -2) && a.split_k == 1) ? -split_k : 0;
   a.slabs = nullptr;
   a.tickets = nullptr;
-  if (a.split_k > 1 && workspace != nullptr) {      // K-splits meet through partial tiles in the caller's workspace instead of atomics
+  if (a.split_k > 1 && workspace != nullptr && a.t_full == 0) {      // K-splits meet through partial tiles in the caller's workspace instead of atomics
     const int64_t slab_bytes = (int64_t)tiles * a.split_k * 65536 * 4, tick_bytes = (int64_t)((tiles + 63) / 64) * 256;
     if (workspace_bytes >= slab_bytes + tick_bytes && reinterpret_cast<uintptr_t>(workspace) % 16 == 0) {
       a.slabs = reinterpret_cast<float*>(workspace);
@@ -2412,12 +2457,13 @@ extern "C" int lako_gemm_tn_grouped(const lako_gemm_tn_item_t* items, int n_item
       }
     }
   }
+  const int grid = a.t_full > 0 ? 8 * (a.t_full / 8 + cdiv((int64_t)(tiles - a.t_full) * a.split_k, 8)) : tiles * a.split_k;
   if (a.glds && a.k_chunk % 64 == 0) {
     LAKO_SET_MAX_LDS((&gemm_tn256_kernel<true>), 4 * TN2_IMG);
-    hipLaunchKernelGGL(gemm_tn256_kernel<true>, dim3(tiles * a.split_k), dim3(512), 4 * TN2_IMG, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(gemm_tn256_kernel<true>, dim3(grid), dim3(512), 4 * TN2_IMG, (hipStream_t)stream, a);
   } else {
     LAKO_SET_MAX_LDS((&gemm_tn256_kernel<false>), 4 * TN2_IMG);
-    hipLaunchKernelGGL(gemm_tn256_kernel<false>, dim3(tiles * a.split_k), dim3(512), 4 * TN2_IMG, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(gemm_tn256_kernel<false>, dim3(grid), dim3(512), 4 * TN2_IMG, (hipStream_t)stream, a);
   }
   LAKO_LAUNCH_CHECK();
   return LAKO_OK;

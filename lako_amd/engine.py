@@ -1034,7 +1034,9 @@ class Engine:
         # K-splits of the grouped launch: 3 (1 296 tiles × 3 = 15.2 rounds of third-K units; measured per step, rocprofv3, 14 steps:
         # one launch per layer 8.70 ms, 12 layers × 2 / 3 / 4 splits 8.35 / 8.32 / 8.30 ms, 6 layers × 3 splits 8.35 — the library's
         # own cost model, built for one-round launches, would pick 1 split = 6 whole rounds: the slowest, 41.3 ms per step)
-        enc_split = int(os.environ.get("LAKO_ENC_DW_SPLIT", "3"))
+        # −3: the hybrid schedule of lako_gemm_tn_grouped — whole rounds of full-K tiles + a finely cut remainder (round 4: 39.8 → 39.1 ms per step
+        # against 3 uniform K-splits; a positive value forces that many uniform splits)
+        enc_split = int(os.environ.get("LAKO_ENC_DW_SPLIT", "-3"))
         slot_of = (lambda i: f".{i % grp}") if grp > 1 else (lambda i: "")
         dy_f = self._buf(tmp, "e.dy.ffn" + slot_of(Le - 1), (Me, d)) if fused else None
         ops.rmsnorm_bwd(dxe, ws[f"e.h{Le}"], self.enc_final.p, ws["e.rsf"], None, deh, self.enc_final.g, dr(S_ENC_FINAL),

@@ -393,6 +393,27 @@ def test_gemm_tn_exclusive_and_overwrite(ops, ref):
     close(C, Cr, T, "gemm_tn_grouped exclusive rmw", tight=True)
 
 
+@pytest.mark.parametrize("extra", [0, 8, 136])
+def test_gemm_tn_grouped_hybrid_schedule(ops, ref, extra):
+    """lako_gemm_tn_grouped split_k −3 (round 4): whole rounds of 256 tiles run their WHOLE K in one workgroup each (plain adds), the
+    remaining `extra` tiles are cut into K-pieces that add by atomics — C += alpha·Aᵀ·B for every problem, onto non-zero C, with a K
+    that is not a multiple of 64 (the full-K units stage its incomplete step first) and ragged tile edges."""
+    T = torch.bfloat16
+    K = 4813
+    shapes = [(768, 3072)] * 7 + [(768, 768)] * 0 + [(256, 256)] * 4            # 252 + 4 = 256 tiles
+    shapes += {0: [], 8: [(520, 1000)], 136: [(768, 3072)] * 3 + [(1792, 1024)]}[extra]      # + 3 × 4 = 12 → the kernel sees cdiv tiles: 8 ↔ (520,1000) = 3 × 4 = 12
+    probs, probs_r = [], []
+    for i, (M, N) in enumerate(shapes):
+        A, B = rnd(K, M, dtype=T, seed=300 + i) * 0.25, rnd(K, N, dtype=T, seed=400 + i) * 0.25
+        C = rnd(M, N, seed=500 + i)
+        probs.append((A, B, C, 0.5))
+        probs_r.append((A, B, C.clone(), 0.5))
+    ops.gemm_tn_grouped(probs, split_k=-3)
+    ref.gemm_tn_grouped(probs_r, split_k=-3)
+    for (_, _, C, _), (_, _, Cr, _), sh in zip(probs, probs_r, shapes):
+        close(C, Cr, T, f"gemm_tn_grouped hybrid {sh} extra {extra}")
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("M,N,K", [(128, 768, 32128), (40, 264, 5000), (128, 132, 2048)])
 def test_gemm_nt_split_k_atomic(ops, ref, dt, M, N, K):
