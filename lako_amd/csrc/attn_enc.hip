@@ -125,6 +125,20 @@ __device__ __forceinline__ f32x4 etail(int t, int g, int Lk) {
   return v;
 }
 
+// Stage rows [0, nrows) of a strided [L, 64] bf16 tensor into a swizzled image by LDS-DMA (nrows a multiple of 8): piece p (8 image rows,
+// 1 KiB) is issued by wave p mod NW; lane → (row, physical 16-byte chunk) of the piece, its source the logical chunk the swizzle puts
+// there (eswz is its own inverse); rows >= L fall out of the descriptor's range: zero-filled.  Asynchronous: the caller waits
+// (s_waitcnt vmcnt(0)) and barriers.
+template <int NW>
+__device__ __forceinline__ void estage_dma(char* img, const char* base, uint32_t stride_b, int nrows, int L, int wave, int lane) {
+  const auto rs = lds_dma_rsrc(base, L > 0 ? (uint32_t)(L - 1) * stride_b + 128u : 0u);
+  const int pr = lane >> 3, pc = lane & 7;
+  for (int pz = wave; pz < (nrows >> 3); pz += NW) {
+    const int row = pz * 8 + pr;
+    lds_dma16(img + (row - pr) * EROW, rs, row < L ? (uint32_t)row * stride_b + (uint32_t)eswz(pc, row) * 16u : 0x80000000u);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // forward: 16 queries of one wave against the staged K / V, keys in chunks of at most 3 tile pairs (online softmax across the
 // up to three chunks of a sequence of <= 256 keys: the score tiles of a chunk are 24 registers, the kernel fits 128)
@@ -229,6 +243,91 @@ __global__ __launch_bounds__(FWD_NW * 64, FWD_NW / 2) void enc_fwd_kernel(AttnAr
     request_q(qb + FWD_NW);
     // bias: tile row0, lane (query qi, group g), register r reads T[row0 + 4g + r − qi + rel_off]; the copy and the aligned
     // base are constants of the block (row0 is a multiple of 16)
+    const int i0 = 4 * g - qi + a.rel_off + EB_PADLO;
+    const float* bptr = b4 + (i0 & 3) * EB_ST + (i0 & ~3);
+    const uint32_t pblk = (uint32_t)((b * a.H + h) * QB + (qi >> 2)) * (uint32_t)KB + (uint32_t)g;
+    const DropRow drc = drop_row_consts(qi);
+    float m = -INFINITY, l = 0.f;
+    f32x4 oacc[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) oacc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define ECH(N, P0, LAST) case N: if constexpr (N <= CH) efwd_chunk<DROP, N>(Kimg, Vimg, P0, LAST, tail, bptr, qf, el, pblk, a.drop_key, drc, t_hi, m, l, oacc); break;
+    switch (n0) { ECH(1, 0, n1 == 0) ECH(2, 0, n1 == 0) ECH(3, 0, n1 == 0) ECH(4, 0, n1 == 0) default: break; }
+    switch (n1) { ECH(1, CH, n2 == 0) ECH(2, CH, n2 == 0) ECH(3, CH, n2 == 0) ECH(4, CH, n2 == 0) default: break; }
+    if constexpr (CH == 3) {
+      switch (n2) { ECH(1, 2 * CH, true) ECH(2, 2 * CH, true) default: break; }
+    }
+#undef ECH
+    l = egroup_sum(l);
+    if (qi < Lq) {
+      const float inv = 1.0f / l;
+      const float f = inv * oscale;
+      bf16_t* op = reinterpret_cast<bf16_t*>(obase + (int64_t)qi * a.ost * 2);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) store4(op + db * 16 + 4 * g, oacc[db] * f);
+      if (g == 0 && a.stats) {
+        float* st = a.stats + (((int64_t)b * a.H + h) * a.Lq + qi) * 4;
+        st[0] = m;
+        st[1] = inv;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward, per (sequence, head) item as enc_fwd_kernel, with the K / V images arriving by LDS-DMA (round 4).  enc_fwd_kernel stages
+// K, then V, through registers and then the bias copies — three dependent memory round trips that nothing in the workgroup overlaps —
+// before its first MFMA; here every wave issues its share of the K and V pieces first (1 KiB = 8 image rows per wave-instruction, the
+// swizzle applied to the per-lane SOURCE address, rows past the sequence's end zero-filled by the descriptor's range check), then
+// requests the bias table and its first Q fragments: everything is in flight together, ONE round trip before the first MFMA.
+// (A version that let the first query block start on key chunk 0 while chunks 1 – 2 were still landing needed the Q fragments loaded
+//  by inline asm — a compiler-visible load is waited for with vmcnt(0), i.e. for every DMA piece — and the dropout instantiation, at its
+//  128-register cap, SPILLED those registers before the load had landed: garbage.  Not kept.)
+// Same arithmetic per block (efwd_chunk): results are bit-identical to enc_fwd_kernel.
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool DROP>
+__global__ __launch_bounds__(FWD_NW * 64, FWD_NW / 2) void enc_fwd_c_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int R = a.chunk_rows;
+  char* Kimg = smem;
+  char* Vimg = smem + R * EROW;
+  float* b4 = reinterpret_cast<float*>(smem + 2 * R * EROW);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, l15 = lane & 15;
+  const int b = attn_seq(a, blockIdx.z), h = blockIdx.y;
+  const int q0 = a.q_off ? __builtin_amdgcn_readfirstlane(a.q_off[b]) : 0;
+  const int k0 = a.k_off ? __builtin_amdgcn_readfirstlane(a.k_off[b]) : 0;
+  const int Lq = a.q_off ? __builtin_amdgcn_readfirstlane(a.q_off[b + 1]) - q0 : a.Lq;
+  const int Lk = a.k_off ? __builtin_amdgcn_readfirstlane(a.k_off[b + 1]) - k0 : a.Lk;
+  const int qb_begin = blockIdx.x * a.blocks_per_wg;
+  const int qb_end = min((Lq + 15) >> 4, qb_begin + a.blocks_per_wg);
+  if (qb_begin >= qb_end || Lk <= 0) return;
+  const int64_t hoff = (int64_t)h * 64;
+  const char* qbase = a.q + ((a.q_off ? (int64_t)q0 * a.qst : (int64_t)b * a.qsb) + hoff) * 2;
+  const char* kbase = a.k + ((a.k_off ? (int64_t)k0 * a.kst : (int64_t)b * a.ksb) + hoff) * 2;
+  const char* vbase = a.v + ((a.k_off ? (int64_t)k0 * a.vst : (int64_t)b * a.vsb) + hoff) * 2;
+  char* obase = a.out + ((a.q_off ? (int64_t)q0 * a.ost : (int64_t)b * a.osb) + hoff) * 2;
+  const int np = (Lk + 31) >> 5;
+  estage_dma<FWD_NW>(Kimg, kbase, (uint32_t)a.kst * 2u, np << 5, Lk, wave, lane);
+  estage_dma<FWD_NW>(Vimg, vbase, (uint32_t)a.vst * 2u, np << 5, Lk, wave, lane);
+  u32x4 qf_next[2];
+  auto request_q = [&](int qbn) { eload_frags(qf_next, qbase, a.qst * 2, qbn < qb_end ? qbn * 16 + l15 : Lq, Lq, g); };
+  request_q(qb_begin + wave);
+  estage_bias<FWD_NW * 64>(b4, a.rel_bias, h, a.R, false);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the wave's DMA pieces have landed (the compiler does not count them)
+  __syncthreads();
+  const ELane el = elane(lane);
+  const uint32_t t_hi = a.drop_t16 << 16;
+  const int KB = (a.Lk + 3) >> 2, QB = (a.Lq + 3) >> 2;
+  const float oscale = DROP ? a.drop_scale : 1.0f;
+  const f32x4 tail[2] = {etail(2 * np - 2, g, Lk), etail(2 * np - 1, g, Lk)};
+  constexpr int CH = DROP ? 3 : 4;
+  const int n0 = min(np, CH), n1 = min(max(np - CH, 0), CH), n2 = max(np - 2 * CH, 0);
+  for (int qb = qb_begin + wave; qb < qb_end; qb += FWD_NW) {
+    const int qi = qb * 16 + l15;
+    u32x4 qf[2] = {qf_next[0], qf_next[1]};
+    request_q(qb + FWD_NW);
     const int i0 = 4 * g - qi + a.rel_off + EB_PADLO;
     const float* bptr = b4 + (i0 & 3) * EB_ST + (i0 & ~3);
     const uint32_t pblk = (uint32_t)((b * a.H + h) * QB + (qi >> 2)) * (uint32_t)KB + (uint32_t)g;
@@ -777,8 +876,14 @@ __global__ __launch_bounds__(DKV_NW * 64, 2) void enc_bwd_dkv_kernel(AttnArgs a)
   const float* stats = a.stats + ((int64_t)b * a.H + h) * a.Lq * 4;
   const float dscale = DROP ? a.drop_scale : 1.0f, inv_dscale = 1.0f / dscale;
   const int npq = (max(Lq, 1) + 31) >> 5, nq = npq << 5;    // query tile pairs, staged query rows
-  estage<DKV_NW * 64>(Qimg, qbase, a.qst * 2, nq, Lq);
-  estage<DKV_NW * 64>(dOimg, dobase, a.ost * 2, nq, Lq);
+  // (round 4) Q / dO by LDS-DMA, issued first: the images, the bias table and the statistics are then ONE memory round trip instead of four
+  if (a.dma_stage) {
+    estage_dma<DKV_NW>(Qimg, qbase, (uint32_t)a.qst * 2u, nq, Lq, wave, lane);
+    estage_dma<DKV_NW>(dOimg, dobase, (uint32_t)a.ost * 2u, nq, Lq, wave, lane);
+  } else {
+    estage<DKV_NW * 64>(Qimg, qbase, a.qst * 2, nq, Lq);
+    estage<DKV_NW * 64>(dOimg, dobase, a.ost * 2, nq, Lq);
+  }
   estage_bias<DKV_NW * 64>(b4, a.rel_bias, h, a.R, true);
   for (int i = threadIdx.x; i < nq; i += DKV_NW * 64) {
     float l2 = INFINITY, nd = 0.f;                          // rows past Lq: p = exp2(−inf) = 0
@@ -790,6 +895,7 @@ __global__ __launch_bounds__(DKV_NW * 64, 2) void enc_bwd_dkv_kernel(AttnArgs a)
     lse_l[i] = l2;
     ndel_l[i] = nd;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the wave's DMA pieces (the compiler does not count them)
   __syncthreads();
   const ELane el = elane(lane);
   const uint32_t t_hi = a.drop_t16 << 16;
@@ -1094,6 +1200,12 @@ int lako_attn_enc_fwd(AttnArgs& a, hipStream_t s) {
   a.blocks_per_wg = eblocks_per_wg(nqb, (int64_t)a.Bn * a.H, FWD_NW);
   const int lds = efwd_lds(a.chunk_rows);
   const dim3 grid((nqb + a.blocks_per_wg - 1) / a.blocks_per_wg, a.H, a.Bn);
+  // K / V by LDS-DMA, everything in flight together (LAKO_ATTN_FWD_DMA=0: register staging, three round trips)
+  static const bool dma_off = getenv("LAKO_ATTN_FWD_DMA") && atoi(getenv("LAKO_ATTN_FWD_DMA")) == 0;
+  if (!dma_off && (int64_t)a.kst * 2 * 256 < (1ll << 31) && (int64_t)a.vst * 2 * 256 < (1ll << 31)) {
+    EDISPATCH(enc_fwd_c_kernel, FWD_NW * 64, a.drop_t16 != 0, grid, lds, s, a);
+    return 0;
+  }
   EDISPATCH(enc_fwd_kernel, FWD_NW * 64, a.drop_t16 != 0, grid, lds, s, a);
   return 0;
 }
@@ -1135,6 +1247,8 @@ dkv_pass:
       EDISPATCH(enc_bwd_dkv_p_kernel, PF_NW * 64, a.drop_t16 != 0, dim3(a.H * nslots), lds, s, k);
       return 0;
     }
+    static const bool dkv_dma_off = getenv("LAKO_ATTN_DKV_DMA") && atoi(getenv("LAKO_ATTN_DKV_DMA")) == 0;
+    k.dma_stage = !dkv_dma_off && (int64_t)a.qst * 2 * 256 < (1ll << 31) && (int64_t)a.ost * 2 * 256 < (1ll << 31);
     k.blocks_per_wg = eblocks_per_wg(nkb, (int64_t)a.Bn * a.H, DKV_NW);
     const int lds = ebwd1_lds(k.chunk_rows);
     const dim3 grid((nkb + k.blocks_per_wg - 1) / k.blocks_per_wg, a.H, a.Bn);
