@@ -2,16 +2,21 @@
 // HF5:83-94 (wi,wo) and HF5:1047 (lm_head), forward and backward.
 //
 //   gemm_nt : C[M,N] = epilogue(alpha * A[M,K] · B[N,K]ᵀ)        activations × weights ([out,in] layout)
-//   gemm_tn : C[M,N] += alpha * A[K,M]ᵀ · B[K,N]   (fp32, split-K) weight gradients dW = dYᵀ·X
+//   gemm_tn : C[M,N] += alpha * A[K,M]ᵀ · B[K,N]   (fp32)          weight gradients dW = dYᵀ·X
 //
-// Design (gfx950): 128×128 output tile per 256-thread workgroup (4 waves as 2×2, 64×64 per wave =
-// 4×4 MFMA 16×16 tiles), K stepped in 128-BYTE slices so the bf16 (K=64) and fp32 (K=32) variants
-// share one LDS image and one staging routine.  Global→LDS goes through `buffer_load … lds`
-// (16 B/lane, no VGPR round trip; out-of-range rows / K-tail chunks are zero-filled by the buffer
-// range check), double-buffered.  The LDS image is lane-linear (a DMA constraint), so the
-// bank-conflict swizzle is applied to the per-lane SOURCE address and again on the fragment read.
-// bf16 uses v_mfma_f32_16x16x32_bf16, fp32 uses the exact-f32 v_mfma_f32_16x16x4_f32 (parity mode).
-// Workgroup ids are remapped so that the tiles sharing an A row-panel run on one XCD (one L2).
+// Kernels (gfx950), all on one LDS image: K stepped in 128-BYTE slices so that bf16 (k = 64, v_mfma_f32_16x16x32_bf16) and fp32
+// (k = 32, the exact-f32 v_mfma_f32_16x16x4_f32: parity mode) share the staging code; global → LDS by LDS-DMA (16 B per lane, no
+// register round trip; ragged edges zero-filled by the buffer range check or clamped), double-buffered; the image is lane-linear
+// (a DMA constraint), so the bank-conflict swizzle sits on the per-lane SOURCE address and again on the fragment read.
+//   gemm_nt_kernel        persistent; 256 × 256 tiles on 8 waves (2 × 4, 128 × 64 per wave) for everything with >= 256 tiles, 288 × 256
+//                         (MT = 9) where that saves a round of the chip or the tail launch (launch_nt prices both per call), 128 × 128
+//                         on 4 waves for small problems; fused epilogues (alpha, ReLU, dropout, residual, ReLU/dropout-backward
+//                         mask), LDS-transposed 16-byte stores; XCD-aware tile order
+//   gemm_nt_skinny_kernel M <= 256 rows (the decoder): 32 × 32 tiles, eight waves split K, operands straight into MFMA fragments
+//   gemm_nt_ring_kernel   a handful of 128 × 128 tiles: 4-slot LDS ring (LM head, row tails where the 288-row plan does not apply)
+//   gemm_tn256_kernel     256 × 256 tiles, both operands k-strided → ds_read_b64_tr_b16; grouped launches of up to 48 problems; K-splits
+//                         by atomics, or (round 4) whole rounds of full-K tiles by plain 16-byte adds + a finely cut remainder
+//   gemm_nt_mx_kernel     MX block-scaled fp8 operands (config 5)
 #include <type_traits>
 
 #include <algorithm>
