@@ -319,6 +319,9 @@ typedef struct {
 } lako_headbatch_t;
 int lako_headbatch_nt(const lako_headbatch_t* p, lako_stream_t stream);
 int lako_headbatch_tn(const lako_headbatch_t* p, lako_stream_t stream);
+/* (round 4) n <= 24 lako_headbatch_tn problems of one N, H and b_dtype in ONE launch — the Wk / Wv gradients of all decoder layers,
+ * deferred to the end of the decoder's backward (each alone is nothing but its dispatch). */
+int lako_headbatch_tn_multi(const lako_headbatch_t* items, int n, lako_stream_t stream);
 
 /* ---- LM-head loss (HF5:1051-1054): CrossEntropyLoss(ignore_index=-100), mean over valid labels ----
  * logits fp32 [M, V]; loss_out[0] = mean loss, loss_out[1] = number of valid labels;

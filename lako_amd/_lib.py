@@ -48,6 +48,7 @@ class GemmTNItem(C.Structure):
 
 
 TN_GROUP_MAX = 48
+HB_MULTI_MAX = 24          # problems per lako_headbatch_tn_multi launch
 
 
 class HeadBatch(C.Structure):
@@ -103,6 +104,7 @@ SIGNATURES = {
     "lako_xattn_decode_combine": [vp, vp, vp, i64, vp, i64, i32, i32, i32, i32, vp],
     "lako_headbatch_nt": [C.POINTER(HeadBatch), vp],
     "lako_headbatch_tn": [C.POINTER(HeadBatch), vp],
+    "lako_headbatch_tn_multi": [C.POINTER(HeadBatch), i32, vp],
     "lako_ce_fwd_bwd": [vp, vp, vp, vp, vp, i64, i64, i32, vp],
     "lako_sumsq": [vp, i64, vp, vp],
     "lako_adamw_step": [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, f32, f32, i32, vp],

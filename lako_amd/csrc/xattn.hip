@@ -822,8 +822,7 @@ __global__ __launch_bounds__(256) void hb_contract_kernel(HbArgs a) {
 }
 
 template <bool BF32>
-__global__ __launch_bounds__(256) void hb_tn_kernel(HbArgs a) {
-  __shared__ __attribute__((aligned(16))) char img[2 * XS_IMG];   // A image [128 m][64 j] | B image [128 m][64 c]
+__device__ __forceinline__ void hb_tn_body(const HbArgs& a, char* img) {      // img: A image [128 m][64 j] | B image [128 m][64 c]
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, l15 = lane & 15;
   const int c0 = blockIdx.x * 64, h = blockIdx.y;
@@ -871,6 +870,22 @@ __global__ __launch_bounds__(256) void hb_tn_kernel(HbArgs a) {
       atomicAdd(cbase + (int64_t)(db * 16 + 4 * g + i) * a.c_st, acc[db][i]);   // one contributor per element and launch: no
                                                                                 // read-modify-write round trip, still deterministic
     }
+}
+
+template <bool BF32>
+__global__ __launch_bounds__(256) void hb_tn_kernel(HbArgs a) {
+  __shared__ __attribute__((aligned(16))) char img[2 * XS_IMG];
+  hb_tn_body<BF32>(a, img);
+}
+
+// several problems of one shape in ONE launch (round 4: the Wk / Wv gradients of all decoder layers after the last layer's backward —
+// 24 launches of ≈ 8 µs for ≈ 0.1 GFLOP each were nothing but their dispatch): blockIdx.z picks the problem
+constexpr int HB_MULTI_MAX = 24;
+struct HbMulti { HbArgs it[HB_MULTI_MAX]; };
+template <bool BF32>
+__global__ __launch_bounds__(256) void hb_tn_multi_kernel(HbMulti m) {
+  __shared__ __attribute__((aligned(16))) char img[2 * XS_IMG];
+  hb_tn_body<BF32>(m.it[blockIdx.z], img);
 }
 
 int xcheck_common(const char* fn, const void* e, int64_t e_ld, const int32_t* k_off, const int32_t* p_off, int R, int D, int B) {
@@ -1046,7 +1061,36 @@ extern "C" int lako_headbatch_nt(const lako_headbatch_t* p, lako_stream_t stream
   return LAKO_OK;
 }
 
+static int hb_tn_args(const lako_headbatch_t* p, HbArgs& a);
+
 extern "C" int lako_headbatch_tn(const lako_headbatch_t* p, lako_stream_t stream) {
+  HbArgs a{};
+  const int rc = hb_tn_args(p, a);
+  if (rc != LAKO_OK) return rc;
+  const dim3 grid((unsigned)(p->N / 64), (unsigned)p->H);
+  if (p->b_dtype == LAKO_F32) hipLaunchKernelGGL((hb_tn_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((hb_tn_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  LAKO_LAUNCH_CHECK();
+  return LAKO_OK;
+}
+
+extern "C" int lako_headbatch_tn_multi(const lako_headbatch_t* items, int n, lako_stream_t stream) {
+  LAKO_CHECK_ARG(items && n >= 1 && n <= HB_MULTI_MAX, "lako_headbatch_tn_multi: 1..%d problems", HB_MULTI_MAX);
+  HbMulti mm{};
+  for (int i = 0; i < n; ++i) {
+    const int rc = hb_tn_args(&items[i], mm.it[i]);
+    if (rc != LAKO_OK) return rc;
+    LAKO_CHECK_ARG(items[i].N == items[0].N && items[i].H == items[0].H && items[i].b_dtype == items[0].b_dtype,
+                   "lako_headbatch_tn_multi: problem %d differs in N / H / b_dtype from problem 0", i);
+  }
+  const dim3 grid((unsigned)(items[0].N / 64), (unsigned)items[0].H, (unsigned)n);
+  if (items[0].b_dtype == LAKO_F32) hipLaunchKernelGGL((hb_tn_multi_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, mm);
+  else hipLaunchKernelGGL((hb_tn_multi_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, mm);
+  LAKO_LAUNCH_CHECK();
+  return LAKO_OK;
+}
+
+static int hb_tn_args(const lako_headbatch_t* p, HbArgs& a) {
   LAKO_CHECK_ARG(p && p->a && p->b && p->c, "lako_headbatch_tn: null operand");
   LAKO_CHECK_ARG(p->M > 0 && p->T > 0 && p->H > 0 && p->N > 0 && p->N % 64 == 0 && p->K == 64,
                  "lako_headbatch_tn: M, T, H > 0, N %% 64 == 0, K (rows of A per head) == 64");
@@ -1057,17 +1101,13 @@ extern "C" int lako_headbatch_tn(const lako_headbatch_t* p, lako_stream_t stream
   LAKO_CHECK_ALIGN(p->a, 16);
   LAKO_CHECK_ALIGN(p->b, 16);
   LAKO_CHECK_ALIGN(p->c, 4);
-  HbArgs a{};
+  a = HbArgs{};
   a.A = (const char*)p->a; a.a_sb = p->a_sb; a.a_st = p->a_st; a.a_sh = p->a_sh;
   a.B = (const char*)p->b; a.b_sb = p->b_sb; a.b_st = p->b_st; a.b_sh = p->b_sh;
   a.C = (char*)p->c; a.c_st = p->c_st; a.c_sh = p->c_sh;
   a.M = p->M; a.T = p->T; a.N = p->N; a.K = p->K; a.H = p->H;
   a.n_slabs = p->n_slabs > 0 ? p->n_slabs : 1; a.slab_stride = p->slab_stride;
   LAKO_CHECK_ARG(a.n_slabs == 1 || (p->b_dtype == LAKO_F32 && p->slab_stride % 4 == 0), "lako_headbatch_tn: slabs need an fp32 B");
-  const dim3 grid((unsigned)(p->N / 64), (unsigned)p->H);
-  if (p->b_dtype == LAKO_F32) hipLaunchKernelGGL((hb_tn_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((hb_tn_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, a);
-  LAKO_LAUNCH_CHECK();
   return LAKO_OK;
 }
 

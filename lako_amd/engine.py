@@ -628,22 +628,30 @@ class Engine:
         ops.xattn_context(pr, enc_out, xa.k_off, xa.p_off, xb["c"][i])
         ops.headbatch_nt(xb["c"][i].unflatten(2, (T, H)), self._xw(i, "v"), c2.view(B, T, H, dk))
 
-    def _xattn_bwd(self, xb, xa, tmp, i, qc, enc_out, dctx, dqc, B, T, max_keys, drop, b0=0, B_all=None):
+    def _xattn_bwd(self, xb, xa, tmp, i, qc, enc_out, dctx, dqc, B, T, max_keys, drop, b0=0, B_all=None, hb=None):
         """Backward of _xattn_fwd: dctx [B·T, inner] → dqc [B·T, inner], the layer's Wk / Wv gradients, and the rows (dC', dS) the
         encoder-state gradient is assembled from after the last layer (_xattn_denc)."""
         ops, H, dk, R, d = self.ops, self.cfg.num_heads, self.cfg.d_kv, xb["R"], self.cfg.d_model
         dcp = xb["dq"][:, 2 * i * R:(2 * i + 1) * R]
         d4 = dctx.view(B, T, H, dk)
         ops.headbatch_nt(d4, self._xw(i, "v", transposed=True), dcp.unflatten(1, (T, H)))
-        ops.headbatch_tn(d4, xb["c"][i].unflatten(2, (T, H)), self._xg(i, "v"))
+        # (`hb`: list collecting the layers' Wk / Wv gradient products for ONE launch after the last layer — their operands then live in
+        # per-layer buffers: the caller's dctx, and dqp below)
+        if hb is not None:
+            hb.append((d4, xb["c"][i].unflatten(2, (T, H)), self._xg(i, "v")))
+        else:
+            ops.headbatch_tn(d4, xb["c"][i].unflatten(2, (T, H)), self._xg(i, "v"))
         dp = self._buf(tmp, "x.dp", (R, xb["cap"]), torch.float32)[:, xa.p0:xa.p0 + xa.ptot]
         ops.xattn_scores(dcp, enc_out, xa.k_off, xa.p_off, xa.ptot, dp)
         ds = xb["ps"][(2 * i + 1) * R:(2 * i + 2) * R, xa.p0:xa.p0 + xa.ptot]
         ops.xattn_softmax_bwd(xb["s"][i][:, xa.p0:xa.p0 + xa.ptot], dp, xb["st"][i], ds, xa.k_off, xa.p_off, T, H, max_keys, drop)
-        dqp = self._buf(tmp, "x.dqp", (xa.splits, B_all or B, R, d), torch.float32)[:, b0:b0 + B]      # (a chain: its samples' slabs)
+        dqp = self._buf(tmp, f"x.dqp.{i}" if hb is not None else "x.dqp", (xa.splits, B_all or B, R, d), torch.float32)[:, b0:b0 + B]      # (a chain: its samples' slabs)
         ops.xattn_context(ds, enc_out, xa.k_off, xa.p_off, dqp)
         ops.headbatch_nt(dqp.unflatten(2, (T, H)), self._xw(i, "k"), dqc.view(B, T, H, dk))
-        ops.headbatch_tn(qc.view(B, T, H, dk), dqp.unflatten(2, (T, H)), self._xg(i, "k"))
+        if hb is not None:
+            hb.append((qc.view(B, T, H, dk), dqp.unflatten(2, (T, H)), self._xg(i, "k")))
+        else:
+            ops.headbatch_tn(qc.view(B, T, H, dk), dqp.unflatten(2, (T, H)), self._xg(i, "k"))
 
     def _xattn_denc(self, xb, xa, tmp, Me, dxe):
         """dE[s, :] = Σ_layers Σ_r P[r, s]·dC'[r, :] + dS[r, s]·Q'[r, :] — per sample one [keys, d] = psᵀ·dq product with
@@ -822,13 +830,14 @@ class Engine:
             if not fused:
                 ops.dropout_apply(dh, dy, dr(_dec_site(i, 3)))
         wgrad("co", f"d.dy.c.{i}", dy, ws[f"d.cctx.{i}"], lw["co"].g)
-        dctx = R("d.dctx", inner)
+        hb = ch.get("hb") if ch["xa"] is not None else None      # the Wk / Wv gradient products of all layers in one launch (backward())
+        dctx = R(f"d.xdctx.{i}" if hb is not None else "d.dctx", inner)
         ops.gemm_nt(dy, lw["co"].wt, dctx)
         dqc = R(f"d.dqc.{i}" if defer else "d.dqc", inner)
         qc = sl(ws[f"d.qc.{i}"])
         if ch["xa"] is not None:
             self._xattn_bwd(ch["xb"], ch["xa"], tmp, i, qc, ws["e.out"], dctx, dqc, Bc, T, S, dr(_dec_site(i, 2)), b0=ch["b0"],
-                            B_all=Md // T)
+                            B_all=Md // T, hb=hb)
         else:
             c2 = sl(ws[f"d.cctx.{i}"])
             ops.attn_bwd(self._heads(qc, Bc, T, 0), self._cross_kv(kv, ch, 2 * i * inner), self._cross_kv(kv, ch, (2 * i + 1) * inner),
@@ -847,6 +856,7 @@ class Engine:
             if not fused:
                 ops.dropout_apply(dh, dy, dr(_dec_site(i, 1)))
         wgrad("o", f"d.dy.{i}", dy, ws[f"d.ctx.{i}"], lw["o"].g)
+        dctx = R("d.dctx", inner)      # (not the cross-attention's buffer: that one may be an operand of the deferred Wv-gradient launch)
         ops.gemm_nt(dy, lw["o"].wt, dctx)
         qkv, c1 = sl(ws[f"d.qkv.{i}"]), sl(ws[f"d.ctx.{i}"])
         dqkv = R(f"d.dqkv.{i}" if defer else "d.dqkv", 3 * inner)
@@ -1007,8 +1017,15 @@ class Engine:
         drel = self._buf(tmp, "d.drel", (H, 2 * T - 1), torch.float32)
         ops.zero_(drel)
         dw_all = []      # every decoder weight gradient of the step (K = B·T rows): grouped launches after the last layer
+        # the 2 · Ld head-batched Wk / Wv gradient products likewise: ONE launch after the last layer (each alone is its dispatch: 24 × 8 µs);
+        # with one chain only (LAKO_DEC_HB_DEFER=0: inside the layers)
+        hb_all = [] if (xa is not None and len(ctx.chains) == 1 and os.environ.get("LAKO_DEC_HB_DEFER", "1") != "0") else None
+        for ch in ctx.chains:
+            ch["hb"] = hb_all
         self._run_chains(ctx.chains, Ld, lambda i, ch: self._dec_layer_bwd(ws, tmp, i, ch, dh, drel, kv, dkv, fused, T, S, dw_all),
                          reverse=True)
+        if hb_all:
+            ops.headbatch_tn_multi(hb_all)
         if dw_all:      # (K = B·T rows: one K-split; the chains have joined and nothing else touches these gradients: plain read-modify-write)
             ops.gemm_tn_grouped(dw_all, split_k=one)
         ops.relpos_reduce(drel, self._lut(T, T, False), self.dec_rel.g)

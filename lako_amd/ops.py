@@ -371,6 +371,23 @@ class HipOps:
 
     def headbatch_tn(self, A, Bm, Cw):
         """Cw[h,j,c] += Σ_{b,t} A[b,t,h,j]·Bm[b,t,h,c]:  A [B,T,H,64] bf16, Bm [B,T,H,N] bf16|fp32, Cw [H,64,N] fp32 (views)"""
+        hb, flops = self._hb_tn_item(A, Bm, Cw)
+        self._timed("headbatch", flops, lambda: check(self.lib.lako_headbatch_tn(hb, self._stream()), "lako_headbatch_tn"))
+
+    def headbatch_tn_multi(self, problems):
+        """[(A, Bm, Cw), …] as headbatch_tn, problems of one shape, HB_MULTI_MAX per launch (lako_headbatch_tn_multi)"""
+        from ._lib import HB_MULTI_MAX, HeadBatch
+        for g0 in range(0, len(problems), HB_MULTI_MAX):
+            grp = problems[g0:g0 + HB_MULTI_MAX]
+            arr = (HeadBatch * len(grp))()
+            flops = 0.0
+            for i, (A, Bm, Cw) in enumerate(grp):
+                hb, fl = self._hb_tn_item(A, Bm, Cw)
+                C.memmove(C.byref(arr, i * C.sizeof(HeadBatch)), C.byref(hb), C.sizeof(HeadBatch))
+                flops += fl
+            self._timed("headbatch", flops, lambda: check(self.lib.lako_headbatch_tn_multi(arr, len(grp), self._stream()), "lako_headbatch_tn_multi"))
+
+    def _hb_tn_item(self, A, Bm, Cw):
         from ._lib import HeadBatch
         slabs, slab_stride = 1, 0
         if Bm.dim() == 5:
@@ -387,7 +404,7 @@ class HipOps:
         hb.M, hb.T, hb.H, hb.N, hb.K = Bz * T, T, H, N, K
         hb.a_dtype, hb.b_dtype = _dt(A), _dt(Bm)
         hb.n_slabs, hb.slab_stride = slabs, slab_stride
-        self._timed("headbatch", 2.0 * Bz * T * H * N * K, lambda: check(self.lib.lako_headbatch_tn(hb, self._stream()), "lako_headbatch_tn"))
+        return hb, 2.0 * Bz * T * H * N * K
 
     def xattn_scores(self, Q, E, k_off, p_off, p_total, S):
         """S[r, p_off[b] + s] = Q[b, r, :]·E[k_off[b] + s, :]:  Q [B, R, D] bf16 view, E [rows, D] bf16, S [R, >= p_total] fp32"""

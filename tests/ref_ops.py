@@ -297,6 +297,10 @@ class RefOps:
             Bm = Bm.sum(0)
         Cw += torch.einsum("bthj,bthc->hjc", f(A), f(Bm).to(A.dtype).float())
 
+    def headbatch_tn_multi(self, problems):
+        for A, Bm, Cw in problems:
+            self.headbatch_tn(A, Bm, Cw)
+
     def xattn_scores(self, Q, E, k_off, p_off, p_total, S):
         ko, po = k_off.tolist(), p_off.tolist()
         for b in range(Q.shape[0]):

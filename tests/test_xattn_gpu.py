@@ -146,6 +146,21 @@ def test_headbatch(ops, ref, Bz, T, H, D):
     ref.headbatch_tn(A, A2, Gr[inner:2 * inner].unflatten(0, (H, 64)))
     assert rel_l2(G - rnd(5 * inner, D, seed=7), Gr - rnd(5 * inner, D, seed=7)) < 3e-3
     assert torch.equal(G[:inner], Gr[:inner]) and torch.equal(G[2 * inner:], Gr[2 * inner:])
+    # the same product for several problems in ONE launch (lako_headbatch_tn_multi: the deferred Wk / Wv gradients of all decoder
+    # layers) equals the single launches bit for bit — 26 problems: more than one launch's 24; fp32 B operands in two slabs too
+    probs, single = [], []
+    for i in range(26):
+        Ai = rnd(Bz * T, inner, dtype=BF, seed=40 + i).view(Bz, T, H, 64)
+        Bi = rnd(2, Bz * T * H, D, seed=80 + i).view(2, Bz, T, H, D) if i % 2 else rnd(Bz * T * H, D, seed=80 + i).view(Bz, T, H, D)
+        Gi = rnd(inner, D, seed=120 + i)
+        probs.append((Ai, Bi, Gi.unflatten(0, (H, 64))))
+        Gs = Gi.clone()
+        single.append((Ai, Bi, Gs))
+    ops.headbatch_tn_multi(probs)
+    for Ai, Bi, Gs in single:
+        ops.headbatch_tn(Ai, Bi, Gs.unflatten(0, (H, 64)))
+    for (_, _, Gm), (_, _, Gs) in zip(probs, single):
+        assert torch.equal(Gm.flatten(0, 1), Gs)
 
 
 @pytest.mark.parametrize("p", [0.0, 0.1])
