@@ -96,7 +96,12 @@ enum {
   LAKO_EPI_RELU = 1,    /* v = max(v, 0)                                  (HF5:85 ReLU)             */
   LAKO_EPI_RESID = 2,   /* v = resid + dropout(v)                         (HF5:400,141 residual)    */
   LAKO_EPI_AUXMASK = 4, /* v = aux > 0 ? v * aux_scale : 0                (ReLU+dropout backward)   */
-  LAKO_EPI_ATOMIC = 8   /* C (fp32) += v with float atomics instead of a store                     */
+  LAKO_EPI_ATOMIC = 8,  /* C (fp32) += v with float atomics instead of a store                     */
+  LAKO_EPI_NORM_A = 16  /* (round 4) A is the UN-normalised input of a T5LayerNorm (HF5:236-256): the operand is
+                           bf16(norm_w * (A * rstd)), rstd = rsqrt(mean(A^2) + norm_eps), formed in the kernel's fragments exactly
+                           as lako_rmsnorm_fwd would write it; optional side outputs norm_out (the normalised rows) and norm_rstd.
+                           Only where the M <= 256 kernel runs (bf16, K % 32 == 0, K <= 1024): LAKO_E_UNSUPPORTED otherwise,
+                           nothing launched — the caller then runs lako_rmsnorm_fwd + a plain product.                       */
 };
 typedef struct {
   const void* A; /* [M, K] row-major, lda */
@@ -113,6 +118,12 @@ typedef struct {
   float aux_scale;
   lako_dropout_t drop; /* applied after relu / before the residual add; idx = m*N + n */
   const lako_tuning_t* tuning; /* HOST pointer, NULL = process defaults */
+  /* LAKO_EPI_NORM_A (round 4; at the END of the struct: a caller that never sets the flag may leave them uninitialised) */
+  const float* norm_w; /* [K] fp32 */
+  float norm_eps;
+  void* norm_out;      /* optional bf16 [M, K], row stride norm_ld elements */
+  int64_t norm_ld;
+  float* norm_rstd;    /* optional fp32 [M] */
 } lako_gemm_nt_t;
 int lako_gemm_nt(const lako_gemm_nt_t* p, lako_stream_t stream);
 

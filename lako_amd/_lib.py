@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("LAKO_LIB") or os.path.join(_HERE, "liblako_hip.so")  
 
 ABI_VERSION = 2          # include/lako_hip.h LAKO_ABI_VERSION this binding was written for
 LAKO_F32, LAKO_BF16, LAKO_FP8_E4M3 = 0, 1, 2
-EPI_RELU, EPI_RESID, EPI_AUXMASK, EPI_ATOMIC = 1, 2, 4, 8
+EPI_RELU, EPI_RESID, EPI_AUXMASK, EPI_ATOMIC, EPI_NORM_A = 1, 2, 4, 8, 16
 
 i64, i32, u32, f32, vp = C.c_int64, C.c_int, C.c_uint32, C.c_float, C.c_void_p
 
@@ -39,7 +39,8 @@ class Tuning(C.Structure):
 class GemmNT(C.Structure):
     _fields_ = [("A", vp), ("B", vp), ("C", vp), ("M", i64), ("N", i64), ("K", i64), ("lda", i64), ("ldb", i64),
                 ("ldc", i64), ("in_dtype", i32), ("out_dtype", i32), ("alpha", f32), ("flags", i32), ("resid", vp),
-                ("ldr", i64), ("aux", vp), ("ldaux", i64), ("aux_scale", f32), ("drop", Dropout), ("tuning", vp)]
+                ("ldr", i64), ("aux", vp), ("ldaux", i64), ("aux_scale", f32), ("drop", Dropout), ("tuning", vp),
+                ("norm_w", vp), ("norm_eps", f32), ("norm_out", vp), ("norm_ld", i64), ("norm_rstd", vp)]
 
 
 class GemmTNItem(C.Structure):

@@ -67,6 +67,11 @@ struct NtArgs {
   int dephase;    // (phases << 16) | ticks: workgroup w of an XCD starts (w mod phases)·ticks·10 ns late (breaks the lockstep of main loops / epilogues)
   int wide_epi;   // 256² bf16 tile: LDS-transposed epilogue with 16-B row-major stores (needs N, ldc, ldr, ldaux % 8 == 0)
   int glds;       // 1: K-slice pieces by global_load_lds where the slice is whole (tuning nt_glds)
+  const float* norm_w;   // LAKO_EPI_NORM_A (skinny kernel): T5 RMSNorm weight [K]; A is the un-normalised input, the operand is bf16(w · (A · rstd))
+  float norm_eps;
+  char* norm_out;        // optional bf16 [M, K] (row stride norm_ld): the normalised rows, written by the workgroups of the first tile column
+  int64_t norm_ld;
+  float* norm_rs;        // optional fp32 [M]: rstd
   int* queue;     // QUEUE instantiation: [0..7] per-XCD tile tickets, [8] workgroups finished (all zero between launches)
 };
 
@@ -872,7 +877,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
 // a full 64×64 partial tile, and the partials meet in LDS (swizzled 16-B chunks); each wave then finishes 16 rows in
 // row-major order: alpha, ReLU, aux mask, dropout, residual, 16-byte stores.  Needs K % 32 == 0, K <= 4096 and 16-byte rows (host).
 // ---------------------------------------------------------------------------------------------
-template <typename TO, int NW, int MAXS, int TB>   // NW waves split K; at most MAXS K-steps of 32 per wave (fully unrolled); tile = (16·TB)²
+// NORM (round 4, MAXS <= NS: every K-step of the wave resident at once): the A operand is the T5-RMSNorm of the rows of a.A, formed in the
+// fragments — the waves' partial sums of squares meet in LDS (fixed order), a_frag = bf16(w · (x · rstd)) exactly as rmsnorm_fwd writes it;
+// the workgroups of tile column 0 also write the normalised rows and rstd (the backward's operands).  Saves the decoder one launch per
+// projection that follows a norm (3 per layer: each ≈ 4.5 µs of kernel and ≈ 15 µs of the dependent chain).
+template <typename TO, int NW, int MAXS, int TB, bool NORM = false>   // NW waves split K; at most MAXS K-steps of 32 per wave (fully unrolled); tile = (16·TB)²
 __global__ __launch_bounds__(NW * 64) void gemm_nt_skinny_kernel(NtArgs a) {
   constexpr int NS = 4;   // register stages: NS - 1 K-steps in flight per wave
   constexpr int TS = TB * 16, CPR = TS / 4, PART = TS * TS * 4;   // tile side, 16-B chunks per fp32 row, bytes of a partial tile
@@ -913,9 +922,56 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_skinny_kernel(NtArgs a) {
   // (s_waitcnt vmcnt(0)) at every loop header
 #pragma unroll
   for (int u = 0; u < NS - 1; ++u) load(u, ks0 + u);
+  if constexpr (NORM) {
+    static_assert(MAXS <= NS, "NORM: all K-steps of a wave in registers");
+    if (MAXS == NS) load(NS - 1, ks0 + NS - 1);
+    // norm weights of the wave's K-steps (8 consecutive k per lane and step), requested with the operands
+    f32x4 wv[MAXS][2];
+#pragma unroll
+    for (int st = 0; st < MAXS; ++st) {
+      const int k = min((ks0 + st) * 32 + g * 8, a.K - 8);
+      wv[st][0] = *reinterpret_cast<const f32x4*>(a.norm_w + k);
+      wv[st][1] = *reinterpret_cast<const f32x4*>(a.norm_w + k + 4);
+    }
+    float* ssl = reinterpret_cast<float*>(smem + NW * PART);      // [NW][TS] partial sums of squares
+    float ss[TB];
+#pragma unroll
+    for (int i = 0; i < TB; ++i) {
+      ss[i] = 0.f;
+#pragma unroll
+      for (int st = 0; st < MAXS; ++st) {       // (steps past the wave's range hold zeros)
+        const bf16x8 x = __builtin_bit_cast(bf16x8, fa[st][i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss[i] += (float)x[e] * (float)x[e];
+      }
+      ss[i] += __shfl_xor(ss[i], 16, 64);
+      ss[i] += __shfl_xor(ss[i], 32, 64);
+      if (g == 0) ssl[wave * TS + i * 16 + r16] = ss[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TB; ++i) {
+      float tot = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) tot += ssl[w * TS + i * 16 + r16];
+      const float rs = rsqrtf(tot / (float)a.K + a.norm_eps);
+      const int m = m0 + i * 16 + r16;
+      if (blockIdx.x == 0 && wave == 0 && g == 0 && m < a.M && a.norm_rs) a.norm_rs[m] = rs;
+#pragma unroll
+      for (int st = 0; st < MAXS; ++st) {
+        const bf16x8 x = __builtin_bit_cast(bf16x8, fa[st][i]);
+        bf16x8 y;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = (bf16_t)(wv[st][e >> 2][e & 3] * ((float)x[e] * rs));
+        fa[st][i] = __builtin_bit_cast(u32x4, y);
+        if (blockIdx.x == 0 && a.norm_out && m < a.M && ks0 + st < ks1)
+          *reinterpret_cast<bf16x8*>(a.norm_out + ((int64_t)m * a.norm_ld + (ks0 + st) * 32 + g * 8) * 2) = y;
+      }
+    }
+  }
 #pragma unroll
   for (int st = 0; st < MAXS; ++st) {
-    if (st + NS - 1 < MAXS) load((st + NS - 1) % NS, ks0 + st + NS - 1);
+    if (!NORM && st + NS - 1 < MAXS) load((st + NS - 1) % NS, ks0 + st + NS - 1);
 #pragma unroll
     for (int mt = 0; mt < TB; ++mt)
 #pragma unroll
@@ -2104,6 +2160,12 @@ LAKO_SET_MAX_LDS((&gemm_nt_skinny_kernel<TO, 8, 16, 4>), 8 * 16384);
       const int ts = small ? 32 : 64;
       const dim3 grid(cdiv(a.N, ts), cdiv(a.M, ts));
       const int per = cdiv(a.K / 32, 8);
+      if (a.flags & LAKO_EPI_NORM_A) {      // RMSNorm of A in the fragments: K <= 1024 (all K-steps of a wave resident), 32² tiles
+        if (per > 4) return LAKO_E_BADARG;
+        const dim3 g32(cdiv(a.N, 32), cdiv(a.M, 32));
+        hipLaunchKernelGGL((gemm_nt_skinny_kernel<TO, 8, 4, 2, true>), g32, dim3(512), 8 * 4096 + 8 * 32 * 4, s, a);
+        return 0;
+      }
       if (tu.nt_skinny == 4) {
         const dim3 g16(cdiv(a.N, 16), cdiv(a.M, 16));
         if (per <= 4) hipLaunchKernelGGL((gemm_nt_skinny_kernel<TO, 8, 4, 1>), g16, dim3(512), 8 * 1024, s, a);
@@ -2122,6 +2184,7 @@ LAKO_SET_MAX_LDS((&gemm_nt_skinny_kernel<TO, 8, 16, 4>), 8 * 16384);
     }
     if (v == 5) v = 4;
   }
+  if (a.flags & LAKO_EPI_NORM_A) return LAKO_E_BADARG;      // only the skinny kernel forms the norm in its fragments
   if (v == 4 || (tu.nt_variant < 0 && tu.nt_ring && (int64_t)cdiv(a.M, RING_BM) * cdiv(a.N, RING_BM) <= 256)) {
     // skinny: at most one 128² tile per CU → the 4-slot ring hides the global→LDS latency inside the workgroup
     LAKO_SET_MAX_LDS((&gemm_nt_ring_kernel<T, TO>), RING_NST * RING_STAGE);
@@ -2208,14 +2271,35 @@ extern "C" int lako_gemm_nt(const lako_gemm_nt_t* p, lako_stream_t stream) {
   a.drop_thresh = p->drop.p > 0.f ? lako_drop_thresh(p->drop.p) : 0u;
   a.drop_scale = p->drop.p > 0.f ? 1.0f / (1.0f - p->drop.p) : 1.0f;
   a.drop_key = lako_drop_key(p->drop.seed, p->drop.site);
+  if (p->flags & LAKO_EPI_NORM_A) {
+    if (p->in_dtype != LAKO_BF16) {
+      lako_set_error("lako_gemm_nt: LAKO_EPI_NORM_A is implemented for bf16 operands only");
+      return LAKO_E_UNSUPPORTED;
+    }
+    LAKO_CHECK_ARG(p->norm_w != nullptr && p->norm_eps > 0.f, "lako_gemm_nt: NORM_A needs norm_w and norm_eps > 0");
+    LAKO_CHECK_ARG(p->norm_out == nullptr || (p->norm_ld >= p->K && p->norm_ld % 8 == 0 && reinterpret_cast<uintptr_t>(p->norm_out) % 16 == 0),
+                   "lako_gemm_nt: norm_out needs norm_ld >= K, norm_ld %% 8 == 0 and a 16-byte aligned pointer");
+    LAKO_CHECK_ALIGN(p->norm_w, 16);
+    a.norm_w = p->norm_w;
+    a.norm_eps = p->norm_eps;
+    a.norm_out = (char*)p->norm_out;
+    a.norm_ld = p->norm_ld;
+    a.norm_rs = p->norm_rstd;
+  }
   hipStream_t s = (hipStream_t)stream;
   const lako_tuning_t& tu = p->tuning ? *p->tuning : process_tuning();
+  int rc = 0;
   if (p->in_dtype == LAKO_BF16) {
-    if (p->out_dtype == LAKO_BF16) launch_nt<bf16_t, bf16_t>(a, tu, s);
-    else launch_nt<bf16_t, float>(a, tu, s);
+    if (p->out_dtype == LAKO_BF16) rc = launch_nt<bf16_t, bf16_t>(a, tu, s);
+    else rc = launch_nt<bf16_t, float>(a, tu, s);
   } else {
-    if (p->out_dtype == LAKO_BF16) launch_nt<float, bf16_t>(a, tu, s);
-    else launch_nt<float, float>(a, tu, s);
+    if (p->out_dtype == LAKO_BF16) rc = launch_nt<float, bf16_t>(a, tu, s);
+    else rc = launch_nt<float, float>(a, tu, s);
+  }
+  if (rc != 0) {      // (nothing was launched)
+    lako_set_error("lako_gemm_nt: LAKO_EPI_NORM_A is formed by the M <= 256 kernel only (bf16, K %% 32 == 0, K <= 1024, 16-byte aligned rows): M=%lld N=%lld K=%lld",
+                   (long long)p->M, (long long)p->N, (long long)p->K);
+    return LAKO_E_UNSUPPORTED;
   }
   LAKO_LAUNCH_CHECK();
   return LAKO_OK;

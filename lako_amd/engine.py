@@ -750,9 +750,15 @@ class Engine:
         if i == 0:
             ops.embed_fwd(ws["d.ids"].view(-1)[ch["r0"]:ch["r1"]], self.shared.w, h, dr(S_DEC_EMBED))
         xn1 = R(f"d.xn1.{i}", d)
-        ops.rmsnorm_fwd(h, lw["ln1"].p, xn1, R(f"d.rs1.{i}", 0, torch.float32), eps)
+        # (the norm in front of a projection is formed inside the projection's kernel where the library can — LAKO_EPI_NORM_A, the decoder's
+        # B·T <= 256 rows: one launch instead of two; xn / rstd are still written, the backward reads them.  LAKO_DEC_FUSE_NORM=0: two launches)
+        fuse_norm = os.environ.get("LAKO_DEC_FUSE_NORM", "1") != "0"
         qkv = R(f"d.qkv.{i}", 3 * inner)
-        ops.gemm_nt(xn1, lw["qkv"].w, qkv)
+        if fuse_norm:
+            ops.gemm_nt(h, lw["qkv"].w, qkv, norm=(lw["ln1"].p, eps, xn1, R(f"d.rs1.{i}", 0, torch.float32)))
+        else:
+            ops.rmsnorm_fwd(h, lw["ln1"].p, xn1, R(f"d.rs1.{i}", 0, torch.float32), eps)
+            ops.gemm_nt(xn1, lw["qkv"].w, qkv)
         c1 = R(f"d.ctx.{i}", inner)
         st = self._buf(ws, f"d.st.{i}", (Md // T, H, T, 4), torch.float32)[ch["b0"]:ch["b1"]]
         ops.attn_fwd(self._heads(qkv, Bc, T, 0), self._heads(qkv, Bc, T, inner), self._heads(qkv, Bc, T, 2 * inner),
@@ -760,9 +766,12 @@ class Engine:
         h1 = R(f"d.h1.{i}", d)
         ops.gemm_nt(c1, lw["o"].w, h1, resid=h, drop=dr(_dec_site(i, 1)))
         xn2 = R(f"d.xn2.{i}", d)
-        ops.rmsnorm_fwd(h1, lw["ln2"].p, xn2, R(f"d.rs2.{i}", 0, torch.float32), eps)
         qc = R(f"d.qc.{i}", inner)
-        ops.gemm_nt(xn2, lw["cq"].w, qc)
+        if fuse_norm:
+            ops.gemm_nt(h1, lw["cq"].w, qc, norm=(lw["ln2"].p, eps, xn2, R(f"d.rs2.{i}", 0, torch.float32)))
+        else:
+            ops.rmsnorm_fwd(h1, lw["ln2"].p, xn2, R(f"d.rs2.{i}", 0, torch.float32), eps)
+            ops.gemm_nt(xn2, lw["cq"].w, qc)
         c2 = R(f"d.cctx.{i}", inner)
         if ch["xa"] is not None:
             self._xattn_fwd(ch["xb"], ch["xa"], i, qc, enc_out, c2, Bc, T, S, dr(_dec_site(i, 2)))
@@ -773,9 +782,12 @@ class Engine:
         h2 = R(f"d.h2.{i}", d)
         ops.gemm_nt(c2, lw["co"].w, h2, resid=h1, drop=dr(_dec_site(i, 3)))
         xn3 = R(f"d.xn3.{i}", d)
-        ops.rmsnorm_fwd(h2, lw["ln3"].p, xn3, R(f"d.rs3.{i}", 0, torch.float32), eps)
         a1 = R(f"d.a1.{i}", f)
-        ops.gemm_nt(xn3, lw["wi"].w, a1, relu=True, drop=dr(_dec_site(i, 4)))
+        if fuse_norm:
+            ops.gemm_nt(h2, lw["wi"].w, a1, relu=True, drop=dr(_dec_site(i, 4)), norm=(lw["ln3"].p, eps, xn3, R(f"d.rs3.{i}", 0, torch.float32)))
+        else:
+            ops.rmsnorm_fwd(h2, lw["ln3"].p, xn3, R(f"d.rs3.{i}", 0, torch.float32), eps)
+            ops.gemm_nt(xn3, lw["wi"].w, a1, relu=True, drop=dr(_dec_site(i, 4)))
         h_out = ws[f"d.h{i + 1}"][ch["r0"]:ch["r1"]]
         ops.gemm_nt(a1, lw["wo"].w, h_out, resid=h2, drop=dr(_dec_site(i, 5)))
         if i == Ld - 1:
@@ -1196,17 +1208,25 @@ class Engine:
         def step(t):
             """enqueue decode step t (reads nxt, writes seq[:, t + 1], nxt, done, ndone[t])"""
             ops.embed_fwd(nxt, self.shared.w, h)
+            fz = os.environ.get("LAKO_DEC_FUSE_NORM", "1") != "0"      # the norm inside the projection's kernel (LAKO_EPI_NORM_A), as in training
+            nrm = (lambda w_: dict(norm=(w_, eps, xn, rs))) if fz else None
             for i in range(Ld):
                 lw = self.dec[i]
-                ops.rmsnorm_fwd(h, lw["ln1"].p, xn, rs, eps)
-                ops.gemm_nt(xn, lw["qkv"].w, cache[i].view(B, ML * 3 * inner)[:, t * 3 * inner:(t + 1) * 3 * inner])
+                if fz:
+                    ops.gemm_nt(h, lw["qkv"].w, cache[i].view(B, ML * 3 * inner)[:, t * 3 * inner:(t + 1) * 3 * inner], **nrm(lw["ln1"].p))
+                else:
+                    ops.rmsnorm_fwd(h, lw["ln1"].p, xn, rs, eps)
+                    ops.gemm_nt(xn, lw["qkv"].w, cache[i].view(B, ML * 3 * inner)[:, t * 3 * inner:(t + 1) * 3 * inner])
                 qs = cache[i][:, t:t + 1, :inner].unflatten(2, (H, dk))
                 kc = cache[i][:, :t + 1, inner:2 * inner].unflatten(2, (H, dk))
                 vc = cache[i][:, :t + 1, 2 * inner:].unflatten(2, (H, dk))
                 ops.attn_fwd(qs, kc, vc, c1.view(B, 1, H, dk), st, rel_bias=rel, rel_off=ML - 1 - t)
                 ops.gemm_nt(c1, lw["o"].w, h1, resid=h)
-                ops.rmsnorm_fwd(h1, lw["ln2"].p, xn, rs, eps)
-                ops.gemm_nt(xn, lw["cq"].w, qc)
+                if fz:
+                    ops.gemm_nt(h1, lw["cq"].w, qc, **nrm(lw["ln2"].p))
+                else:
+                    ops.rmsnorm_fwd(h1, lw["ln2"].p, xn, rs, eps)
+                    ops.gemm_nt(xn, lw["cq"].w, qc)
                 if xa is None:
                     ops.attn_fwd(qc.view(B, 1, H, dk), self._heads(kv, kb, kt, 2 * i * inner),
                                  self._heads(kv, kb, kt, (2 * i + 1) * inner), c2.view(B, 1, H, dk), st,
@@ -1223,8 +1243,11 @@ class Engine:
                         ops.xattn_context(xp, enc_out, xoff[0], xoff[1], xc)
                         ops.headbatch_nt(xc.view(xa.splits, B, 1, H, d), self._xw(i, "v"), c2.view(B, 1, H, dk))
                 ops.gemm_nt(c2, lw["co"].w, h2, resid=h1)
-                ops.rmsnorm_fwd(h2, lw["ln3"].p, xn, rs, eps)
-                ops.gemm_nt(xn, lw["wi"].w, a1, relu=True)
+                if fz:
+                    ops.gemm_nt(h2, lw["wi"].w, a1, relu=True, **nrm(lw["ln3"].p))
+                else:
+                    ops.rmsnorm_fwd(h2, lw["ln3"].p, xn, rs, eps)
+                    ops.gemm_nt(xn, lw["wi"].w, a1, relu=True)
                 ops.gemm_nt(a1, lw["wo"].w, h, resid=h2)
             ops.rmsnorm_fwd(h, self.dec_final.p, xn, rs, eps)
             ops.gemm_nt(xn, self.shared.w, logits, alpha=d ** -0.5)

@@ -15,7 +15,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (EPI_ATOMIC, EPI_AUXMASK, EPI_RELU, EPI_RESID, LAKO_BF16, LAKO_F32, LAKO_FP8_E4M3, AttnBwd, AttnFwd, Dropout,
+from ._lib import (EPI_ATOMIC, EPI_AUXMASK, EPI_NORM_A, EPI_RELU, EPI_RESID, LAKO_BF16, LAKO_F32, LAKO_FP8_E4M3, AttnBwd, AttnFwd, Dropout,
                    GemmNT, LakoError, NO_DROP, check)
 
 
@@ -152,14 +152,28 @@ class HipOps:
 
     # ---- GEMMs -----------------------------------------------------------------------------
     def gemm_nt(self, A, B, Cm, *, alpha=1.0, relu=False, resid=None, aux=None, aux_scale=1.0, drop=None,
-                atomic=False):
+                atomic=False, norm=None):
+        """`norm` = (w fp32 [K], eps, xn bf16 [M, K], rstd fp32 [M]): A is the un-normalised input of a T5LayerNorm — the product runs on
+        bf16(w·(A·rstd)) formed inside the kernel (LAKO_EPI_NORM_A: one launch instead of two), xn / rstd receive what lako_rmsnorm_fwd would
+        have written.  Where the library cannot do that (rows > 256, K > 1024, fp32 …) the norm runs as its own launch first."""
+        if norm is not None:
+            w, eps, xn, rstd = norm
+            if self._gemm_nt_call(A, B, Cm, alpha, relu, resid, aux, aux_scale, drop, atomic, norm) == 0:
+                return
+            self.rmsnorm_fwd(A, w, xn, rstd, eps)         # (LAKO_E_UNSUPPORTED: nothing was launched)
+            A = xn
+        rc = self._gemm_nt_call(A, B, Cm, alpha, relu, resid, aux, aux_scale, drop, atomic, None)
+        if rc != 0:
+            check(rc, "lako_gemm_nt")
+
+    def _gemm_nt_call(self, A, B, Cm, alpha, relu, resid, aux, aux_scale, drop, atomic, norm):
         M, K, lda = _rowmajor2d(A, "gemm_nt A")
         N, K2, ldb = _rowmajor2d(B, "gemm_nt B")
         M2, N2, ldc = _rowmajor2d(Cm, "gemm_nt C")
         if K != K2 or M != M2 or N != N2 or A.dtype != B.dtype:
             raise LakoError(f"gemm_nt: shape/dtype mismatch A{tuple(A.shape)} B{tuple(B.shape)} C{tuple(Cm.shape)}")
         flags = (EPI_RELU if relu else 0) | (EPI_RESID if resid is not None else 0) | \
-                (EPI_AUXMASK if aux is not None else 0) | (EPI_ATOMIC if atomic else 0)
+                (EPI_AUXMASK if aux is not None else 0) | (EPI_ATOMIC if atomic else 0) | (EPI_NORM_A if norm is not None else 0)
         p = GemmNT()
         p.A, p.B, p.C = A.data_ptr(), B.data_ptr(), Cm.data_ptr()
         p.M, p.N, p.K, p.lda, p.ldb, p.ldc = M, N, K, lda, ldb, ldc
@@ -176,8 +190,21 @@ class HipOps:
         p.aux_scale = float(aux_scale)
         p.drop = _drop(drop)
         p.tuning = self._tuning_p
+        if norm is not None:
+            w, eps, xn, rstd = norm
+            if w.dtype != torch.float32 or w.numel() != K or xn.shape != A.shape or xn.dtype != A.dtype or xn.stride(1) != 1 or \
+                    rstd.dtype != torch.float32 or rstd.numel() != M:
+                raise LakoError("gemm_nt: norm = (w fp32 [K], eps, xn like A, rstd fp32 [M])")
+            p.norm_w, p.norm_eps, p.norm_out, p.norm_ld, p.norm_rstd = _p(w), float(eps), _p(xn), xn.stride(0), _p(rstd)
         # probe classes follow the kernel the library picks: M <= 256 rows (the decoder) runs on the split-K / ring kernels
-        self._timed(f"gemm_nt{'_skinny' if M <= 256 else ''}.{p.in_dtype}{p.out_dtype}", 2.0 * M * N * K, lambda: check(self.lib.lako_gemm_nt(C.byref(p), self._stream()), "lako_gemm_nt"))
+        rc = [0]
+
+        def go():
+            rc[0] = self.lib.lako_gemm_nt(C.byref(p), self._stream())
+            if rc[0] != 0 and not (norm is not None and rc[0] == -4):        # -4 = LAKO_E_UNSUPPORTED: the caller falls back
+                check(rc[0], "lako_gemm_nt")
+        self._timed(f"gemm_nt{'_skinny' if M <= 256 else ''}.{p.in_dtype}{p.out_dtype}", 2.0 * M * N * K, go)
+        return rc[0]
 
     def gemm_tn(self, A, B, Cm, *, alpha=1.0, split_k=0):
         K, M, lda = _rowmajor2d(A, "gemm_tn A")

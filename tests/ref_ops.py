@@ -110,7 +110,11 @@ class RefOps:
 
     # ---- GEMMs -----------------------------------------------------------------------------
     def gemm_nt(self, A, B, Cm, *, alpha=1.0, relu=False, resid=None, aux=None, aux_scale=1.0, drop=None,
-                atomic=False):
+                atomic=False, norm=None):
+        if norm is not None:          # A is the un-normalised input: the product runs on the RMSNorm'd rows, which are also handed back
+            w, eps, xn, rstd = norm
+            self.rmsnorm_fwd(A, w, xn, rstd, eps)
+            A = xn
         v = (f(A) @ f(B).t()) * alpha
         if relu:
             v = torch.relu(v)

@@ -272,6 +272,35 @@ def test_gemm_nt_tile_queue(ops, ref):
         ops.set_tuning("gemm_nt_queue", 0)
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 2304, 768), (128, 3072, 768), (16, 768, 768), (200, 1024, 1024), (37, 776, 512), (128, 768, 2048),
+                                   (300, 768, 768)])
+def test_gemm_nt_norm_fused(ops, ref, M, N, K):
+    """LAKO_EPI_NORM_A (round 4): the product on the T5-RMSNorm of A's rows, formed inside the M <= 256 kernel — against the two
+    launches it replaces (lako_rmsnorm_fwd + the plain product): the normalised rows and rstd handed back are what rmsnorm_fwd writes
+    (rstd to fp32 summation order, rows to one bf16 rounding), the product agrees with the reference, with fused epilogues; shapes the
+    kernel does not take (K > 1024, rows > 256) run as two launches through the same call."""
+    T = torch.bfloat16
+    A, B = rnd(M, K, dtype=T, seed=71) * 3.0, rnd(N, K, dtype=T, seed=72)
+    w = (1.0 + 0.2 * rnd(K, seed=73)).contiguous()
+    R = rnd(M, N, dtype=T, seed=74)
+    eps = 1e-6
+    xn0, rs0 = torch.empty(M, K, dtype=T, device=dev()), torch.empty(M, device=dev())
+    ops.rmsnorm_fwd(A, w, xn0, rs0, eps)
+    for kw in (dict(), dict(relu=True, drop=(0.1, 5, 6)), dict(resid=R, drop=(0.1, 7, 8), alpha=0.5)):
+        C0 = torch.empty(M, N, dtype=T, device=dev())
+        ops.gemm_nt(xn0, B, C0, **kw)
+        C1 = torch.empty(M, N, dtype=T, device=dev())
+        xn1, rs1 = torch.full((M, K), 7.0, dtype=T, device=dev()), torch.full((M,), 7.0, device=dev())
+        ops.gemm_nt(A, B, C1, norm=(w, eps, xn1, rs1), **kw)
+        torch.testing.assert_close(rs1, rs0, rtol=2e-6, atol=0)
+        assert float((xn1.float() - xn0.float()).abs().max()) <= 2.0 ** -7 * float(xn0.float().abs().max())      # one bf16 ulp at most
+        assert float((xn1 != xn0).float().mean()) < 1e-3
+        Cr = torch.zeros(M, N, device=dev())
+        ref.gemm_nt(xn1, B, Cr, **kw)                    # the product of the rows the kernel says it used
+        close(C1, Cr, T, f"gemm_nt norm-fused {list(kw)} {M}x{N}x{K}", tight=True)
+        close(C1, C0.float(), T, f"gemm_nt norm-fused vs two launches {list(kw)} {M}x{N}x{K}")
+
+
 def test_gemm_nt_tile_height_plan(ops, ref):
     """(`gemm_nt_tile288`, round 4, on by default: 288-row tiles where they save the tail launch or a round — two rounds of 498 tiles here.)
     With `gemm_nt_tile192` on, launch_nt prices 256-row and 192-row tiles per call: 47 757 rows x 768 columns — the benchmark's
