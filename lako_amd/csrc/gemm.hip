@@ -1135,6 +1135,7 @@ struct TnArgs {
   float* slabs;     // several K-splits WITHOUT atomics: [tile][split][64 Ki floats] partial tiles + tickets (below); nullptr = atomics
   int* tickets;     // [tiles] arrival counters, zeroed before the launch
   int wide_out;     // out_mode 1 / 2 with 16-byte aligned rows (every item: C % 16 == 0, ldc % 4 == 0, N % 4 == 0): 16-byte epilogue accesses
+  int no_stagger;   // 1 (default): every wave issues its DMA at the top of the K-step; 0 (LAKO_TN_STAGGER=1): waves 4-7 two MFMA rows later
   int t_full;       // HYBRID schedule (grouped launch, split_k −3): the first t_full tiles (a multiple of 256: whole rounds of the chip) run their
                     // WHOLE K in one workgroup each (plain C += v, no atomics), the remaining tiles are cut into split_k pieces of k_chunk that
                     // add by atomics; 0 = uniform splits
@@ -1446,7 +1447,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(TnArgs a) {
     // K-step schedule as in gemm_nt_kernel: fragment reads of a K-half back to back (sched_barrier: the machine
     // scheduler would fold them into one register quad and wait per read), the second half of the workgroup issues
     // its DMA after two rows of MFMAs, and the wait + barrier sit two rows before the end of the step
-    const bool late = wave >= 4;
+    const bool late = wave >= 4 && !a.no_stagger;
     if (!late) prefetch();
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -2384,6 +2385,7 @@ static int tn_single(const void* A, const void* B, float* C, int64_t M, int64_t 
     a.k_chunk = chunk;
     a.no_atomics = tu.tn_big == 2;
     a.glds = tu.nt_glds;
+    a.no_stagger = 1;      // (as the grouped launch: see lako_gemm_tn_grouped)
     a.out_mode = a.split_k == 1 ? out_mode : 0;
     a.wide_out = reinterpret_cast<uintptr_t>(C) % 16 == 0 && ldc % 4 == 0 && N % 4 == 0;
     a.slabs = nullptr;
@@ -2496,6 +2498,10 @@ extern "C" int lako_gemm_tn_grouped(const lako_gemm_tn_item_t* items, int n_item
     d.tile_start = tiles;
     tiles += cdiv((int)p.M, 256) * d.tiles_n;
   }
+  // every wave issues its DMA at the top of the K-step (round 4, with the full-K units: 7.29 -> 7.04 ms per step against waves 4-7 issuing
+  // theirs two MFMA rows later, the NT kernel's order; LAKO_TN_STAGGER=1 restores that)
+  static const bool tn_stag = getenv("LAKO_TN_STAGGER") && atoi(getenv("LAKO_TN_STAGGER")) == 1;
+  a.no_stagger = !tn_stag;
   a.tiles_m = tiles;     // the kernel only uses the product
   a.tiles_n = 1;
   a.wide_out = 1;
