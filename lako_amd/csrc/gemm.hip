@@ -31,6 +31,11 @@
 // tests below are compile-time zero and lako_set_tuning rejects the keys that would set them.
 // cache-policy bits of the NT kernels' LDS-DMA loads (gfx940 encoding of the builtin's aux operand: 1 = sc0, 2 = nt, 16 = sc1): 0 in the
 // product; other values only in throw-away A/B builds (-DLAKO_LOAD_AUX=…, tools/gemm_pp_probe.py)
+// m-tile rows of MFMAs of a K-step's second half that the TN kernel issues BEFORE the wait for the next K-slice + barrier (8 = all of them);
+// 6 in the product, other values in throw-away A/B builds (-DLAKO_TN_WAIT_ROWS=…)
+#ifndef LAKO_TN_WAIT_ROWS
+#define LAKO_TN_WAIT_ROWS 6
+#endif
 #ifndef LAKO_LOAD_AUX
 #define LAKO_LOAD_AUX 0
 #endif
@@ -1472,12 +1477,12 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(TnArgs a) {
         }
         mma_rows(2, 8);
       } else {
-        mma_rows(0, 6);
+        mma_rows(0, LAKO_TN_WAIT_ROWS);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
-        mma_rows(6, 8);
+        mma_rows(LAKO_TN_WAIT_ROWS, 8);
       }
     }
   }
