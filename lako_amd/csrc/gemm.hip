@@ -36,6 +36,11 @@
 #ifndef LAKO_TN_WAIT_ROWS
 #define LAKO_TN_WAIT_ROWS 6
 #endif
+// m-tile rows of MFMAs of a K-step's second half that the NT kernel issues AFTER the wait for the next K-slice + barrier (0 = MT / 4, the
+// product; other values in throw-away A/B builds)
+#ifndef LAKO_NT_WAIT_Q
+#define LAKO_NT_WAIT_Q 0
+#endif
 #ifndef LAKO_LOAD_AUX
 #define LAKO_LOAD_AUX 0
 #endif
@@ -645,7 +650,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[nt][mt] = Mma<T>::run(bf[nt], af[mt], acc[nt][mt]);
         };
-        constexpr int Q = MT / 4;
+        constexpr int Q = LAKO_NT_WAIT_Q > 0 ? LAKO_NT_WAIT_Q : MT / 4;
         if (kh == 0) {
           mma_rows(0, Q);
           if (late) {
