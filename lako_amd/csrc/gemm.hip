@@ -2119,7 +2119,7 @@ int launch_nt(const NtArgs& a_in, const lako_tuning_t& tu, hipStream_t s) {
         // fewer).  144 accumulator registers: 243 VGPRs with the plain epilogues; with a side operand 288-row tiles need the 16-row side passes
         // (launch_nt_256<…, 9>).
         if (tu.nt_tile288 && !(a.flags & LAKO_EPI_ATOMIC) && nt288_ok<T, TO>(a, tu)) {
-          const Plan p288 = plan(288, 1.13);
+          const Plan p288 = plan(288, tu.nt_tile288 >= 2 ? 1.0 + 0.01 * tu.nt_tile288 : 1.13);      // (values >= 2: the price in percent over a 256-row tile, A/B)
           if (p288.cost < 0.99 * pl.cost) {
             pl = p288;
             bm = 288;
