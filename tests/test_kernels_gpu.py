@@ -420,6 +420,14 @@ def test_gemm_tn_exclusive_and_overwrite(ops, ref):
     ops.gemm_tn_grouped([(A, B, C, 1.0)] * 1 + [(B, A, torch.zeros(3072, 768, device=dev()), 1.0)], split_k=-1)
     ref.gemm_tn_grouped([(A, B, Cr, 1.0)], split_k=-1)
     close(C, Cr, T, "gemm_tn_grouped exclusive rmw", tight=True)
+    # an output whose rows are not 16-byte aligned (row stride 3074 floats) takes the dword form of the same epilogue
+    for mode in (-1, -2):
+        big = torch.full((768, 3074), 2.0, device=dev())
+        Cv, want = big[:, 1:3073], torch.full((768, 3072), 2.0, device=dev())
+        ops.gemm_tn_grouped([(A, B, Cv, 0.5), (B, A, torch.zeros(3072, 768, device=dev()), 1.0)], split_k=mode)
+        ref.gemm_tn_grouped([(A, B, want, 0.5)], split_k=mode)
+        close(Cv, want, T, f"gemm_tn_grouped split_k {mode}, unaligned rows", tight=True)
+        assert torch.all(big[:, 0] == 2.0) and torch.all(big[:, 3073] == 2.0)
 
 
 @pytest.mark.parametrize("extra", [0, 8, 136])
