@@ -78,10 +78,9 @@ typedef struct lako_tuning {
   int32_t nt_tile192;    /* 1: 192-row tiles (variant 7) where the round count favours them (default 0: measured no faster) */
   int32_t nt_queue;      /* 1: the persistent 256x256 kernel pulls its tiles from per-XCD ticket counters (a launch that shares the chip
                             with RCCL kernels — LAKO_DP_MODE=overlap — ends when the tiles do, not when the last-started workgroup does) */
-  int32_t nt_pp;         /* 1 (default): the 8-phase main loop of the 256x256 / 8-wave bf16 kernel (K >= 128): quadrant-wise fragment reads,
-                            half-tile LDS-DMA stagings retired by counted waits, waves 4-7 one barrier behind waves 0-3 (on every SIMD one
-                            wave is in a 16-MFMA cluster while the other reads / stages); 0: the two-phase loop of rounds 1-3.  Same results
-                            bit for bit */
+  int32_t nt_pp;         /* 0 (default): the two-phase main loop of rounds 1-3; 1 (A/B only, measured 3-11 % slower): the 8-phase loop of the
+                            256x256 / 8-wave bf16 kernel (K >= 128): quadrant-wise fragment reads, half-tile LDS-DMA stagings retired by
+                            counted waits, waves 4-7 one barrier behind waves 0-3.  Same results bit for bit */
   int32_t nt_glds;       /* 1 (default): whole K-slices are staged by global_load_lds (rows past the edge clamped) instead of
                             buffer_load ... lds; partial K-slices (K % 64) keep the buffer form and its zero fill */
   int32_t nt_tile288;    /* 1 (default): 288-row tiles (variant 8) where they save a round or the tail launch — plain epilogues only */

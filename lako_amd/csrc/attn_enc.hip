@@ -110,6 +110,21 @@ __device__ __forceinline__ void epv(f32x4 (&acc)[4], f32x4 w0, f32x4 w1, const c
   }
 }
 
+// the same with the two weight tiles already rounded to bf16 (4 values per tile in 2 registers)
+__device__ __forceinline__ void epv_packed(f32x4 (&acc)[4], u32x2 w0, u32x2 w1, const char* img, int row0, const uint32_t (&toff)[4]) {
+  const u32x4 bw = {w0[0], w0[1], w1[0], w1[1]};
+  const bf16x8 bfrag = __builtin_bit_cast(bf16x8, bw);
+#pragma unroll
+  for (int db = 0; db < 4; ++db) {
+    const char* ap = img + row0 * EROW + toff[db];
+    s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ap));
+    s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ap + 16 * EROW));
+    u32x2 u0 = __builtin_bit_cast(u32x2, t0), u1 = __builtin_bit_cast(u32x2, t1);
+    u32x4 afrag = {u0[0], u0[1], u1[0], u1[1]};
+    acc[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, afrag), bfrag, acc[db], 0, 0, 0);
+  }
+}
+
 // DPP move of a float inside 16-lane rows (CTRL: 0x100 + n row_shl:n — lane j reads lane j + n; 0x110 + n row_shr:n — lane j
 // reads lane j − n); lanes whose source lies outside the row read 0
 template <int CTRL>
@@ -1122,6 +1137,505 @@ __global__ __launch_bounds__(PF_NW * 64) void enc_bwd_dkv_p_kernel(AttnArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// backward, ONE pass (round 5): dQ, dK, dV and the bias gradient of a (sequence, head) item from one workgroup that reads
+// q, k, v, dO and O ONCE.  The two-pass form above recomputes the score tiles (and their exp / dropout hashes — the bulk
+// of the vector work) in both passes and reads q, k, v, dO from HBM twice; round 2's one-pass attempt summed dQ through
+// LDS float atomics (≈ 0.3 lane-operations per clock and CU) and was 7× slower.  Here nothing is summed across waves:
+//   * one 16-wave workgroup per CU walks the items of ONE head; wave w owns key tile w (16 keys: its V rows stay in
+//     registers for the whole item, dKᵀ and dVᵀ of those keys accumulate in registers);
+//   * the queries stream through in slabs of 32 rows — the Q, dO and O rows plus the row statistics of a slab are one
+//     ring stage filled by LDS-DMA NST − 1 slabs ahead, ACROSS item boundaries: no staging phase per item;
+//   * P1 (per slab, every wave with a key tile): S = Q·Kᵀ + bias and dP = dO·Vᵀ − δ for (32 queries × its 16 keys),
+//     P̃, dS, dKᵀ += Qᵀ·dS, dVᵀ += dOᵀ·P̃ as in the dK/dV pass above, the bias gradient in diagonal-indexed registers
+//     (DPP row shifts; the wave's tile diagonal depends on the slab only), and dS — rounded to bf16 exactly as the MFMA
+//     operand is — goes into a [key][32 queries] LDS slab;
+//   * P2 (one slab later, waves 14 and 15 — beyond the key tiles of every sequence of ≤ 224 keys, so they are dedicated):
+//     dQᵀ[64 d × 16 queries] = Kᵀ·dSᵀ contracted over ALL keys of the item — both operands transposed reads (the K image
+//     of the item, staged once by LDS-DMA during the previous item, and the dS slab): every output element has ONE
+//     owning wave and a complete sum — no atomics, no cross-wave reduction;
+//   * wave 14 also issues the ring's DMA; wave 15 forms δ = rowsum(dO ∘ O) and the (lse₂, −δ/scale) vectors of the slab
+//     that has just landed, one slab ahead of its use, and issues the next item's K image.
+// One barrier per slab; every role walks the same stage sequence with its own cursor (P1 waves carry no state of the
+// other roles).  The dS slabs are double-buffered (P2 of slab n − 1 runs beside P1 of slab n), the K image too (item
+// j + 1's arrives while item j computes; every item takes at least two slab iterations so that the image being
+// overwritten is dead).  HBM traffic per item: q, k, v, dO, O read once, dq, dk, dv written once.
+// Results: dk, dv as the dK/dV pass (same arithmetic per tile); dq sums the same bf16 dS values in fp32 over all keys
+// in another order than the dQ pass.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int FB_NW = 16;
+constexpr int FB_SLAB = 32 * EROW;                      // one 32-row slab image
+constexpr int FB_STAGE = 3 * FB_SLAB + 1024;            // Q | dO | O | raw statistics (32 × 16 B, then 512 B of DMA zero fill)
+constexpr int FB_TBL = 64;                              // items per table pass
+// LDS: 2 K images | 2 dS slabs [rows][32 q] | ring | 4 reversed bias copies | lse2 / −δ/scale per stage | item table + header
+__host__ __device__ constexpr int efb_lds(int rows, int nst) {
+  return 2 * rows * EROW + 2 * rows * 64 + nst * FB_STAGE + 4 * EB_ST * 4 + nst * 2 * 32 * 4 + FB_TBL * 16 + 16;
+}
+
+struct FbItem { int b, q0, k0, Lq, Lk; };
+// a role's position in the stage stream: stage = (item j, slab s); advance() steps to the next stage
+struct FbCur { int j, s, ns; FbItem it; };
+
+// byte offset of the 8-byte slot (q-tile u, lane group g) of key row `row` in a dS slab: 64-byte rows, slot bits swizzled by the
+// row so that the transposed reads of P2 (8 rows × 4 slots per half wave) and the writes of P1 (16 rows × 1 slot) spread over the banks
+__device__ __forceinline__ uint32_t fb_ds_off(int row, int u, int g) {
+  return (uint32_t)(row * 64 + ((((u ^ ((row >> 2) & 1)) << 2) | (g ^ ((row >> 1) & 3))) << 3));
+}
+
+// Rows are addressed in ONE form: row r of sequence b of a tensor with token stride st (elements) sits at (off + r)·st + h·64, where
+// off = q_off[b] for ragged launches and b·(batch stride ÷ token stride) for padded ones (the launcher checks the divisibility and puts the
+// quotients into rq / rk).
+template <bool DROP, int NST>
+__global__ __launch_bounds__(FB_NW * 64) void enc_bwd_fused_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int R = a.chunk_rows;                       // key image rows: a multiple of 32 ≥ every sequence's key count
+  char* Kimg0 = smem;
+  char* dST0 = smem + 2 * R * EROW;
+  char* ring = dST0 + 2 * R * 64;
+  float* b4 = reinterpret_cast<float*>(ring + NST * FB_STAGE);
+  float* lse_l = b4 + 4 * EB_ST;
+  float* ndel_l = lse_l + NST * 32;
+  int* tbl = reinterpret_cast<int*>(ndel_l + NST * 32);     // [FB_TBL][4] + header {items, stages}
+  float* drel_l = reinterpret_cast<float*>(smem);   // the end flush reuses the K images
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = blockIdx.x % a.H, slot0 = blockIdx.x / a.H, nslots = gridDim.x / a.H;
+  if (slot0 >= a.Bn) return;
+  const bool want_drel = a.drel != nullptr;
+  estage_bias<FB_NW * 64>(b4, a.rel_bias, h, a.R, true);
+  const int KB = (a.Lk + 3) >> 2, QB = (a.Lq + 3) >> 2;
+  const float dscale = DROP ? a.drop_scale : 1.0f, inv_dscale = 1.0f / dscale;
+  const int nmine = (a.Bn - slot0 + nslots - 1) / nslots;         // items of this workgroup (empty ones included)
+  if (wave >= 14) {
+    // ================= waves 14 / 15: the ring's DMA, δ, the K images, P2 — no key tile (the launcher takes sequences of ≤ 224 keys) =================
+    for (int t0 = 0; t0 < nmine; t0 += FB_TBL) {
+      __syncthreads();
+      __syncthreads();                                              // (wave 0 builds the item table between these two)
+      const int nit = __builtin_amdgcn_readfirstlane(tbl[FB_TBL * 4]);
+      const int nstage = __builtin_amdgcn_readfirstlane(tbl[FB_TBL * 4 + 1]);
+      if (nit == 0) continue;
+    auto item = [&](int j) {
+      const u32x4 e = *reinterpret_cast<const u32x4*>(tbl + j * 4);
+      FbItem it;
+      it.b = __builtin_amdgcn_readfirstlane((int)e[0]);
+      it.q0 = __builtin_amdgcn_readfirstlane((int)e[1]);
+      it.k0 = __builtin_amdgcn_readfirstlane((int)e[2]);
+      const int w3 = __builtin_amdgcn_readfirstlane((int)e[3]);
+      it.Lq = w3 & 0xFFFF;
+      it.Lk = w3 >> 16;
+      return it;
+    };
+    auto cur_at = [&](int j) {                                        // cursor at the first stage of item j (j == nit: past the end)
+      FbCur c;
+      c.j = j; c.s = 0;
+      c.it = item(j < nit ? j : 0);
+      c.ns = max(2, (c.it.Lq + 31) >> 5);
+      return c;
+    };
+    auto advance = [&](FbCur& c) {
+      if (c.j >= nit) return;
+      if (++c.s >= c.ns) {
+        c.s = 0;
+        ++c.j;
+        if (c.j < nit) {
+          c.it = item(c.j);
+          c.ns = max(2, (c.it.Lq + 31) >> 5);
+        }
+      }
+    };
+    // ---- the ring's DMA (wave 14): Q, dO, O rows of slab s of the item (4 pieces of 8 rows each) and its 32 raw statistics records
+    auto issue_stage = [&](const FbItem& it, int s, int slot) {
+      int le = lane;
+      asm volatile("" : "+v"(le));
+      char* st = ring + slot * FB_STAGE;
+      const int nrow = min(max(it.Lq - 32 * s, 0), 32);              // rows of this slab that exist
+      const int64_t r0 = (int64_t)(it.q0 + 32 * s);
+      const uint32_t qstb = (uint32_t)a.qst * 2u, ostb = (uint32_t)a.ost * 2u;
+      const auto qrs = lds_dma_rsrc(a.q + h * 128 + r0 * qstb, nrow > 0 ? (uint32_t)(nrow - 1) * qstb + 128u : 0u);
+      const auto drs = lds_dma_rsrc(a.dout + h * 128 + r0 * ostb, nrow > 0 ? (uint32_t)(nrow - 1) * ostb + 128u : 0u);
+      const auto ors = lds_dma_rsrc(a.o + h * 128 + r0 * ostb, nrow > 0 ? (uint32_t)(nrow - 1) * ostb + 128u : 0u);
+      const auto srs = lds_dma_rsrc(a.stats + (((int64_t)it.b * a.H + h) * a.Lq + 32 * s) * 4, (uint32_t)nrow * 16u);
+      const int pr = le >> 3, pc = le & 7;
+#pragma unroll
+      for (int pz = 0; pz < 4; ++pz) {
+        const int row = pz * 8 + pr;
+        const uint32_t sw = (uint32_t)eswz(pc, row) * 16u;
+        const bool in = row < nrow;
+        lds_dma16(st + pz * 1024, qrs, in ? (uint32_t)row * qstb + sw : 0x80000000u);
+        lds_dma16(st + FB_SLAB + pz * 1024, drs, in ? (uint32_t)row * ostb + sw : 0x80000000u);
+        lds_dma16(st + 2 * FB_SLAB + pz * 1024, ors, in ? (uint32_t)row * ostb + sw : 0x80000000u);
+      }
+      lds_dma16(st + 3 * FB_SLAB, srs, le < nrow ? (uint32_t)le * 16u : 0x80000000u);
+    };
+    constexpr int PIECES = 13;
+    auto issue_kimg = [&](const FbItem& it, int j) {                  // K image of item j, all pieces by the calling wave
+      const uint32_t kstb = (uint32_t)a.kst * 2u;
+      estage_dma<1>(Kimg0 + (j & 1) * R * EROW, a.k + h * 128 + (int64_t)it.k0 * kstb, kstb, ((it.Lk + 31) >> 5) << 5, it.Lk, 0, lane);
+    };
+    // ---- δ and the row constants of a stage that has landed: 32 queries, 2 lanes per query
+    auto cstage = [&](const FbItem& it, int s, int slot) {
+      const char* st = ring + slot * FB_STAGE;
+      const int ql = lane >> 1, qh2 = lane & 1;
+      float part = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int off = ql * EROW + eswz(4 * qh2 + c, ql) * 16;
+        const bf16x8 dv = *reinterpret_cast<const bf16x8*>(st + FB_SLAB + off), ov = *reinterpret_cast<const bf16x8*>(st + 2 * FB_SLAB + off);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part += (float)dv[e] * (float)ov[e];
+      }
+      part += __shfl_xor(part, 1, 64);
+      const f32x4 raw = *reinterpret_cast<const f32x4*>(st + 3 * FB_SLAB + ql * 16);
+      if (qh2 == 0) {
+        lse_l[slot * 32 + ql] = raw[1] > 0.f ? raw[0] * LOG2E - __builtin_amdgcn_logf(raw[1] * dscale) : INFINITY;
+        ndel_l[slot * 32 + ql] = -part * inv_dscale;
+        if (32 * s + ql < it.Lq) a.stats[(((int64_t)it.b * a.H + h) * a.Lq + 32 * s + ql) * 4 + 2] = part;   // (the contract of lako_attn_bwd_t.lse)
+      }
+    };
+    // ---- P2: dQᵀ[64 d × 16 queries] of q-tile qt of stage (item, slab s) whose dS slab is dS[par]
+    auto p2 = [&](const FbItem& it, int j, int s, int par, int qt) {
+      int le = lane;
+      asm volatile("" : "+v"(le));
+      const int trr = 4 * (le >> 4) + ((le & 15) >> 2), trp = le & 3;
+      const char* ap = Kimg0 + (j & 1) * R * EROW + (trr * EROW + (((trr >> 1) & 3) << 5) + trp * 8);     // d-block db: ^ (db << 5)
+      const char* bp = dST0 + par * R * 64 + fb_ds_off(trr, qt, trp);
+      const int nkp = (it.Lk + 31) >> 5;
+      f32x4 acc[4];
+#pragma unroll
+      for (int db = 0; db < 4; ++db) acc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+      auto trd = [](const char* p) { return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p))); };
+      for (int kk = 0; kk < nkp; ++kk, ap += 32 * EROW, bp += 32 * 64) {
+        const u32x2 b0 = trd(bp), b1 = trd(bp + 16 * 64);
+        u32x2 a0[4], a1[4];
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          const char* q = reinterpret_cast<const char*>(reinterpret_cast<uintptr_t>(ap) ^ (uintptr_t)(db << 5));
+          a0[db] = trd(q);
+          a1[db] = trd(q + 16 * EROW);
+        }
+        const u32x4 bf = {b0[0], b0[1], b1[0], b1[1]};
+#pragma unroll
+        for (int db = 0; db < 4; ++db) acc[db] = emma(u32x4{a0[db][0], a0[db][1], a1[db][0], a1[db][1]}, bf, acc[db]);
+      }
+      const int qi = 32 * s + 16 * qt + (le & 15);
+      if (qi < it.Lq) {
+        bf16_t* op = reinterpret_cast<bf16_t*>(a.dq + h * 128 + (int64_t)(it.q0 + qi) * ((int64_t)a.qst * 2)) + 4 * (le >> 4);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) store4(op + db * 16, acc[db]);
+      }
+    };
+    auto bar = [&]() {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    };
+      // prologue: item 0's K image, the first NST − 1 stages; δ of stage 0
+      {
+        const FbItem it0 = item(0);
+        if (wave == 15) issue_kimg(it0, 0);
+        if (wave == 14) {
+          FbCur c = cur_at(0);
+#pragma unroll
+          for (int k = 0; k < NST - 1; ++k) {
+            if (c.j < nit) issue_stage(c.it, c.s, k);
+            advance(c);
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (wave == 15) cstage(it0, 0, 0);
+      }
+      // the stage stream: iteration n = P1 of stage n (the other waves), P2 of stage n − 1, δ of stage n + 1, DMA of stage n + NST − 1
+      FbCur ca = cur_at(0), c2 = cur_at(0);                           // ca: the DMA cursor (wave 14) / the δ cursor (wave 15)
+      int cj1 = 0, cs1 = 0, cn1 = ca.ns;                              // P1's cursor: only (item, slab, slabs) are needed here
+      if (wave == 14) {
+#pragma unroll
+        for (int k = 0; k < NST - 1; ++k) advance(ca);
+      } else {
+        advance(ca);
+      }
+      bool issued = false;
+      for (int n = 0; n <= nstage; ++n) {
+        if (wave == 14) {
+          // the pieces issued in the previous iteration (the wave's newest operations) may stay in flight with a ring of 4
+          if (NST >= 4 && issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (n < nstage && cs1 == 0) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // a new item: its K image (issued during the previous item) has landed
+        }
+        bar();
+        const int slot = n % NST;
+        if (wave == 15 && ca.j < nit && !ATTN_DBG(a, 16384)) cstage(ca.it, ca.s, (slot + 1) % NST);
+        if (n > 0) {
+          if (!ATTN_DBG(a, 2048)) p2(c2.it, c2.j, c2.s, (n - 1) & 1, wave - 14);
+          advance(c2);
+        }
+        if (wave == 14) {                                             // (after P2's stores: the newest PIECES operations of the wave are exactly this stage's)
+          issued = ca.j < nit;
+          if (issued && !ATTN_DBG(a, 8192)) issue_stage(ca.it, ca.s, (slot + NST - 1) % NST);
+        }
+        advance(ca);
+        if (n < nstage) {
+          // the next item's K image: its buffer's last reader was P2 of item j − 1, one iteration ago
+          if (wave == 15 && cs1 == 1 && cj1 + 1 < nit) issue_kimg(item(cj1 + 1), cj1 + 1);
+          if (++cs1 >= cn1) {
+            cs1 = 0;
+            ++cj1;
+            if (cj1 < nit) cn1 = max(2, ((item(cj1).Lq) + 31) >> 5);
+          }
+        }
+      }
+    }
+    if (want_drel) {                                                 // (the barriers of the other waves' bias-gradient flush)
+      __syncthreads();
+      __syncthreads();
+      __syncthreads();
+    }
+    return;
+  }
+  // ================= waves 0 – 13: P1 =================
+  // bias-gradient accumulators: lane (key j = l15, group g) sums the elements with key − query = 16·(w − qt) + j − 4g of q-tile qt in
+  // acc_lo[qt]; the elements that wrap around the 16-lane row (key − query = 16·(w − qt) + j − 16 − 4g, lanes 13..15) of the four
+  // q-tiles 4u … 4u + 3 share acc_hi[u], q-tile 4u + k's three lanes moved down by 3k lanes (as in enc_bwd_dq_p_kernel)
+  float acc_lo[16], acc_hi[4];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) acc_lo[t] = 0.f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc_hi[t] = 0.f;
+  u32x4 vf[2] = {};
+  f32x4 dkacc[4], dvacc[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) dkacc[db] = dvacc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int t0 = 0; t0 < nmine; t0 += FB_TBL) {
+    // ---- item table of this pass: (sequence, q row offset, k row offset, Lq | Lk << 16) of the non-empty items, in walk order
+    __syncthreads();                                                // the previous pass is done with the table, the images and the slabs
+    if (wave == 0) {
+      const int t = t0 + lane;
+      int b = 0, q0 = 0, k0 = 0, Lq = 0, Lk = 0;
+      if (t < nmine) {
+        const int bi = slot0 + t * nslots;
+        b = a.order ? a.order[bi] : bi;
+        q0 = a.q_off ? a.q_off[b] : b * a.rq;
+        k0 = a.k_off ? a.k_off[b] : b * a.rk;
+        Lq = a.q_off ? a.q_off[b + 1] - q0 : a.Lq;
+        Lk = a.k_off ? a.k_off[b + 1] - k0 : a.Lk;
+      }
+      const bool ok = Lq > 0 && Lk > 0;
+      const uint64_t m = __ballot(ok);
+      const int pos = __popcll(m & ((1ull << lane) - 1ull));
+      if (ok) {
+        int* e = tbl + pos * 4;
+        e[0] = b; e[1] = q0; e[2] = k0; e[3] = Lq | (Lk << 16);
+      }
+      int ns = ok ? max(2, (Lq + 31) >> 5) : 0;                      // slab iterations of the item (≥ 2: the K image double buffer)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) ns += __shfl_xor(ns, o, 64);
+      if (lane == 0) {
+        tbl[FB_TBL * 4] = (int)__popcll(m);
+        tbl[FB_TBL * 4 + 1] = ns;
+      }
+    }
+    __syncthreads();
+    const int nit = __builtin_amdgcn_readfirstlane(tbl[FB_TBL * 4]);
+    const int nstage = __builtin_amdgcn_readfirstlane(tbl[FB_TBL * 4 + 1]);
+    if (nit == 0) continue;
+    auto item = [&](int j) {
+      const u32x4 e = *reinterpret_cast<const u32x4*>(tbl + j * 4);
+      FbItem it;
+      it.b = __builtin_amdgcn_readfirstlane((int)e[0]);
+      it.q0 = __builtin_amdgcn_readfirstlane((int)e[1]);
+      it.k0 = __builtin_amdgcn_readfirstlane((int)e[2]);
+      const int w3 = __builtin_amdgcn_readfirstlane((int)e[3]);
+      it.Lq = w3 & 0xFFFF;
+      it.Lk = w3 >> 16;
+      return it;
+    };
+    auto cur_at = [&](int j) {                                        // cursor at the first stage of item j (j == nit: past the end)
+      FbCur c;
+      c.j = j; c.s = 0;
+      c.it = item(j < nit ? j : 0);
+      c.ns = max(2, (c.it.Lq + 31) >> 5);
+      return c;
+    };
+    auto advance = [&](FbCur& c) {
+      if (c.j >= nit) return;
+      if (++c.s >= c.ns) {
+        c.s = 0;
+        ++c.j;
+        if (c.j < nit) {
+          c.it = item(c.j);
+          c.ns = max(2, (c.it.Lq + 31) >> 5);
+        }
+      }
+    };
+    auto load_v = [&](const FbItem& it) {                             // this wave's V rows of an item → vf
+      const uint32_t vstb = (uint32_t)a.vst * 2u;
+      eload_frags_buf(vf, a.v + h * 128 + (int64_t)it.k0 * vstb, vstb, wave * 16, it.Lk, (uint32_t)(lane & 15) * vstb + (uint32_t)(lane >> 4) * 16u);
+    };
+    // ---- P1: the wave's key tile against slab s of the item (ring slot `slot`), dS → dS[par]
+    auto p1 = [&](const FbCur& c, int slot, int par) {
+      const FbItem& it = c.it;
+      const int j = c.j, s = c.s;
+      int le = lane;
+      asm volatile("" : "+v"(le));                                    // every lane constant below is rebuilt per call: nothing lane-derived stays live across the slabs
+      const int g = le >> 4, l15 = le & 15, ki = wave * 16 + l15;
+      const int nkt2 = ((it.Lk + 31) >> 5) << 1;                      // key tiles, rounded up to whole pairs (P2 contracts over pairs)
+      const bool lastslab = s == c.ns - 1;
+      char* dS = dST0 + par * R * 64;
+      const uint32_t dsw0 = fb_ds_off(ki, 0, g);                      // (q-tile 1: ^ 32)
+      if (wave * 16 >= it.Lk) {                                       // no key tile for this wave in this item
+        if (wave < nkt2) {                                            // … but the odd tile of the last pair: its dS rows are zeros
+          *reinterpret_cast<u32x2*>(dS + dsw0) = u32x2{0u, 0u};
+          *reinterpret_cast<u32x2*>(dS + (dsw0 ^ 32u)) = u32x2{0u, 0u};
+        }
+        if (lastslab && j + 1 < nit) load_v(item(j + 1));
+        return;
+      }
+      const char* Qs = ring + slot * FB_STAGE;
+      const char* dOs = Qs + FB_SLAB;
+      if (ATTN_DBG(a, 4096)) return;                                  // (timing experiment: no P1 arithmetic)
+      if (s == 0) {
+#pragma unroll
+        for (int db = 0; db < 4; ++db) dkacc[db] = dvacc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      // row-fragment offset of fragment step 0 (step 1: ^ 64) — lds_image.h::elane
+      const uint32_t roff0 = (uint32_t)(l15 * EROW + eswz(g, l15) * 16);
+      const uint32_t roff[2] = {roff0, roff0 ^ 64u};
+      const char* Kimg = Kimg0 + (j & 1) * R * EROW + wave * 16 * EROW;
+      const bool tailk = (wave + 1) * 16 > it.Lk;                     // (wave-uniform) the tile holds keys past the sequence's end
+      const int last = a.R - 1 + EB_PADLO + 36;
+      const int j0 = last - (ki - 4 * g + a.rel_off + EB_PADLO);
+      const float* bptr = b4 + (j0 & 3) * EB_ST + (j0 & ~3) + 32 * s;
+      const uint32_t cblk = (uint32_t)((it.b * a.H + h) * QB + g + 8 * s) * (uint32_t)KB + (uint32_t)(ki >> 2);
+      const uint32_t kb4 = 4u * (uint32_t)KB;
+      const uint32_t t_hi = a.drop_t16 << 16;
+      u32x2 ptb[2], dsb[2];                                            // P̃ and dS of the two tiles, rounded to bf16 as the MFMA operands are
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        f32x4 sv, dp;
+        {
+          const u32x4 kf[2] = {*reinterpret_cast<const u32x4*>(Kimg + roff[0]), *reinterpret_cast<const u32x4*>(Kimg + roff[1])};
+          f32x4 init = *reinterpret_cast<const f32x4*>(bptr + 16 * u);
+          if (tailk) {
+            const float kadd_lane = ki < it.Lk ? 0.f : -INFINITY;
+            init += f32x4{kadd_lane, kadd_lane, kadd_lane, kadd_lane};
+          }
+          const f32x4 nd = *reinterpret_cast<const f32x4*>(ndel_l + slot * 32 + 16 * u + 4 * g);
+          sv = escore(Qs, 16 * u, kf, roff, init);
+          dp = escore(dOs, 16 * u, vf, roff, nd);
+        }
+        if (u == 1 && lastslab && j + 1 < nit) {     // the V rows are dead: the next item's arrive under the rest of this slab's work
+          __builtin_amdgcn_sched_barrier(0);
+          load_v(item(j + 1));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        const f32x4 l2 = *reinterpret_cast<const f32x4*>(lse_l + slot * 32 + 16 * u + 4 * g);
+        f32x4 p, pt;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[r], LOG2E, -l2[r]));
+        pt = p;
+        if (DROP && !ATTN_DBG(a, 1024)) {
+          bool kp[4];
+          const DropCol dcc = drop_col_consts(ki);
+          drop_keep_col(drop_base(cblk + (uint32_t)u * kb4, a.drop_key), dcc, t_hi, kp);
+          const f32x4 nd = *reinterpret_cast<const f32x4*>(ndel_l + slot * 32 + 16 * u + 4 * g);     // (re-read: 4 registers less across the hashes)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            pt[r] = kp[r] ? p[r] : 0.f;
+            dp[r] = kp[r] ? dp[r] : nd[r];
+          }
+        }
+        f32x4 ds;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ds[r] = p[r] * dp[r];
+        // dS slab: the 4 queries of this lane's key, rounded as the MFMA operand of the dK product is
+        const bf16x4 dsv = {(bf16_t)ds[0], (bf16_t)ds[1], (bf16_t)ds[2], (bf16_t)ds[3]};
+        const bf16x4 ptv = {(bf16_t)pt[0], (bf16_t)pt[1], (bf16_t)pt[2], (bf16_t)pt[3]};
+        dsb[u] = __builtin_bit_cast(u32x2, dsv);
+        ptb[u] = __builtin_bit_cast(u32x2, ptv);
+        *reinterpret_cast<u32x2*>(dS + (u ? dsw0 ^ 32u : dsw0)) = dsb[u];
+        if (want_drel && !ATTN_DBG(a, 32768)) {
+          // lane j' collects, by DPP row shifts, the elements (key j' + r, query 4g + r) of the tile: key − query = 16·(w − qt) + j' − 4g
+          const float lo = ds[0] + edpp<0x101>(ds[1]) + edpp<0x102>(ds[2]) + edpp<0x103>(ds[3]);
+          const float hs = edpp<0x11F>(ds[1]) + edpp<0x11E>(ds[2]) + edpp<0x11D>(ds[3]);      // lanes 13..15, 0 elsewhere
+          static_for<8>([&](auto S) {
+            constexpr int sc = decltype(S)::value;
+            if (s == sc) {
+              acc_lo[2 * sc + u] += lo;
+              // q-tile 4v + k of a group of four: moved down by 3k lanes
+              constexpr int k3 = (2 * sc) & 3;
+              if (u == 0) acc_hi[sc >> 1] += k3 ? edpp<0x106>(hs) : hs;
+              else acc_hi[sc >> 1] += k3 ? edpp<0x109>(hs) : edpp<0x103>(hs);
+            }
+          });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      {
+        // transposed-read offsets (lds_image.h::elane), built here — not kept across the hashes: d-block db is ^ (db << 5)
+        const int tr = 4 * g + (l15 >> 2);
+        const uint32_t toff0 = (uint32_t)(tr * EROW + (((tr >> 1) & 3) << 5) + (l15 & 3) * 8);
+        const uint32_t toff[4] = {toff0, toff0 ^ 32u, toff0 ^ 64u, toff0 ^ 96u};
+        if (!ATTN_DBG(a, 65536)) {
+        epv_packed(dkacc, dsb[0], dsb[1], Qs, 0, toff);            // dKᵀ += Qᵀ·dS
+        epv_packed(dvacc, ptb[0], ptb[1], dOs, 0, toff);           // dVᵀ += dOᵀ·P̃
+        }
+      }
+      if (lastslab && ki < it.Lk) {
+        bf16_t* kp_ = reinterpret_cast<bf16_t*>(a.dk + h * 128 + (int64_t)(it.k0 + ki) * ((int64_t)a.kst * 2));
+        bf16_t* vp_ = reinterpret_cast<bf16_t*>(a.dv + h * 128 + (int64_t)(it.k0 + ki) * ((int64_t)a.vst * 2));
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          store4(kp_ + db * 16 + 4 * g, dkacc[db]);
+          store4(vp_ + db * 16 + 4 * g, dvacc[db]);
+        }
+      }
+    };
+    auto bar = [&]() {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    };
+    // prologue: item 0's V rows
+    load_v(item(0));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    FbCur c1 = cur_at(0);
+    for (int n = 0; n <= nstage; ++n) {
+      bar();
+      if (n < nstage) {
+        p1(c1, n % NST, n & 1);
+        advance(c1);
+      }
+    }
+  }
+  if (want_drel) {
+    const int g = lane >> 4, l15 = lane & 15;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 512; i += FB_NW * 64) drel_l[i] = 0.f;
+    __syncthreads();
+    // acc_lo[qt], lane (j = l15, g): key − query = 16·(w − qt) + j − 4g; the wrapped elements of q-tile 4u + k sit in acc_hi[u] at lane
+    // j'' − 3k (j'' = 13..15) and belong to key − query = 16·(w − qt) + j'' − 16 − 4g
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int d0 = 16 * (wave - t) + l15 - 4 * g + a.rel_off;
+      if (acc_lo[t] != 0.f && d0 >= 0 && d0 < a.R) atomicAdd(&drel_l[d0], acc_lo[t]);
+    }
+    if (l15 >= 4) {
+      const int k = (15 - l15) / 3, jj = l15 + 3 * k;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int d1 = 16 * (wave - (4 * u + k)) + jj - 16 - 4 * g + a.rel_off;
+        if (acc_hi[u] != 0.f && d1 >= 0 && d1 < a.R) atomicAdd(&drel_l[d1], acc_hi[u]);
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.R; i += FB_NW * 64) {
+      const float v = drel_l[i];
+      if (v != 0.f) atomicAdd(a.drel + (int64_t)h * a.R + i, v);
+    }
+  }
+}
+
 template <typename K>
 void eset_lds(K kern, int bytes, lako_lds_cur_t& cur) {
   lako_raise_max_lds(reinterpret_cast<const void*>(kern), bytes, cur);
@@ -1178,7 +1692,7 @@ static void enorm_nobias(AttnArgs& a) {
 // in the dQ pass, whose per-item kernel re-stages K / V three times per workgroup and keeps 4 query blocks per wave.
 static bool epersist(int bit, const AttnArgs& a) {
   const char* pe = getenv("LAKO_ATTN_PERSIST");      // read per call: a test switches it
-  const int m = pe ? atoi(pe) : 2;
+  const int m = pe ? atoi(pe) : 18;
   return (m & bit) && a.H <= 256 && ((int64_t)a.Bn * a.H >= 1024 || (m & 8));
 }
 
@@ -1217,6 +1731,43 @@ int lako_attn_enc_bwd(AttnArgs& a, hipStream_t s) {
   if (dbg & 256) goto dkv_pass;      // time the passes separately
 #endif
   enorm_nobias(a);
+  // one-pass backward (round 5, the default where its LDS layout fits): bit 16 of LAKO_ATTN_PERSIST (default 18 = persistent dQ pass as the
+  // fallback + the fused kernel); a ring of 4 stages where 160 KiB hold it (<= 256 key rows do), else 3
+  {
+    const char* pe = getenv("LAKO_ATTN_PERSIST");      // read per call: a test switches it
+    const int m = pe ? atoi(pe) : 18;
+    const int rows = ((a.Lk + 31) / 32) * 32;
+    const bool fits32 = (int64_t)a.kst * 2 * 256 < (1ll << 31) && (int64_t)a.vst * 2 * 256 < (1ll << 31) && (int64_t)a.qst * 2 * 256 < (1ll << 31) &&
+                        (int64_t)a.ost * 2 * 256 < (1ll << 31);
+    // one addressing form for ragged and padded launches (row offset × token stride): the batch strides must be whole rows, the same number
+    // on every tensor of a side; dq / dk / dv share the strides of q / k / v by contract
+    const bool ragged = a.q_off && a.k_off;
+    const bool padded = !a.q_off && !a.k_off && a.qst > 0 && a.ost > 0 && a.kst > 0 && a.vst > 0 && a.qsb % a.qst == 0 && a.osb % a.ost == 0 &&
+                        a.qsb / a.qst == a.osb / a.ost && a.ksb % a.kst == 0 && a.vsb % a.vst == 0 && a.ksb / a.kst == a.vsb / a.vst &&
+                        a.qsb / a.qst * a.Bn < (1ll << 31) && a.ksb / a.kst * a.Bn < (1ll << 31);
+    if ((m & 16) && a.H <= 256 && fits32 && (ragged || padded) && rows <= 224 && a.Lq <= 256 && efb_lds(rows, 3) <= 160 * 1024) {
+      AttnArgs f = a;
+      f.chunk_rows = rows;
+      f.rq = padded ? (int)(a.qsb / a.qst) : 0;
+      f.rk = padded ? (int)(a.ksb / a.kst) : 0;
+      const int nslots = std::min(a.Bn, std::max(1, 256 / a.H));
+      const bool drop = a.drop_t16 != 0;
+      static const int nst_env = getenv("LAKO_ATTN_FUSED_NST") ? atoi(getenv("LAKO_ATTN_FUSED_NST")) : 4;
+      const int nst = (nst_env >= 4 && efb_lds(rows, 4) <= 160 * 1024) ? 4 : 3;
+      const int lds = efb_lds(rows, nst);
+      const dim3 grid(a.H * nslots);
+#define EFB(D, N)                                                                                          \
+  do {                                                                                                     \
+    static lako_lds_cur_t c;                                                                               \
+    eset_lds(&enc_bwd_fused_kernel<D, N>, lds, c);                                                         \
+    hipLaunchKernelGGL((enc_bwd_fused_kernel<D, N>), grid, dim3(FB_NW * 64), lds, s, f);                   \
+  } while (0)
+      if (nst == 4) { if (drop) EFB(true, 4); else EFB(false, 4); }
+      else { if (drop) EFB(true, 3); else EFB(false, 3); }
+#undef EFB
+      return 0;
+    }
+  }
   {  // dQ pass: every query block of a sequence in one workgroup, several batch rows per workgroup (bias gradient in registers)
     AttnArgs q = a;
     q.chunk_rows = ((a.Lk + 31) / 32) * 32;

@@ -2075,6 +2075,20 @@ template <typename T, typename TO>
 int launch_nt(const NtArgs& a_in, const lako_tuning_t& tu, hipStream_t s) {
   NtArgs a = a_in;
   int v = tu.nt_variant;
+  if (a.flags & LAKO_EPI_NORM_A) {
+    // the norm is formed by the M <= 256 kernel only: decide BEFORE any planning or launch (round 5, ADVICE: with a tail plan the head
+    // rows used to be launched un-normalised before the flag was refused) — the conditions of the skinny branch below, restated
+    bool ok = false;
+    if constexpr (sizeof(T) == 2) {
+      ok = a.K % 32 == 0 && a.K >= 128 && a.K <= 1024 && a.N % 8 == 0 && (int64_t)a.M * a.lda * 2 < (1ll << 31) && (int64_t)a.N * a.ldb * 2 < (1ll << 31) &&
+           a.lda % 8 == 0 && a.ldb % 8 == 0 && a.ldc % 8 == 0 && !(a.flags & LAKO_EPI_ATOMIC) &&
+           (!(a.flags & LAKO_EPI_RESID) || (a.ldr % 8 == 0 && reinterpret_cast<uintptr_t>(a.resid) % 16 == 0)) &&
+           (!(a.flags & LAKO_EPI_AUXMASK) || (a.ldaux % 8 == 0 && reinterpret_cast<uintptr_t>(a.aux) % 16 == 0)) &&
+           reinterpret_cast<uintptr_t>(a.A) % 16 == 0 && reinterpret_cast<uintptr_t>(a.B) % 16 == 0 && reinterpret_cast<uintptr_t>(a.C) % 16 == 0 &&
+           (v == 5 || (v < 0 && tu.nt_skinny && a.M <= 256 && a.N <= 4096));
+    }
+    if (!ok) return LAKO_E_BADARG;
+  }
   if (v < 0) {
     // big tiles once there is enough work to fill the chip with them (>= 1 tile per CU), else 128x128
     const int tn = cdiv(a.N, 256);

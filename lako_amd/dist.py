@@ -16,8 +16,9 @@ reports finished ranges through `Engine.grad_hook`.  Two modes:
                         counters (`gemm_nt_queue`), so the CUs the RCCL kernels hold cost a share of the tiles, not a whole
                         extra pass.  Correct (2-rank gloo test, world-1 RCCL test) — to be measured on 8 GPUs (tools/scale.sh).
 
-Which of the two transports is the default depends on the world size and the gradient bytes — `choose_dp` below, a stated cost table
-(bf16 at N = 2 and 4 for T5-base, fp32 at N = 8); `LAKO_DP_MODE`, `LAKO_DP_GRAD_DTYPE` and the constructor arguments override it.
+The default transport is fp32 in place, as the reference's DDP (round 5; round 4 let an unmeasured cost table pick bf16 at N = 2 / 4).
+`LAKO_DP_GRAD_DTYPE=auto` opts into that table (`estimate_dp_transport`), `=bf16` forces bf16; `LAKO_DP_MODE` and the constructor
+arguments override the mode.
 
 `LAKO_DP_GRAD_DTYPE=bf16` (or `grad_dtype=torch.bfloat16`): the gradients travel as bf16 — half the bytes over the xGMI links (446 MB
 instead of 892 MB at T5-base; it is the 2- and 4-GPU runs, with one link per peer, that pay most for the collective) — through a
@@ -60,12 +61,18 @@ def dp_cost_table(n_grad: int, world: int) -> dict:
 
 
 def choose_dp(n_grad: int, world: int) -> tuple:
-    """(mode, gradient transport) GradSync uses when neither the caller nor LAKO_DP_MODE / LAKO_DP_GRAD_DTYPE say otherwise.
-    Mode: "deferred" — the one mode that cannot slow the step's kernels down (the persistent GEMMs hold every CU; "overlap" stays an
-    opt-in until it has been measured on a node).  Transport: bf16 where the table says it saves ≥ BF16_MIN_GAIN_MS — at T5-base
-    (892 MB of fp32 gradients) that is N = 2 (13.9 → 7.5 ms) and N = 4 (7.0 → 4.0 ms), not N = 8 (3.5 → 2.3 ms)."""
+    """(mode, gradient transport) GradSync uses when neither the caller nor LAKO_DP_MODE / LAKO_DP_GRAD_DTYPE say otherwise: ALWAYS
+    ("deferred", "fp32") — the reference's DDP all-reduces fp32 gradients (`src/util.py:248-275`), and the default multi-GPU numerics
+    must not depend on an unmeasured cost table (round 5, ADVICE).  Mode "deferred" is the one mode that cannot slow the step's kernels
+    down (the persistent GEMMs hold every CU; "overlap" stays an opt-in until it has been measured on a node)."""
+    return "deferred", "fp32"
+
+
+def estimate_dp_transport(n_grad: int, world: int) -> str:
+    """What the cost table WOULD pick (`LAKO_DP_GRAD_DTYPE=auto` opts into it; reported on every bench line as an estimate): bf16 where
+    it saves ≥ BF16_MIN_GAIN_MS — at T5-base (892 MB of fp32 gradients) N = 2 (13.9 → 7.5 ms) and N = 4 (7.0 → 4.0 ms), not N = 8."""
     t = dp_cost_table(n_grad, world)
-    return "deferred", ("bf16" if t["fp32"] - t["bf16"] >= BF16_MIN_GAIN_MS else "fp32")
+    return "bf16" if t["fp32"] - t["bf16"] >= BF16_MIN_GAIN_MS else "fp32"
 
 
 class GradSync:
@@ -88,6 +95,8 @@ class GradSync:
         self._dirty = False
         if grad_dtype is None:      # the caller did not say: the environment, else the cost table
             name = os.environ.get("LAKO_DP_GRAD_DTYPE") or auto_dtype
+            if name == "auto":      # explicit opt-in to the (unmeasured) cost table
+                name = estimate_dp_transport(eng.G.numel(), self.world_size)
             if name not in ("bf16", "fp32", "f32"):
                 raise ValueError(f"unknown LAKO_DP_GRAD_DTYPE {name!r}")
             grad_dtype = torch.bfloat16 if name == "bf16" else torch.float32

@@ -301,6 +301,37 @@ def test_gemm_nt_norm_fused(ops, ref, M, N, K):
         close(C1, C0.float(), T, f"gemm_nt norm-fused vs two launches {list(kw)} {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("knobs", [dict(gemm_nt_queue=1), dict(gemm_nt_tile288=0), dict()], ids=["queue", "no288", "default"])
+def test_gemm_nt_norm_refused_before_any_launch(ops, knobs):
+    """(round 5, ADVICE) LAKO_EPI_NORM_A on a shape only the big-tile kernels take — M = 5 600 rows x N = 3 072: 22 x 12 = 264 tiles of 256²,
+    i.e. a tail plan with the 256-row tiles (tile queue on, or 288-row tiles off) — must be refused with LAKO_E_UNSUPPORTED before ANYTHING is
+    launched: round 4 ran the head rows of the tail plan on the un-normalised A before refusing the flag.  C, the normalised rows and
+    rstd stay untouched; the Python op then runs the two launches."""
+    T = torch.bfloat16
+    M, N, K = 5600, 3072, 768
+    A, B = rnd(M, K, dtype=T, seed=75) * 3.0, rnd(N, K, dtype=T, seed=76)
+    w = (1.0 + 0.2 * rnd(K, seed=77)).contiguous()
+    try:
+        for k_, v_ in knobs.items():
+            ops.set_tuning(k_, v_)
+        C1 = torch.full((M, N), 7.0, dtype=T, device=dev())
+        xn1, rs1 = torch.full((M, K), 7.0, dtype=T, device=dev()), torch.full((M,), 7.0, device=dev())
+        rc = ops._gemm_nt_call(A, B, C1, 1.0, False, None, None, 1.0, None, False, (w, 1e-6, xn1, rs1))
+        torch.cuda.synchronize()
+        assert rc == -4, rc                                     # LAKO_E_UNSUPPORTED
+        assert bool((C1 == 7.0).all()) and bool((xn1 == 7.0).all()) and bool((rs1 == 7.0).all()), "a refused call must not launch anything"
+        # the op's fallback: norm, then the plain product — equal to doing the two by hand
+        ops.gemm_nt(A, B, C1, norm=(w, 1e-6, xn1, rs1))
+        xn0, rs0 = torch.empty_like(xn1), torch.empty_like(rs1)
+        ops.rmsnorm_fwd(A, w, xn0, rs0, 1e-6)
+        C0 = torch.empty_like(C1)
+        ops.gemm_nt(xn0, B, C0)
+        assert torch.equal(C1, C0) and torch.equal(xn1, xn0) and torch.equal(rs1, rs0)
+    finally:
+        ops.set_tuning("gemm_nt_queue", 0)
+        ops.set_tuning("gemm_nt_tile288", 1)
+
+
 def test_gemm_nt_tile_height_plan(ops, ref):
     """(`gemm_nt_tile288`, round 4, on by default: 288-row tiles where they save the tail launch or a round — two rounds of 498 tiles here.)
     With `gemm_nt_tile192` on, launch_nt prices 256-row and 192-row tiles per call: 47 757 rows x 768 columns — the benchmark's
@@ -630,13 +661,19 @@ def make_attn(case, T):
     return q, k, v, rel, rel_off, km, causal, drop
 
 
-@pytest.mark.parametrize("dt", ["f32", "bf16", "bf16_persistent"])
+@pytest.mark.parametrize("dt", ["f32", "bf16", "bf16_persistent", "bf16_fused", "bf16_fused_ring3"])
 @pytest.mark.parametrize("case", ATTN_CASES, ids=[c[0] for c in ATTN_CASES])
 def test_attention(ops, ref, dt, case, monkeypatch):
     if dt == "bf16_persistent":      # the encoder fast path's persistent kernels (backward here; forward: test_attention_fast_path_forward)
         if not case[0].startswith("enc_fast"):
             pytest.skip("persistent kernels serve the encoder fast path only")
         monkeypatch.setenv("LAKO_ATTN_PERSIST", "15")
+        dt = "bf16"
+    elif dt.startswith("bf16_fused"):  # round 5: the one-pass backward (enc_bwd_fused_kernel), ring of 4 (default) and of 3 stages
+        if not case[0].startswith("enc_fast"):
+            pytest.skip("the one-pass backward serves the encoder fast path only")
+        monkeypatch.setenv("LAKO_ATTN_PERSIST", "16")
+        monkeypatch.setenv("LAKO_ATTN_FUSED_NST", "3" if dt.endswith("ring3") else "4")
         dt = "bf16"
     else:
         monkeypatch.setenv("LAKO_ATTN_PERSIST", "0")
@@ -738,7 +775,7 @@ def test_attention_persistent_kernels_equal_per_item_kernels(ops, drop, monkeypa
     # dQ to the dK/dV pass through the statistics) and the bias gradient to fp32 summation order
     dout = rnd(1, rows, H, dk, dtype=T, seed=53)
     outs = []
-    for persist in ("0", "15"):
+    for persist in ("0", "15", "16"):       # per-item kernels, persistent two-pass kernels, the one-pass kernel (round 5)
         monkeypatch.setenv("LAKO_ATTN_PERSIST", persist)
         st = res[0][1].clone()
         dqkv = torch.zeros(1, rows, 3 * inner, dtype=T, device=dev())
@@ -750,17 +787,18 @@ def test_attention_persistent_kernels_equal_per_item_kernels(ops, drop, monkeypa
         outs.append((dqkv, st, drel))
     # (measured: 121 of 7 000 dq rows differ by ONE bf16 ulp — the compiler contracts p·dP′ into different fused multiply-adds in the
     #  two kernels; the forward above is bit-identical)
-    for i, nm in enumerate(("dq", "dk", "dv")):
-        a0, a1 = (o[0][0, :, i * inner:(i + 1) * inner].float() for o in outs)
-        assert float((a0 - a1).abs().max()) <= 2.0 ** -7 * max(1.0, float(a0.abs().max())), (nm, float((a0 - a1).abs().max()))
-        assert float((a0 != a1).float().mean()) < 0.01, nm
-    assert torch.allclose(outs[0][1][..., :3], outs[1][1][..., :3], rtol=1e-5, atol=1e-6)
-    close(outs[1][2], outs[0][2], torch.float32, "persistent drel", k=5)
-    assert float(outs[1][0].float().abs().max()) > 0 and float(outs[1][2].abs().max()) > 0
+    for other in outs[1:]:
+        for i, nm in enumerate(("dq", "dk", "dv")):
+            a0, a1 = (o[0][0, :, i * inner:(i + 1) * inner].float() for o in (outs[0], other))
+            assert float((a0 - a1).abs().max()) <= 2.0 ** -7 * max(1.0, float(a0.abs().max())), (nm, float((a0 - a1).abs().max()))
+            assert float((a0 != a1).float().mean()) < 0.01, nm
+        assert torch.allclose(outs[0][1][..., :3], other[1][..., :3], rtol=1e-5, atol=1e-5)     # (δ: 64 products summed in another order)
+        close(other[2], outs[0][2], torch.float32, "persistent drel", k=5)
+        assert float(other[0].float().abs().max()) > 0 and float(other[2].abs().max()) > 0
 
 
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("persist", ["2", "7", "0"])
+@pytest.mark.parametrize("persist", ["18", "2", "7", "0"])
 def test_attention_processing_order_does_not_change_results(ops, persist, monkeypatch):
     """lako_attn_*_t.order (round 4): the order in which the encoder fast path's workgroups take the sequences — longest first for load
     balance — is a pure scheduling choice: forward outputs, statistics, dq / dk / dv are BIT-identical for the natural order, the

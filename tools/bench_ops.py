@@ -18,6 +18,7 @@ ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--dephase", default="0", help="gemm_nt_dephase values (10-ns ticks) to time, e.g. 0,500,1000")
 ap.add_argument("--variants", default="-1", help="gemm_nt tile variants to time, e.g. 0,1,2")
+ap.add_argument("--rows", type=int, default=0, help="encoder token rows of the GEMM shapes (default B*N*L = 64000; 47757 = the bench's valid tokens)")
 ap.add_argument("--vendor", action="store_true", help="also time torch.matmul (hipBLASLt / rocBLAS) on the GEMM shapes: a yardstick, "
                 "never part of the product path")
 args = ap.parse_args()
@@ -28,6 +29,8 @@ dev = torch.device("cuda:0")
 ops = HipOps()
 B, N, L, Tt, d, f, H, dk, V, Ld = 16, 20, 200, 8, 768, 3072, 12, 64, 32128, 12
 inner, Me, Md, S = H * dk, B * N * L, B * Tt, N * L
+if args.rows:
+    Me = args.rows
 
 
 def rnd(*shape, dtype=T, scale=1.0):
@@ -70,6 +73,10 @@ for variant, dephase in ([(int(v), int(dp)) for v in args.variants.split(",") fo
         ("nt o+res [Me,768]x[768,768]", (Me, d, inner), dict(resid=True, drop=drop)),
         ("nt wi    [Me,768]x[3072,768] relu+drop", (Me, f, d), dict(relu=True, drop=drop)),
         ("nt wo    [Me,3072]x[768,3072] res+drop", (Me, d, f), dict(resid=True, drop=drop)),
+        ("nt plain [Me,768]x[768,768]", (Me, d, inner), {}),
+        ("nt plain [Me,768]x[3072,768]", (Me, f, d), {}),
+        ("nt plain [Me,3072]x[768,3072]", (Me, d, f), {}),
+        ("nt plain [Me,2304]x[768,2304] (dX of QKV)", (Me, d, 3 * inner), {}),
         ("nt kvall [Me,768]x[18432,768]", (Me, Ld * 2 * inner, d), {}),
         ("nt dxkv  [Me,18432]x[768,18432]", (Me, d, Ld * 2 * inner), {}),
         ("nt dpre  [Me,768]x[3072,768] auxmask", (Me, f, d), dict(aux=True)),
@@ -102,6 +109,7 @@ if args.vendor:
     print("--- vendor yardstick: torch.matmul, plain bf16 GEMM without any fused epilogue", flush=True)
     for nm, (M, Nn, K) in [("nt [Me,768]x[2304,768]", (Me, 3 * inner, d)), ("nt [Me,768]x[768,768]", (Me, d, inner)),
                            ("nt [Me,768]x[3072,768]", (Me, f, d)), ("nt [Me,3072]x[768,3072]", (Me, d, f)),
+                           ("nt [Me,2304]x[768,2304]", (Me, d, 3 * inner)),
                            ("nt [Me,768]x[18432,768]", (Me, Ld * 2 * inner, d)), ("nt [Me,18432]x[768,18432]", (Me, d, Ld * 2 * inner)),
                            ("nt 4096^3", (4096,) * 3), ("nt 8192^3", (8192,) * 3)]:
         A, Bm = rnd(M, K), rnd(Nn, K)
