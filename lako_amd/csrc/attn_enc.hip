@@ -132,6 +132,31 @@ __device__ __forceinline__ float edpp(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
 
+// The bias-gradient sums of one score tile in six instructions (hipcc emits v_mov_b32_dpp + v_add_f32 pairs for the builtin form: twelve):
+// lo = d0 + shl1(d1) + shl2(d2) + shl3(d3), hs = shr15(d1) + shr14(d2) + shr13(d3) (row shifts inside 16-lane rows, lanes shifted in from
+// outside a row read 0).  The leading s_nop covers the VALU-write → DPP-read hazard for operands written just before the statement (the
+// hazard recogniser does not look inside inline asm).
+__device__ __forceinline__ void edpp_diag_sums(float d0, float d1, float d2, float d3, float& lo, float& hs) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %3, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_mov_b32_dpp %1, %3 row_shr:15 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %0, %4, %0 row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %1, %4, %1 row_shr:14 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %0, %5, %0 row_shl:3 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %1, %5, %1 row_shr:13 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+      : "=&v"(lo), "=&v"(hs)
+      : "v"(d0), "v"(d1), "v"(d2), "v"(d3));
+}
+// acc += x moved down by N lanes inside its 16-lane row (row_shl:N — lane j reads lane j + N; N = 0: a plain add)
+template <int N>
+__device__ __forceinline__ void eacc_shl(float& acc, float x) {
+  if constexpr (N == 0) acc += x;
+  else if constexpr (N == 3) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %0 row_shl:3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(x));
+  else if constexpr (N == 6) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %0 row_shl:6 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(x));
+  else asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %0 row_shl:9 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(x));
+}
+
 // −inf for keys past the sequence's end in tile `t` (rows t·16 + 4g + r), 0 elsewhere
 __device__ __forceinline__ f32x4 etail(int t, int g, int Lk) {
   f32x4 v;
@@ -1167,14 +1192,29 @@ constexpr int FB_NW = 16;
 constexpr int FB_SLAB = 32 * EROW;                      // one 32-row slab image
 constexpr int FB_STAGE = 3 * FB_SLAB + 1024;            // Q | dO | O | raw statistics (32 × 16 B, then 512 B of DMA zero fill)
 constexpr int FB_TBL = 64;                              // items per table pass
-// LDS: 2 K images | 2 dS slabs [rows][32 q] | ring | 4 reversed bias copies | lse2 / −δ/scale per stage | item table + header
+// LDS: 2 K images | 2 dS slabs [rows][32 q] | ring | 4 reversed bias copies | lse2 / −δ/scale per stage | item table + header | lane constants [64][12] |
+// stage table [FB_TBL·8][4]
 __host__ __device__ constexpr int efb_lds(int rows, int nst) {
-  return 2 * rows * EROW + 2 * rows * 64 + nst * FB_STAGE + 4 * EB_ST * 4 + nst * 2 * 32 * 4 + FB_TBL * 16 + 16;
+  return 2 * rows * EROW + 2 * rows * 64 + nst * FB_STAGE + 4 * EB_ST * 4 + nst * 2 * 32 * 4 + FB_TBL * 16 + 16 + 64 * 48 + FB_TBL * 8 * 16;
 }
 
+// (experiments build) cycle stamps of workgroup 0: [wave][iteration < 256][point < 8] s_memtime values in a.scores_out
+#define FB_STAMP(P)                                                                                                          \
+  do {                                                                                                                       \
+    if (ATTN_DBG(a, 131072) && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && itn < 256)                                     \
+      reinterpret_cast<unsigned long long*>(a.scores_out)[(wave * 256 + itn) * 8 + (P)] = __builtin_amdgcn_s_memtime();       \
+  } while (0)
+
+#define FB_STAMP_AT(IT, P)                                                                                                   \
+  do {                                                                                                                       \
+    if (ATTN_DBG(a, 131072) && blockIdx.x == 0 && (threadIdx.x & 63) == 0)                                                  \
+      reinterpret_cast<unsigned long long*>(a.scores_out)[(wave * 256 + (IT)) * 8 + (P)] = __builtin_amdgcn_s_memtime();      \
+  } while (0)
+
 struct FbItem { int b, q0, k0, Lq, Lk; };
-// a role's position in the stage stream: stage = (item j, slab s); advance() steps to the next stage
-struct FbCur { int j, s, ns; FbItem it; };
+// one stage of the stream = (item j, query slab s), decoded from its 16-byte record in the stage table
+struct FbStage { int b, s, kpar, last, qrow, left, Lk, j; };
+constexpr int FB_MAXST = FB_TBL * 8;                    // stages per table pass (≤ 8 slabs per item)
 
 // byte offset of the 8-byte slot (q-tile u, lane group g) of key row `row` in a dS slab: 64-byte rows, slot bits swizzled by the
 // row so that the transposed reads of P2 (8 rows × 4 slots per half wave) and the writes of P1 (16 rows × 1 slot) spread over the banks
@@ -1195,204 +1235,245 @@ __global__ __launch_bounds__(FB_NW * 64) void enc_bwd_fused_kernel(AttnArgs a) {
   float* b4 = reinterpret_cast<float*>(ring + NST * FB_STAGE);
   float* lse_l = b4 + 4 * EB_ST;
   float* ndel_l = lse_l + NST * 32;
-  int* tbl = reinterpret_cast<int*>(ndel_l + NST * 32);     // [FB_TBL][4] + header {items, stages}
-  float* drel_l = reinterpret_cast<float*>(smem);   // the end flush reuses the K images
+  int* tbl = reinterpret_cast<int*>(ndel_l + NST * 32);                       // items [FB_TBL][4] + header {items, stages, -, -}
+  uint32_t* ltab = reinterpret_cast<uint32_t*>(tbl + FB_TBL * 4 + 4);         // P1's lane constants: 3 × 16 bytes per lane (below)
+  uint32_t* stab = ltab + 64 * 12;                                            // stages [FB_MAXST][4]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = blockIdx.x % a.H, slot0 = blockIdx.x / a.H, nslots = gridDim.x / a.H;
   if (slot0 >= a.Bn) return;
   const bool want_drel = a.drel != nullptr;
+  int itn = 0;                                      // (stamps only) iterations so far
+  FB_STAMP_AT(255, 0);
   estage_bias<FB_NW * 64>(b4, a.rel_bias, h, a.R, true);
   const int KB = (a.Lk + 3) >> 2, QB = (a.Lq + 3) >> 2;
   const float dscale = DROP ? a.drop_scale : 1.0f, inv_dscale = 1.0f / dscale;
   const int nmine = (a.Bn - slot0 + nslots - 1) / nslots;         // items of this workgroup (empty ones included)
+  auto item = [&](int j) {
+    const u32x4 e = *reinterpret_cast<const u32x4*>(tbl + j * 4);
+    FbItem it;
+    it.b = __builtin_amdgcn_readfirstlane((int)e[0]);
+    it.q0 = __builtin_amdgcn_readfirstlane((int)e[1]);
+    it.k0 = __builtin_amdgcn_readfirstlane((int)e[2]);
+    const int w3 = __builtin_amdgcn_readfirstlane((int)e[3]);
+    it.Lq = w3 & 0xFFFF;
+    it.Lk = w3 >> 16;
+    return it;
+  };
+  auto stage_raw = [&](int n) { return *reinterpret_cast<const u32x4*>(stab + n * 4); };
+  auto stage_dec = [&](u32x4 e) {
+    FbStage st;
+    const int w0 = __builtin_amdgcn_readfirstlane((int)e[0]), w2 = __builtin_amdgcn_readfirstlane((int)e[2]);
+    st.b = w0 & 0xFFFF;
+    st.s = (w0 >> 16) & 0xFF;
+    st.kpar = (w0 >> 24) & 1;
+    st.last = (w0 >> 25) & 1;
+    st.qrow = __builtin_amdgcn_readfirstlane((int)e[1]);
+    st.left = w2 & 0xFFFF;
+    st.Lk = w2 >> 16;
+    st.j = __builtin_amdgcn_readfirstlane((int)e[3]);
+    return st;
+  };
+  auto bar = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
   if (wave >= 14) {
     // ================= waves 14 / 15: the ring's DMA, δ, the K images, P2 — no key tile (the launcher takes sequences of ≤ 224 keys) =================
-    for (int t0 = 0; t0 < nmine; t0 += FB_TBL) {
-      __syncthreads();
-      __syncthreads();                                              // (wave 0 builds the item table between these two)
-      const int nit = __builtin_amdgcn_readfirstlane(tbl[FB_TBL * 4]);
-      const int nstage = __builtin_amdgcn_readfirstlane(tbl[FB_TBL * 4 + 1]);
-      if (nit == 0) continue;
-    auto item = [&](int j) {
-      const u32x4 e = *reinterpret_cast<const u32x4*>(tbl + j * 4);
-      FbItem it;
-      it.b = __builtin_amdgcn_readfirstlane((int)e[0]);
-      it.q0 = __builtin_amdgcn_readfirstlane((int)e[1]);
-      it.k0 = __builtin_amdgcn_readfirstlane((int)e[2]);
-      const int w3 = __builtin_amdgcn_readfirstlane((int)e[3]);
-      it.Lq = w3 & 0xFFFF;
-      it.Lk = w3 >> 16;
-      return it;
-    };
-    auto cur_at = [&](int j) {                                        // cursor at the first stage of item j (j == nit: past the end)
-      FbCur c;
-      c.j = j; c.s = 0;
-      c.it = item(j < nit ? j : 0);
-      c.ns = max(2, (c.it.Lq + 31) >> 5);
-      return c;
-    };
-    auto advance = [&](FbCur& c) {
-      if (c.j >= nit) return;
-      if (++c.s >= c.ns) {
-        c.s = 0;
-        ++c.j;
-        if (c.j < nit) {
-          c.it = item(c.j);
-          c.ns = max(2, (c.it.Lq + 31) >> 5);
-        }
-      }
-    };
-    // ---- the ring's DMA (wave 14): Q, dO, O rows of slab s of the item (4 pieces of 8 rows each) and its 32 raw statistics records
-    auto issue_stage = [&](const FbItem& it, int s, int slot) {
+    // They are the youngest waves of their SIMDs: at equal priority the arbiter serves them last, and every other wave then waits for them at
+    // the barrier (stamps: P2 took 4 500 cycles beside three busy P1 waves) — raise their priority once.
+    __builtin_amdgcn_s_setprio(3);
+    const int part = wave - 14;
+    // ---- the ring's DMA: Q and dO rows of a slab (part 0: 8 pieces of 8 rows, wave 14), O rows and the 32 raw statistics records (part 1: 5 pieces)
+    auto issue_stage = [&](const FbStage& st, int slot) {
       int le = lane;
       asm volatile("" : "+v"(le));
-      char* st = ring + slot * FB_STAGE;
-      const int nrow = min(max(it.Lq - 32 * s, 0), 32);              // rows of this slab that exist
-      const int64_t r0 = (int64_t)(it.q0 + 32 * s);
+      char* sp = ring + slot * FB_STAGE;
+      const int nrow = min(st.left, 32);                              // rows of this slab that exist
       const uint32_t qstb = (uint32_t)a.qst * 2u, ostb = (uint32_t)a.ost * 2u;
-      const auto qrs = lds_dma_rsrc(a.q + h * 128 + r0 * qstb, nrow > 0 ? (uint32_t)(nrow - 1) * qstb + 128u : 0u);
-      const auto drs = lds_dma_rsrc(a.dout + h * 128 + r0 * ostb, nrow > 0 ? (uint32_t)(nrow - 1) * ostb + 128u : 0u);
-      const auto ors = lds_dma_rsrc(a.o + h * 128 + r0 * ostb, nrow > 0 ? (uint32_t)(nrow - 1) * ostb + 128u : 0u);
-      const auto srs = lds_dma_rsrc(a.stats + (((int64_t)it.b * a.H + h) * a.Lq + 32 * s) * 4, (uint32_t)nrow * 16u);
       const int pr = le >> 3, pc = le & 7;
+      const uint32_t sw = (uint32_t)eswz(pc, pr) * 16u;               // (the swizzle key repeats every 8 rows)
+      if (part == 0) {
+        const auto qrs = lds_dma_rsrc(a.q + h * 128 + (int64_t)st.qrow * qstb, nrow > 0 ? (uint32_t)(nrow - 1) * qstb + 128u : 0u);
+        const auto drs = lds_dma_rsrc(a.dout + h * 128 + (int64_t)st.qrow * ostb, nrow > 0 ? (uint32_t)(nrow - 1) * ostb + 128u : 0u);
 #pragma unroll
-      for (int pz = 0; pz < 4; ++pz) {
-        const int row = pz * 8 + pr;
-        const uint32_t sw = (uint32_t)eswz(pc, row) * 16u;
-        const bool in = row < nrow;
-        lds_dma16(st + pz * 1024, qrs, in ? (uint32_t)row * qstb + sw : 0x80000000u);
-        lds_dma16(st + FB_SLAB + pz * 1024, drs, in ? (uint32_t)row * ostb + sw : 0x80000000u);
-        lds_dma16(st + 2 * FB_SLAB + pz * 1024, ors, in ? (uint32_t)row * ostb + sw : 0x80000000u);
+        for (int pz = 0; pz < 4; ++pz) {
+          const int row = pz * 8 + pr;
+          const bool in = row < nrow;
+          lds_dma16(sp + pz * 1024, qrs, in ? (uint32_t)row * qstb + sw : 0x80000000u);
+          lds_dma16(sp + FB_SLAB + pz * 1024, drs, in ? (uint32_t)row * ostb + sw : 0x80000000u);
+        }
+      } else {
+        const auto ors = lds_dma_rsrc(a.o + h * 128 + (int64_t)st.qrow * ostb, nrow > 0 ? (uint32_t)(nrow - 1) * ostb + 128u : 0u);
+        const auto srs = lds_dma_rsrc(a.stats + (((int64_t)st.b * a.H + h) * a.Lq + 32 * st.s) * 4, (uint32_t)nrow * 16u);
+#pragma unroll
+        for (int pz = 0; pz < 4; ++pz) {
+          const int row = pz * 8 + pr;
+          lds_dma16(sp + 2 * FB_SLAB + pz * 1024, ors, row < nrow ? (uint32_t)row * ostb + sw : 0x80000000u);
+        }
+        lds_dma16(sp + 3 * FB_SLAB, srs, le < nrow ? (uint32_t)le * 16u : 0x80000000u);
       }
-      lds_dma16(st + 3 * FB_SLAB, srs, le < nrow ? (uint32_t)le * 16u : 0x80000000u);
     };
-    constexpr int PIECES = 13;
+    constexpr int PIECES0 = 8, PIECES1 = 5;
     auto issue_kimg = [&](const FbItem& it, int j) {                  // K image of item j, all pieces by the calling wave
       const uint32_t kstb = (uint32_t)a.kst * 2u;
       estage_dma<1>(Kimg0 + (j & 1) * R * EROW, a.k + h * 128 + (int64_t)it.k0 * kstb, kstb, ((it.Lk + 31) >> 5) << 5, it.Lk, 0, lane);
     };
     // ---- δ and the row constants of a stage that has landed: 32 queries, 2 lanes per query
-    auto cstage = [&](const FbItem& it, int s, int slot) {
-      const char* st = ring + slot * FB_STAGE;
+    auto cstage = [&](const FbStage& st, int slot) {
+      const char* sp = ring + slot * FB_STAGE;
       const int ql = lane >> 1, qh2 = lane & 1;
-      float part = 0.f;
+      float part_ = 0.f;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int off = ql * EROW + eswz(4 * qh2 + c, ql) * 16;
-        const bf16x8 dv = *reinterpret_cast<const bf16x8*>(st + FB_SLAB + off), ov = *reinterpret_cast<const bf16x8*>(st + 2 * FB_SLAB + off);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) part += (float)dv[e] * (float)ov[e];
+        const u32x4 dv = *reinterpret_cast<const u32x4*>(sp + FB_SLAB + off), ov = *reinterpret_cast<const u32x4*>(sp + 2 * FB_SLAB + off);
+        // v_dot2c_f32_bf16: two exact products and the running fp32 sum per instruction.  (The pairs are taken by shufflevector: hipcc 7.2
+        // turns `bit_cast<bf16x2>(u32x4[e])` of an unrolled e into FOUR uses of element 0 — found by the parity tests.)
+        const bf16x8 dvb = __builtin_bit_cast(bf16x8, dv), ovb = __builtin_bit_cast(bf16x8, ov);
+        part_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(dvb, dvb, 0, 1), __builtin_shufflevector(ovb, ovb, 0, 1), part_, false);
+        part_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(dvb, dvb, 2, 3), __builtin_shufflevector(ovb, ovb, 2, 3), part_, false);
+        part_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(dvb, dvb, 4, 5), __builtin_shufflevector(ovb, ovb, 4, 5), part_, false);
+        part_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(dvb, dvb, 6, 7), __builtin_shufflevector(ovb, ovb, 6, 7), part_, false);
       }
-      part += __shfl_xor(part, 1, 64);
-      const f32x4 raw = *reinterpret_cast<const f32x4*>(st + 3 * FB_SLAB + ql * 16);
+      part_ += __shfl_xor(part_, 1, 64);
+      const f32x4 raw = *reinterpret_cast<const f32x4*>(sp + 3 * FB_SLAB + ql * 16);
       if (qh2 == 0) {
         lse_l[slot * 32 + ql] = raw[1] > 0.f ? raw[0] * LOG2E - __builtin_amdgcn_logf(raw[1] * dscale) : INFINITY;
-        ndel_l[slot * 32 + ql] = -part * inv_dscale;
-        if (32 * s + ql < it.Lq) a.stats[(((int64_t)it.b * a.H + h) * a.Lq + 32 * s + ql) * 4 + 2] = part;   // (the contract of lako_attn_bwd_t.lse)
+        ndel_l[slot * 32 + ql] = -part_ * inv_dscale;
+        if (ql < st.left) a.stats[(((int64_t)st.b * a.H + h) * a.Lq + 32 * st.s + ql) * 4 + 2] = part_;   // (the contract of lako_attn_bwd_t.lse)
       }
     };
-    // ---- P2: dQᵀ[64 d × 16 queries] of q-tile qt of stage (item, slab s) whose dS slab is dS[par]
-    auto p2 = [&](const FbItem& it, int j, int s, int par, int qt) {
+    // ---- P2: dQᵀ[d-blocks 2·part, 2·part + 1 × both q-tiles] of a stage whose dS slab is dS[par]: the two waves share the key range and split
+    // the d-blocks, so each K fragment (A) and each dS fragment (B) is read once per wave and used twice: 8 transposed reads per 4 MFMAs
+    auto p2 = [&](const FbStage& st, int par) {
       int le = lane;
       asm volatile("" : "+v"(le));
       const int trr = 4 * (le >> 4) + ((le & 15) >> 2), trp = le & 3;
-      const char* ap = Kimg0 + (j & 1) * R * EROW + (trr * EROW + (((trr >> 1) & 3) << 5) + trp * 8);     // d-block db: ^ (db << 5)
-      const char* bp = dST0 + par * R * 64 + fb_ds_off(trr, qt, trp);
-      const int nkp = (it.Lk + 31) >> 5;
-      f32x4 acc[4];
+      const char* ap = Kimg0 + st.kpar * R * EROW + (trr * EROW + ((((trr >> 1) & 3) ^ (2 * part)) << 5) + trp * 8);     // d-block 2·part (the next: ^ 32)
+      const char* bp = dST0 + par * R * 64 + fb_ds_off(trr, 0, trp);                                                      // q-tile 0 (q-tile 1: ^ 32)
+      const int nkp = (st.Lk + 31) >> 5;
+      f32x4 acc[2][2];                                                 // [d-block][q-tile]
 #pragma unroll
-      for (int db = 0; db < 4; ++db) acc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int x = 0; x < 4; ++x) acc[x >> 1][x & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
       auto trd = [](const char* p) { return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p))); };
-      for (int kk = 0; kk < nkp; ++kk, ap += 32 * EROW, bp += 32 * 64) {
-        const u32x2 b0 = trd(bp), b1 = trd(bp + 16 * 64);
-        u32x2 a0[4], a1[4];
+      auto x32 = [](const char* p) { return reinterpret_cast<const char*>(reinterpret_cast<uintptr_t>(p) ^ (uintptr_t)32); };
+      // the fragments of key step kk + 1 are requested before the MFMAs of step kk
+      struct Frag { u32x2 a0[2], a1[2], b0[2], b1[2]; };
+      auto fetch = [&](Frag& f, const char* ap_, const char* bp_) {
+        f.a0[0] = trd(ap_);      f.a1[0] = trd(ap_ + 16 * EROW);
+        f.a0[1] = trd(x32(ap_)); f.a1[1] = trd(x32(ap_) + 16 * EROW);
+        f.b0[0] = trd(bp_);      f.b1[0] = trd(bp_ + 16 * 64);
+        f.b0[1] = trd(x32(bp_)); f.b1[1] = trd(x32(bp_) + 16 * 64);
+      };
+      auto mma = [&](const Frag& f) {
 #pragma unroll
-        for (int db = 0; db < 4; ++db) {
-          const char* q = reinterpret_cast<const char*>(reinterpret_cast<uintptr_t>(ap) ^ (uintptr_t)(db << 5));
-          a0[db] = trd(q);
-          a1[db] = trd(q + 16 * EROW);
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+            acc[d][q] = emma(u32x4{f.a0[d][0], f.a0[d][1], f.a1[d][0], f.a1[d][1]}, u32x4{f.b0[q][0], f.b0[q][1], f.b1[q][0], f.b1[q][1]}, acc[d][q]);
+      };
+      Frag f0, f1;
+      fetch(f0, ap, bp);
+      for (int kk = 0; kk < nkp; kk += 2) {
+        if (kk + 1 < nkp) fetch(f1, ap + (kk + 1) * 32 * EROW, bp + (kk + 1) * 32 * 64);
+        mma(f0);
+        if (kk + 1 < nkp) {
+          if (kk + 2 < nkp) fetch(f0, ap + (kk + 2) * 32 * EROW, bp + (kk + 2) * 32 * 64);
+          mma(f1);
         }
-        const u32x4 bf = {b0[0], b0[1], b1[0], b1[1]};
-#pragma unroll
-        for (int db = 0; db < 4; ++db) acc[db] = emma(u32x4{a0[db][0], a0[db][1], a1[db][0], a1[db][1]}, bf, acc[db]);
       }
-      const int qi = 32 * s + 16 * qt + (le & 15);
-      if (qi < it.Lq) {
-        bf16_t* op = reinterpret_cast<bf16_t*>(a.dq + h * 128 + (int64_t)(it.q0 + qi) * ((int64_t)a.qst * 2)) + 4 * (le >> 4);
 #pragma unroll
-        for (int db = 0; db < 4; ++db) store4(op + db * 16, acc[db]);
+      for (int q = 0; q < 2; ++q) {
+        const int ql = 16 * q + (le & 15);
+        if (ql < st.left) {
+          bf16_t* op = reinterpret_cast<bf16_t*>(a.dq + h * 128 + (int64_t)(st.qrow + ql) * ((int64_t)a.qst * 2)) + 32 * part + 4 * (le >> 4);
+          store4(op, acc[0][q]);
+          store4(op + 16, acc[1][q]);
+        }
       }
     };
-    auto bar = [&]() {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    };
+    for (int t0 = 0; t0 < nmine; t0 += FB_TBL) {
+      __syncthreads();
+      __syncthreads();                                              // (wave 0 builds the item and stage tables between these two)
+      const int nit = __builtin_amdgcn_readfirstlane(tbl[FB_TBL * 4]);
+      const int nstage = __builtin_amdgcn_readfirstlane(tbl[FB_TBL * 4 + 1]);
+      if (nit == 0) continue;
       // prologue: item 0's K image, the first NST − 1 stages; δ of stage 0
-      {
-        const FbItem it0 = item(0);
-        if (wave == 15) issue_kimg(it0, 0);
-        if (wave == 14) {
-          FbCur c = cur_at(0);
+      if (wave == 15) issue_kimg(item(0), 0);
 #pragma unroll
-          for (int k = 0; k < NST - 1; ++k) {
-            if (c.j < nit) issue_stage(c.it, c.s, k);
-            advance(c);
-          }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (wave == 15) cstage(it0, 0, 0);
-      }
+      for (int k = 0; k < NST - 1; ++k)
+        if (k < nstage) issue_stage(stage_dec(stage_raw(k)), k);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (wave == 15) cstage(stage_dec(stage_raw(0)), 0);
       // the stage stream: iteration n = P1 of stage n (the other waves), P2 of stage n − 1, δ of stage n + 1, DMA of stage n + NST − 1
-      FbCur ca = cur_at(0), c2 = cur_at(0);                           // ca: the DMA cursor (wave 14) / the δ cursor (wave 15)
-      int cj1 = 0, cs1 = 0, cn1 = ca.ns;                              // P1's cursor: only (item, slab, slabs) are needed here
-      if (wave == 14) {
-#pragma unroll
-        for (int k = 0; k < NST - 1; ++k) advance(ca);
-      } else {
-        advance(ca);
-      }
-      bool issued = false;
+      bool issued = false, newitem = true;
       for (int n = 0; n <= nstage; ++n) {
-        if (wave == 14) {
-          // the pieces issued in the previous iteration (the wave's newest operations) may stay in flight with a ring of 4
-          if (NST >= 4 && issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
-          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else if (n < nstage && cs1 == 0) {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // a new item: its K image (issued during the previous item) has landed
+        // the pieces issued in the previous iteration (the wave's newest operations) may stay in flight with a ring of 4; wave 15 at a new item:
+        // its K image (issued during the previous item) must have landed
+        if (NST >= 4 && issued && !(wave == 15 && newitem)) {
+          if (wave == 14) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES0) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES1) : "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        FB_STAMP(0);
         bar();
+        FB_STAMP(1);
         const int slot = n % NST;
-        if (wave == 15 && ca.j < nit && !ATTN_DBG(a, 16384)) cstage(ca.it, ca.s, (slot + 1) % NST);
-        if (n > 0) {
-          if (!ATTN_DBG(a, 2048)) p2(c2.it, c2.j, c2.s, (n - 1) & 1, wave - 14);
-          advance(c2);
-        }
-        if (wave == 14) {                                             // (after P2's stores: the newest PIECES operations of the wave are exactly this stage's)
-          issued = ca.j < nit;
-          if (issued && !ATTN_DBG(a, 8192)) issue_stage(ca.it, ca.s, (slot + NST - 1) % NST);
-        }
-        advance(ca);
-        if (n < nstage) {
-          // the next item's K image: its buffer's last reader was P2 of item j − 1, one iteration ago
-          if (wave == 15 && cs1 == 1 && cj1 + 1 < nit) issue_kimg(item(cj1 + 1), cj1 + 1);
-          if (++cs1 >= cn1) {
-            cs1 = 0;
-            ++cj1;
-            if (cj1 < nit) cn1 = max(2, ((item(cj1).Lq) + 31) >> 5);
+        // the records of this iteration's stages, requested together
+        const u32x4 r1 = stage_raw(min(n + 1, FB_MAXST - 1)), r2 = stage_raw(max(n - 1, 0)), rd = stage_raw(min(n + NST - 1, FB_MAXST - 1));
+        if (wave == 15 && n + 1 < nstage && !ATTN_DBG(a, 16384)) cstage(stage_dec(r1), (slot + 1) % NST);
+        FB_STAMP(2);
+        if (n > 0 && !ATTN_DBG(a, 2048)) p2(stage_dec(r2), (n - 1) & 1);
+        FB_STAMP(3);
+        {
+          // the next item's K image when P1 is at slab 1 of an item: the buffer's last reader was P2 of the item before, one iteration ago
+          // (issued before the ring pieces: the wave's newest operations stay the ring's)
+          const FbStage s1 = stage_dec(r1);                            // stage n + 1 — a first slab there means P1 starts a new item next
+          newitem = n + 1 < nstage && s1.s == 0;
+          if (wave == 15 && n < nstage) {
+            const FbStage s0 = stage_dec(stage_raw(n));
+            if (s0.s == 1 && s0.j + 1 < nit) issue_kimg(item(s0.j + 1), s0.j + 1);
           }
         }
+        issued = n + NST - 1 < nstage;
+        if (issued && !ATTN_DBG(a, 8192)) issue_stage(stage_dec(rd), (slot + NST - 1) % NST);
+        FB_STAMP(4);
+        ++itn;
       }
     }
     if (want_drel) {                                                 // (the barriers of the other waves' bias-gradient flush)
-      __syncthreads();
       __syncthreads();
       __syncthreads();
     }
     return;
   }
   // ================= waves 0 – 13: P1 =================
+  // Lane constants of P1 as a table in LDS, read where they are used: held in registers across the slabs they would cost the dK / dV
+  // accumulators their room (148 registers), rebuilt per slab ≈ 50 vector instructions of the ≈ 200 a slab takes — and P1 is bound by
+  // vector issue.  Lane l = (l15, g) of key tile 0; the wave's tile adds multiples of 16 keys in scalar arithmetic.
+  //   [0] row-fragment offset (step 1: ^ 64)   [1] byte offset of its reversed bias copy   [2] dS slab offset of q-tile 0 (q-tile 1: ^ 32)
+  //   [3] dropout block index, lane part       [4..7] the four multipliers of its key column   [8] 5·((k & 3) >> 1)   [9] 16·(k & 1)
+  //   [10] transposed-read offset of d-block 0 (d-block db: ^ (db << 5))
+  if (wave == 0) {
+    const int g = lane >> 4, l15 = lane & 15;
+    const int last = a.R - 1 + EB_PADLO + 36;
+    const int j0 = last - (l15 - 4 * g + a.rel_off + EB_PADLO);
+    const int tr = 4 * g + (l15 >> 2);
+    const DropCol dc = drop_col_consts(l15);
+    uint32_t* e = ltab + lane * 12;
+    e[0] = (uint32_t)(l15 * EROW + eswz(g, l15) * 16);
+    e[1] = (uint32_t)(((j0 & 3) * EB_ST + (j0 & ~3)) * 4);
+    e[2] = fb_ds_off(l15, 0, g);
+    e[3] = (uint32_t)(g * KB + (l15 >> 2));
+    e[4] = dc.m[0]; e[5] = dc.m[1]; e[6] = dc.m[2]; e[7] = dc.m[3];
+    e[8] = 5u * (uint32_t)((l15 >> 1) & 1);
+    e[9] = dc.sh;
+    e[10] = (uint32_t)(tr * EROW + (((tr >> 1) & 3) << 5) + (l15 & 3) * 8);
+    e[11] = 0u;
+  }
   // bias-gradient accumulators: lane (key j = l15, group g) sums the elements with key − query = 16·(w − qt) + j − 4g of q-tile qt in
   // acc_lo[qt]; the elements that wrap around the 16-lane row (key − query = 16·(w − qt) + j − 16 − 4g, lanes 13..15) of the four
   // q-tiles 4u … 4u + 3 share acc_hi[u], q-tile 4u + k's three lanes moved down by 3k lanes (as in enc_bwd_dq_p_kernel)
@@ -1405,10 +1486,14 @@ __global__ __launch_bounds__(FB_NW * 64) void enc_bwd_fused_kernel(AttnArgs a) {
   f32x4 dkacc[4], dvacc[4];
 #pragma unroll
   for (int db = 0; db < 4; ++db) dkacc[db] = dvacc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto load_v = [&](const FbItem& it) {                             // this wave's V rows of an item → vf
+    const uint32_t vstb = (uint32_t)a.vst * 2u;
+    eload_frags_buf(vf, a.v + h * 128 + (int64_t)it.k0 * vstb, vstb, wave * 16, it.Lk, (uint32_t)(lane & 15) * vstb + (uint32_t)(lane >> 4) * 16u);
+  };
 
   for (int t0 = 0; t0 < nmine; t0 += FB_TBL) {
-    // ---- item table of this pass: (sequence, q row offset, k row offset, Lq | Lk << 16) of the non-empty items, in walk order
-    __syncthreads();                                                // the previous pass is done with the table, the images and the slabs
+    // ---- tables of this pass: the non-empty items in walk order (sequence, q row offset, k row offset, Lq | Lk << 16) and their stages
+    __syncthreads();                                                // the previous pass is done with the tables, the images and the slabs
     if (wave == 0) {
       const int t = t0 + lane;
       int b = 0, q0 = 0, k0 = 0, Lq = 0, Lk = 0;
@@ -1427,68 +1512,42 @@ __global__ __launch_bounds__(FB_NW * 64) void enc_bwd_fused_kernel(AttnArgs a) {
         int* e = tbl + pos * 4;
         e[0] = b; e[1] = q0; e[2] = k0; e[3] = Lq | (Lk << 16);
       }
-      int ns = ok ? max(2, (Lq + 31) >> 5) : 0;                      // slab iterations of the item (≥ 2: the K image double buffer)
+      const int ns = ok ? max(2, (Lq + 31) >> 5) : 0;                // slab iterations of the item (≥ 2: the K image double buffer)
+      int incl = ns;                                                  // inclusive prefix sum over the lanes
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) ns += __shfl_xor(ns, o, 64);
-      if (lane == 0) {
-        tbl[FB_TBL * 4] = (int)__popcll(m);
-        tbl[FB_TBL * 4 + 1] = ns;
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
       }
+      const int first = incl - ns;
+      for (int sl = 0; sl < ns; ++sl) {
+        uint32_t* e = stab + (first + sl) * 4;
+        e[0] = (uint32_t)b | ((uint32_t)sl << 16) | ((uint32_t)(pos & 1) << 24) | ((uint32_t)(sl == ns - 1) << 25);
+        e[1] = (uint32_t)(q0 + 32 * sl);
+        e[2] = (uint32_t)max(Lq - 32 * sl, 0) | ((uint32_t)Lk << 16);
+        e[3] = (uint32_t)pos;
+      }
+      if (lane == 63) tbl[FB_TBL * 4 + 1] = incl;
+      if (lane == 0) tbl[FB_TBL * 4] = (int)__popcll(m);
     }
     __syncthreads();
     const int nit = __builtin_amdgcn_readfirstlane(tbl[FB_TBL * 4]);
     const int nstage = __builtin_amdgcn_readfirstlane(tbl[FB_TBL * 4 + 1]);
     if (nit == 0) continue;
-    auto item = [&](int j) {
-      const u32x4 e = *reinterpret_cast<const u32x4*>(tbl + j * 4);
-      FbItem it;
-      it.b = __builtin_amdgcn_readfirstlane((int)e[0]);
-      it.q0 = __builtin_amdgcn_readfirstlane((int)e[1]);
-      it.k0 = __builtin_amdgcn_readfirstlane((int)e[2]);
-      const int w3 = __builtin_amdgcn_readfirstlane((int)e[3]);
-      it.Lq = w3 & 0xFFFF;
-      it.Lk = w3 >> 16;
-      return it;
-    };
-    auto cur_at = [&](int j) {                                        // cursor at the first stage of item j (j == nit: past the end)
-      FbCur c;
-      c.j = j; c.s = 0;
-      c.it = item(j < nit ? j : 0);
-      c.ns = max(2, (c.it.Lq + 31) >> 5);
-      return c;
-    };
-    auto advance = [&](FbCur& c) {
-      if (c.j >= nit) return;
-      if (++c.s >= c.ns) {
-        c.s = 0;
-        ++c.j;
-        if (c.j < nit) {
-          c.it = item(c.j);
-          c.ns = max(2, (c.it.Lq + 31) >> 5);
-        }
-      }
-    };
-    auto load_v = [&](const FbItem& it) {                             // this wave's V rows of an item → vf
-      const uint32_t vstb = (uint32_t)a.vst * 2u;
-      eload_frags_buf(vf, a.v + h * 128 + (int64_t)it.k0 * vstb, vstb, wave * 16, it.Lk, (uint32_t)(lane & 15) * vstb + (uint32_t)(lane >> 4) * 16u);
-    };
-    // ---- P1: the wave's key tile against slab s of the item (ring slot `slot`), dS → dS[par]
-    auto p1 = [&](const FbCur& c, int slot, int par) {
-      const FbItem& it = c.it;
-      const int j = c.j, s = c.s;
-      int le = lane;
-      asm volatile("" : "+v"(le));                                    // every lane constant below is rebuilt per call: nothing lane-derived stays live across the slabs
-      const int g = le >> 4, l15 = le & 15, ki = wave * 16 + l15;
-      const int nkt2 = ((it.Lk + 31) >> 5) << 1;                      // key tiles, rounded up to whole pairs (P2 contracts over pairs)
-      const bool lastslab = s == c.ns - 1;
-      char* dS = dST0 + par * R * 64;
-      const uint32_t dsw0 = fb_ds_off(ki, 0, g);                      // (q-tile 1: ^ 32)
-      if (wave * 16 >= it.Lk) {                                       // no key tile for this wave in this item
+    // ---- P1: the wave's key tile against the slab of stage st (ring slot `slot`), dS → dS[par]
+    auto p1 = [&](const FbStage& st, int slot, int par) {
+      const int s = st.s;
+      const int nkt2 = ((st.Lk + 31) >> 5) << 1;                      // key tiles, rounded up to whole pairs (P2 contracts over pairs)
+      const char* lrow = reinterpret_cast<const char*>(ltab) + lane * 48;
+      const u32x4 c0 = *reinterpret_cast<const u32x4*>(lrow);
+      char* dS = dST0 + par * R * 64 + wave * 16 * 64;
+      const uint32_t dsw0 = c0[2];                                    // (q-tile 1: ^ 32)
+      if (wave * 16 >= st.Lk) {                                       // no key tile for this wave in this item
         if (wave < nkt2) {                                            // … but the odd tile of the last pair: its dS rows are zeros
           *reinterpret_cast<u32x2*>(dS + dsw0) = u32x2{0u, 0u};
           *reinterpret_cast<u32x2*>(dS + (dsw0 ^ 32u)) = u32x2{0u, 0u};
         }
-        if (lastslab && j + 1 < nit) load_v(item(j + 1));
+        if (st.last && st.j + 1 < nit) load_v(item(st.j + 1));
         return;
       }
       const char* Qs = ring + slot * FB_STAGE;
@@ -1498,51 +1557,56 @@ __global__ __launch_bounds__(FB_NW * 64) void enc_bwd_fused_kernel(AttnArgs a) {
 #pragma unroll
         for (int db = 0; db < 4; ++db) dkacc[db] = dvacc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      // row-fragment offset of fragment step 0 (step 1: ^ 64) — lds_image.h::elane
-      const uint32_t roff0 = (uint32_t)(l15 * EROW + eswz(g, l15) * 16);
-      const uint32_t roff[2] = {roff0, roff0 ^ 64u};
-      const char* Kimg = Kimg0 + (j & 1) * R * EROW + wave * 16 * EROW;
-      const bool tailk = (wave + 1) * 16 > it.Lk;                     // (wave-uniform) the tile holds keys past the sequence's end
-      const int last = a.R - 1 + EB_PADLO + 36;
-      const int j0 = last - (ki - 4 * g + a.rel_off + EB_PADLO);
-      const float* bptr = b4 + (j0 & 3) * EB_ST + (j0 & ~3) + 32 * s;
-      const uint32_t cblk = (uint32_t)((it.b * a.H + h) * QB + g + 8 * s) * (uint32_t)KB + (uint32_t)(ki >> 2);
+      const uint32_t roff[2] = {c0[0], c0[0] ^ 64u};
+      const char* Kimg = Kimg0 + st.kpar * R * EROW + wave * 16 * EROW;
+      const bool tailk = (wave + 1) * 16 > st.Lk;                     // (wave-uniform) the tile holds keys past the sequence's end
+      const char* bptr = reinterpret_cast<const char*>(b4) + c0[1] + (32 * s - 16 * wave) * 4;
+      const char* ndp = reinterpret_cast<const char*>(ndel_l) + slot * 128 + (lane >> 4) * 16;       // this lane's 4 queries of q-tile 0 (q-tile 1: + 64)
+      const char* lsp = reinterpret_cast<const char*>(lse_l) + slot * 128 + (lane >> 4) * 16;
+      const uint32_t cblk = (uint32_t)((st.b * a.H + h) * QB + 8 * s) * (uint32_t)KB + 4u * (uint32_t)wave + c0[3];
       const uint32_t kb4 = 4u * (uint32_t)KB;
       const uint32_t t_hi = a.drop_t16 << 16;
       u32x2 ptb[2], dsb[2];                                            // P̃ and dS of the two tiles, rounded to bf16 as the MFMA operands are
+      const u32x4 kfa = *reinterpret_cast<const u32x4*>(Kimg + roff[0]), kfb = *reinterpret_cast<const u32x4*>(Kimg + roff[1]);
+      const u32x4 kf[2] = {kfa, kfb};
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         f32x4 sv, dp;
         {
-          const u32x4 kf[2] = {*reinterpret_cast<const u32x4*>(Kimg + roff[0]), *reinterpret_cast<const u32x4*>(Kimg + roff[1])};
-          f32x4 init = *reinterpret_cast<const f32x4*>(bptr + 16 * u);
+          f32x4 init = *reinterpret_cast<const f32x4*>(bptr + 64 * u);
           if (tailk) {
-            const float kadd_lane = ki < it.Lk ? 0.f : -INFINITY;
+            const float kadd_lane = wave * 16 + (lane & 15) < st.Lk ? 0.f : -INFINITY;
             init += f32x4{kadd_lane, kadd_lane, kadd_lane, kadd_lane};
           }
-          const f32x4 nd = *reinterpret_cast<const f32x4*>(ndel_l + slot * 32 + 16 * u + 4 * g);
+          const f32x4 nd = *reinterpret_cast<const f32x4*>(ndp + 64 * u);
           sv = escore(Qs, 16 * u, kf, roff, init);
           dp = escore(dOs, 16 * u, vf, roff, nd);
         }
-        if (u == 1 && lastslab && j + 1 < nit) {     // the V rows are dead: the next item's arrive under the rest of this slab's work
+        if (ATTN_DBG(a, 131072)) { asm volatile("" :: "v"(sv), "v"(dp)); if (u == 0) FB_STAMP(2); else FB_STAMP(4); }
+        if (u == 1 && st.last && st.j + 1 < nit) {     // the V rows are dead: the next item's arrive under the rest of this slab's work
           __builtin_amdgcn_sched_barrier(0);
-          load_v(item(j + 1));
+          load_v(item(st.j + 1));
           __builtin_amdgcn_sched_barrier(0);
         }
-        const f32x4 l2 = *reinterpret_cast<const f32x4*>(lse_l + slot * 32 + 16 * u + 4 * g);
+        const f32x4 l2 = *reinterpret_cast<const f32x4*>(lsp + 64 * u);
         f32x4 p, pt;
 #pragma unroll
         for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[r], LOG2E, -l2[r]));
         pt = p;
         if (DROP && !ATTN_DBG(a, 1024)) {
-          bool kp[4];
-          const DropCol dcc = drop_col_consts(ki);
-          drop_keep_col(drop_base(cblk + (uint32_t)u * kb4, a.drop_key), dcc, t_hi, kp);
-          const f32x4 nd = *reinterpret_cast<const f32x4*>(ndel_l + slot * 32 + 16 * u + 4 * g);     // (re-read: 4 registers less across the hashes)
+          // the column form of the block recipe (attn_shared.h::drop_keep_col) with the lane's constants from the table: word (r, (k & 3) >> 1)
+          // = mix(h, M[r][·], 6 + 2r + 5·((k & 3) >> 1)), its half k & 1 against the threshold
+          const u32x4 c1 = *reinterpret_cast<const u32x4*>(lrow + 16);
+          const u32x2 c2 = *reinterpret_cast<const u32x2*>(lrow + 32);
+          const uint32_t hb = drop_base(cblk + (uint32_t)u * kb4, a.drop_key);
+          const uint32_t hs5 = hb >> c2[0];
+          const f32x4 nd = *reinterpret_cast<const f32x4*>(ndp + 64 * u);     // (re-read: 4 registers less across the hashes)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            pt[r] = kp[r] ? p[r] : 0.f;
-            dp[r] = kp[r] ? dp[r] : nd[r];
+            const uint32_t t = __umul24(hb, c1[r]) + (hs5 >> (6u + 2u * (uint32_t)r));
+            const bool kp = ((t ^ (t >> 16)) << c2[1]) >= t_hi;
+            pt[r] = kp ? p[r] : 0.f;
+            dp[r] = kp ? dp[r] : nd[r];
           }
         }
         f32x4 ds;
@@ -1555,85 +1619,95 @@ __global__ __launch_bounds__(FB_NW * 64) void enc_bwd_fused_kernel(AttnArgs a) {
         ptb[u] = __builtin_bit_cast(u32x2, ptv);
         *reinterpret_cast<u32x2*>(dS + (u ? dsw0 ^ 32u : dsw0)) = dsb[u];
         if (want_drel && !ATTN_DBG(a, 32768)) {
-          // lane j' collects, by DPP row shifts, the elements (key j' + r, query 4g + r) of the tile: key − query = 16·(w − qt) + j' − 4g
-          const float lo = ds[0] + edpp<0x101>(ds[1]) + edpp<0x102>(ds[2]) + edpp<0x103>(ds[3]);
-          const float hs = edpp<0x11F>(ds[1]) + edpp<0x11E>(ds[2]) + edpp<0x11D>(ds[3]);      // lanes 13..15, 0 elsewhere
+          // lane j' collects, by DPP row shifts, the elements (key j' + r, query 4g + r) of the tile: key − query = 16·(w − qt) + j' − 4g;
+          // those that wrap around the row land in lanes 13..15 of `hs`
+          float lo, hs;
+          edpp_diag_sums(ds[0], ds[1], ds[2], ds[3], lo, hs);
           static_for<8>([&](auto S) {
             constexpr int sc = decltype(S)::value;
             if (s == sc) {
               acc_lo[2 * sc + u] += lo;
               // q-tile 4v + k of a group of four: moved down by 3k lanes
               constexpr int k3 = (2 * sc) & 3;
-              if (u == 0) acc_hi[sc >> 1] += k3 ? edpp<0x106>(hs) : hs;
-              else acc_hi[sc >> 1] += k3 ? edpp<0x109>(hs) : edpp<0x103>(hs);
+              if (u == 0) eacc_shl<3 * k3>(acc_hi[sc >> 1], hs);
+              else eacc_shl<3 * (k3 + 1)>(acc_hi[sc >> 1], hs);
             }
           });
         }
+        if (ATTN_DBG(a, 131072)) { if (u == 0) FB_STAMP(3); else FB_STAMP(5); }
         __builtin_amdgcn_sched_barrier(0);
       }
       {
-        // transposed-read offsets (lds_image.h::elane), built here — not kept across the hashes: d-block db is ^ (db << 5)
-        const int tr = 4 * g + (l15 >> 2);
-        const uint32_t toff0 = (uint32_t)(tr * EROW + (((tr >> 1) & 3) << 5) + (l15 & 3) * 8);
+        // transposed-read offsets: d-block db is ^ (db << 5)
+        const uint32_t toff0 = *reinterpret_cast<const uint32_t*>(lrow + 40);
         const uint32_t toff[4] = {toff0, toff0 ^ 32u, toff0 ^ 64u, toff0 ^ 96u};
         if (!ATTN_DBG(a, 65536)) {
         epv_packed(dkacc, dsb[0], dsb[1], Qs, 0, toff);            // dKᵀ += Qᵀ·dS
         epv_packed(dvacc, ptb[0], ptb[1], dOs, 0, toff);           // dVᵀ += dOᵀ·P̃
         }
       }
-      if (lastslab && ki < it.Lk) {
-        bf16_t* kp_ = reinterpret_cast<bf16_t*>(a.dk + h * 128 + (int64_t)(it.k0 + ki) * ((int64_t)a.kst * 2));
-        bf16_t* vp_ = reinterpret_cast<bf16_t*>(a.dv + h * 128 + (int64_t)(it.k0 + ki) * ((int64_t)a.vst * 2));
+      if (ATTN_DBG(a, 131072)) { asm volatile("" :: "v"(dkacc[0]), "v"(dvacc[3])); FB_STAMP(6); }
+      if (st.last) {
+        const int g = lane >> 4, ki = wave * 16 + (lane & 15);
+        if (ki < st.Lk) {
+          const int k0 = item(st.j).k0;
+          bf16_t* kp_ = reinterpret_cast<bf16_t*>(a.dk + h * 128 + (int64_t)(k0 + ki) * ((int64_t)a.kst * 2));
+          bf16_t* vp_ = reinterpret_cast<bf16_t*>(a.dv + h * 128 + (int64_t)(k0 + ki) * ((int64_t)a.vst * 2));
 #pragma unroll
-        for (int db = 0; db < 4; ++db) {
-          store4(kp_ + db * 16 + 4 * g, dkacc[db]);
-          store4(vp_ + db * 16 + 4 * g, dvacc[db]);
+          for (int db = 0; db < 4; ++db) {
+            store4(kp_ + db * 16 + 4 * g, dkacc[db]);
+            store4(vp_ + db * 16 + 4 * g, dvacc[db]);
+          }
         }
       }
-    };
-    auto bar = [&]() {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
     };
     // prologue: item 0's V rows
     load_v(item(0));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    FbCur c1 = cur_at(0);
+    FB_STAMP_AT(255, 1);
     for (int n = 0; n <= nstage; ++n) {
+      FB_STAMP(0);
       bar();
-      if (n < nstage) {
-        p1(c1, n % NST, n & 1);
-        advance(c1);
-      }
+      FB_STAMP(1);
+      if (n < nstage) p1(stage_dec(stage_raw(n)), n % NST, n & 1);
+      FB_STAMP(7);
+      ++itn;
     }
   }
+  FB_STAMP_AT(255, 2);
   if (want_drel) {
-    const int g = lane >> 4, l15 = lane & 15;
+    // Flush without atomics (the two-pass kernels add every accumulator lane to an LDS table by ds_add_f32: ≈ 0.3 lane-operations per clock and
+    // CU — 18 000 of them were ≈ 28 µs of a 270 µs launch): every wave lays its 20 accumulator registers out in LDS (the images are dead),
+    // then thread d sums the ≤ 112 lanes that hold diagonal d in a FIXED order and adds the sum to the head's table with one global atomic.
+    // acc_lo[qt], lane (j, g) of wave w: key − query = 16·(w − qt) + j − 4g; the wrapped elements of q-tile qt sit in acc_hi[qt >> 2] at
+    // lane jj − 3·(qt & 3) (jj = 13..15) and belong to key − query = 16·(w − qt) + jj − 16 − 4g.
+    float* F = reinterpret_cast<float*>(smem);            // [14 waves][20][64]
     __syncthreads();
-    for (int i = threadIdx.x; i < 512; i += FB_NW * 64) drel_l[i] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) F[(wave * 20 + t) * 64 + lane] = acc_lo[t];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) F[(wave * 20 + 16 + t) * 64 + lane] = acc_hi[t];
     __syncthreads();
-    // acc_lo[qt], lane (j = l15, g): key − query = 16·(w − qt) + j − 4g; the wrapped elements of q-tile 4u + k sit in acc_hi[u] at lane
-    // j'' − 3k (j'' = 13..15) and belong to key − query = 16·(w − qt) + j'' − 16 − 4g
+    for (int d = threadIdx.x; d < a.R; d += FB_NW * 64) {
+      const int dd = d - a.rel_off;                         // key − query
+      float sum = 0.f;
+      for (int w = 0; w < 14; ++w) {
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int d0 = 16 * (wave - t) + l15 - 4 * g + a.rel_off;
-      if (acc_lo[t] != 0.f && d0 >= 0 && d0 < a.R) atomicAdd(&drel_l[d0], acc_lo[t]);
-    }
-    if (l15 >= 4) {
-      const int k = (15 - l15) / 3, jj = l15 + 3 * k;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int d1 = 16 * (wave - (4 * u + k)) + jj - 16 - 4 * g + a.rel_off;
-        if (acc_hi[u] != 0.f && d1 >= 0 && d1 < a.R) atomicAdd(&drel_l[d1], acc_hi[u]);
+        for (int g = 0; g < 4; ++g) {
+          const int x = dd + 4 * g, j = x & 15;             // 16·(w − qt) + j = x
+          const int qt = w - ((x - j) >> 4);
+          if (qt >= 0 && qt < 16) sum += F[(w * 20 + qt) * 64 + g * 16 + j];
+          if (j >= 13) {                                    // the same lane index in the wrapped part: 16·(w − qt') + j − 16 = x
+            const int q2 = qt - 1;
+            if (q2 >= 0 && q2 < 16) sum += F[(w * 20 + 16 + (q2 >> 2)) * 64 + g * 16 + j - 3 * (q2 & 3)];
+          }
+        }
       }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < a.R; i += FB_NW * 64) {
-      const float v = drel_l[i];
-      if (v != 0.f) atomicAdd(a.drel + (int64_t)h * a.R + i, v);
+      if (sum != 0.f) atomicAdd(a.drel + (int64_t)h * a.R + d, sum);
     }
   }
+  FB_STAMP_AT(255, 3);
 }
 
 template <typename K>
@@ -1659,6 +1733,23 @@ inline int eblocks_per_wg(int nblocks, int64_t bh, int nw) {
   } while (0)
 
 }  // namespace
+
+#ifdef LAKO_EXPERIMENTS
+// (experiments build only) cycle stamps of enc_bwd_fused_kernel: one static device buffer, read back by tools/attn_stamps.py
+constexpr size_t FB_STAMP_BYTES = 16 * 256 * 8 * 8;
+static void* lako_exp_stamp_buffer() {
+  static void* buf = nullptr;
+  if (!buf) {
+    (void)hipMalloc(&buf, FB_STAMP_BYTES);
+    (void)hipMemset(buf, 0, FB_STAMP_BYTES);
+  }
+  return buf;
+}
+extern "C" int lako_exp_attn_stamps(void* host_dst, size_t bytes) {
+  (void)hipDeviceSynchronize();
+  return (int)hipMemcpy(host_dst, lako_exp_stamp_buffer(), bytes < FB_STAMP_BYTES ? bytes : FB_STAMP_BYTES, hipMemcpyDeviceToHost);
+}
+#endif
 
 // Shapes the fast path takes (attn.hip asks before falling back to its generic kernels).
 bool lako_attn_enc_supported(const AttnArgs& a, int dtype, int d_head) {
@@ -1756,6 +1847,9 @@ int lako_attn_enc_bwd(AttnArgs& a, hipStream_t s) {
       const int nst = (nst_env >= 4 && efb_lds(rows, 4) <= 160 * 1024) ? 4 : 3;
       const int lds = efb_lds(rows, nst);
       const dim3 grid(a.H * nslots);
+#ifdef LAKO_EXPERIMENTS
+      if (f.dbg_flags & 131072) f.scores_out = reinterpret_cast<float*>(lako_exp_stamp_buffer());
+#endif
 #define EFB(D, N)                                                                                          \
   do {                                                                                                     \
     static lako_lds_cur_t c;                                                                               \
