@@ -193,8 +193,27 @@ def cpu_baseline(args):
 
 
 def visible_gpus() -> int:
-    """Devices this process could use (torch.cuda.device_count() counts without initialising the GPU on this image)."""
-    return int(torch.cuda.device_count())
+    """Devices this process could use, counted WITHOUT creating a HIP context in this process: the KFD topology under /sys
+    (GPU nodes carry a non-zero simd_count), narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when they are set.  Only when /sys has no
+    topology (a container without it) does it fall back to torch.cuda.device_count(), which may initialise the runtime here — harmless,
+    because the ranks are always started as fresh child processes (subprocess, never exec), but then this parent holds a context meanwhile."""
+    n = None
+    try:
+        root = "/sys/class/kfd/kfd/topology/nodes"
+        n = 0
+        for d in os.listdir(root):
+            with open(os.path.join(root, d, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+    except OSError:
+        n = None
+    if not n:
+        return int(torch.cuda.device_count())
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
 
 
 def rank_launch_cmd(n: int, argv: list, port: int | None = None) -> list:
@@ -207,7 +226,7 @@ def rank_launch_cmd(n: int, argv: list, port: int | None = None) -> list:
 
 def self_launch(args, argv) -> int:
     """`python bench.py --gpus N` (N > 1) WITHOUT torchrun around it: start the N rank processes as a CHILD (subprocess, never exec; this
-    parent has not touched a GPU — device_count() does not initialise HIP), relay its stdout (rank 0's JSON line) and return its exit
+    parent counts the devices from /sys, see visible_gpus), relay its stdout (rank 0's JSON line) and return its exit
     code.  Fewer than N visible devices is an error, never a silent 1-GPU line (the reference's scaffolding for this: src/slurm.py:157-160,
     src/util.py:248-275)."""
     import subprocess
@@ -231,7 +250,7 @@ def check_world(args, env=os.environ):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=150, help="timed steps (default 150 ≈ 5.5 s of GPU work at config 2: long enough for a 5-s device-utilisation sampler to see)")
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--model", default="base")
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (run_okvqa_train.sh:25-27: 16 for base)")

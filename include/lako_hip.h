@@ -452,6 +452,35 @@ int lako_bert_embed_bwd(const int64_t* ids, const float* word, const float* pos,
                         int d, int64_t vocab, float eps, int dtype, lako_stream_t stream);
 
 
+/* ---- data-parallel communication (round 5; SURVEY.md §8 b2 / e): the gradient all-reduce of the data-parallel reader over RCCL / xGMI, for
+ * hosts that do not go through torch.distributed (which lako_amd/dist.py uses — backend "nccl" is the same RCCL).  Replaces what
+ * /root/reference gets from torch's process group: src/slurm.py:157-160 (init_process_group), src/util.py:248-275 (the reductions).
+ * One process per GPU; rank 0 makes the rendezvous id and hands its 128 bytes to the other ranks out of band (a file, a socket, MPI);
+ * every rank then calls lako_comm_init on ITS device (hipSetDevice first).  The communicator is a caller-owned handle: no process state.
+ * lako_allreduce is an in-place SUM on the caller's stream (asynchronous like every entry point here; order it against the kernels that
+ * produce / consume the buffer by using the same stream or events).  Divide by the world size in the consumer: lako_adamw_step's grad_scale.
+ * RCCL is looked up when first needed (the library already in the process, else the system's librccl.so.1); without it these return
+ * LAKO_E_UNSUPPORTED and everything else in this header still works. */
+#define LAKO_COMM_ID_BYTES 128
+typedef struct lako_comm lako_comm_t;
+int lako_comm_unique_id(uint8_t id[LAKO_COMM_ID_BYTES]);
+int lako_comm_init(lako_comm_t** comm, int rank, int world, const uint8_t id[LAKO_COMM_ID_BYTES]);
+int lako_comm_world_size(const lako_comm_t* comm);   /* as RCCL reports it; negative on error */
+int lako_allreduce(lako_comm_t* comm, void* buf, int64_t count, int dtype /* LAKO_F32 | LAKO_BF16 */, lako_stream_t stream);
+int lako_comm_destroy(lako_comm_t* comm);
+
+/* ---- caller scratch: bytes of workspace an entry point wants for the given arguments; 0 = none.  Every kernel works in
+ * the caller's buffers; the one optional scratch is lako_gemm_tn_grouped's slab reduction (its own query above, forwarded here). */
+#define LAKO_WS_GEMM_TN_GROUPED 1
+typedef struct {
+  const lako_gemm_tn_item_t* items;
+  int n_items;
+  int64_t K;
+  int in_dtype, split_k;
+  const lako_tuning_t* tuning;
+} lako_ws_gemm_tn_grouped_t;
+int64_t lako_workspace_bytes(int op, const void* args);
+
 #ifdef __cplusplus
 }
 #endif

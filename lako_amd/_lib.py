@@ -89,6 +89,14 @@ SIGNATURES = {
     "lako_gemm_tn": [vp, vp, vp, i64, i64, i64, i64, i64, i64, i32, f32, i32, vp, vp],
     "lako_gemm_tn_grouped": [C.POINTER(GemmTNItem), i32, i64, i32, i32, vp, vp, i64, vp],
     "lako_gemm_tn_grouped_workspace": [C.POINTER(GemmTNItem), i32, i64, i32, i32, vp],
+    # data-parallel communication (RCCL behind the C-ABI; the Python host itself uses torch.distributed — lako_amd/dist.py) and the
+    # workspace query of SURVEY.md §8 b2
+    "lako_comm_unique_id": [C.POINTER(C.c_uint8)],
+    "lako_comm_init": [C.POINTER(vp), i32, i32, C.POINTER(C.c_uint8)],
+    "lako_comm_world_size": [vp],
+    "lako_allreduce": [vp, vp, i64, i32, vp],
+    "lako_comm_destroy": [vp],
+    "lako_workspace_bytes": [i32, vp],
     "lako_rmsnorm_fwd": [vp, vp, vp, vp, i64, i32, f32, i32, Dropout, vp],
     "lako_rmsnorm_bwd": [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, Dropout, vp, Dropout, vp],
     "lako_embed_fwd": [vp, vp, vp, i64, i32, i64, i32, Dropout, vp],
@@ -154,7 +162,7 @@ def load(path: str | None = None):
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
-        fn.restype = C.c_int64 if name == "lako_gemm_tn_grouped_workspace" else C.c_int
+        fn.restype = C.c_int64 if name in ("lako_gemm_tn_grouped_workspace", "lako_workspace_bytes") else C.c_int
     if lib.lako_version() != ABI_VERSION:     # structs and argument lists differ between versions: a mismatch reads garbage pointers
         raise LakoError(f"{path} implements C-ABI version {lib.lako_version()}, this package binds version {ABI_VERSION} "
                         f"(include/lako_hip.h LAKO_ABI_VERSION): rebuild with lako_amd/csrc/build.sh")

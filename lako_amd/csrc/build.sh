@@ -28,7 +28,7 @@ if [ "${LAKO_ASAN:-0}" = "1" ]; then
 fi
 objs=()
 pids=()
-for f in gemm rowops attn attn_enc xattn index pq bertops bertbwd; do
+for f in gemm rowops attn attn_enc xattn index pq bertops bertbwd comm; do
   [ -f $f.hip ] || continue
   o=$f.$SFX
   if [ $FORCE = 1 ] || [ ! -f $o ] || [ $f.hip -nt $o ] || [ common.h -nt $o ] || [ attn_shared.h -nt $o ] || [ lds_image.h -nt $o ] || [ ../../include/lako_hip.h -nt $o ] || [ build.sh -nt $o ]; then
@@ -42,5 +42,5 @@ for f in gemm rowops attn attn_enc xattn index pq bertops bertbwd; do
 done
 for p in "${pids[@]:-}"; do if [ -n "$p" ]; then wait $p || { echo "COMPILE FAILED"; exit 1; }; fi; done
 # link WITHOUT an rpath to /opt/rocm: the library must bind to the HIP runtime torch already loaded
-$HIPCC --offload-arch=gfx950 -shared -fPIC $LINKFLAGS -o $OUT "${objs[@]}"
+$HIPCC --offload-arch=gfx950 -shared -fPIC $LINKFLAGS -o $OUT "${objs[@]}" -ldl
 echo "built $(realpath $OUT) (${#pids[@]} source(s) compiled)"

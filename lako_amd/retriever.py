@@ -246,7 +246,7 @@ class Retriever(nn.Module):
             from safetensors.torch import load_file
             sd = load_file(st)
         else:
-            sd = torch.load(os.path.join(path, "pytorch_model.bin"), map_location="cpu")
+            sd = torch.load(os.path.join(path, "pytorch_model.bin"), map_location="cpu", weights_only=True)      # a state dict: tensors only
         model.load_state_dict(sd)
         return model
 

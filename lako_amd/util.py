@@ -236,9 +236,13 @@ def load(model_class, dir_path, opt, reset_params=False, **model_kw):
     if device is not None and torch.device(device).type == "cuda":
         model = model.to(device)
     logger.info("loading checkpoint %s", optimizer_path)
-    # (the reference's format: `opt` is the pickled argparse Namespace, src/util.py:113-118 — a checkpoint directory is as trusted
-    # as the code that reads it, exactly as with the reference; the model weights themselves are safetensors)
-    checkpoint = torch.load(optimizer_path, map_location="cpu", weights_only=False)
+    # (the reference's format: `opt` is the pickled argparse Namespace, src/util.py:113-118.  Round 5: the file is read with
+    # weights_only=True — tensors, containers and plain numbers, plus the two allow-listed attribute bags an `opt` can be (argparse.Namespace,
+    # types.SimpleNamespace); anything else in the pickle is refused instead of executed)
+    import argparse
+    import types
+    with torch.serialization.safe_globals([argparse.Namespace, types.SimpleNamespace]):
+        checkpoint = torch.load(optimizer_path, map_location="cpu", weights_only=True)
     opt_checkpoint = checkpoint["opt"]
     step = checkpoint["step"]
     best_eval_metric = checkpoint["best_eval_metric"] if "best_eval_metric" in checkpoint else checkpoint["best_dev_em"]

@@ -108,6 +108,28 @@ def test_bad_arguments_return_error_codes(lib):
     assert L.lako_layernorm_bwd(x, x, None, None, x, x, x, x, None, 16, 2000, 1e-5, 1, None) == -1   # d > the kernel's register budget
 
 
+def test_comm_and_workspace_entry_points_validate_their_arguments(lib):
+    """(round 5) lako_comm_* / lako_allreduce / lako_workspace_bytes exist behind the C-ABI; on a host without a GPU only
+    their argument validation runs: null handles and bad ranks are LAKO_E_BADARG (-1), an op without scratch wants 0 bytes."""
+    lib.lako_workspace_bytes.restype = ctypes.c_int64
+    lib.lako_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_void_p]
+    assert lib.lako_workspace_bytes(0, None) == 0 and lib.lako_workspace_bytes(12345, None) == 0
+    assert lib.lako_workspace_bytes(1, None) == -1                      # LAKO_WS_GEMM_TN_GROUPED without its arguments
+    lib.lako_comm_init.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    h = ctypes.c_void_p()
+    idb = (ctypes.c_uint8 * 128)()
+    assert lib.lako_comm_init(None, 0, 1, idb) == -1
+    assert lib.lako_comm_init(ctypes.byref(h), 0, 1, None) == -1
+    assert lib.lako_comm_init(ctypes.byref(h), 2, 2, idb) == -1 and lib.lako_comm_init(ctypes.byref(h), 0, 0, idb) == -1 and not h.value
+    lib.lako_allreduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+    assert lib.lako_allreduce(None, None, 4, 0, None) == -1
+    lib.lako_comm_destroy.argtypes = [ctypes.c_void_p]
+    assert lib.lako_comm_destroy(None) == 0                             # destroying nothing is fine
+    lib.lako_comm_world_size.argtypes = [ctypes.c_void_p]
+    assert lib.lako_comm_world_size(None) == -1
+    assert lib.lako_comm_unique_id(None) == -1
+
+
 def test_product_fails_loudly_without_library(monkeypatch, tmp_path):
     from lako_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)

@@ -7,6 +7,7 @@ import json
 import os
 import types
 
+import pytest
 import torch
 
 from lako_amd import FiDT5
@@ -106,6 +107,26 @@ def test_save_load_resume_is_exact(tmp_path):
     m3, o3, s3, _, step3, best3 = U.load(FiDT5, str(ck / "step-2"), _opt(), reset_params=True, dtype=torch.float32,
                                          _ops=RefOps())
     assert step3 == 2 and s3.last_epoch == 0 and m3._get_engine().opt_m is None
+
+
+class _Evil:
+    def __reduce__(self):                       # what an attacker's pickle would run on load
+        return (os.system, ("true",))
+
+
+def test_load_refuses_a_checkpoint_that_carries_code(tmp_path):
+    """(round 5) optimizer.pth.tar is read with torch.load(weights_only=True) + an allow-list of the two attribute-bag classes an `opt` can
+    be: a pickle that names any other global — here os.system through __reduce__ — is refused, not executed."""
+    import pickle
+    _, _, _, model = build("tiny_a")
+    optimizer, scheduler = U.set_optim(_opt(), model)
+    U.save(model, optimizer, scheduler, 7, 0.1, _opt(), str(tmp_path), "bad")
+    fp = tmp_path / "checkpoint" / "bad" / "optimizer.pth.tar"
+    ck = torch.load(fp, weights_only=False)
+    ck["opt"] = _Evil()
+    torch.save(ck, fp)
+    with pytest.raises(pickle.UnpicklingError):
+        U.load(FiDT5, str(tmp_path / "checkpoint" / "bad"), _opt(), dtype=torch.float32, _ops=RefOps())
 
 
 def test_load_accepts_legacy_metric_key(tmp_path):

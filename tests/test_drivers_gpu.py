@@ -51,6 +51,77 @@ def test_rccl_gradient_path_in_child_process(mode):
     assert abs(out["config"]["final_mean_loss"] - out2["config"]["final_mean_loss"]) < 2e-3
 
 
+_COMM_CHILD = r"""
+import ctypes as C, sys, torch
+sys.path.insert(0, {root!r})
+from lako_amd import _lib
+lib = _lib.load()
+torch.cuda.set_device(0)
+idb = (C.c_uint8 * 128)()
+assert lib.lako_comm_unique_id(idb) == 0
+h = C.c_void_p()
+assert lib.lako_comm_init(C.byref(h), 0, 1, idb) == 0 and h.value
+assert lib.lako_comm_world_size(h) == 1
+s = torch.cuda.Stream()
+for dt, code in ((torch.float32, 0), (torch.bfloat16, 1)):
+    g = torch.randn(1 << 20, device="cuda").to(dt)
+    want = g.clone()
+    with torch.cuda.stream(s):
+        s.wait_stream(torch.cuda.current_stream())
+        assert lib.lako_allreduce(h, C.c_void_p(g.data_ptr()), g.numel(), code, C.c_void_p(s.cuda_stream)) == 0
+    s.synchronize()
+    assert torch.equal(g, want), dt                 # SUM over one rank: the identity, in place
+assert lib.lako_allreduce(h, C.c_void_p(g.data_ptr()), g.numel(), 2, None) == -1       # fp8 gradients are not a transport
+assert lib.lako_comm_destroy(h) == 0
+print("comm ok")
+"""
+
+
+def test_comm_c_abi_world_of_one_in_child_process():
+    """(round 5) lako_comm_unique_id → lako_comm_init → lako_allreduce (fp32 and bf16, in place, on the caller's stream)
+    → lako_comm_destroy through the C-ABI alone, RCCL resolved at run time: over one rank the SUM is the identity.  A fresh process, as for
+    the torch.distributed path above."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", _COMM_CHILD.format(root=ROOT)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "comm ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_training_step_issues_no_host_sync_when_the_collator_hands_over_lengths():
+    """(round 5; SURVEY.md §5.8 names host-side launch jitter as the data-parallel risk) With the collator's host-side passage lengths the
+    whole step — forward, backward, clip, optimizer — must be pure enqueueing: no device→host read-back, no synchronise.  torch's sync
+    debug mode turns any synchronising torch call into an error; the library itself never synchronises (include/lako_hip.h).  The
+    reference's bare call (no lengths: one read-back of the mask per new batch) is the documented exception and is not exercised here."""
+    import bench
+    cfg = FiDConfig.named("small", dropout_rate=0.1)
+    model = FiDT5(cfg, dtype=torch.bfloat16).cuda().train()
+    opt = types.SimpleNamespace(lr=1e-4, optim="adamw", scheduler="linear", weight_decay=0.01, warmup_steps=2, total_steps=10,
+                                scheduler_steps=None, fixed_lr=False)
+    optimizer, scheduler = U.set_optim(opt, model)
+    batches = [bench.synthetic_batch(2, 4, 64, 6, cfg.vocab_size, seed=90 + i, device="cuda", with_lengths=True) for i in range(3)]
+
+    def step(i):
+        ids, mask, labels, lens = batches[i]
+        loss = model(input_ids=ids, attention_mask=mask, labels=labels, passage_lengths=lens)[0]
+        loss.backward()
+        U.clip_grad_norm_(model, 1.0)
+        optimizer.step()
+        scheduler.step()
+        model.zero_grad()
+        return loss
+
+    step(0)                                      # first call: allocations, workspace sizing, LDS attributes
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        losses = [step(1), step(2)]
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    assert all(bool(torch.isfinite(x)) for x in losses)
+
+
 def _examples(n=6):
     rng = np.random.RandomState(3)
     words = "red blue dog cat rain tennis racket sofa street sign man woman ball tree car bus".split()
