@@ -1246,6 +1246,7 @@ __global__ __launch_bounds__(FB_NW * 64) void enc_bwd_fused_kernel(AttnArgs a) {
   int itn = 0;                                      // (stamps only) iterations so far
   FB_STAMP_AT(255, 0);
   estage_bias<FB_NW * 64>(b4, a.rel_bias, h, a.R, true);
+  for (int i = threadIdx.x * 16; i < 2 * R * 64; i += FB_NW * 64 * 16) *reinterpret_cast<u32x4*>(dST0 + i) = u32x4{0u, 0u, 0u, 0u};     // (P2 reads every row of a slab)
   const int KB = (a.Lk + 3) >> 2, QB = (a.Lq + 3) >> 2;
   const float dscale = DROP ? a.drop_scale : 1.0f, inv_dscale = 1.0f / dscale;
   const int nmine = (a.Bn - slot0 + nslots - 1) / nslots;         // items of this workgroup (empty ones included)
@@ -1317,7 +1318,7 @@ __global__ __launch_bounds__(FB_NW * 64) void enc_bwd_fused_kernel(AttnArgs a) {
     constexpr int PIECES0 = 8, PIECES1 = 5;
     auto issue_kimg = [&](const FbItem& it, int j) {                  // K image of item j, all pieces by the calling wave
       const uint32_t kstb = (uint32_t)a.kst * 2u;
-      estage_dma<1>(Kimg0 + (j & 1) * R * EROW, a.k + h * 128 + (int64_t)it.k0 * kstb, kstb, ((it.Lk + 31) >> 5) << 5, it.Lk, 0, lane);
+      estage_dma<1>(Kimg0 + (j & 1) * R * EROW, a.k + h * 128 + (int64_t)it.k0 * kstb, kstb, R, it.Lk, 0, lane);     // all R rows: zeros past the sequence's end (P2)
     };
     // ---- δ and the row constants of a stage that has landed: 32 queries, 2 lanes per query
     auto cstage = [&](const FbStage& st, int slot) {
@@ -1345,26 +1346,31 @@ __global__ __launch_bounds__(FB_NW * 64) void enc_bwd_fused_kernel(AttnArgs a) {
       }
     };
     // ---- P2: dQᵀ[d-blocks 2·part, 2·part + 1 × both q-tiles] of a stage whose dS slab is dS[par]: the two waves share the key range and split
-    // the d-blocks, so each K fragment (A) and each dS fragment (B) is read once per wave and used twice: 8 transposed reads per 4 MFMAs
+    // the d-blocks, so each K fragment (A) and each dS fragment (B) is read once per wave and used twice: 8 transposed reads per 4 MFMAs.
+    // The key steps are fully unrolled over ALL R / 32 steps of the image (the K image is staged whole — rows past the sequence's end are
+    // zeros — and the dS slabs start as zeros, so the steps past an item's keys add exact zeros): in straight-line code hipcc's wait counts
+    // are exact and the fragments of step k + 1 really are in flight under the MFMAs of step k (in a loop it waits lgkmcnt(0) before every
+    // step's MFMAs — the stamps showed 2 700 cycles per call for 28 MFMAs).  Addresses are 32-bit LDS offsets: xor on a generic pointer makes
+    // hipcc re-derive the LDS address with a null check per read.
     auto p2 = [&](const FbStage& st, int par) {
       int le = lane;
       asm volatile("" : "+v"(le));
       const int trr = 4 * (le >> 4) + ((le & 15) >> 2), trp = le & 3;
-      const char* ap = Kimg0 + st.kpar * R * EROW + (trr * EROW + ((((trr >> 1) & 3) ^ (2 * part)) << 5) + trp * 8);     // d-block 2·part (the next: ^ 32)
-      const char* bp = dST0 + par * R * 64 + fb_ds_off(trr, 0, trp);                                                      // q-tile 0 (q-tile 1: ^ 32)
-      const int nkp = (st.Lk + 31) >> 5;
+      const uint32_t Ka = (uint32_t)(uintptr_t)LDS_PTR(Kimg0) + (uint32_t)(st.kpar * R * EROW + trr * EROW + ((((trr >> 1) & 3) ^ (2 * part)) << 5) + trp * 8);
+      const uint32_t Da = (uint32_t)(uintptr_t)LDS_PTR(dST0) + (uint32_t)(par * R * 64) + fb_ds_off(trr, 0, trp);
+      const uint32_t Kx = Ka ^ 32u, Dx = Da ^ 32u;                    // the next d-block / q-tile 1
       f32x4 acc[2][2];                                                 // [d-block][q-tile]
 #pragma unroll
       for (int x = 0; x < 4; ++x) acc[x >> 1][x & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
-      auto trd = [](const char* p) { return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p))); };
-      auto x32 = [](const char* p) { return reinterpret_cast<const char*>(reinterpret_cast<uintptr_t>(p) ^ (uintptr_t)32); };
-      // the fragments of key step kk + 1 are requested before the MFMAs of step kk
+      auto trd = [](uint32_t off) {
+        return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uintptr_t)off));
+      };
       struct Frag { u32x2 a0[2], a1[2], b0[2], b1[2]; };
-      auto fetch = [&](Frag& f, const char* ap_, const char* bp_) {
-        f.a0[0] = trd(ap_);      f.a1[0] = trd(ap_ + 16 * EROW);
-        f.a0[1] = trd(x32(ap_)); f.a1[1] = trd(x32(ap_) + 16 * EROW);
-        f.b0[0] = trd(bp_);      f.b1[0] = trd(bp_ + 16 * 64);
-        f.b0[1] = trd(x32(bp_)); f.b1[1] = trd(x32(bp_) + 16 * 64);
+      auto fetch = [&](Frag& f, int kk) {
+        f.a0[0] = trd(Ka + kk * 32 * EROW); f.a1[0] = trd(Ka + kk * 32 * EROW + 16 * EROW);
+        f.a0[1] = trd(Kx + kk * 32 * EROW); f.a1[1] = trd(Kx + kk * 32 * EROW + 16 * EROW);
+        f.b0[0] = trd(Da + kk * 32 * 64);   f.b1[0] = trd(Da + kk * 32 * 64 + 16 * 64);
+        f.b0[1] = trd(Dx + kk * 32 * 64);   f.b1[1] = trd(Dx + kk * 32 * 64 + 16 * 64);
       };
       auto mma = [&](const Frag& f) {
 #pragma unroll
@@ -1373,15 +1379,24 @@ __global__ __launch_bounds__(FB_NW * 64) void enc_bwd_fused_kernel(AttnArgs a) {
           for (int q = 0; q < 2; ++q)
             acc[d][q] = emma(u32x4{f.a0[d][0], f.a0[d][1], f.a1[d][0], f.a1[d][1]}, u32x4{f.b0[q][0], f.b0[q][1], f.b1[q][0], f.b1[q][1]}, acc[d][q]);
       };
-      Frag f0, f1;
-      fetch(f0, ap, bp);
-      for (int kk = 0; kk < nkp; kk += 2) {
-        if (kk + 1 < nkp) fetch(f1, ap + (kk + 1) * 32 * EROW, bp + (kk + 1) * 32 * 64);
-        mma(f0);
-        if (kk + 1 < nkp) {
-          if (kk + 2 < nkp) fetch(f0, ap + (kk + 2) * 32 * EROW, bp + (kk + 2) * 32 * 64);
-          mma(f1);
-        }
+      auto run = [&](auto NKc) {
+        constexpr int NK = decltype(NKc)::value;
+        Frag f[2];
+        fetch(f[0], 0);
+        static_for<NK>([&](auto Kc) {
+          constexpr int k = decltype(Kc)::value;
+          if constexpr (k + 1 < NK) fetch(f[(k + 1) & 1], k + 1);
+          mma(f[k & 1]);
+        });
+      };
+      switch (R >> 5) {
+        case 1: run(std::integral_constant<int, 1>{}); break;
+        case 2: run(std::integral_constant<int, 2>{}); break;
+        case 3: run(std::integral_constant<int, 3>{}); break;
+        case 4: run(std::integral_constant<int, 4>{}); break;
+        case 5: run(std::integral_constant<int, 5>{}); break;
+        case 6: run(std::integral_constant<int, 6>{}); break;
+        default: run(std::integral_constant<int, 7>{}); break;
       }
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
@@ -1408,11 +1423,12 @@ __global__ __launch_bounds__(FB_NW * 64) void enc_bwd_fused_kernel(AttnArgs a) {
       __syncthreads();
       if (wave == 15) cstage(stage_dec(stage_raw(0)), 0);
       // the stage stream: iteration n = P1 of stage n (the other waves), P2 of stage n − 1, δ of stage n + 1, DMA of stage n + NST − 1
-      bool issued = false, newitem = true;
+      bool issued = false;
       for (int n = 0; n <= nstage; ++n) {
-        // the pieces issued in the previous iteration (the wave's newest operations) may stay in flight with a ring of 4; wave 15 at a new item:
-        // its K image (issued during the previous item) must have landed
-        if (NST >= 4 && issued && !(wave == 15 && newitem)) {
+        // the pieces issued in the previous iteration (the wave's newest operations) may stay in flight with a ring of 4.  (The next item's K
+        // image needs no wait of its own: wave 15 issues it BEFORE the ring pieces of that iteration, so the counted wait of the following
+        // iteration already covers it — a vmcnt(0) at every new item made wave 15 wait for ring pieces it had just issued: ≈ 2 000 cycles per item.)
+        if (NST >= 4 && issued) {
           if (wave == 14) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES0) : "memory");
           else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES1) : "memory");
         } else {
@@ -1431,8 +1447,6 @@ __global__ __launch_bounds__(FB_NW * 64) void enc_bwd_fused_kernel(AttnArgs a) {
         {
           // the next item's K image when P1 is at slab 1 of an item: the buffer's last reader was P2 of the item before, one iteration ago
           // (issued before the ring pieces: the wave's newest operations stay the ring's)
-          const FbStage s1 = stage_dec(r1);                            // stage n + 1 — a first slab there means P1 starts a new item next
-          newitem = n + 1 < nstage && s1.s == 0;
           if (wave == 15 && n < nstage) {
             const FbStage s0 = stage_dec(stage_raw(n));
             if (s0.s == 1 && s0.j + 1 < nit) issue_kimg(item(s0.j + 1), s0.j + 1);

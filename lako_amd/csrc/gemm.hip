@@ -44,6 +44,16 @@
 #ifndef LAKO_LOAD_AUX
 #define LAKO_LOAD_AUX 0
 #endif
+#ifndef LAKO_NT_SPREAD
+// 1 (default, round 5): the K-slice DMA of the PLAIN 256² / 288-row kernels is dealt out one piece per row of K-half 0's MFMAs instead of a
+// burst of eight per wave.  The stamps of one workgroup (tools/gemm_stamps.py, profiles/r05c_gemm_stamps.txt) show a wave spending ≈ 1 300 of a
+// K-step's ≈ 3 900 cycles issuing its eight pieces back to back — the vector-memory queue is full, the wave's MFMAs wait behind the
+// issue — and the early half of the waves then ≈ 830 cycles at the barrier for the late half.  Same-box A/B of two builds
+// (tools/gemm_lib_ab.sh, profiles/r05c_gemm_spread_dma.txt): QKV 193 → 186 µs, dX of QKV 155 → 150, dX of FFN 200 → 195, 8192³ 870 → 860;
+// the step 37.16 → 36.90 ms.  0: the staggered bursts of rounds 1 – 4.  2: also in the side-operand kernels — measured SLOWER there
+// (dpre 278 → 286 µs: the side pass's counted waits want the pieces together) and not correct yet; A/B only.
+#define LAKO_NT_SPREAD 1
+#endif
 #ifdef LAKO_EXPERIMENTS
 #define NT_DBG(a, bits) ((a).debug & (bits))
 #else
@@ -55,6 +65,14 @@ namespace {
 constexpr int TM = 128, TN_ = 128, TKB = 128;  // TN-kernel tile rows / cols; K bytes per step (both kernels)
 constexpr int TILE_BYTES = TM * TKB;            // 16 KiB per operand per buffer
 constexpr int GEMM_LDS = 4 * TILE_BYTES;        // A,B × 2 buffers (TN kernel)
+
+// (experiments build, gemm_nt_debug bit 6) s_memtime stamps of workgroup 0 of the 256² / 288-row kernel: [wave][K-step < 128][point < 8] in
+// the buffer the (unused, non-QUEUE) queue pointer carries — tools/gemm_stamps.py reads it back
+#define NT_STAMP(P)                                                                                                              \
+  do {                                                                                                                           \
+    if (NT_DBG(a, 64) && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && kst < 128)                                               \
+      reinterpret_cast<unsigned long long*>(a.queue)[((threadIdx.x >> 6) * 128 + kst) * 8 + (P)] = __builtin_amdgcn_s_memtime();   \
+  } while (0)
 
 struct NtArgs {
   const char* A;
@@ -84,6 +102,18 @@ struct NtArgs {
   float* norm_rs;        // optional fp32 [M]: rstd
   int* queue;     // QUEUE instantiation: [0..7] per-XCD tile tickets, [8] workgroups finished (all zero between launches)
 };
+
+#ifdef LAKO_EXPERIMENTS
+constexpr size_t NT_STAMP_BYTES = 8 * 128 * 8 * 8;
+static void* lako_exp_nt_stamp_buffer() {
+  static void* buf = nullptr;
+  if (!buf) {
+    (void)hipMalloc(&buf, NT_STAMP_BYTES);
+    (void)hipMemset(buf, 0, NT_STAMP_BYTES);
+  }
+  return buf;
+}
+#endif
 
 // bijective XCD-aware remap (blocks b and b+8 share an XCD): give each XCD a contiguous id range
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -387,6 +417,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
     }
   };
 
+  int kst = 0;      // (stamps only) K-steps so far, over all tiles of the workgroup
   while (true) {
     int next_tile = tile + gridDim.x;
     bool has_next = next_tile < nwg;
@@ -551,7 +582,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
       if (!late) bar();                      // the two halves of the workgroup are in step again
       fence();
     } else
-    for (int t = 0; t < nk; ++t) {
+    for (int t = 0; t < nk; ++t, ++kst) {
+      NT_STAMP(0);
       const char* As = smem + cur * BUF;
       const char* Bs = As + A_BYTES;
       char* An = smem + (cur ^ 1) * BUF;
@@ -618,8 +650,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
       // DMA placement: STAGGER — waves w and w + NW/2 share a SIMD; the first half issues its burst before the
       // K-step's fragment reads, the second half after the first MT/4 rows of MFMAs.  (Dealing the pieces out one per
       // row of MFMAs instead measured equal to 3 % slower: the L2→LDS path, not the issue slot, is the limit.)
-      const bool late = a.stagger && NW == 8 && wave >= NW / 2;
-      if (!late) prefetch();
+      // stagger 2 (round 5 A/B): no burst at all — ONE piece after every row of K-half 0's MFMAs (8 / 9 pieces over its 8 / 9 rows): the
+      // stamps show ≈ 1 300 cycles of a 3 900-cycle K-step spent issuing a wave's eight pieces back to back (profiles/r05c_gemm_stamps.txt)
+      constexpr bool spread = LAKO_NT_SPREAD == 1 ? !SIDE : LAKO_NT_SPREAD == 2;      // a BUILD-time constant (1: plain kernels, 2: all): as a run-time branch the two copies of the MFMA rows
+                                                                // make the accumulators meet at a control-flow merge — 244-341 VGPRs of spills
+      const bool late = a.stagger == 1 && NW == 8 && wave >= NW / 2;
+      if (!late && !spread) prefetch();
+      NT_STAMP(1);
       // (288-row tile with a side operand: 256 registers — the lane parts of the fragment addresses are rebuilt per K-step; kept across the
       //  loop one of them is spilled and its reload sits, with a vmcnt(0), between the DMA issue and the fragment reads)
       int r16k = r16, gk = g;
@@ -652,6 +689,22 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
         };
         constexpr int Q = LAKO_NT_WAIT_Q > 0 ? LAKO_NT_WAIT_Q : MT / 4;
         if (kh == 0) {
+          if constexpr (spread) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            mma_rows(mt, mt + 1);
+            if (mt < PA + PB) {
+              __builtin_amdgcn_sched_barrier(0);
+              piece(mt);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+          if (SIDE && t == 0) {   // pass 0 of the side operand behind this step's K-slice pieces (the counted wait below assumes that order)
+            __builtin_amdgcn_sched_barrier(0);
+            side_issue(0, smem + 2 * BUF + wave * SLOT, m0, n0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          } else {
           mma_rows(0, Q);
           if (late) {
             __builtin_amdgcn_sched_barrier(0);
@@ -664,17 +717,23 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
             __builtin_amdgcn_sched_barrier(0);
           }
           mma_rows(Q, MT);
+          }
+          if (NT_DBG(a, 64)) { asm volatile("" :: "v"(acc[0][MT - 1])); NT_STAMP(2); }
         } else {
           // the wait for the next K-slice and the barrier sit Q rows of MFMAs before the end of the step: late enough
           // that the DMA had the step to land (the scheduler would hoist them to the top of this K-half), early
           // enough that the barrier round trip is covered by MFMAs already queued
           mma_rows(0, MT - Q);
           __builtin_amdgcn_sched_barrier(0);
+          if (NT_DBG(a, 64)) { asm volatile("" :: "v"(acc[0][MT - Q - 1])); NT_STAMP(3); }
           if (SIDE && t == 0 && nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SP) : "memory");   // the side pass may land during the next K-step
           else if (!NT_DBG(a, 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          NT_STAMP(4);
           __syncthreads();
+          NT_STAMP(5);
           __builtin_amdgcn_sched_barrier(0);
           mma_rows(MT - Q, MT);
+          if (NT_DBG(a, 64)) { asm volatile("" :: "v"(acc[0][MT - 1])); NT_STAMP(6); }
         }
       }
       cur ^= 1;
@@ -2034,6 +2093,9 @@ void launch_nt_cfg(NtArgs a, const lako_tuning_t& tu, hipStream_t s) {
     }
   } else {
     a.queue = nullptr;
+#ifdef LAKO_EXPERIMENTS
+    if (tu.nt_debug & 64) a.queue = reinterpret_cast<int*>(lako_exp_nt_stamp_buffer());
+#endif
   }
   hipLaunchKernelGGL((gemm_nt_kernel<T, TO, WM, WN, MT, NT, SIDE, QUEUE, PP>), dim3(grid), dim3(WM * WN * 64), LDS, s, a);
 }
@@ -2666,3 +2728,11 @@ extern "C" int lako_tuning_init(lako_tuning_t* t) {
 }
 
 extern "C" int lako_tuning_set(lako_tuning_t* t, const char* key, int value) { return tuning_set(t, key, value); }
+
+#ifdef LAKO_EXPERIMENTS
+// (experiments build only) the stamps of gemm_nt_debug bit 6, for tools/gemm_stamps.py
+extern "C" int lako_exp_nt_stamps(void* host_dst, size_t bytes) {
+  (void)hipDeviceSynchronize();
+  return (int)hipMemcpy(host_dst, lako_exp_nt_stamp_buffer(), bytes < NT_STAMP_BYTES ? bytes : NT_STAMP_BYTES, hipMemcpyDeviceToHost);
+}
+#endif

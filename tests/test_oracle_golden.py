@@ -125,3 +125,21 @@ def test_per_sample_oracle_evaluation_equals_batch():
     torch.testing.assert_close(logits_s, logits.detach(), atol=1e-5, rtol=1e-5)
     for k, v in leaves.items():
         torch.testing.assert_close(grads_s[k], v.grad, atol=1e-6, rtol=1e-4, msg=lambda m, k=k: f"{k}: {m}")
+
+
+def test_generate_fixture_is_the_oracles_decode():
+    """tests/golden/gen_d512.npz (oracle/make_generate_fixture.py): the expected tokens of the bf16 decode test ARE the oracle's fp32 greedy
+    decode of the committed (bf16-representable) weights, and that decode reproduces the training answers — the GPU test compares the HIP
+    path with these tokens without running the oracle again."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gen_d512.npz"))
+    names = ("vocab_size", "d_model", "d_kv", "d_ff", "num_layers", "num_decoder_layers", "num_heads")
+    dims = O.T5Dims(dropout=0.0, **{k: int(v) for k, v in zip(names, z["dims"])})
+    w = {k[2:]: torch.from_numpy(z[k]).view(torch.bfloat16).float() for k in z.files if k.startswith("w.")}
+    ids, mask, labels = (torch.from_numpy(z[k]) for k in ("ids", "mask", "labels"))
+    tok = O.fid_generate(w, dims, ids, mask, int(z["max_length"]))
+    assert tok.tolist() == z["tokens"].tolist()
+    for b in range(ids.shape[0]):
+        n = int((labels[b] != -100).sum())
+        assert tok[b, 1:1 + n].tolist() == labels[b, :n].tolist()
+    assert float(z["min_gap"]) > 1.0

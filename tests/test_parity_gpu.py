@@ -410,57 +410,25 @@ def test_generate_graph_replay_equals_eager(dtype, monkeypatch):
 @pytest.mark.gpu
 def test_bf16_generate_encoder_space_decode_vs_oracle_tokens():
     """Greedy decode in bf16 on the DEFAULT decode path — HIP graphs, cross-attention in the encoder-state space, the one-pass
-    `xdecode_kernel` + combine (src/model.py:54-60, train_reader.py:142-146) — against the oracle's tokens on the same weights.
-    T5-small shapes (d_model 512, 8 heads: the smallest model the decode kernel takes), 10 passages x 200 tokens = up to 2 000
-    keys per sample, i.e. every sample spans all 64 key ranges of the decode kernel.  A random-init model's argmax margins are
-    within bf16 noise, so the weights are first trained on the batch (on the HIP path) until the answers are reproduced with
-    wide margins — the `tiny_eos` recipe of oracle/make_fixtures.py at a size the decode kernel accepts; the ORACLE then decodes
-    those weights in fp32 on the CPU and the bf16 HIP path must emit the same tokens, ragged EOS rows included."""
-    cfg = FiDConfig.named("small", dropout_rate=0.0)
-    dims = O.T5Dims.named("small")
-    dims.dropout = 0.0
-    B, N, L, T, ML = 4, 10, 200, 6, 9
-    ids_c, mask_c, labels_c = O.synthetic_batch(B, N, L, T, cfg.vocab_size, seed=91)
-    ids, mask, labels = dev(ids_c, mask_c, labels_c)
-    opt = types.SimpleNamespace(optim="adamw", lr=1e-3, weight_decay=0.0, scheduler="fixed", fixed_lr=True,
-                                scheduler_steps=None, total_steps=4000, warmup_steps=0)
-    # The fit usually takes 100-200 steps, but a run can settle on a plateau (observed once: loss 0.37 after 600 steps — the fp32
-    # atomics of the weight gradients make trajectories differ from run to run); the test is about DECODING trained weights, so a
-    # stalled fit is restarted from another initialisation instead of failing the comparison that follows.
-    last, tried = None, []
-    for attempt in range(4):
-        torch.manual_seed(attempt)
-        m = FiDT5(cfg, dtype=torch.bfloat16, seed=1 + attempt)   # (embeddings at their N(0, 1) init: with the 0.05 scale of the throughput
-        m = m.cuda().train()                                     #  runs the passages hardly tell the samples apart and the loss stalls near 0.5)
-        optimizer, scheduler = U.set_optim(opt, m)
-        for k in range(600):           # (the oracle on the CPU reaches 1.5e-3 after 50 such steps at 2 x 32-token passages)
-            loss = m(input_ids=ids, attention_mask=mask, labels=labels)[0]
-            loss.backward()
-            U.clip_grad_norm_(m, 1.0)
-            optimizer.step()
-            scheduler.step()
-            m.zero_grad()
-            if k % 20 == 19:
-                last = loss.item()
-                if last < 0.005:
-                    break
-        tried.append(last)
-        if last >= 0.05:
-            continue
-        # the ORACLE (fp32, free-running greedy decode of the trained fp32 master weights) must reproduce the training answers — then the
-        # comparison below is about trained margins, not about noise.  A fit whose teacher-forced bf16 loss is small can still leave one
-        # token of the free-running fp32 decode on a thin margin (seen once in round 4: loss < 0.05, first token off): such a fit is
-        # a bad FIXTURE, not a decode error — take the next initialisation instead of failing
-        w = {plain_name(n): p.detach().float().cpu().clone() for n, p in m.named_parameters()}
-        want = O.fid_generate(w, dims, ids_c, mask_c, ML)
-        ok = all(want[b, 1:1 + int((labels_c[b] != -100).sum())].tolist() == labels_c[b, :int((labels_c[b] != -100).sum())].tolist()
-                 for b in range(B))
-        tried[-1] = (last, "oracle reproduces the answers" if ok else "oracle decode differs from the answers")
-        if ok:
-            break
-    else:
-        pytest.fail(f"no usable fixture in 4 fits: {tried}")
-    m.eval()
+    `xdecode_kernel` + combine (src/model.py:54-60, train_reader.py:142-146) — against the ORACLE's tokens on the same weights.
+    The fixture (tests/golden/gen_d512.npz, made by oracle/make_generate_fixture.py on a GPU box; round 4 trained it inside this test with up
+    to four restarts) is a reader at the smallest dimensions the decode kernel takes — d_model 512, 8 heads, 1 + 2 layers — trained on one
+    batch of 4 samples x 10 passages x 200 tokens (up to 2 000 keys per sample: every sample spans all key ranges of the decode kernel) until
+    the answers are reproduced with a top-1 / top-2 logit gap of 6.4, far above bf16 noise; its weights are bf16-representable, so the HIP
+    path and the oracle compute on the same numbers.  The oracle's fp32 decode of those weights is pinned on the CPU
+    (tests/test_oracle_golden.py::test_generate_fixture_is_the_oracles_decode); here the bf16 HIP path must emit the same tokens, ragged EOS rows
+    included."""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gen_d512.npz"))
+    names = ("vocab_size", "d_model", "d_kv", "d_ff", "num_layers", "num_decoder_layers", "num_heads")
+    cfg = FiDConfig(dropout_rate=0.0, **{k: int(v) for k, v in zip(names, z["dims"])})
+    w = {k[2:]: torch.from_numpy(z[k]).view(torch.bfloat16).float() for k in z.files if k.startswith("w.")}
+    ids_c, mask_c = torch.from_numpy(z["ids"]), torch.from_numpy(z["mask"])
+    want, ML = torch.from_numpy(z["tokens"]), int(z["max_length"])
+    B, N, L = ids_c.shape
+    m = FiDT5(cfg, dtype=torch.bfloat16)
+    m.load_t5(w)
+    m = m.cuda().eval()
+    ids, mask = dev(ids_c, mask_c)
     for rnd in range(3):                                    # eager warm-up of the mode, graph capture, pure replay
         got = m.generate(input_ids=ids, attention_mask=mask, max_length=ML)
         assert got.cpu().tolist() == want.tolist(), (rnd, got.cpu().tolist(), want.tolist())
