@@ -44,6 +44,13 @@
 #ifndef LAKO_LOAD_AUX
 #define LAKO_LOAD_AUX 0
 #endif
+#ifndef LAKO_NT_ROLL
+#define LAKO_NT_ROLL 0        // 1: rolling A fragments in the plain bf16 256² / 288-row kernels (see the K loop); A/B build
+#endif
+#ifndef LAKO_TN_SPREAD
+#define LAKO_TN_SPREAD 0      // the same for the 256² weight-gradient kernel: measured SLOWER (7.14 -> 7.65 ms per step, two alternations on one box,
+                              // profiles/r05c_gemm_spread_dma.txt) — its K loop is 747 steps deep and already runs at 0.47 of peak; A/B build only
+#endif
 #ifndef LAKO_NT_SPREAD
 // 1 (default, round 5): the K-slice DMA of the PLAIN 256² / 288-row kernels is dealt out one piece per row of K-half 0's MFMAs instead of a
 // burst of eight per wave.  The stamps of one workgroup (tools/gemm_stamps.py, profiles/r05c_gemm_stamps.txt) show a wave spending ≈ 1 300 of a
@@ -61,6 +68,15 @@
 #endif
 
 namespace {
+
+// f(integral_constant<int, 0>) … f(integral_constant<int, N-1>): a compile-time-indexed unrolled loop
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
 
 constexpr int TM = 128, TN_ = 128, TKB = 128;  // TN-kernel tile rows / cols; K bytes per step (both kernels)
 constexpr int TILE_BYTES = TM * TKB;            // 16 KiB per operand per buffer
@@ -665,6 +681,55 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
         r16k = lf & 15;
         gk = lf >> 4;
       }
+      // LAKO_NT_ROLL (round 5, A/B build; plain bf16 kernels): the A fragments ROLL through a ring of four register quads — row r + 4 of the
+      // K-step's 2·MT MFMA rows is requested as soon as row r's MFMAs have been issued, every row waits for exactly its own fragment
+      // (counted lgkmcnt: LDS returns in order) — instead of twelve reads, a wait and 32 MFMAs twice per K-step.  The stamps
+      // (profiles/r05c_gemm_stamps.txt) put ≈ 600 cycles of exposed read latency in front of each K-half.  The reads are inline asm (the
+      // compiler would fold the ring into one quad and wait per read); nothing else touches LDS inside the K loop.
+      constexpr bool ROLL = LAKO_NT_ROLL != 0 && !SIDE && !PP && sizeof(T) == 2 && NW == 8;
+      if constexpr (ROLL) {
+        constexpr int NR = 2 * MT, RD = 4;
+        const uint32_t key16 = (uint32_t)((g ^ ((r16 >> 1) & 7)) << 4);
+        const uint32_t aA = (uint32_t)(uintptr_t)LDS_PTR(As) + (uint32_t)((wr * MT * 16 + r16) * TKB) + key16;      // K-half 1: ^ 64
+        const uint32_t aB = (uint32_t)(uintptr_t)LDS_PTR(Bs) + (uint32_t)((wc * NT * 16 + r16) * TKB) + key16;
+        const uint32_t aA1 = aA ^ 64u, aB1 = aB ^ 64u;
+        u32x4 bfr[2][NT], ar[RD];
+        auto rd = [](u32x4& dst, uint32_t addr, auto OFF) {
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(decltype(OFF)::value) : "memory");
+        };
+        static_for<NT>([&](auto N_) { rd(bfr[0][decltype(N_)::value], aB, std::integral_constant<int, decltype(N_)::value * 16 * TKB>{}); });
+        static_for<NT>([&](auto N_) { rd(bfr[1][decltype(N_)::value], aB1, std::integral_constant<int, decltype(N_)::value * 16 * TKB>{}); });
+        static_for<RD>([&](auto R_) {
+          constexpr int r = decltype(R_)::value;
+          rd(ar[r], r / MT ? aA1 : aA, std::integral_constant<int, (r % MT) * 16 * TKB>{});
+        });
+        constexpr int Q = LAKO_NT_WAIT_Q > 0 ? LAKO_NT_WAIT_Q : MT / 4;
+        static_for<NR>([&](auto R_) {
+          constexpr int r = decltype(R_)::value, kh = r / MT, mt = r % MT;
+          if constexpr (r == NR - Q) {
+            // the wait for the next K-slice and the barrier, Q rows before the end of the step (as in the two-phase loop); every fragment read of
+            // this buffer has been issued by now (RD > Q) and must have LANDED before another wave's next K-step may DMA into the buffer
+            if (!NT_DBG(a, 4)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+          } else if constexpr (r < NR - Q) {
+            constexpr int newer = (NR - 1 - r) < (RD - 1) ? (NR - 1 - r) : (RD - 1);      // reads issued after row r's
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(newer) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[nt][mt] = Mma<T>::run(bfr[kh][nt], ar[r % RD], acc[nt][mt]);
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (r + RD < NR) rd(ar[r % RD], (r + RD) / MT ? aA1 : aA, std::integral_constant<int, ((r + RD) % MT) * 16 * TKB>{});
+          if constexpr (kh == 0) {
+#pragma unroll
+            for (int j = 0; j < PA + PB; ++j)
+              if (j * MT / (PA + PB) == mt) piece(j);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      } else
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh) {
         u32x4 af[MT], bf[NT];
@@ -693,11 +758,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             mma_rows(mt, mt + 1);
-            if (mt < PA + PB) {
-              __builtin_amdgcn_sched_barrier(0);
-              piece(mt);
-              __builtin_amdgcn_sched_barrier(0);
-            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < PA + PB; ++j)      // the pieces dealt evenly over the MT rows (256-row tiles: 8 over 8; 128-row tiles: 8 over 4)
+              if (j * MT / (PA + PB) == mt) piece(j);
+            __builtin_amdgcn_sched_barrier(0);
           }
           if (SIDE && t == 0) {   // pass 0 of the side operand behind this step's K-slice pieces (the counted wait below assumes that order)
             __builtin_amdgcn_sched_barrier(0);
@@ -1406,6 +1471,14 @@ __device__ __forceinline__ void stage_cols256(char* img, const char* base, int k
   }
 }
 
+// one of the four pieces a wave stages of an operand's K-step (global_load_lds form: whole steps only, columns clamped)
+__device__ __forceinline__ void stage_cols256_piece(char* img, const char* base, int64_t ld_bytes, int colbytes_valid, int wave, int lane, int i) {
+  const int inst = wave + i * 8;
+  const int row = inst * 2 + (lane >> 5);
+  const int cb = min(((lane & 31) ^ (tn_key(row) << 1)) * 16, colbytes_valid - 16);
+  lds_dma16_g(img + inst * 1024, base, (uint32_t)(row * ld_bytes + cb));
+}
+
 __device__ __forceinline__ u32x4 read_frag_tr256(const char* img, int kk, int c0, int lane) {
   const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
   const int s = c0 >> 4;
@@ -1516,8 +1589,17 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(TnArgs a) {
     // K-step schedule as in gemm_nt_kernel: fragment reads of a K-half back to back (sched_barrier: the machine
     // scheduler would fold them into one register quad and wait per read), the second half of the workgroup issues
     // its DMA after two rows of MFMAs, and the wait + barrier sit two rows before the end of the step
+    // LAKO_TN_SPREAD (round 5, as LAKO_NT_SPREAD): the eight pieces go out one per row of K-half 0's MFMAs instead of in a burst
+    constexpr bool spread = LAKO_TN_SPREAD != 0 && GLDS;
+    auto piece = [&](int j) {
+      if (t + 1 >= nk) return;
+      char* An = smem + (cur ^ 1) * 2 * TN2_IMG;
+      const int kr = (t + 1 - (tail ? 1 : 0)) * 64;
+      if (j < 4) stage_cols256_piece(An, Abase + (int64_t)kr * lda_b, lda_b, acols_b, wave, lane, j);
+      else stage_cols256_piece(An + TN2_IMG, Bbase + (int64_t)kr * ldb_b, ldb_b, bcols_b, wave, lane, j - 4);
+    };
     const bool late = wave >= 4 && !a.no_stagger;
-    if (!late) prefetch();
+    if (!late && !spread) prefetch();
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       u32x4 af[8], bf[4];
@@ -1533,6 +1615,15 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(TnArgs a) {
           for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = Mma<bf16_t>::run(af[mt], bf[nt], acc[mt][nt]);
       };
       if (kk == 0) {
+        if constexpr (spread) {
+#pragma unroll
+          for (int mt = 0; mt < 8; ++mt) {
+            mma_rows(mt, mt + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            piece(mt);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
         mma_rows(0, 2);
         if (late) {
           __builtin_amdgcn_sched_barrier(0);
@@ -1540,6 +1631,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(TnArgs a) {
           __builtin_amdgcn_sched_barrier(0);
         }
         mma_rows(2, 8);
+        }
       } else {
         mma_rows(0, LAKO_TN_WAIT_ROWS);
         __builtin_amdgcn_sched_barrier(0);
