@@ -45,7 +45,8 @@
 #define LAKO_LOAD_AUX 0
 #endif
 #ifndef LAKO_NT_ROLL
-#define LAKO_NT_ROLL 0        // 1: rolling A fragments in the plain bf16 256² / 288-row kernels (see the K loop); A/B build
+#define LAKO_NT_ROLL 0        // 1: rolling A fragments in the plain bf16 256² / 288-row kernels (see the K loop).  Measured: no gain (± 1 % per launch,
+                              // profiles/r05c_gemm_roll.txt); A/B build only
 #endif
 #ifndef LAKO_TN_SPREAD
 #define LAKO_TN_SPREAD 0      // the same for the 256² weight-gradient kernel: measured SLOWER (7.14 -> 7.65 ms per step, two alternations on one box,
