@@ -40,14 +40,14 @@ sys.path.insert(0, ROOT)
 def gemm_traffic_bytes(args):
     """HBM-side bytes per launch of the dominant kernel from the committed PMC profile (separate rocprofv3 --pmc passes
     over tools/gemm_probe.py, FETCH_SIZE doubled as the gfx950 guide prescribes; tools/gemm_traffic.py): the mean over the encoder's
-    NT GEMM shapes weighted by their launches per layer, measured at the row count this run executes (profiles/r04_gemm_traffic.json
-    = 48 k valid tokens when padding is skipped, …_padded.json = 64 k rows on the padded path / --all-valid — re-measured in round 4 on
-    the kernels that stage by global_load_lds; the r03 files are the fallback).  null for any other workload or when the file is absent — counters cannot be collected from inside a timed run."""
+    NT GEMM shapes weighted by their launches per layer, measured at the row count this run executes (profiles/r05_gemm_traffic.json
+    = 48 k valid tokens when padding is skipped, …_padded.json = 64 k rows on the padded path / --all-valid — re-measured in round 5 on
+    the kernels that spread their staging over the K step; the r04 / r03 files are the fallback).  null for any other workload or when the file is absent — counters cannot be collected from inside a timed run."""
     if (args.model, args.batch, args.n_passages, args.seq_len, args.dtype) != ("base", 16, 20, 200, "bf16"):
         return None, None, None
     padded = os.environ.get("LAKO_UNPAD", "1") == "0" or args.all_valid
-    for name in (("r04_gemm_traffic_padded.json", "r03_gemm_traffic_padded.json") if padded else
-                 ("r04_gemm_traffic.json", "r03_gemm_traffic.json")):
+    for name in (("r05_gemm_traffic_padded.json", "r04_gemm_traffic_padded.json", "r03_gemm_traffic_padded.json") if padded else
+                 ("r05_gemm_traffic.json", "r04_gemm_traffic.json", "r03_gemm_traffic.json")):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 j = json.load(f)

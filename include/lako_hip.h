@@ -219,7 +219,10 @@ typedef struct {
                             scratch for delta = rowsum(dO∘O) written by lako_attn_bwd, unused) */
   int64_t q_stride_b, q_stride_t, k_stride_b, k_stride_t, v_stride_b, v_stride_t, o_stride_b, o_stride_t;
   const float* rel_bias; /* [H, R] fp32 or NULL */
-  int R, rel_off;        /* bias index = j - i + rel_off */
+  int R, rel_off;        /* bias index = clamp(j - i + rel_off, 0, R - 1): a distance outside the table takes the nearest entry
+                            (and, in lako_attn_bwd, adds its gradient there) — a table whose far entries are all one bucket may
+                            be cut short: the decoder-side bias of transformers 3.0.2's cross-attention (keys at or after the query:
+                            bucket 0) is [H, 2T - 1] for any number of keys */
   const uint8_t* key_mask; /* [Bn, Lk] 1 = attend, 0 = padding; or NULL */
   int causal, causal_off;  /* causal: key j visible iff j <= i + causal_off */
   int Bn, H, Lq, Lk, d_head;

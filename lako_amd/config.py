@@ -21,6 +21,11 @@ class FiDConfig:
     decoder_start_token_id: int = 0
     pad_token_id: int = 0
     eos_token_id: int = 1
+    # transformers 3.0.2 — the version the reference pins (README.md:21) — gives the decoder's FIRST cross-attention layer a
+    # relative-position table and adds its bias in every cross-attention (src/model.py:301-303,323-329); from transformers 4 on
+    # the table does not exist and the bias is zero.  False: the table of a checkpoint is ignored (the semantics of every current
+    # transformers and of the golden fixtures); True: the table is a parameter and the bias is applied (engine.py "legacy").
+    legacy_cross_bias: bool = False
 
     @property
     def inner_dim(self) -> int:
@@ -55,7 +60,8 @@ class FiDConfig:
             relative_attention_max_distance=get("relative_attention_max_distance", 128),
             dropout_rate=get("dropout_rate", 0.1), layer_norm_epsilon=get("layer_norm_epsilon", 1e-6),
             decoder_start_token_id=get("decoder_start_token_id", 0) or 0, pad_token_id=get("pad_token_id", 0) or 0,
-            eos_token_id=get("eos_token_id", 1) if get("eos_token_id", 1) is not None else 1)
+            eos_token_id=get("eos_token_id", 1) if get("eos_token_id", 1) is not None else 1,
+            legacy_cross_bias=bool(get("legacy_cross_bias", False)))
 
     def to_dict(self) -> dict:
         d = asdict(self)

@@ -88,6 +88,8 @@ def build_layout(cfg: FiDConfig) -> list[Block]:
         add(f"dec.{i}.wo", (d, f), [(p + "2.DenseReluDense.wo.weight", 0, d)], True)
         add(f"dec.{i}.ln3", (d,), [(p + "2.layer_norm.weight", 0, d)])
     add("dec.rel", (nb, H), [("decoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight", 0, nb)])
+    if cfg.legacy_cross_bias:     # transformers 3.0.2: the first cross-attention layer owns a table, every cross-attention adds its bias
+        add("dec.xrel", (nb, H), [("decoder.block.0.layer.1.EncDecAttention.relative_attention_bias.weight", 0, nb)])
     kv = []
     for i in range(Ld):
         p = f"decoder.block.{i}.layer.1.EncDecAttention."
@@ -132,6 +134,7 @@ class _Ragged:
     idx: torch.Tensor       # int64 [M] position of each packed token in the flat [B·N·L] input (None: use pack(), lengths from the host)
     soff_h: list = None     # the sample offsets on the host
     order: torch.Tensor = None   # int32 [B·N] passages by descending length: the processing order of the attention kernels
+    first_min: int = 0      # the shortest FIRST passage of a sample (legacy cross-attention bias: see Engine._legacy_layout)
 
 
 @dataclass
@@ -239,6 +242,7 @@ class Engine:
         self.kv_all = self._mat("dec.kv_all")
         self.enc_final, self.dec_final = self._vec("enc.final_ln"), self._vec("dec.final_ln")
         self.enc_rel, self.dec_rel = self._vec("enc.rel"), self._vec("dec.rel")
+        self.dec_xrel = self._vec("dec.xrel") if cfg.legacy_cross_bias else None
         self.enc, self.dec = [], []
         for i in range(cfg.num_layers):
             self.enc.append(dict(qkv=self._mat(f"enc.{i}.qkv"), o=self._mat(f"enc.{i}.o"), ln1=self._vec(f"enc.{i}.ln1"),
@@ -334,6 +338,19 @@ class Engine:
                              self.cfg.relative_attention_max_distance)
             self._lut_cache[key] = torch.from_numpy(lut).to(self.device)
         return self._lut_cache[key]
+
+    def _legacy_layout(self, rag, T):
+        """`legacy_cross_bias` (transformers 3.0.2, src/model.py:323-329): every cross-attention adds
+        `bias[h, t, s] = table[bucket(s − t)][h]` with the DECODER's one-sided buckets (`bidirectional = not is_decoder`), s the position of
+        the key in the concatenated [n_passages · text_maxlength] sequence.  Keys at or after the query position all share bucket 0, so
+        the bias differs from a per-head constant only for the first t keys of the FIRST passage — which is why it is an ordinary
+        relative table for the projected kernels (index key − query + T − 1 into `[H, 2T − 1]`, indices past the end clamped onto
+        "distance >= 0") as long as a key's index IS its position there: always on the padded layout; on the packed layout when every
+        sample's first passage has at least T − 1 valid tokens (the packed index of a later passage's token is smaller than its
+        position).  Returns the layout to use: `rag`, or None (padded) when a first passage is too short."""
+        if rag is not None and self.cfg.legacy_cross_bias and rag.first_min < T - 1:
+            return None
+        return rag
 
     def _buf(self, ws, name, shape, dtype=None):
         """Workspace tensor `name` of this shape.  The backing allocation only grows: a request with fewer ROWS (the
@@ -476,7 +493,8 @@ class Engine:
             # attention −0.24 ms per step)
             order = torch.argsort(lens_h, descending=True, stable=True).to(torch.int32)
             order_d = pin(order).to(dev, non_blocking=True) if os.environ.get("LAKO_ATTN_ORDER", "1") != "0" else None
-            return _Ragged(M=M, off=off_d, soff=off_d[::N].contiguous(), idx=idx, soff_h=off[::N].tolist(), order=order_d)
+            return _Ragged(M=M, off=off_d, soff=off_d[::N].contiguous(), idx=idx, soff_h=off[::N].tolist(), order=order_d,
+                           first_min=int(lens_h.view(B, N)[:, 0].min()))
         key = (attention_mask.data_ptr(), attention_mask._version, B, N, L)
         hit = self._rag_cache.get(key)
         if hit is not None:
@@ -495,7 +513,8 @@ class Engine:
             rag = _Ragged(M=int(off[-1]), off=off.to(dev), soff=off[::N].contiguous().to(dev),
                           idx=m.reshape(-1).nonzero().reshape(-1), soff_h=off[::N].tolist(),
                           order=torch.argsort(lens_h, descending=True, stable=True).to(torch.int32).to(dev)
-                          if os.environ.get("LAKO_ATTN_ORDER", "1") != "0" else None)
+                          if os.environ.get("LAKO_ATTN_ORDER", "1") != "0" else None,
+                          first_min=int(lens_h.view(B, N)[:, 0].min()))
         self._all_valid = ok and int(lens_h.sum()) == B * N * L
         if len(self._rag_cache) >= 16:
             self._rag_cache.clear()
@@ -537,6 +556,8 @@ class Engine:
         do not take (fp32 engine, d_kv != 64, d_model % 128) keep the projected formulation (lako_attn_fwd with a key mask)."""
         cfg = self.cfg
         ok = getattr(self.ops, "xattn_ok", None)
+        if cfg.legacy_cross_bias:      # the bias is an argument of the projected kernels only (_legacy_layout)
+            return None
         if os.environ.get("LAKO_XATTN", "1") == "0" or ok is None or not ok(self.dtype, cfg.d_kv, cfg.d_model) or B > 512:
             return None
         if rag is not None:
@@ -696,9 +717,9 @@ class Engine:
                 ch["xb"] = dict(xb, dq=xb["dq"][b0:b1], st=xb["st"][:, b0:b1], c=xb["c"][:, :, b0:b1]) if n > 1 else xb
             elif n > 1:
                 if rag is None:        # padded keys: the chain's samples are rows [b0·S, b1·S) of the projected K / V
-                    ch.update(kv_b=b1 - b0, kv_r=(b0 * kt, b1 * kt), ckw=dict(key_mask=ckw["key_mask"][b0:b1]))
+                    ch.update(kv_b=b1 - b0, kv_r=(b0 * kt, b1 * kt), ckw=dict(ckw, key_mask=ckw["key_mask"][b0:b1]))
                 else:                  # packed keys: the whole buffer, the chain's sample offsets
-                    ch["ckw"] = dict(k_off=ckw["k_off"][b0:b1 + 1], max_k=ckw["max_k"])
+                    ch["ckw"] = dict(ckw, k_off=ckw["k_off"][b0:b1 + 1])
             chains.append(ch)
         return chains
 
@@ -904,7 +925,7 @@ class Engine:
         dr = (lambda site: (p, seed, site)) if p > 0 else (lambda site: None)
         eps = cfg.layer_norm_epsilon
         ctx.ckpt = bool(self.use_checkpoint and training)
-        rag = ctx.rag = self._ragged_batch(attention_mask, B, N, L, lengths)
+        rag = ctx.rag = self._legacy_layout(self._ragged_batch(attention_mask, B, N, L, lengths), T)
         self._row_cap = {rag.M: B * N * L} if rag is not None else {}
         enc_ids = ctx.ids if rag is None else self._packed_ids(ws, ctx.ids, rag, L)
         ctx.enc_ids = enc_ids
@@ -923,6 +944,10 @@ class Engine:
         ctx.dec_ids = dec_ids
         rel = self._buf(ws, "d.rel", (H, 2 * T - 1), torch.float32)
         ops.relpos_expand(self.dec_rel.p, self._lut(T, T, False), rel)
+        if self.dec_xrel is not None:      # (_legacy_layout)
+            xrel = self._buf(ws, "d.xrel", (H, 2 * T - 1), torch.float32)
+            ops.relpos_expand(self.dec_xrel.p, self._lut(T, T, False), xrel)
+            ckw = dict(ckw, rel_bias=xrel, rel_off=T - 1)
         xb = self._xattn_buffers(ws, B, N, L, T, Ld, xa.splits) if xa is not None else None
         for i in range(Ld + 1):
             self._buf(ws, f"d.h{i}", (Md, d))
@@ -1028,6 +1053,12 @@ class Engine:
             kv = ws["e.kv"]
         drel = self._buf(tmp, "d.drel", (H, 2 * T - 1), torch.float32)
         ops.zero_(drel)
+        dxrel = None
+        if self.dec_xrel is not None:      # (the chains' key arguments were built in forward_loss without the gradient table)
+            dxrel = self._buf(tmp, "d.dxrel", (H, 2 * T - 1), torch.float32)
+            ops.zero_(dxrel)
+            for ch in ctx.chains:
+                ch["ckw"] = dict(ch["ckw"], drel=dxrel)
         dw_all = []      # every decoder weight gradient of the step (K = B·T rows): grouped launches after the last layer
         # the 2 · Ld head-batched Wk / Wv gradient products likewise: ONE launch after the last layer (each alone is its dispatch: 24 × 8 µs);
         # with one chain only (LAKO_DEC_HB_DEFER=0: inside the layers)
@@ -1041,6 +1072,10 @@ class Engine:
         if dw_all:      # (K = B·T rows: one K-split; the chains have joined and nothing else touches these gradients: plain read-modify-write)
             ops.gemm_tn_grouped(dw_all, split_k=one)
         ops.relpos_reduce(drel, self._lut(T, T, False), self.dec_rel.g)
+        if dxrel is not None:
+            ops.relpos_reduce(dxrel, self._lut(T, T, False), self.dec_xrel.g)
+            for ch in ctx.chains:
+                ch["ckw"] = {k: v for k, v in ch["ckw"].items() if k != "drel"}
         # ---- cross K/V projection of all decoder layers -----------------------------------------
         deh = self._buf(tmp, "e.dh", (Me, d))
         dxe = self._buf(tmp, "e.dxn", (Me, d))
@@ -1139,7 +1174,7 @@ class Engine:
         ids = input_ids.reshape(-1).contiguous()
         mask_u8 = attention_mask.reshape(B * N, L).to(torch.uint8).contiguous()
         # valid tokens only (as in forward_loss) unless the raw scores are captured: those are laid out per padded position
-        rag = None if capture_scores else self._ragged_batch(attention_mask, B, N, L, lengths)
+        rag = None if capture_scores else self._legacy_layout(self._ragged_batch(attention_mask, B, N, L, lengths), max_length)
         self._row_cap = {rag.M: B * N * L} if rag is not None else {}
         # what changes from call to call is COPIED into workspace buffers (stable addresses: the decode steps below are captured
         # into HIP graphs): the samples' key offsets of the unpadded batch, or the key mask of the padded one
@@ -1195,6 +1230,13 @@ class Engine:
             ops.zero_(t_)                                  # decoder_start_token_id = pad = 0
         rel = self._buf(ws, "g.rel", (H, 2 * ML - 1), torch.float32)
         ops.relpos_expand(self.dec_rel.p, self._lut(ML, ML, False), rel)
+        xrel = None
+        if self.dec_xrel is not None:
+            # legacy_cross_bias (_legacy_layout).  Step t's query sits at position t: table index key − t + ML − 1.  With score capture the
+            # reference runs ITS cross-attention forward (src/model.py:286-349), which sizes the bias by the step's own query length —
+            # 1 under the key / value cache — so every step sees the bias of position 0: one constant per head (src/model.py:323-325)
+            xrel = self._buf(ws, "g.xrel", (H, 2 * ML - 1), torch.float32)
+            ops.relpos_expand(self.dec_xrel.p, self._lut(ML, ML, False), xrel)
         # per layer [B, max_length, (q | k | v)]: ONE projection GEMM per step writes the step's q, k and v into row t; q is read
         # back from there, k and v stay as the cache
         cache = [self._buf(ws, f"g.cache.{i}", (B, ML, 3 * inner)) for i in range(Ld)]
@@ -1210,6 +1252,7 @@ class Engine:
             ops.embed_fwd(nxt, self.shared.w, h)
             fz = os.environ.get("LAKO_DEC_FUSE_NORM", "1") != "0"      # the norm inside the projection's kernel (LAKO_EPI_NORM_A), as in training
             nrm = (lambda w_: dict(norm=(w_, eps, xn, rs))) if fz else None
+            xkw = ckw if xrel is None else dict(ckw, rel_bias=xrel, rel_off=ML - 1 - (0 if capture_scores else t))
             for i in range(Ld):
                 lw = self.dec[i]
                 if fz:
@@ -1230,7 +1273,7 @@ class Engine:
                 if xa is None:
                     ops.attn_fwd(qc.view(B, 1, H, dk), self._heads(kv, kb, kt, 2 * i * inner),
                                  self._heads(kv, kb, kt, (2 * i + 1) * inner), c2.view(B, 1, H, dk), st,
-                                 scores_out=scores[i] if (capture_scores and t == 0) else None, **ckw)
+                                 scores_out=scores[i] if (capture_scores and t == 0) else None, **xkw)
                 else:
                     ops.headbatch_nt(qc.view(B, 1, H, dk), self._xw(i, "k", transposed=True), xq.view(B, 1, H, d))
                     if fused:

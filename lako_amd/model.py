@@ -23,7 +23,9 @@ from torch import nn
 from .config import FiDConfig
 from .engine import Engine, build_layout, layout_sizes
 
-LEGACY_IGNORED = ("decoder.block.0.layer.1.EncDecAttention.relative_attention_bias.weight",)   # HF5:899-901
+# the relative-position table transformers 3.0.2 gives the decoder's first cross-attention layer (dropped on load by every later
+# transformers: HF5:899-901).  Ignored unless the config says `legacy_cross_bias` — then it is a parameter (config.py, engine.py)
+LEGACY_IGNORED = ("decoder.block.0.layer.1.EncDecAttention.relative_attention_bias.weight",)
 ALIASES = ("lm_head.weight", "encoder.embed_tokens.weight", "decoder.embed_tokens.weight")
 
 
@@ -255,7 +257,7 @@ class FiDT5(nn.Module):
         with torch.no_grad():
             for k, v in state_dict.items():
                 pk = plain_name(k)
-                if pk in ALIASES or pk in LEGACY_IGNORED:
+                if pk in ALIASES or (pk in LEGACY_IGNORED and pk not in self._params_by_plain):
                     continue
                 if pk not in self._params_by_plain:
                     if strict:
@@ -283,9 +285,14 @@ class FiDT5(nn.Module):
         save_file(sd, os.path.join(path, "model.safetensors"), metadata={"format": "pt"})
 
     @classmethod
-    def from_pretrained(cls, path, **kw):
+    def from_pretrained(cls, path, legacy_cross_bias=None, **kw):
+        """`legacy_cross_bias=True`: read the checkpoint as transformers 3.0.2 wrote and ran it — the reference's own checkpoints
+        (README.md:21) carry the first cross-attention layer's relative-position table, and their config.json knows nothing of the
+        flag (config.py).  None: what config.json says (False when it says nothing: the table is ignored)."""
         with open(os.path.join(path, "config.json")) as f:
             cfg = FiDConfig.from_hf(json.load(f))
+        if legacy_cross_bias is not None:
+            cfg.legacy_cross_bias = bool(legacy_cross_bias)
         model = cls(cfg, **kw)
         st = os.path.join(path, "model.safetensors")
         if os.path.exists(st):

@@ -76,6 +76,10 @@ class Options:
         p.add_argument("--answer_maxlength", type=int, default=-1)
         p.add_argument("--no_title", action="store_true")
         p.add_argument("--n_context", type=int, default=1)
+        # not a reference flag: the reference IS transformers 3.0.2 (README.md:21), where the decoder's first cross-attention layer owns a
+        # relative-position table and every cross-attention adds its bias (src/model.py:301-303,323-329).  Set it to train / evaluate a
+        # checkpoint of the reference with those semantics; without it the table is ignored, as every transformers >= 4 does
+        p.add_argument("--legacy_cross_bias", action="store_true")
         return self
 
     def add_retriever_options(self):

@@ -43,6 +43,9 @@ class T5Dims:
     max_distance: int = 128
     eps: float = 1e-6
     dropout: float = 0.1
+    # transformers 3.0.2 (the version the reference pins, README.md:21): the decoder's first cross-attention layer owns a
+    # relative-position table and every cross-attention adds its bias (src/model.py:301-303,323-329).  False = transformers >= 4.
+    legacy_cross_bias: bool = False
 
     @staticmethod
     def named(size: str) -> "T5Dims":
@@ -61,6 +64,9 @@ class T5Dims:
 # ----------------------------------------------------------------------------------------------
 # parameter naming / init
 # ----------------------------------------------------------------------------------------------
+XREL = "decoder.block.0.layer.1.EncDecAttention.relative_attention_bias.weight"
+
+
 def param_shapes(dims: T5Dims) -> dict[str, tuple[int, ...]]:
     """Plain-T5 state-dict layout (HF5:640-655, 176-215, 75-82, 50-57)."""
     inner = dims.num_heads * dims.d_kv
@@ -85,6 +91,8 @@ def param_shapes(dims: T5Dims) -> dict[str, tuple[int, ...]]:
             out[p + f"{ff}.DenseReluDense.wo.weight"] = (dims.d_model, dims.d_ff)
             out[p + f"{ff}.layer_norm.weight"] = (dims.d_model,)
         out[f"{stack}.final_layer_norm.weight"] = (dims.d_model,)
+    if dims.legacy_cross_bias:      # (last: the other weights of a seed do not depend on the flag)
+        out[XREL] = (dims.num_buckets, dims.num_heads)
     return out
 
 
@@ -229,10 +237,18 @@ def shift_right(labels: torch.Tensor) -> torch.Tensor:
 
 
 def decoder_stack(w, dims: T5Dims, dec_ids: torch.Tensor, enc_out: torch.Tensor, enc_mask: torch.Tensor,
-                  training: bool, capture: dict | None = None) -> torch.Tensor:
+                  training: bool, capture: dict | None = None, legacy_pos0: bool = False) -> torch.Tensor:
     """T5Stack.forward for the decoder, HF5:663-750 (+ cross-attention HF5:404-432).  No
     decoder_attention_mask is passed by the reference (train_reader.py:67-71), so the self-attention
-    mask is purely causal; cross-attention has no positional term (HF >= 4: zeros, HF5:337-342)."""
+    mask is purely causal; cross-attention has no positional term (HF >= 4: zeros, HF5:337-342).
+
+    `dims.legacy_cross_bias` (transformers 3.0.2, what src/model.py:301-303,323-329 is written against): block 0's
+    cross-attention computes `compute_bias(qlen, klen)` from ITS table with the decoder's one-sided buckets
+    (`bidirectional = not is_decoder`) and every block adds it to the scores before the softmax; the stored score
+    includes it.  `legacy_pos0`: the bias of a decode step under the reference's own cross-attention forward with the
+    key / value cache — sized by the step's query length 1 (src/model.py:305,323-324), i.e. the row of position 0 for
+    every step (stock 3.0.2 slices the row of the step's true position instead; that is `legacy_pos0 = False` on the
+    recomputed prefix)."""
     p = dims.dropout
     B, T = dec_ids.shape
     h = _drop(w["shared.weight"][dec_ids], p, training)
@@ -240,6 +256,9 @@ def decoder_stack(w, dims: T5Dims, dec_ids: torch.Tensor, enc_out: torch.Tensor,
     bias = compute_bias(w["decoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"], T, T, False,
                         dims.num_buckets, dims.max_distance)
     xmask = torch.zeros(enc_mask.shape, dtype=torch.float32).masked_fill(~enc_mask.bool(), NEG)[:, None, None, :]
+    xbias = None
+    if dims.legacy_cross_bias:
+        xbias = compute_bias(w[XREL], 1 if legacy_pos0 else T, enc_out.shape[1], False, dims.num_buckets, dims.max_distance)
     for i in range(dims.num_decoder_layers):
         pre = f"decoder.block.{i}.layer."
         xn = rmsnorm(h, w[pre + "0.layer_norm.weight"], dims.eps)
@@ -251,7 +270,7 @@ def decoder_stack(w, dims: T5Dims, dec_ids: torch.Tensor, enc_out: torch.Tensor,
         cap = {} if capture is not None else None
         a = attention(xn, enc_out, w[pre + "1.EncDecAttention.q.weight"], w[pre + "1.EncDecAttention.k.weight"],
                       w[pre + "1.EncDecAttention.v.weight"], w[pre + "1.EncDecAttention.o.weight"],
-                      dims.num_heads, dims.d_kv, xmask, None, p, training, cap)
+                      dims.num_heads, dims.d_kv, xmask, xbias, p, training, cap)
         if cap is not None:
             capture[f"cross_scores_{i}"] = cap["scores"]
         h = h + _drop(a, p, training)
@@ -299,7 +318,7 @@ def fid_generate(w, dims: T5Dims, input_ids, attention_mask, max_length: int,
     done = torch.zeros(B, dtype=torch.bool)
     for step in range(max_length - 1):
         cap = {} if (capture is not None and step == 0) else None
-        h = decoder_stack(w, dims, seq, enc, enc_mask, False, cap)
+        h = decoder_stack(w, dims, seq, enc, enc_mask, False, cap, legacy_pos0=capture is not None)
         if cap is not None:
             capture.update(cap)
         logits = (h[:, -1] * dims.d_model ** -0.5) @ w["shared.weight"].t()

@@ -520,7 +520,56 @@ def make_rerank():
     print("wrote rerank.json", [len(e["ids"]) for e in out["expected"]])
 
 
+def make_legacy_cross():
+    """The reference's OWN cross-attention forward (src/model.py:286-349) called as it was written to be called — the
+    transformers-3.0.2 argument list, `position_bias=None` on a layer with `has_relative_attention_bias`, so that line 323-325
+    computes `self.compute_bias(qlen, klen)` and adds it — on an installed-transformers `T5Attention(is_decoder=True,
+    has_relative_attention_bias=True)` (its q / k / v / o / relative_attention_bias / compute_bias are what the function touches;
+    `d_kv` is set beside transformers' newer name for it).  Pins what `legacy_cross_bias` means: WHICH bias (the decoder's one-sided
+    buckets of key position − query position over (qlen, klen)), WHERE (before the softmax, inside the stored score), and that a
+    decode step of query length 1 gets the row of position 0.  → tests/golden/legacy_cross.npz"""
+    from transformers.models.t5.modeling_t5 import T5Attention
+    g = torch.Generator().manual_seed(11)
+    B, T, S, d, H, dk = 2, 7, 45, 48, 3, 16
+    cfg = transformers.T5Config(vocab_size=32, d_model=d, d_kv=dk, d_ff=64, num_layers=1, num_decoder_layers=1, num_heads=H,
+                                relative_attention_num_buckets=32, relative_attention_max_distance=128, dropout_rate=0.0,
+                                is_decoder=True)
+    try:
+        att = T5Attention(cfg, has_relative_attention_bias=True, layer_idx=0)
+    except TypeError:
+        att = T5Attention(cfg, has_relative_attention_bias=True)
+    att.eval()
+    att.is_decoder = True
+    att.d_kv = dk
+    w = {n: torch.randn(sh, generator=g) * sc for n, sh, sc in (("q", (H * dk, d), 0.12), ("k", (H * dk, d), 0.3), ("v", (H * dk, d), 0.3),
+                                                               ("o", (d, H * dk), 0.2), ("table", (32, H), 0.7))}
+    with torch.no_grad():
+        for n in "qkvo":
+            getattr(att, n).weight.copy_(w[n])
+        att.relative_attention_bias.weight.copy_(w["table"])
+    x = torch.randn(B, T, d, generator=g)
+    kv = torch.randn(B, S, d, generator=g)
+    keep = torch.ones(B, S, dtype=torch.bool)
+    keep[0, 30:] = False
+    keep[1, 3:9] = False         # a hole INSIDE the first positions: the bias is by position, not by count of valid keys
+    mask = torch.zeros(B, 1, 1, S).masked_fill(~keep[:, None, None, :], -1e9)
+    out = {k: v.numpy() for k, v in w.items()}
+    out.update(x=x.numpy(), kv=kv.numpy(), keep=keep.numpy())
+    with torch.no_grad():
+        for tag, xin in (("full", x), ("step", x[:, 3:4])):          # the training call (qlen = T) and one cached decode step (qlen = 1)
+            att.score_storage = None
+            res = rm.cross_attention_forward(att, xin, mask=mask.clone(), kv=kv, position_bias=None)
+            out[f"out_{tag}"] = res[0].numpy()
+            out[f"scores_{tag}"] = att.score_storage.numpy()
+            out[f"bias_{tag}"] = res[-1].numpy()                      # (position_bias is returned when the layer owns the table, :346-347)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "legacy_cross.npz"), **out)
+    print("legacy_cross ok", out["bias_full"].shape, out["bias_step"].shape)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "legacy_cross":
+        make_legacy_cross()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "rerank":
         make_rerank()
         sys.exit(0)
@@ -536,6 +585,7 @@ if __name__ == "__main__":
     make_rank_metrics()
     make_rerank()
     make_evaluation()
+    make_legacy_cross()
     make_case("tiny_a", tiny, B=3, N=3, L=12, T=5, seed=1, full_pad=(1, 2))
     make_case("tiny_fact", tiny, B=3, N=2, L=24, T=4, seed=2, fact_case=True)
     make_case("tiny_eos", tiny, B=4, N=3, L=12, T=6, seed=5, pretrain=150)

@@ -147,7 +147,8 @@ def main():
     except Exception as e:
         raise SystemExit(f"cannot load a T5 tokenizer ({e}); pass --tokenizer /path/to/t5-tokenizer")
     dir_path = opt.checkpoint_dir
-    model = FiDT5.from_pretrained(os.path.realpath(opt.model_path), dtype=torch.bfloat16 if opt.dtype == "bf16" else torch.float32)
+    model = FiDT5.from_pretrained(os.path.realpath(opt.model_path), dtype=torch.bfloat16 if opt.dtype == "bf16" else torch.float32,
+                                  legacy_cross_bias=True if opt.legacy_cross_bias else None)
     model = model.cuda(opt.gpu)
     with open(opt.eval_data) as f:
         dataset = Dataset(json.load(f), opt)

@@ -189,9 +189,8 @@ class RefOps:
         i = torch.arange(Lq, device=dev)[:, None]
         j = torch.arange(Lk, device=dev)[None, :]
         if rel_bias is not None:
-            bi = j - i + rel_off
-            ok = (bi >= 0) & (bi < rel_bias.shape[1])
-            bias = rel_bias[:, bi.clamp(0, rel_bias.shape[1] - 1)] * ok
+            bi = j - i + rel_off            # an index outside the table takes its nearest entry (include/lako_hip.h: a one-sided table —
+            bias = rel_bias[:, bi.clamp(0, rel_bias.shape[1] - 1)]      # the legacy cross-attention bias — relies on it)
             s = s + bias[None]
         masked = torch.zeros(B, 1, Lq, Lk, dtype=torch.bool, device=dev)
         if key_mask is not None:

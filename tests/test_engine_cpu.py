@@ -518,3 +518,64 @@ def test_adam_and_bias_corrected_adamw_match_torch(mode):
         torch.testing.assert_close(eng.P, p_ref.detach(), atol=2e-7, rtol=2e-5)
     sd = ours.state_dict()
     assert sd["lako_step"] == 4
+
+
+@pytest.mark.parametrize("short_first", [False, True])
+def test_legacy_cross_bias_engine_vs_oracle(short_first, tmp_path):
+    """`legacy_cross_bias` (transformers 3.0.2: src/model.py:301-303,323-329; the oracle's version of it is pinned to the reference's own
+    cross-attention forward in tests/test_oracle_golden.py): loss, logits, every gradient incl. the cross-attention table's, greedy decode
+    (each step at its own position) and the captured scores (the reference's override: position 0) against the oracle.
+    `short_first`: a sample whose FIRST passage has fewer valid tokens than the answer has positions — the packed key index is then
+    not the key's position, and the engine must fall back to the padded layout for that batch (Engine._legacy_layout)."""
+    import dataclasses
+    dims = dataclasses.replace(O.T5Dims.named("tiny"), legacy_cross_bias=True)
+    w = O.init_weights(dims, 4)
+    w[O.XREL] = w[O.XREL] * 3.0          # make the bias matter
+    B, N, L, T = 3, 3, 14, 6
+    ids, mask, labels = O.synthetic_batch(B, N, L, T, dims.vocab_size, 7)[:3]
+    mask = mask.clone()
+    mask[:, 0, :] = True                  # first passages full …
+    if short_first:
+        mask[1, 0, 2:] = False            # … but one with 2 valid tokens < T − 1
+    ids = ids * mask
+    cfg = dataclasses.replace(cfg_of(dims), legacy_cross_bias=True)
+    model = FiDT5(cfg, dtype=torch.float32, _ops=RefOps())
+    assert len(list(model.named_parameters())) == len(w)
+    model.load_t5(w)
+    model.train()
+    out = model(input_ids=ids, attention_mask=mask, labels=labels)
+    assert (model._engine.ctx.rag is None) == short_first
+    leaves = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+    loss, logits = O.fid_forward(leaves, dims, ids, mask, labels)
+    assert abs(out[0].item() - loss.item()) < 2e-5
+    torch.testing.assert_close(out.logits, logits.detach(), atol=5e-5, rtol=1e-4)
+    out[0].backward()
+    loss.backward()
+    for n, p in model.named_parameters():
+        torch.testing.assert_close(p.grad, leaves[plain_name(n)].grad, atol=5e-5, rtol=2e-4, msg=lambda m, n=n: f"{n}: {m}")
+    assert leaves[O.XREL].grad.abs().max() > 1e-4
+    # the flag off on the same weights is a different model
+    plain = FiDT5(cfg_of(dims), dtype=torch.float32, _ops=RefOps())
+    plain.load_t5(w)                       # (the table is load-and-ignore there)
+    plain.train()
+    assert abs(plain(input_ids=ids, attention_mask=mask, labels=labels)[0].item() - loss.item()) > 1e-4
+    # decode: stock 3.0.2 — the bias row of the step's own position
+    model.eval()
+    want = O.fid_generate(w, dims, ids, mask, 6)
+    got = model.generate(input_ids=ids, attention_mask=mask, max_length=6)
+    assert got.tolist() == want.tolist()
+    # capture: the reference's own forward — the row of position 0 at every step, inside the stored score
+    cap = {}
+    O.fid_generate(w, dims, ids, mask, 4, capture=cap)
+    model.overwrite_forward_crossattention()
+    model.reset_score_storage()
+    model.generate(input_ids=ids, attention_mask=mask, max_length=4)
+    ref = torch.cat([cap[f"cross_scores_{i}"] for i in range(dims.num_decoder_layers)], dim=2)
+    keep = mask.view(B, 1, 1, -1).expand_as(ref)
+    torch.testing.assert_close(model._score_storage[keep], ref[keep], atol=5e-5, rtol=1e-4)
+    # the flag survives save_pretrained / from_pretrained (config.json) and so does the table
+    model.save_pretrained(str(tmp_path / "m"))
+    back = FiDT5.from_pretrained(str(tmp_path / "m"), dtype=torch.float32, _ops=RefOps())
+    assert back.config.legacy_cross_bias
+    sd = back.state_dict()
+    assert torch.equal(sd[O.XREL], w[O.XREL])

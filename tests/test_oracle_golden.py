@@ -143,3 +143,63 @@ def test_generate_fixture_is_the_oracles_decode():
         n = int((labels[b] != -100).sum())
         assert tok[b, 1:1 + n].tolist() == labels[b, :n].tolist()
     assert float(z["min_gap"]) > 1.0
+
+
+def test_legacy_cross_bias_is_the_references_cross_attention(golden_dir):
+    """`legacy_cross_bias` (transformers 3.0.2 semantics, src/model.py:301-303,323-329): tests/golden/legacy_cross.npz holds what the
+    reference's OWN cross_attention_forward returns and stores when it is called the way it was written to be called (oracle/make_fixtures.py
+    ::make_legacy_cross).  The oracle's attention with `compute_bias(table, qlen, klen, bidirectional=False)` reproduces the output, the
+    stored score (bias included, masked keys as the reference leaves them) and the bias itself — for the training call (qlen = T) and for a
+    cached decode step (qlen = 1: the row of position 0)."""
+    z = np.load(golden_dir + "/legacy_cross.npz")
+    w = {k: torch.from_numpy(z[k]) for k in ("q", "k", "v", "o", "table")}
+    x, kv, keep = torch.from_numpy(z["x"]), torch.from_numpy(z["kv"]), torch.from_numpy(z["keep"])
+    H, dk = w["table"].shape[1], w["q"].shape[0] // w["table"].shape[1]
+    add_mask = torch.zeros(keep.shape).masked_fill(~keep, -1e9)[:, None, None, :]
+    for tag, xin in (("full", x), ("step", x[:, 3:4])):
+        bias = O.compute_bias(w["table"], xin.shape[1], kv.shape[1], False, 32, 128)
+        assert torch.equal(bias, torch.from_numpy(z[f"bias_{tag}"]))
+        cap = {}
+        out = O.attention(xin, kv, w["q"], w["k"], w["v"], w["o"], H, dk, add_mask, bias, 0.0, False, cap)
+        torch.testing.assert_close(out, torch.from_numpy(z[f"out_{tag}"]), atol=2e-6, rtol=1e-5)
+        torch.testing.assert_close(cap["scores"], torch.from_numpy(z[f"scores_{tag}"]), atol=1e-5, rtol=1e-6)
+    # the bias of a key at or after the query's position is ONE value per head; before it, one per distance (the decoder's buckets)
+    b = torch.from_numpy(z["bias_full"])[0]
+    for t in range(b.shape[1]):
+        assert torch.equal(b[:, t, t:], w["table"][0][:, None].expand(-1, b.shape[2] - t))
+        for n in range(1, t + 1):
+            assert torch.equal(b[:, t, t - n], w["table"][n])
+
+
+def test_legacy_cross_bias_oracle_model_level():
+    """The flag at model level: a zero table is the model without the flag (same seed → same other weights), a non-zero one changes the
+    loss; the bias reaches the gradient of the table through every decoder layer; greedy decode with the recomputed prefix uses each
+    row's own position (stock 3.0.2), the capture path the row of position 0 (the reference's override: src/model.py:305,323)."""
+    import dataclasses
+    d0 = O.T5Dims.named("tiny")
+    d1 = dataclasses.replace(d0, legacy_cross_bias=True)
+    w0, w1 = O.init_weights(d0, 3), O.init_weights(d1, 3)
+    assert set(w1) - set(w0) == {O.XREL} and all(torch.equal(w0[k], w1[k]) for k in w0)
+    ids, mask, labels = O.synthetic_batch(2, 3, 16, 6, d0.vocab_size, 0)[:3]
+    l0, _ = O.fid_forward(w0, d0, ids, mask, labels)
+    wz = dict(w1)
+    wz[O.XREL] = torch.zeros_like(w1[O.XREL])
+    lz, _ = O.fid_forward(wz, d1, ids, mask, labels)
+    assert torch.equal(l0, lz)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in w1.items()}
+    l1, _ = O.fid_forward(leaves, d1, ids, mask, labels)
+    assert abs(l1.item() - l0.item()) > 1e-4
+    l1.backward()
+    g = leaves[O.XREL].grad
+    T = labels.shape[1]
+    assert g[:T].abs().sum() > 0 and g[T:].abs().sum() == 0        # distances 0 … T − 1 only
+    # rows of the score matrix sum to zero in the softmax backward, so the table's gradient sums to zero over the buckets in use
+    assert abs(float(g.sum())) < 1e-5 * float(g.abs().sum())
+    cap = {}
+    O.fid_generate(w1, d1, ids, mask, 5, capture=cap)
+    capz = {}
+    O.fid_generate(wz, d1, ids, mask, 5, capture=capz)
+    shift = cap["cross_scores_0"] - capz["cross_scores_0"]          # [B, H, 1, S]: the row of position 0 = bucket 0 for every key
+    valid = mask.view(2, -1).bool()
+    for h in range(d0.num_heads):
+        assert torch.allclose(shift[:, h, 0][valid], w1[O.XREL][0, h].expand(int(valid.sum())), atol=1e-5)

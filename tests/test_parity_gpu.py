@@ -464,3 +464,65 @@ def test_encoder_space_cross_attention_long_answers_and_small_model(monkeypatch)
     rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
     assert rel(res[1][1], res[0][1]) < 0.02, rel(res[1][1], res[0][1])
     assert rel(res[1][2], res[0][2]) < 0.06, rel(res[1][2], res[0][2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,short_first", [(torch.float32, False), (torch.float32, True), (torch.bfloat16, False)])
+def test_legacy_cross_bias_vs_oracle(dtype, short_first):
+    """`legacy_cross_bias` — transformers 3.0.2's relative-position bias in every cross-attention (src/model.py:301-303,323-329; the oracle's
+    version is pinned to the reference's own cross_attention_forward by tests/golden/legacy_cross.npz) — through the HIP kernels: T5-small
+    dimensions, 6 passages of 48, answers of 9 positions, dropout off.  fp32: loss / logits / every gradient (the table's included)
+    within 1e-3 of the oracle, greedy tokens and the captured step-0 scores equal; bf16: loss within 3 %, gradient direction of the table.
+    `short_first`: one sample's first passage is shorter than the answer → the batch runs on the padded layout (Engine._legacy_layout)."""
+    import dataclasses
+    dims = dataclasses.replace(O.T5Dims.named("small"), legacy_cross_bias=True, dropout=0.0, num_layers=2, num_decoder_layers=3,
+                               vocab_size=512)
+    w = O.init_weights(dims, seed=21)
+    w[O.XREL] = w[O.XREL] * 4.0
+    B, N, L, T = 3, 6, 48, 9
+    ids, mask, labels = O.synthetic_batch(B, N, L, T, dims.vocab_size, seed=22)[:3]
+    mask = mask.clone()
+    mask[:, 0, :12] = True
+    if short_first:
+        mask[2, 0, 5:] = False
+    ids = ids * mask
+    leaves = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+    loss, logits = O.fid_forward(leaves, dims, ids, mask, labels, training=False)
+    loss.backward()
+    cfg = dataclasses.replace(cfg_of(dims), legacy_cross_bias=True)
+    model = FiDT5(cfg, dtype=dtype)
+    model.load_t5(w)
+    model = model.cuda().train()
+    out = model(input_ids=ids.to(DEV), attention_mask=mask.to(DEV), labels=labels.to(DEV))
+    assert (model._engine.ctx.rag is None) == short_first
+    assert not model._engine.xattn_active           # the bias is an argument of the projected kernels
+    out[0].backward()
+    grads = {plain_name(n): p.grad.cpu() for n, p in model.named_parameters()}
+    gx, rx = grads[O.XREL].flatten().double(), leaves[O.XREL].grad.flatten().double()
+    assert rx.abs().max() > 1e-4
+    if dtype == torch.float32:
+        assert abs(out[0].item() - loss.item()) < 1e-3
+        torch.testing.assert_close(out.logits.cpu(), logits.detach(), atol=1e-3, rtol=1e-3)
+        for k, g in grads.items():
+            ref = leaves[k].grad
+            torch.testing.assert_close(g, ref, atol=1e-3 * max(1.0, ref.abs().max().item()), rtol=1e-3, msg=lambda m, k=k: f"{k}: {m}")
+        # without the table the same weights give another loss: the bias is really applied
+        plain = FiDT5(cfg_of(dims), dtype=dtype)
+        plain.load_t5(w)
+        plain = plain.cuda().train()
+        assert abs(plain(input_ids=ids.to(DEV), attention_mask=mask.to(DEV), labels=labels.to(DEV))[0].item() - loss.item()) > 1e-3
+        model.eval()
+        toks = model.generate(input_ids=ids.to(DEV), attention_mask=mask.to(DEV), max_length=8)
+        assert toks.cpu().tolist() == O.fid_generate(w, dims, ids, mask, 8).tolist()
+        cap = {}
+        O.fid_generate(w, dims, ids, mask, 4, capture=cap)
+        model.overwrite_forward_crossattention()
+        model.reset_score_storage()
+        model.generate(input_ids=ids.to(DEV), attention_mask=mask.to(DEV), max_length=4)
+        ref = torch.cat([cap[f"cross_scores_{i}"] for i in range(dims.num_decoder_layers)], dim=2)
+        keep = mask.view(B, 1, 1, -1).expand_as(ref)
+        torch.testing.assert_close(model._score_storage.cpu()[keep], ref[keep], atol=1e-3, rtol=1e-3)
+    else:
+        assert abs(out[0].item() - loss.item()) < 0.03 * max(1.0, abs(loss.item()))
+        cos = float(torch.dot(gx, rx) / (gx.norm() * rx.norm() + 1e-30))
+        assert cos > 0.98, cos

@@ -15,6 +15,8 @@
 #   pmcstep                 whole-step PMC totals (three separate --pmc passes)
 #   pmcgemm                 FETCH_SIZE / WRITE_SIZE of the encoder GEMM shapes at 48 000 and 64 000 rows → gemm_traffic*.json; MFMA-busy pass
 #   pmcattn                 SQ / MFMA counters of the encoder attention kernels (tools/attn_probe.py)
+#   dp1                     the one data-parallel number one GPU can give: the quick bench at world size 1 through RCCL (LAKO_FORCE_DIST=1) with
+#                           LAKO_DP_MODE=deferred and =overlap (ticket-queue GEMMs + per-range all-reduce on a second stream), twice each → $OUT/dp1.txt
 #   full                    = tests "" smoke bench trace c45 generate
 set -x
 TAG=${TAG:-round}
@@ -74,6 +76,17 @@ step_pmcattn() {
   python tools/pmc_summary.py /tmp/pmc_attn --match enc_ > $OUT/attn_pmc.txt 2>&1
   tail -30 $OUT/attn_pmc.txt
 }
+step_dp1() {
+  for rep in 1 2; do
+    for m in deferred overlap; do
+      LAKO_FORCE_DIST=1 LAKO_DP_MODE=$m MASTER_ADDR=127.0.0.1 MASTER_PORT=2967$rep RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 \
+        python bench.py $QUICK > $OUT/dp1_${m}_$rep.json 2> $OUT/dp1_${m}_$rep.err
+      echo "world 1 through RCCL, LAKO_DP_MODE=$m rep $rep: $(python -c "import json; j=json.loads(open('$OUT/dp1_${m}_$rep.json').read().splitlines()[-1]); print(j['ms_per_step'], 'ms/step', j['value'], 'samples/s', j['config'].get('dp'))")" | tee -a $OUT/dp1.txt
+    done
+  done
+  python bench.py $QUICK > $OUT/dp1_none.json 2>/dev/null
+  echo "no process group: $(python -c "import json; j=json.loads(open('$OUT/dp1_none.json').read().splitlines()[-1]); print(j['ms_per_step'], 'ms/step')")" | tee -a $OUT/dp1.txt
+}
 [ $# -eq 0 ] && set -- full
 while [ $# -gt 0 ]; do
   s=$1; shift
@@ -82,7 +95,7 @@ while [ $# -gt 0 ]; do
     ab) step_ab "$1"; shift;;
     ops) step_ops "$1"; shift;;
     full) step_tests ""; step_smoke; step_bench; step_trace; step_c45; step_generate;;
-    smoke|bench|quick|trace|c45|generate|pmcstep|pmcgemm|pmcattn) step_$s;;
+    smoke|bench|quick|trace|c45|generate|pmcstep|pmcgemm|pmcattn|dp1) step_$s;;
     *) echo "unknown step $s"; exit 2;;
   esac
 done

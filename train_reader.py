@@ -114,7 +114,8 @@ def main():
             tokenizer = transformers.T5Tokenizer.from_pretrained(opt.tokenizer or ("t5-" + opt.model_size))
         except Exception as e:      # no network in the build container: a local tokenizer directory is required
             raise SystemExit(f"cannot load a T5 tokenizer ({e}); pass --tokenizer /path/to/t5-tokenizer or use --synthetic")
-    cfg = FiDConfig.named(opt.model_size, dropout_rate=opt.dropout)
+    cfg = FiDConfig.named(opt.model_size, dropout_rate=opt.dropout, legacy_cross_bias=opt.legacy_cross_bias)
+    legacy = True if opt.legacy_cross_bias else None       # (None: a checkpoint's own config.json decides)
     dtype = torch.bfloat16 if opt.dtype == "bf16" else torch.float32
     train_ds = eval_ds = None
     if tokenizer is not None:
@@ -144,12 +145,12 @@ def main():
     elif os.path.exists(os.path.join(os.path.realpath(opt.model_path), "optimizer.pth.tar")):
         # a checkpoint directory written by util.save: weights kept, fresh optimizer / scheduler (train_reader.py:255)
         model, optimizer, scheduler, _, step, best = U.load(FiDT5, opt.model_path, opt, reset_params=True, dtype=dtype,
-                                                            seed=opt.seed + opt.global_rank)
+                                                            seed=opt.seed + opt.global_rank, legacy_cross_bias=legacy)
         model = model.cuda(local_rank)
         logger.info(f"model loaded from {opt.model_path} (was at step {step}, best {best})")
         step, best = 0, 0.0       # train_reader.py:266: a warm start, not a resume — counters restart like the reference's
     else:
-        model = FiDT5.from_pretrained(opt.model_path, dtype=dtype, seed=opt.seed + opt.global_rank).cuda(local_rank)
+        model = FiDT5.from_pretrained(opt.model_path, dtype=dtype, seed=opt.seed + opt.global_rank, legacy_cross_bias=legacy).cuda(local_rank)
         optimizer, scheduler = U.set_optim(opt, model)
     model.set_checkpoint(opt.use_checkpoint)
     if opt.is_distributed:
