@@ -687,7 +687,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
       // (counted lgkmcnt: LDS returns in order) — instead of twelve reads, a wait and 32 MFMAs twice per K-step.  The stamps
       // (profiles/r05c_gemm_stamps.txt) put ≈ 600 cycles of exposed read latency in front of each K-half.  The reads are inline asm (the
       // compiler would fold the ring into one quad and wait per read); nothing else touches LDS inside the K loop.
-      constexpr bool ROLL = LAKO_NT_ROLL != 0 && !SIDE && !PP && sizeof(T) == 2 && NW == 8;
+      constexpr bool ROLL = LAKO_NT_ROLL != 0 && !SIDE && !PP && sizeof(T) == 2 && (NW == 8 || (NW == 4 && MT == 8 && NT == 8));
       if constexpr (ROLL) {
         constexpr int NR = 2 * MT, RD = 4;
         const uint32_t key16 = (uint32_t)((g ^ ((r16 >> 1) & 7)) << 4);

@@ -34,6 +34,13 @@ for nm, N, K, kw in cases:
     if kw.get("drop"):
         k2["drop"] = kw["drop"]
     res = {v: [] for v in vals}
+    outs = {}
+    for v in vals:       # the values must not change the result: compare the outputs bit for bit with the first value's
+        ops.set_tuning(key, v)
+        ops.gemm_nt(A, B, C, **k2)
+        torch.cuda.synchronize()
+        outs[v] = C.clone()
+    same = " ".join("same" if torch.equal(outs[v], outs[vals[0]]) else f"DIFF({(outs[v].float() - outs[vals[0]].float()).abs().max().item():.3g})" for v in vals[1:])
     for r in range(R + 1):
         for v in vals:
             ops.set_tuning(key, v)
@@ -48,4 +55,4 @@ for nm, N, K, kw in cases:
             torch.cuda.synchronize()
             if r:
                 res[v].append(e0.elapsed_time(e1) * 100.0)
-    print(f"{nm:28s} " + "   ".join(f"{key}={v}: median {sorted(res[v])[len(res[v]) // 2]:7.1f} min {min(res[v]):7.1f} us" for v in vals), flush=True)
+    print(f"{nm:28s} " + "   ".join(f"{key}={v}: median {sorted(res[v])[len(res[v]) // 2]:7.1f} min {min(res[v]):7.1f} us" for v in vals) + "   " + same, flush=True)
