@@ -162,6 +162,7 @@ class _Ctx:
     seed: int = 0
     ids: torch.Tensor = None
     mask_u8: torch.Tensor = None
+    enc_mask: torch.Tensor = None      # the ENCODER's key mask: mask_u8, or None when the batch has no padding at all (Engine._enc_mask)
     labels: torch.Tensor = None
     dec_ids: torch.Tensor = None
     ckpt: bool = False
@@ -425,9 +426,18 @@ class Engine:
     def _enc_attn_layout(rag, BN, L, mask_u8):
         """(batch, time) of the [·, ·, H, dk] head views of the token-major buffers + the attention kwargs: padded
         [BN, L] with a key mask, or ONE packed run of rows with per-passage offsets."""
-        if rag is None:
-            return BN, L, dict(key_mask=mask_u8)
+        if rag is None:      # (mask_u8 None: a batch without any padding — no mask to apply, and the encoder's fast attention kernels take it)
+            return BN, L, (dict(key_mask=mask_u8) if mask_u8 is not None else {})
         return 1, rag.M, dict(q_off=rag.off, k_off=rag.off, max_q=L, max_k=L, order=rag.order)
+
+    def _enc_mask(self, rag, mask_u8):
+        """The key mask of the encoder's self-attention on the padded layout — None when the batch has no padded position at all (what
+        _ragged_batch found: every passage at text_maxlength, e.g. `bench.py --all-valid`): a mask of ones adds nothing, and without one
+        the padded [B·N, L] batch is a set of exact-length sequences for the fast encoder kernels (csrc/attn_enc.hip) instead of the generic
+        masked ones.  LAKO_ENC_ALLVALID_MASK=1 keeps the mask (A/B)."""
+        if rag is None and self._all_valid and os.environ.get("LAKO_ENC_ALLVALID_MASK", "0") != "1":
+            return None
+        return mask_u8
 
     def _encode(self, ws, ids_flat, mask_u8, BN, L, p, seed, save, rag=None, want_kv=True):
         """save: True  — keep every intermediate of every layer (training; 288 GB of HBM make this the default);
@@ -931,7 +941,8 @@ class Engine:
         ctx.enc_ids = enc_ids
         xa = ctx.xa = self._xattn_plan(rag, B, N, L, T * H)
         self.xattn_active = xa is not None         # (bench.py / tests: which formulation the last forward ran)
-        enc_out, kv = self._encode(ws, enc_ids, ctx.mask_u8, B * N, L, p, seed, save="ckpt" if ctx.ckpt else True, rag=rag,
+        ctx.enc_mask = self._enc_mask(rag, ctx.mask_u8)
+        enc_out, kv = self._encode(ws, enc_ids, ctx.enc_mask, B * N, L, p, seed, save="ckpt" if ctx.ckpt else True, rag=rag,
                                    want_kv=xa is None)
         # ---- decoder ------------------------------------------------------------------------
         Md, S, Ld = B * T, N * L, cfg.num_decoder_layers
@@ -1116,7 +1127,7 @@ class Engine:
             j, sl = i, slot_of(i)
             if ctx.ckpt:   # recompute this block's intermediates from its saved input (same seeds → same dropout masks)
                 j = 0
-                self._enc_layer_fwd(ws, i, 0, ws[f"e.h{i}"], None, BN, L, ctx.mask_u8, ws["e.rel"], dr, rag)
+                self._enc_layer_fwd(ws, i, 0, ws[f"e.h{i}"], None, BN, L, ctx.enc_mask, ws["e.rel"], dr, rag)
             # the layer's four weight gradients (K = all tokens, small M×N) go out in ONE grouped launch (with those of the other
             # layers of its group): 108 tiles per layer fill the chip with ~2 K-splits, where four separate launches need 7–28 splits
             # each and pay one fp32 atomic pass over the output per split
@@ -1135,7 +1146,7 @@ class Engine:
             ops.gemm_nt(dy, lw["o"].wt, dctx)
             qkv = ws[f"e.qkv.{j}"]
             dqkv = self._buf(tmp, "e.dqkv" + sl, (Me, 3 * inner))
-            hb, ht, akw = self._enc_attn_layout(rag, BN, L, ctx.mask_u8)
+            hb, ht, akw = self._enc_attn_layout(rag, BN, L, ctx.enc_mask)
             ops.attn_bwd(self._heads(qkv, hb, ht, 0), self._heads(qkv, hb, ht, inner), self._heads(qkv, hb, ht, 2 * inner),
                          self._heads(ws[f"e.ctx.{j}"], hb, ht, 0), self._heads(dctx, hb, ht, 0), ws[f"e.st.{j}"],
                          self._heads(dqkv, hb, ht, 0), self._heads(dqkv, hb, ht, inner),
@@ -1175,6 +1186,8 @@ class Engine:
         mask_u8 = attention_mask.reshape(B * N, L).to(torch.uint8).contiguous()
         # valid tokens only (as in forward_loss) unless the raw scores are captured: those are laid out per padded position
         rag = None if capture_scores else self._legacy_layout(self._ragged_batch(attention_mask, B, N, L, lengths), max_length)
+        if capture_scores:
+            self._all_valid = False      # (_ragged_batch did not look at this mask: nothing is known about its padding — _enc_mask keeps it)
         self._row_cap = {rag.M: B * N * L} if rag is not None else {}
         # what changes from call to call is COPIED into workspace buffers (stable addresses: the decode steps below are captured
         # into HIP graphs): the samples' key offsets of the unpadded batch, or the key mask of the padded one
@@ -1195,7 +1208,7 @@ class Engine:
         use_x = os.environ.get("LAKO_XATTN_GENERATE", "1" if use_graph else "0") == "1" and not capture_scores
         xa = self._xattn_plan(rag, B, N, L, H) if use_x else None
         self.xattn_active = xa is not None
-        enc_out, kv = self._encode(ws, ids, mask_u8, B * N, L, 0.0, 0, save=False, rag=rag, want_kv=xa is None)
+        enc_out, kv = self._encode(ws, ids, self._enc_mask(rag, mask_u8), B * N, L, 0.0, 0, save=False, rag=rag, want_kv=xa is None)
         if xa is not None:
             mode += "x"
             cap = B * (-(-S // 256) * 256)

@@ -579,3 +579,41 @@ def test_legacy_cross_bias_engine_vs_oracle(short_first, tmp_path):
     assert back.config.legacy_cross_bias
     sd = back.state_dict()
     assert torch.equal(sd[O.XREL], w[O.XREL])
+
+
+def test_batch_without_padding_runs_the_encoder_without_a_key_mask(monkeypatch):
+    """A batch whose passages are all at text_maxlength has no position to mask: the encoder's self-attention gets no key mask (on the
+    GPU that is what lets the fast encoder kernels take the padded [B·N, L] layout, Engine._enc_mask) and the results are those of the
+    masked call; one padded position anywhere brings the mask back; the capture path never trusts a stale flag."""
+    z, dims, w, model = build("tiny_a")
+    B, N, L = z["input_ids"].shape
+    ids = torch.from_numpy(z["input_ids"]).clamp(min=2)
+    full = torch.ones(B, N, L, dtype=torch.bool)
+    labels = torch.from_numpy(z["labels"])
+    model.train()
+    out = model(input_ids=ids, attention_mask=full, labels=labels)
+    assert model._engine.ctx.rag is None and model._engine.ctx.enc_mask is None
+    out[0].backward()
+    g = {n: p.grad.clone() for n, p in model.named_parameters()}
+    monkeypatch.setenv("LAKO_ENC_ALLVALID_MASK", "1")
+    model.zero_grad()
+    out2 = model(input_ids=ids, attention_mask=full.clone(), labels=labels)
+    assert model._engine.ctx.enc_mask is not None
+    out2[0].backward()
+    assert torch.equal(out[0], out2[0]) and torch.equal(out.logits, out2.logits)
+    for n, p in model.named_parameters():
+        assert torch.equal(p.grad, g[n]), n
+    monkeypatch.delenv("LAKO_ENC_ALLVALID_MASK")
+    part = full.clone()
+    part[1, 2, L - 1] = False
+    model(input_ids=ids * part, attention_mask=part, labels=labels)
+    assert model._engine.ctx.rag is not None or model._engine.ctx.enc_mask is not None
+    # generate with score capture does not inspect the mask's padding: the flag of the previous (all-valid) call must not leak into it
+    model.eval()
+    model(input_ids=ids, attention_mask=full, labels=labels)
+    assert model._engine._all_valid
+    model.overwrite_forward_crossattention()
+    model.reset_score_storage()
+    toks = model.generate(input_ids=ids * part, attention_mask=part, max_length=4)
+    assert not model._engine._all_valid
+    assert toks.tolist() == O.fid_generate(w, dims, ids * part, part, 4).tolist()

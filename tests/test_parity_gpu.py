@@ -526,3 +526,35 @@ def test_legacy_cross_bias_vs_oracle(dtype, short_first):
         assert abs(out[0].item() - loss.item()) < 0.03 * max(1.0, abs(loss.item()))
         cos = float(torch.dot(gx, rx) / (gx.norm() * rx.norm() + 1e-30))
         assert cos > 0.98, cos
+
+
+@pytest.mark.gpu
+def test_all_valid_batch_takes_the_fast_encoder_kernels_and_matches_the_masked_ones(monkeypatch):
+    """A batch without any padding (every passage at text_maxlength; `bench.py`'s all-valid leg) runs the encoder's self-attention
+    WITHOUT a key mask, i.e. on the fast encoder kernels (one-pass backward included) instead of the generic masked ones
+    (Engine._enc_mask).  Same inputs with the mask kept (LAKO_ENC_ALLVALID_MASK=1 → generic kernels): bf16, dropout off — loss within
+    1e-3 relative, every gradient's direction cosine > 0.995 (two kernel families: different summation orders, both bf16)."""
+    cfg = FiDConfig.named("small", dropout_rate=0.0, vocab_size=512, num_layers=3, num_decoder_layers=2)
+    torch.manual_seed(5)
+    B, N, L, T = 4, 8, 96, 6
+    ids = torch.randint(2, cfg.vocab_size, (B, N, L), device=DEV)
+    mask = torch.ones(B, N, L, dtype=torch.bool, device=DEV)
+    labels = torch.randint(2, cfg.vocab_size, (B, T), device=DEV)
+    res = {}
+    for keep in ("0", "1"):
+        monkeypatch.setenv("LAKO_ENC_ALLVALID_MASK", keep)
+        m = FiDT5(cfg, dtype=torch.bfloat16, seed=3)
+        with torch.no_grad():
+            m._params_by_plain["shared.weight"].mul_(0.2)
+        m = m.cuda().train()
+        out = m(input_ids=ids, attention_mask=mask, labels=labels)
+        assert (m._engine.ctx.enc_mask is None) == (keep == "0")
+        out[0].backward()
+        res[keep] = (out[0].item(), {n: p.grad.float().cpu().flatten() for n, p in m.named_parameters()})
+    l0, l1 = res["0"][0], res["1"][0]
+    assert abs(l0 - l1) < 1e-3 * max(1.0, abs(l1)), (l0, l1)
+    for n, g0 in res["0"][1].items():
+        g1 = res["1"][1][n]
+        if g1.norm() > 1e-6 * g1.numel() ** 0.5:
+            cos = float(torch.dot(g0.double(), g1.double()) / (g0.double().norm() * g1.double().norm() + 1e-30))
+            assert cos > 0.995, f"{n}: {cos:.5f}"
