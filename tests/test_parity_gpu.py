@@ -543,6 +543,7 @@ def test_all_valid_batch_takes_the_fast_encoder_kernels_and_matches_the_masked_o
     res = {}
     for keep in ("0", "1"):
         monkeypatch.setenv("LAKO_ENC_ALLVALID_MASK", keep)
+        torch.manual_seed(6)            # the same initial weights for both runs
         m = FiDT5(cfg, dtype=torch.bfloat16, seed=3)
         with torch.no_grad():
             m._params_by_plain["shared.weight"].mul_(0.2)
