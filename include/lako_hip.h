@@ -155,7 +155,8 @@ int lako_gemm_tn(const void* A, const void* B, float* C, int64_t M, int64_t N, i
  * encoder-state gradient of the cross-attention); -3 (grouped only) = HYBRID under the same promise as -1: the first
  * 256 * floor(tiles / 256) output tiles — whole rounds of the chip — run their whole K in one workgroup each and add by plain loads
  * and stores, the remaining tiles are cut into up to 16 K-pieces that add by atomics (the encoder's weight gradients: 1 296 tiles =
- * five rounds of full-K tiles + 16 tiles x 16 pieces, instead of 15.2 -> 16 rounds of third-K units with one atomic pass each). */
+ * five rounds of full-K tiles + 16 tiles x 16 pieces, instead of 15.2 -> 16 rounds of third-K units with one atomic pass each).
+ * With split_k < 0 the items' output ranges must be disjoint: overlapping ones are refused with LAKO_E_BADARG before anything is launched. */
 #define LAKO_TN_GROUP_MAX 48
 typedef struct {
   const void* a; /* [K, M] row-major, lda */

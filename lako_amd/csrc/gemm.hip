@@ -1649,7 +1649,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(TnArgs a) {
   // agent-scope release fence and draws a ticket; the workgroup that draws the last ticket acquires, sums ALL splits' slabs in split
   // order (its own included: the sum does not depend on who arrived last — the gradients are bit-reproducible, which float atomics
   // were not) and adds the tile to C by plain loads / stores.  Replaces two atomic passes over every tile (≈ 1.3 TB/s chip-wide).
-  if (a.slabs != nullptr && a.split_k > 1) {
+  if (a.slabs != nullptr && a.split_k > 1 && a.t_full == 0) {      // (never with the hybrid schedule: its full-K units draw no ticket)
     float* mine = a.slabs + ((int64_t)gtile * a.split_k + split) * 65536 + (int64_t)wave * 8192;
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
@@ -1689,7 +1689,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(TnArgs a) {
       }
     }
   }
-  const int out_mode = (a.slabs != nullptr && a.split_k > 1) ? 1 : unit_mode;
+  const int out_mode = (a.slabs != nullptr && a.split_k > 1 && a.t_full == 0) ? 1 : unit_mode;
   // epilogue: per wave a private 16×64 fp32 slab in LDS (staging buffers are free after the last barrier)
   float* slab = reinterpret_cast<float*>(smem) + wave * 1024;
   const int r16 = lane & 15, g = lane >> 4;
@@ -2642,6 +2642,19 @@ extern "C" int lako_gemm_tn_grouped(const lako_gemm_tn_item_t* items, int n_item
   LAKO_CHECK_ARG(items && n_items >= 1 && n_items <= LAKO_TN_GROUP_MAX, "lako_gemm_tn_grouped: 1..%d items", LAKO_TN_GROUP_MAX);
   LAKO_CHECK_ARG(split_k >= -3, "lako_gemm_tn_grouped: split_k %d", split_k);
   LAKO_CHECK_ARG(K > 0 && K < (1 << 30), "lako_gemm_tn_grouped: bad K");
+  if (split_k < 0) {
+    // split_k < 0 promises "one contributor per element of C" (plain read-modify-write / overwrite / the hybrid schedule): two items whose
+    // outputs overlap would race or overwrite each other silently — refuse them here (byte ranges [c, c + ((M − 1)·ldc + N)·4); n <= 64)
+    for (int i = 0; i < n_items; ++i) {
+      if (!items[i].c || items[i].M <= 0 || items[i].N <= 0) continue;      // (reported per item below)
+      const uintptr_t b0 = reinterpret_cast<uintptr_t>(items[i].c), e0 = b0 + (uintptr_t)(((items[i].M - 1) * items[i].ldc + items[i].N) * 4);
+      for (int j = i + 1; j < n_items; ++j) {
+        if (!items[j].c || items[j].M <= 0 || items[j].N <= 0) continue;
+        const uintptr_t b1 = reinterpret_cast<uintptr_t>(items[j].c), e1 = b1 + (uintptr_t)(((items[j].M - 1) * items[j].ldc + items[j].N) * 4);
+        LAKO_CHECK_ARG(e0 <= b1 || e1 <= b0, "lako_gemm_tn_grouped: split_k %d needs disjoint outputs, items %d and %d overlap", split_k, i, j);
+      }
+    }
+  }
   bool big = in_dtype == LAKO_BF16 && tu.tn_big;
   for (int i = 0; i < n_items; ++i) big = big && items[i].M >= 256 && items[i].N >= 256;
   if (!big) {   // shapes the 256×256 kernel does not take: one launch per problem

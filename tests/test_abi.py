@@ -130,6 +130,30 @@ def test_comm_and_workspace_entry_points_validate_their_arguments(lib):
     assert lib.lako_comm_unique_id(None) == -1
 
 
+def test_exclusive_weight_gradient_modes_refuse_overlapping_outputs(lib):
+    """lako_gemm_tn_grouped with split_k < 0 promises ONE contributor per element of C (plain read-modify-write, overwrite, the hybrid
+    schedule): two items whose output ranges overlap would race or overwrite each other silently — refused before anything is
+    planned or launched."""
+    from lako_amd import _lib
+    base = 0x7F0000000000
+    def items(c1):
+        arr = (_lib.GemmTNItem * 2)()
+        for it, c in zip(arr, (base, c1)):
+            it.a, it.b, it.c = base + (1 << 30), base + (2 << 30), c
+            it.M, it.N, it.lda, it.ldb, it.ldc, it.alpha, it.rows_out = 256, 256, 256, 256, 256, 1.0, 0
+        return arr
+    lib.lako_gemm_tn_grouped.restype = ctypes.c_int
+    call = lambda arr, sk: lib.lako_gemm_tn_grouped(arr, 2, 1024, 0, sk, None, None, 0, None)      # noqa: E731
+    for sk in (-1, -2, -3):
+        assert call(items(base), sk) == -1                                # the same C twice
+        assert call(items(base + 255 * 256 * 4), sk) == -1                # second C starts inside the first's last row
+        buf = ctypes.create_string_buffer(512)
+        lib.lako_last_error.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+        lib.lako_last_error(buf, 512)
+        assert b"overlap" in buf.value, buf.value
+    # (disjoint outputs — every grouped launch of the training step — run in the GPU suite; nothing is launched from this host)
+
+
 def test_product_fails_loudly_without_library(monkeypatch, tmp_path):
     from lako_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
