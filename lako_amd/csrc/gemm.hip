@@ -2644,14 +2644,24 @@ extern "C" int lako_gemm_tn_grouped(const lako_gemm_tn_item_t* items, int n_item
   LAKO_CHECK_ARG(K > 0 && K < (1 << 30), "lako_gemm_tn_grouped: bad K");
   if (split_k < 0) {
     // split_k < 0 promises "one contributor per element of C" (plain read-modify-write / overwrite / the hybrid schedule): two items whose
-    // outputs overlap would race or overwrite each other silently — refuse them here (byte ranges [c, c + ((M − 1)·ldc + N)·4); n <= 64)
+    // outputs share an element would race or overwrite each other silently — refuse them here (n <= 48).  An item touches rows
+    // [0, rows_out or M) × columns [0, N) of its C; two items with the same ldc are compared as rectangles of one matrix (column blocks of
+    // one gradient are fine), others by their byte ranges.
+    auto rows_of = [](const lako_gemm_tn_item_t& p) { return p.rows_out > 0 ? (int64_t)p.rows_out : p.M; };
     for (int i = 0; i < n_items; ++i) {
-      if (!items[i].c || items[i].M <= 0 || items[i].N <= 0) continue;      // (reported per item below)
-      const uintptr_t b0 = reinterpret_cast<uintptr_t>(items[i].c), e0 = b0 + (uintptr_t)(((items[i].M - 1) * items[i].ldc + items[i].N) * 4);
+      const lako_gemm_tn_item_t& p = items[i];
+      if (!p.c || p.M <= 0 || p.N <= 0) continue;      // (reported per item below)
       for (int j = i + 1; j < n_items; ++j) {
-        if (!items[j].c || items[j].M <= 0 || items[j].N <= 0) continue;
-        const uintptr_t b1 = reinterpret_cast<uintptr_t>(items[j].c), e1 = b1 + (uintptr_t)(((items[j].M - 1) * items[j].ldc + items[j].N) * 4);
-        LAKO_CHECK_ARG(e0 <= b1 || e1 <= b0, "lako_gemm_tn_grouped: split_k %d needs disjoint outputs, items %d and %d overlap", split_k, i, j);
+        const lako_gemm_tn_item_t& q = items[j];
+        if (!q.c || q.M <= 0 || q.N <= 0) continue;
+        const lako_gemm_tn_item_t &lo = p.c <= q.c ? p : q, &hi = p.c <= q.c ? q : p;
+        const int64_t d = hi.c - lo.c;                   // in elements
+        bool overlap;
+        if (lo.ldc == hi.ldc && lo.ldc > 0 && lo.N <= lo.ldc && d % lo.ldc + hi.N <= lo.ldc)
+          overlap = d / lo.ldc < rows_of(lo) && d % lo.ldc < lo.N;
+        else
+          overlap = d < (rows_of(lo) - 1) * lo.ldc + lo.N;
+        LAKO_CHECK_ARG(!overlap, "lako_gemm_tn_grouped: split_k %d needs disjoint outputs, items %d and %d overlap", split_k, i, j);
       }
     }
   }

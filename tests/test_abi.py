@@ -146,7 +146,7 @@ def test_exclusive_weight_gradient_modes_refuse_overlapping_outputs(lib):
     call = lambda arr, sk: lib.lako_gemm_tn_grouped(arr, 2, 1024, 0, sk, None, None, 0, None)      # noqa: E731
     for sk in (-1, -2, -3):
         assert call(items(base), sk) == -1                                # the same C twice
-        assert call(items(base + 255 * 256 * 4), sk) == -1                # second C starts inside the first's last row
+        assert call(items(base + 255 * 256 * 4 + 16), sk) == -1           # second C starts inside the first's last row
         buf = ctypes.create_string_buffer(512)
         lib.lako_last_error.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
         lib.lako_last_error(buf, 512)

@@ -797,6 +797,62 @@ def test_attention_persistent_kernels_equal_per_item_kernels(ops, drop, monkeypa
         assert float(other[0].float().abs().max()) > 0 and float(other[2].abs().max()) > 0
 
 
+@pytest.mark.parametrize("lengths", ["config2", "short", "full", "mixed"])
+def test_attention_fast_path_race_screen(ops, lengths, monkeypatch):
+    """The encoder fast path's kernels hand data between waves through LDS rings filled by LDS-DMA across item boundaries, ordered only by
+    counted `s_waitcnt vmcnt` + barriers (the one-pass backward: a 4-stage slab ring, a K image staged one item ahead, a dS slab read one
+    slab later).  A misplaced wait shows as RARE wrong tiles that come and go with timing — so: the same launch 40 times at the
+    benchmark's scale (320 passages x 12 heads = 15 items per workgroup) and at length mixes that move every boundary (1 … 40 tokens:
+    an item per slab; all 200; a mix with empty and one-token passages), forward and backward, every output BIT-identical to the first
+    run's (the kernels have no atomics on these outputs; the bias gradient's cross-workgroup float atomics are compared to summation
+    noise)."""
+    monkeypatch.setenv("LAKO_ATTN_PERSIST", "18")
+    T = torch.bfloat16
+    H, dk, Lmax = 12, 64, 200
+    inner = H * dk
+    g = torch.Generator().manual_seed(11)
+    if lengths == "config2":
+        lens = torch.randint(100, 201, (320,), generator=g).tolist()
+    elif lengths == "short":
+        lens = torch.randint(1, 41, (700,), generator=g).tolist()
+    elif lengths == "full":
+        lens = [200] * 160
+    else:
+        lens = torch.randint(1, 201, (300,), generator=g).tolist()
+        for i in (0, 17, 18, 150, 299):
+            lens[i] = 0
+        for i in (5, 6, 151):
+            lens[i] = 1
+    Bn = len(lens)
+    off = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=dev())
+    rows = int(off[-1])
+    qkv = rnd(1, rows, 3 * inner, dtype=T, seed=61, scale=0.5)
+    dout = rnd(1, rows, inner, dtype=T, seed=62, scale=0.5)
+    rel = rnd(H, 2 * Lmax - 1, seed=63)
+    heads = lambda t, c0: t[:, :, c0:c0 + inner].unflatten(2, (H, dk))      # noqa: E731
+    args = tuple(heads(qkv, c) for c in (0, inner, 2 * inner))
+    order = torch.argsort(torch.tensor(lens), descending=True, stable=True).to(torch.int32).to(dev())
+    kw = dict(rel_bias=rel, rel_off=Lmax - 1, drop=(0.1, 5, 6), q_off=off, k_off=off, max_q=Lmax, max_k=Lmax, order=order)
+    first = None
+    for rep in range(40):
+        out = torch.zeros(1, rows, inner, dtype=T, device=dev())
+        st = torch.zeros(Bn, H, Lmax, 4, device=dev())
+        ops.attn_fwd(*args, out.unflatten(2, (H, dk)), st, **kw)
+        dqkv = torch.zeros_like(qkv)
+        drel = torch.zeros_like(rel)
+        ops.attn_bwd(*args, out.unflatten(2, (H, dk)), heads(dout, 0), st, *(heads(dqkv, c) for c in (0, inner, 2 * inner)), drel=drel, **kw)
+        torch.cuda.synchronize()
+        if first is None:
+            first = (out, dqkv, drel)
+            assert float(dqkv.float().abs().max()) > 0 and bool(torch.isfinite(dqkv.float()).all())
+            continue
+        assert torch.equal(out, first[0]), f"forward differs in run {rep}"
+        if not torch.equal(dqkv, first[1]):
+            bad = (dqkv != first[1]).nonzero()
+            raise AssertionError(f"backward differs in run {rep}: {bad.shape[0]} elements, first at {bad[0].tolist()}")
+        close(drel, first[2], torch.float32, f"race screen drel run {rep}", k=5)
+
+
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("persist", ["18", "2", "7", "0"])
 def test_attention_processing_order_does_not_change_results(ops, persist, monkeypatch):
