@@ -230,6 +230,20 @@ __device__ __forceinline__ void efwd_chunk(const char* Kimg, const char* Vimg, i
   for (int p = 0; p < NPC; ++p) epv(oacc, s[2 * p], s[2 * p + 1], Vimg, (pair0 + p) * 32, el.toff);
 }
 
+// (experiments build) enc_fwd_c_kernel under the clock: per workgroup (< 4096) and wave eight 64-bit words in a.dbg_buf —
+// 0 entry, 1 everything requested (K / V DMA, Q, bias copies), 2 landed + barrier passed, 3 first query block done, 4 exit,
+// 5 HW_ID, 6 XCC_ID, 7 (Lq << 16 | query blocks of this wave) — read back by tools/attn_fwd_stamps.py (LAKO_ATTN_DEBUG bit 262144)
+#ifdef LAKO_EXPERIMENTS
+#define FWD_STAMP(P, VAL)                                                                                                    \
+  do {                                                                                                                       \
+    if (a.dbg_buf && (threadIdx.x & 63) == 0) {                                                                              \
+      const int wg_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;                                        \
+      if (wg_ < 4096) reinterpret_cast<unsigned long long*>(a.dbg_buf)[(wg_ * 8 + wave) * 8 + (P)] = (VAL);                  \
+    }                                                                                                                        \
+  } while (0)
+#else
+#define FWD_STAMP(P, VAL) do {} while (0)
+#endif
 constexpr int FWD_NW = 8;     // waves per forward workgroup: 2 workgroups (133 KB of LDS) = 16 waves per CU, 4 per SIMD
 // LDS: K image | V image | 4 bias copies
 __host__ __device__ constexpr int efwd_lds(int rows) { return 2 * rows * EROW + 4 * EB_ST * 4; }
@@ -335,6 +349,7 @@ __global__ __launch_bounds__(FWD_NW * 64, FWD_NW / 2) void enc_fwd_c_kernel(Attn
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, l15 = lane & 15;
+  FWD_STAMP(0, __builtin_amdgcn_s_memtime());
   const int b = attn_seq(a, blockIdx.z), h = blockIdx.y;
   const int q0 = a.q_off ? __builtin_amdgcn_readfirstlane(a.q_off[b]) : 0;
   const int k0 = a.k_off ? __builtin_amdgcn_readfirstlane(a.k_off[b]) : 0;
@@ -355,8 +370,11 @@ __global__ __launch_bounds__(FWD_NW * 64, FWD_NW / 2) void enc_fwd_c_kernel(Attn
   auto request_q = [&](int qbn) { eload_frags(qf_next, qbase, a.qst * 2, qbn < qb_end ? qbn * 16 + l15 : Lq, Lq, g); };
   request_q(qb_begin + wave);
   estage_bias<FWD_NW * 64>(b4, a.rel_bias, h, a.R, false);
+  FWD_STAMP(1, __builtin_amdgcn_s_memtime());
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the wave's DMA pieces have landed (the compiler does not count them)
   __syncthreads();
+  FWD_STAMP(2, __builtin_amdgcn_s_memtime());
+  int nblk_ = 0;
   const ELane el = elane(lane);
   const uint32_t t_hi = a.drop_t16 << 16;
   const int KB = (a.Lk + 3) >> 2, QB = (a.Lq + 3) >> 2;
@@ -384,6 +402,7 @@ __global__ __launch_bounds__(FWD_NW * 64, FWD_NW / 2) void enc_fwd_c_kernel(Attn
     }
 #undef ECH
     l = egroup_sum(l);
+    if (nblk_++ == 0) { asm volatile("" :: "v"(oacc[0]), "v"(l)); FWD_STAMP(3, __builtin_amdgcn_s_memtime()); }
     if (qi < Lq) {
       const float inv = 1.0f / l;
       const float f = inv * oscale;
@@ -397,6 +416,10 @@ __global__ __launch_bounds__(FWD_NW * 64, FWD_NW / 2) void enc_fwd_c_kernel(Attn
       }
     }
   }
+  FWD_STAMP(4, __builtin_amdgcn_s_memtime());
+  FWD_STAMP(5, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4));
+  FWD_STAMP(6, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20));
+  FWD_STAMP(7, ((unsigned long long)Lq << 16) | (unsigned long long)nblk_);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1759,6 +1782,16 @@ static void* lako_exp_stamp_buffer() {
   }
   return buf;
 }
+constexpr size_t FWD_STAMP_BYTES = 4096 * 8 * 8 * 8;
+static void* lako_exp_fwd_stamp_buffer() {
+  static void* buf = nullptr;
+  if (!buf) (void)hipMalloc(&buf, FWD_STAMP_BYTES);
+  return buf;
+}
+extern "C" int lako_exp_attn_fwd_stamps(void* host_dst, size_t bytes) {
+  (void)hipDeviceSynchronize();
+  return (int)hipMemcpy(host_dst, lako_exp_fwd_stamp_buffer(), bytes < FWD_STAMP_BYTES ? bytes : FWD_STAMP_BYTES, hipMemcpyDeviceToHost);
+}
 extern "C" int lako_exp_attn_stamps(void* host_dst, size_t bytes) {
   (void)hipDeviceSynchronize();
   return (int)hipMemcpy(host_dst, lako_exp_stamp_buffer(), bytes < FB_STAMP_BYTES ? bytes : FB_STAMP_BYTES, hipMemcpyDeviceToHost);
@@ -1805,6 +1838,7 @@ int lako_attn_enc_fwd(AttnArgs& a, hipStream_t s) {
 #ifdef LAKO_EXPERIMENTS
   static const int dbg = getenv("LAKO_ATTN_DEBUG") ? atoi(getenv("LAKO_ATTN_DEBUG")) : 0;
   a.dbg_flags = dbg;
+  a.dbg_buf = (dbg & 262144) ? lako_exp_fwd_stamp_buffer() : nullptr;
 #endif
   enorm_nobias(a);
   a.chunk_rows = ((a.Lk + 31) / 32) * 32;

@@ -45,6 +45,7 @@ struct AttnArgs {
   int bn_per_wg;      // dQ pass: batch rows walked by one workgroup (bias-gradient register accumulation)
   int dma_stage;      // attn_enc.hip per-item kernels: 1 = the LDS images arrive by LDS-DMA, everything in flight together (round 4); 0 = register staging
   int dbg_flags;      // timing experiments (LAKO_ATTN_DEBUG): bit 2 = skip the global bias-gradient flush, bit 3 = skip the LDS flush too
+  void* dbg_buf;      // (experiments build) stamp buffer of the forward kernel, see FWD_STAMP in attn_enc.hip
   int rq, rk;         // fused backward of attn_enc.hip, padded launches: rows per sequence of the q / k side (batch stride ÷ token stride)
   int grid_x, grid_z; // dQ pass, grid_x > 0: 1-D XCD-grouped grid standing for (grid_x, H, grid_z) — see attn_bwd_kernel
   uint32_t drop_t16, drop_key;   // attention dropout: keep iff 16-bit half >= drop_t16 (0 = off)
