@@ -1685,15 +1685,41 @@ __global__ __launch_bounds__(FB_NW * 64) void enc_bwd_fused_kernel(AttnArgs a) {
       }
       if (ATTN_DBG(a, 131072)) { asm volatile("" :: "v"(dkacc[0]), "v"(dvacc[3])); FB_STAMP(6); }
       if (st.last) {
+        // dK / dV of the item.  A lane holds, per 16-wide d-block, the 4 d-values 4g … 4g + 3 of its key: stored as they are that is sixteen
+        // 8-byte stores per wave and item, each touching 16 rows x 32 bytes — 2 000 – 4 000 cycles of store issue at every item boundary
+        // (profiles/r05b_attn_fused_stamps.txt).  The lanes g and g ^ 1 of a key (lane ^ 16: one ds_swizzle) swap halves instead — the even
+        // one ends up with the full 16 bytes of d-blocks 0 and 1, the odd one with those of d-blocks 2 and 3 — and the item leaves in eight
+        // 16-byte stores per wave.  Same values, same bytes.
         const int g = lane >> 4, ki = wave * 16 + (lane & 15);
+        const bool odd = g & 1;
+        auto pack = [](f32x4 v) {
+          const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+          return __builtin_bit_cast(u32x2, o);
+        };
+        auto pair16 = [&](const f32x4 (&acc)[4], u32x4 (&out)[2]) {
+          const u32x2 pk[4] = {pack(acc[0]), pack(acc[1]), pack(acc[2]), pack(acc[3])};
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const u32x2 send = odd ? pk[i] : pk[2 + i], keep = odd ? pk[2 + i] : pk[i];
+            u32x2 recv;
+            recv[0] = (uint32_t)__builtin_amdgcn_ds_swizzle((int)send[0], 0x401F);      // BITMASK_PERM: lane ^ 16
+            recv[1] = (uint32_t)__builtin_amdgcn_ds_swizzle((int)send[1], 0x401F);
+            out[i] = odd ? u32x4{recv[0], recv[1], keep[0], keep[1]} : u32x4{keep[0], keep[1], recv[0], recv[1]};
+          }
+        };
+        u32x4 ko[2], vo[2];
+        pair16(dkacc, ko);
+        pair16(dvacc, vo);
         if (ki < st.Lk) {
           const int k0 = item(st.j).k0;
-          bf16_t* kp_ = reinterpret_cast<bf16_t*>(a.dk + h * 128 + (int64_t)(k0 + ki) * ((int64_t)a.kst * 2));
-          bf16_t* vp_ = reinterpret_cast<bf16_t*>(a.dv + h * 128 + (int64_t)(k0 + ki) * ((int64_t)a.vst * 2));
+          // even lanes: d-blocks 0, 1 at d = 16i + 4g;  odd lanes: d-blocks 2, 3 at d = 16(2 + i) + 4(g − 1)
+          const int dcol = odd ? 32 + 4 * (g - 1) : 4 * g;
+          bf16_t* kp_ = reinterpret_cast<bf16_t*>(a.dk + h * 128 + (int64_t)(k0 + ki) * ((int64_t)a.kst * 2)) + dcol;
+          bf16_t* vp_ = reinterpret_cast<bf16_t*>(a.dv + h * 128 + (int64_t)(k0 + ki) * ((int64_t)a.vst * 2)) + dcol;
 #pragma unroll
-          for (int db = 0; db < 4; ++db) {
-            store4(kp_ + db * 16 + 4 * g, dkacc[db]);
-            store4(vp_ + db * 16 + 4 * g, dvacc[db]);
+          for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<u32x4*>(kp_ + 16 * i) = ko[i];
+            *reinterpret_cast<u32x4*>(vp_ + 16 * i) = vo[i];
           }
         }
       }
