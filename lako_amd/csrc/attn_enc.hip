@@ -39,15 +39,28 @@ constexpr float LOG2E = 1.4426950408889634f;
 // The four shifted copies of the (optionally reversed) bias table of head h:  copy c, float j  =  T'[j + c],
 // T'[t] = rel_bias[h][t − PADLO] inside [0, R) and 0 outside (only masked keys / discarded queries ever read the padding);
 // REV: T' is read backwards, T'rev[t] = T'[last − t] (the dK/dV pass walks key − query downwards along the registers).
+// (Round 5: ALL of a thread's table reads are requested before the first one is waited for.  As a plain loop — read, store to LDS, next —
+//  hipcc waits `vmcnt(0)` in front of every store: five serialised L2 round trips at the start of every forward workgroup, the first of
+//  them behind the K / V image DMA, ≈ 3 000 – 4 000 of a workgroup's ≈ 27 000 cycles — profiles/r05t_attn_fwd_stamps.txt.)
 template <int NT = 256>
 __device__ __forceinline__ void estage_bias(float* b4, const float* rel_bias, int h, int R, bool rev) {
   const int last = R - 1 + EB_PADLO + 36;
-  for (int i = threadIdx.x; i < 4 * EB_ST; i += NT) {
+  constexpr int IT = (4 * EB_ST + NT - 1) / NT;
+  float v[IT];
+#pragma unroll
+  for (int k = 0; k < IT; ++k) {
+    const int i = (int)threadIdx.x + k * NT;
     const int c = i / EB_ST, j = i - c * EB_ST;
     int t = j + c;
     if (rev) t = last - t;
     t -= EB_PADLO;
-    b4[i] = (rel_bias != nullptr && t >= 0 && t < R) ? rel_bias[(int64_t)h * R + t] : 0.f;
+    const bool in = rel_bias != nullptr && i < 4 * EB_ST && t >= 0 && t < R;
+    v[k] = in ? rel_bias[(int64_t)h * R + (in ? t : 0)] : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < IT; ++k) {
+    const int i = (int)threadIdx.x + k * NT;
+    if (i < 4 * EB_ST) b4[i] = v[k];
   }
 }
 
@@ -232,7 +245,7 @@ __device__ __forceinline__ void efwd_chunk(const char* Kimg, const char* Vimg, i
 
 // (experiments build) enc_fwd_c_kernel under the clock: per workgroup (< 4096) and wave eight 64-bit words in a.dbg_buf —
 // 0 entry, 1 everything requested (K / V DMA, Q, bias copies), 2 landed + barrier passed, 3 first query block done, 4 exit,
-// 5 HW_ID, 6 XCC_ID, 7 (Lq << 16 | query blocks of this wave) — read back by tools/attn_fwd_stamps.py (LAKO_ATTN_DEBUG bit 262144)
+// 5 HW_ID[15:0] | XCC_ID << 16, 6 the scalar-load chain done (DMA issue starts), 7 (Lq << 16 | query blocks of this wave) — read back by tools/attn_fwd_stamps.py (LAKO_ATTN_DEBUG bit 262144)
 #ifdef LAKO_EXPERIMENTS
 #define FWD_STAMP(P, VAL)                                                                                                    \
   do {                                                                                                                       \
@@ -351,10 +364,25 @@ __global__ __launch_bounds__(FWD_NW * 64, FWD_NW / 2) void enc_fwd_c_kernel(Attn
   const int g = lane >> 4, l15 = lane & 15;
   FWD_STAMP(0, __builtin_amdgcn_s_memtime());
   const int b = attn_seq(a, blockIdx.z), h = blockIdx.y;
-  const int q0 = a.q_off ? __builtin_amdgcn_readfirstlane(a.q_off[b]) : 0;
-  const int k0 = a.k_off ? __builtin_amdgcn_readfirstlane(a.k_off[b]) : 0;
-  const int Lq = a.q_off ? __builtin_amdgcn_readfirstlane(a.q_off[b + 1]) - q0 : a.Lq;
-  const int Lk = a.k_off ? __builtin_amdgcn_readfirstlane(a.k_off[b + 1]) - k0 : a.Lk;
+  // (the ragged launch reads its four offsets in ONE batch of scalar loads: one by one behind a null test each, as the general form below
+  //  compiles, they were four dependent round trips of ≈ 900 cycles at the start of every workgroup — profiles/r05t_attn_fwd_stamps.txt)
+  int q0 = 0, k0 = 0, Lq = a.Lq, Lk = a.Lk;
+  if (a.q_off != nullptr && a.k_off != nullptr) {
+    const int qa = a.q_off[b], qe = a.q_off[b + 1], ka = a.k_off[b], ke = a.k_off[b + 1];
+    q0 = __builtin_amdgcn_readfirstlane(qa);
+    k0 = __builtin_amdgcn_readfirstlane(ka);
+    Lq = __builtin_amdgcn_readfirstlane(qe) - q0;
+    Lk = __builtin_amdgcn_readfirstlane(ke) - k0;
+  } else {
+    if (a.q_off) {
+      q0 = __builtin_amdgcn_readfirstlane(a.q_off[b]);
+      Lq = __builtin_amdgcn_readfirstlane(a.q_off[b + 1]) - q0;
+    }
+    if (a.k_off) {
+      k0 = __builtin_amdgcn_readfirstlane(a.k_off[b]);
+      Lk = __builtin_amdgcn_readfirstlane(a.k_off[b + 1]) - k0;
+    }
+  }
   const int qb_begin = blockIdx.x * a.blocks_per_wg;
   const int qb_end = min((Lq + 15) >> 4, qb_begin + a.blocks_per_wg);
   if (qb_begin >= qb_end || Lk <= 0) return;
@@ -364,6 +392,7 @@ __global__ __launch_bounds__(FWD_NW * 64, FWD_NW / 2) void enc_fwd_c_kernel(Attn
   const char* vbase = a.v + ((a.k_off ? (int64_t)k0 * a.vst : (int64_t)b * a.vsb) + hoff) * 2;
   char* obase = a.out + ((a.q_off ? (int64_t)q0 * a.ost : (int64_t)b * a.osb) + hoff) * 2;
   const int np = (Lk + 31) >> 5;
+  FWD_STAMP(6, __builtin_amdgcn_s_memtime());        // (the sequence id and its offsets are known: the scalar-load chain is behind us)
   estage_dma<FWD_NW>(Kimg, kbase, (uint32_t)a.kst * 2u, np << 5, Lk, wave, lane);
   estage_dma<FWD_NW>(Vimg, vbase, (uint32_t)a.vst * 2u, np << 5, Lk, wave, lane);
   u32x4 qf_next[2];
@@ -417,8 +446,7 @@ __global__ __launch_bounds__(FWD_NW * 64, FWD_NW / 2) void enc_fwd_c_kernel(Attn
     }
   }
   FWD_STAMP(4, __builtin_amdgcn_s_memtime());
-  FWD_STAMP(5, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4));
-  FWD_STAMP(6, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20));
+  FWD_STAMP(5, (unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xFFFFu) | ((unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu) << 16));
   FWD_STAMP(7, ((unsigned long long)Lq << 16) | (unsigned long long)nblk_);
 }
 

@@ -50,7 +50,8 @@ assert rc == 0, rc
 s = buf[:BN * H].astype(np.int64)                     # [workgroup = item z * H + head][wave][point]
 t0 = s[:, :, 0].min()
 start, req, land, first, end = (s[:, :, i] - t0 for i in range(5))
-hw, xcc = s[:, 0, 5], s[:, 0, 6] & 0xF
+hw, xcc = s[:, 0, 5] & 0xFFFF, (s[:, 0, 5] >> 16) & 0xF
+chain = s[:, :, 6] - t0
 cu = ((xcc << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15))      # (xcc, se, sh, cu)
 nblk = s[:, :, 7] & 0xFFFF
 Lq = s[:, 0, 7] >> 16
@@ -58,7 +59,8 @@ span = end.max() - start.min()
 print(f"launch: {BN * H} workgroups, span {span} cycles = {span / 2400:.1f} us at 2.4 GHz; distinct CUs seen: {len(np.unique(cu))}")
 wg_start, wg_end = start.min(1), end.max(1)
 print("per workgroup (cycles, median / p90):")
-for nm, v in (("entry -> everything requested (scalar loads of order / offsets, descriptor set-up, DMA + Q + bias issue)", (req - start).max(1)),
+for nm, v in (("entry -> sequence id and offsets known (the scalar-load chain)", (chain - start).max(1)),
+              ("offsets known -> everything requested AND the bias copies written (DMA + Q + bias issue, one wait for all of it)", (req - chain).max(1)),
               ("requested -> landed + barrier (the global round trip nothing overlaps inside the workgroup)", (land - req).max(1)),
               ("first query block of a wave (compute)", (first - land).max(1)),
               ("barrier -> exit of the LAST wave (compute phase of the workgroup)", wg_end - land.max(1)),
