@@ -1003,6 +1003,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
   }
 }
 
+#include "gemm_nt4.h"
+
 // ---------------------------------------------------------------------------------------------
 // NT, VERY SKINNY problems (M <= 256 rows: every GEMM of the decoder at the reader's batch sizes) — bf16.  One K-step of the
 // ring kernel below costs a global→LDS round trip however small the tile, and K is walked sequentially: 15 µs for
@@ -2226,6 +2228,23 @@ void launch_nt_256(const NtArgs& a, const lako_tuning_t& tu, hipStream_t s) {
   launch_nt_cfg<T, TO, 2, 4, MT, 4>(a, tu, s);
 }
 
+// the four-wave hand-scheduled 256² kernel (gemm_nt4.h): bf16 in and out, whole 128-byte K-slices in pairs, plain epilogues
+template <typename T, typename TO>
+bool nt4_ok(const NtArgs& a) {
+  return sizeof(T) == 2 && sizeof(TO) == 2 && a.K % 128 == 0 && a.K >= 256 && !(a.flags & ~LAKO_EPI_RELU) && a.N % 8 == 0 && a.ldc % 8 == 0 &&
+         reinterpret_cast<uintptr_t>(a.C) % 16 == 0 && (int64_t)256 * std::max(a.lda, a.ldb) * 2 < (1ll << 31);
+}
+inline void launch_nt4(NtArgs a, const lako_tuning_t& tu, hipStream_t s) {
+  LAKO_SET_MAX_LDS((&gemm_nt4_kernel), nt4::LDS_BYTES);
+  a.tiles_m = cdiv(a.M, 256);
+  a.tiles_n = cdiv(a.N, 256);
+  a.group_m = tu.nt_group_m < 0 ? -tu.nt_group_m : (a.tiles_n >= 8 ? tu.nt_group_m : 0);
+  int grid = a.tiles_m * a.tiles_n;
+  if (grid > 256) grid = 256;
+  a.dephase = (tu.nt_dephase > 0 && a.tiles_m * a.tiles_n > grid) ? ((tu.nt_dephase_n << 16) | (tu.nt_dephase & 0xffff)) : 0;
+  hipLaunchKernelGGL(gemm_nt4_kernel, dim3(grid), dim3(256), nt4::LDS_BYTES, s, a);
+}
+
 template <typename T, typename TO>
 int launch_nt(const NtArgs& a_in, const lako_tuning_t& tu, hipStream_t s) {
   NtArgs a = a_in;
@@ -2392,6 +2411,8 @@ LAKO_SET_MAX_LDS((&gemm_nt_skinny_kernel<TO, 8, 16, 4>), 8 * 16384);
       if (nt288_ok<T, TO>(a, tu)) launch_nt_256<T, TO, 9>(a, tu, s);
       else launch_nt_256<T, TO>(a, tu, s);
     }
+  } else if (v == 9 && nt4_ok<T, TO>(a)) {
+    launch_nt4(a, tu, s);
   } else if (v == 6 && sizeof(T) == 2) launch_nt_cfg<T, TO, 2, 2, 8, 8>(a, tu, s);   // EXPERIMENT: 256x256 on 4 waves of 128x128 (hipBLASLt's MT256x256x64 MIWT8_8 shape)
   else if (v == 1) launch_nt_cfg<T, TO, 4, 2, 4, 4>(a, tu, s);
   else launch_nt_cfg<T, TO, 2, 2, 4, 4>(a, tu, s);
