@@ -28,7 +28,7 @@ extern "C" {
 /* 2 (round 4): the struct and argument changes of round 3 (lako_gemm_nt_t.tuning, the tuning / alpha arguments of lako_gemm_tn*,
  * lako_fact_scores, no lako_set_tuning) are incompatible with callers built against version 1 — such a caller must be rebuilt.
  * lako_amd/_lib.py::load() refuses a library whose lako_version() is not the one it was written for. */
-#define LAKO_ABI_VERSION 2
+#define LAKO_ABI_VERSION 3
 
 enum { LAKO_F32 = 0, LAKO_BF16 = 1, LAKO_FP8_E4M3 = 2 /* MX block-scaled operands of lako_gemm_nt_mx only */ };
 enum { LAKO_OK = 0, LAKO_E_BADARG = -1, LAKO_E_ALIGN = -2, LAKO_E_LAUNCH = -3, LAKO_E_UNSUPPORTED = -4 };
@@ -60,7 +60,8 @@ typedef struct {
 typedef struct lako_tuning {
   int32_t nt_variant;    /* -1 heuristics (default); 0 = 128x128 tile / 4 waves, 1 = 256x128 / 8 waves, 2 = 256x256 / 8 waves,
                             4 = 128x128 4-slot ring, 5 = small tiles with K split over the waves (M <= 256),
-                            6 = 256x256 / 4 waves (measured slower, kept for A/B), 7 = 192x256 / 8 waves */
+                            6 = 256x256 / 4 waves with hipcc's schedule (measured slower, kept for A/B), 7 = 192x256 / 8 waves,
+                            8 = 288x256 / 8 waves, 9 = 256x256 / 4 waves with the hand-placed K loop (round 6), 3 = the same, 192x256 */
   int32_t nt_tail_split; /* 1: rows beyond the full rounds of 256x256 tiles go to a second launch with small tiles */
   int32_t nt_ring;       /* 1: few-tile problems on the 4-slot ring kernel */
   int32_t nt_skinny;     /* 1: M <= 256 on the split-K kernel; 2 / 3 / 4 force 64² / 32² / 16² tiles */
@@ -84,7 +85,12 @@ typedef struct lako_tuning {
   int32_t nt_glds;       /* 1 (default): whole K-slices are staged by global_load_lds (rows past the edge clamped) instead of
                             buffer_load ... lds; partial K-slices (K % 64) keep the buffer form and its zero fill */
   int32_t nt_tile288;    /* 1 (default): 288-row tiles (variant 8) where they save a round or the tail launch — plain epilogues only */
-  int32_t reserved[12];  /* zero */
+  int32_t nt_four;       /* 1 (default, round 6): problems of at least one round of 256x256 tiles with bf16 operands and output, K % 128 == 0 and
+                            one of the epilogues {alpha, ReLU, dropout} / {residual, dropout} / {aux mask} run on the four-wave kernels with
+                            the hand-placed K loop (256- or 192-row tiles, whichever needs less time for the launch's rounds of the chip);
+                            0: the eight-wave kernels of rounds 1-5.  nt_variant 9 / 3 force the 256- / 192-row four-wave kernel.  Same
+                            results bit for bit */
+  int32_t reserved[11];  /* zero */
 } lako_tuning_t;
 int lako_tuning_init(lako_tuning_t* t);
 int lako_tuning_set(lako_tuning_t* t, const char* key, int value);

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LAKO_LIB") or os.path.join(_HERE, "liblako_hip.so")   # LAKO_LIB: A/B measurements of two builds
 
-ABI_VERSION = 2          # include/lako_hip.h LAKO_ABI_VERSION this binding was written for
+ABI_VERSION = 3          # include/lako_hip.h LAKO_ABI_VERSION this binding was written for
 LAKO_F32, LAKO_BF16, LAKO_FP8_E4M3 = 0, 1, 2
 EPI_RELU, EPI_RESID, EPI_AUXMASK, EPI_ATOMIC, EPI_NORM_A = 1, 2, 4, 8, 16
 
@@ -33,7 +33,7 @@ class Tuning(C.Structure):
     """lako_tuning_t: kernel-selection knobs, owned by the caller (one per HipOps — the library keeps no tuning state)"""
     _fields_ = [(n, i32) for n in ("nt_variant", "nt_tail_split", "nt_ring", "nt_skinny", "nt_side_lds", "nt_wide_epi", "nt_group_m",
                                    "nt_persistent", "nt_stagger", "nt_dephase", "nt_dephase_n", "tn_big", "tn_split", "nt_debug",
-                                   "nt_store_aux", "nt_tile192", "nt_queue", "nt_pp", "nt_glds", "nt_tile288")] + [("reserved", i32 * 12)]
+                                   "nt_store_aux", "nt_tile192", "nt_queue", "nt_pp", "nt_glds", "nt_tile288", "nt_four")] + [("reserved", i32 * 11)]
 
 
 class GemmNT(C.Structure):
@@ -159,13 +159,19 @@ def load(path: str | None = None):
         raise LakoError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                         f"(lako_amd/csrc/build.sh).  There is no CPU fallback.")
     lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    # the version FIRST: a stale library lacks symbols this binding names, and a bare AttributeError would hide the reason
+    try:
+        lib.lako_version.restype = C.c_int
+        have = lib.lako_version()
+    except AttributeError:
+        have = None
+    if have != ABI_VERSION:     # structs and argument lists differ between versions: a mismatch reads garbage pointers
+        raise LakoError(f"{path} implements C-ABI version {have}, this package binds version {ABI_VERSION} "
+                        f"(include/lako_hip.h LAKO_ABI_VERSION): rebuild with lako_amd/csrc/build.sh")
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = C.c_int64 if name in ("lako_gemm_tn_grouped_workspace", "lako_workspace_bytes") else C.c_int
-    if lib.lako_version() != ABI_VERSION:     # structs and argument lists differ between versions: a mismatch reads garbage pointers
-        raise LakoError(f"{path} implements C-ABI version {lib.lako_version()}, this package binds version {ABI_VERSION} "
-                        f"(include/lako_hip.h LAKO_ABI_VERSION): rebuild with lako_amd/csrc/build.sh")
     _lib = lib
     return lib
 

@@ -2028,7 +2028,7 @@ const TuneKey TUNE_KEYS[] = {
     {"gemm_nt_store_aux", &lako_tuning_t::nt_store_aux, true},    {"gemm_nt_tile192", &lako_tuning_t::nt_tile192, false},
     {"gemm_nt_tile288", &lako_tuning_t::nt_tile288, false},
     {"gemm_nt_queue", &lako_tuning_t::nt_queue, false},           {"gemm_nt_pp", &lako_tuning_t::nt_pp, false},
-    {"gemm_nt_glds", &lako_tuning_t::nt_glds, false},
+    {"gemm_nt_glds", &lako_tuning_t::nt_glds, false},             {"gemm_nt_four", &lako_tuning_t::nt_four, false},
 };
 
 void tuning_defaults(lako_tuning_t* t) {
@@ -2050,6 +2050,7 @@ void tuning_defaults(lako_tuning_t* t) {
   t->nt_pp = 0;            // 1: the 8-phase main loop of the 256² / 8-wave bf16 kernel (measured slower, A/B only); 0: the two-phase loop
   t->nt_tile288 = 1;       // 1: 288-row tiles where the round count favours them (launch_nt; plain epilogues)
   t->nt_tile192 = 0;       // 1: 192-row tiles where the round count favours them (launch_nt) — measured no faster, off
+  t->nt_four = 1;          // 1: the four-wave kernels with the hand-placed K loop (gemm_nt4.h) wherever they apply
 }
 
 int tuning_set(lako_tuning_t* t, const char* key, int value) {
@@ -2228,21 +2229,46 @@ void launch_nt_256(const NtArgs& a, const lako_tuning_t& tu, hipStream_t s) {
   launch_nt_cfg<T, TO, 2, 4, MT, 4>(a, tu, s);
 }
 
-// the four-wave hand-scheduled 256² kernel (gemm_nt4.h): bf16 in and out, whole 128-byte K-slices in pairs, plain epilogues
+// the four-wave hand-scheduled kernels (gemm_nt4.h): bf16 in and out, whole 128-byte K-slices in pairs, every epilogue but the atomic one
+// and the fused norm; a residual OR an aux operand (16-byte aligned rows), not both
 template <typename T, typename TO>
 bool nt4_ok(const NtArgs& a) {
-  return sizeof(T) == 2 && sizeof(TO) == 2 && a.K % 128 == 0 && a.K >= 256 && !(a.flags & ~LAKO_EPI_RELU) && a.N % 8 == 0 && a.ldc % 8 == 0 &&
-         reinterpret_cast<uintptr_t>(a.C) % 16 == 0 && (int64_t)256 * std::max(a.lda, a.ldb) * 2 < (1ll << 31);
+  if (sizeof(T) != 2 || sizeof(TO) != 2 || a.K % 128 != 0 || a.K < 256 || (a.flags & (LAKO_EPI_ATOMIC | LAKO_EPI_NORM_A)) || a.N % 8 != 0 || a.ldc % 8 != 0 ||
+      reinterpret_cast<uintptr_t>(a.C) % 16 != 0 || (int64_t)256 * std::max(a.lda, a.ldb) * 2 >= (1ll << 31))
+    return false;
+  // epilogues built into the kernels: {alpha, ReLU, dropout}; residual with or without dropout; the aux mask alone
+  const int side = a.flags & (LAKO_EPI_RESID | LAKO_EPI_AUXMASK);
+  if (side == (LAKO_EPI_RESID | LAKO_EPI_AUXMASK)) return false;
+  if (side && (a.flags & LAKO_EPI_RELU)) return false;
+  if (side == LAKO_EPI_AUXMASK && a.drop_thresh != 0) return false;
+  if (side == LAKO_EPI_RESID && (a.ldr % 8 != 0 || reinterpret_cast<uintptr_t>(a.resid) % 16 != 0 || (int64_t)128 * a.ldr * 2 >= (1ll << 31))) return false;
+  if (side == LAKO_EPI_AUXMASK && (a.ldaux % 8 != 0 || reinterpret_cast<uintptr_t>(a.aux) % 16 != 0 || (int64_t)128 * a.ldaux * 2 >= (1ll << 31))) return false;
+  if ((int64_t)128 * a.ldc * 2 >= (1ll << 31)) return false;      // (32-bit offsets inside a wave's region)
+  return true;
 }
-inline void launch_nt4(NtArgs a, const lako_tuning_t& tu, hipStream_t s) {
-  LAKO_SET_MAX_LDS((&gemm_nt4_kernel), nt4::LDS_BYTES);
-  a.tiles_m = cdiv(a.M, 256);
+template <int MT>
+void launch_nt4(NtArgs a, const lako_tuning_t& tu, hipStream_t s) {
+  const bool side = a.flags & (LAKO_EPI_RESID | LAKO_EPI_AUXMASK);
+  a.tiles_m = cdiv(a.M, MT * 32);
   a.tiles_n = cdiv(a.N, 256);
   a.group_m = tu.nt_group_m < 0 ? -tu.nt_group_m : (a.tiles_n >= 8 ? tu.nt_group_m : 0);
   int grid = a.tiles_m * a.tiles_n;
   if (grid > 256) grid = 256;
-  a.dephase = (tu.nt_dephase > 0 && a.tiles_m * a.tiles_n > grid) ? ((tu.nt_dephase_n << 16) | (tu.nt_dephase & 0xffff)) : 0;
-  hipLaunchKernelGGL(gemm_nt4_kernel, dim3(grid), dim3(256), nt4::LDS_BYTES, s, a);
+  // no start offsets between the workgroups: with this loop every offset costs at the end of the launch what it saves in the store
+  // phases (tools/gemm_nt4_dephase.py, profiles/r06d_nt4_dephase.txt: lockstep is the fastest of nine settings on all five shapes)
+  a.dephase = 0;
+  a.debug = tu.nt_debug;
+  a.queue = nullptr;
+#ifdef LAKO_EXPERIMENTS
+  if (tu.nt_debug & 64) a.queue = reinterpret_cast<int*>(lako_exp_nt_stamp_buffer());
+#endif
+  if (side) {
+    LAKO_SET_MAX_LDS((&gemm_nt4_kernel<MT, true>), nt4::LDS_BYTES);
+    hipLaunchKernelGGL((gemm_nt4_kernel<MT, true>), dim3(grid), dim3(256), nt4::LDS_BYTES, s, a);
+  } else {
+    LAKO_SET_MAX_LDS((&gemm_nt4_kernel<MT, false>), nt4::LDS_BYTES);
+    hipLaunchKernelGGL((gemm_nt4_kernel<MT, false>), dim3(grid), dim3(256), nt4::LDS_BYTES, s, a);
+  }
 }
 
 template <typename T, typename TO>
@@ -2262,6 +2288,18 @@ int launch_nt(const NtArgs& a_in, const lako_tuning_t& tu, hipStream_t s) {
            (v == 5 || (v < 0 && tu.nt_skinny && a.M <= 256 && a.N <= 4096));
     }
     if (!ok) return LAKO_E_BADARG;
+  }
+  if (v < 0 && tu.nt_four && !tu.nt_queue && nt4_ok<T, TO>(a) && (int64_t)cdiv(a.M, 256) * cdiv(a.N, 256) >= 256) {
+    // ROUND 6: the four-wave kernels.  A launch walks its tiles in rounds of 256 (one workgroup per CU), a partly filled round costs a
+    // whole one, and a tile costs ≈ 4.5 µs + nk · (1.32 µs for 256 rows | 0.99 µs for 192 rows) (nk = K-steps; fitted to
+    // profiles/r06c_nt4_probe.txt — the K loop is MFMA-bound, so three quarters of the rows take three quarters of the K-step): take the
+    // height whose rounds cost less.  47 757 × 768 outputs: 561 tiles of 256 rows = 3 rounds, 747 of 192 rows = 3 shorter ones.
+    const int nk = a.K / 64, tn = cdiv(a.N, 256);
+    const double c8 = (double)cdiv((int64_t)cdiv(a.M, 256) * tn, 256) * (4.5 + 1.32 * nk);
+    const double c6 = (double)cdiv((int64_t)cdiv(a.M, 192) * tn, 256) * (4.5 + 0.99 * nk);
+    if (c6 < c8) launch_nt4<6>(a, tu, s);
+    else launch_nt4<8>(a, tu, s);
+    return 0;
   }
   if (v < 0) {
     // big tiles once there is enough work to fill the chip with them (>= 1 tile per CU), else 128x128
@@ -2339,7 +2377,7 @@ int launch_nt(const NtArgs& a_in, const lako_tuning_t& tu, hipStream_t s) {
       }
     }
   }
-  if (v == 3) v = 2;   // (the 4-slot 256² ring kernel of round 1 measured slower and was removed)
+  if ((v == 3 || v == 9) && !nt4_ok<T, TO>(a)) v = 2;   // (forced four-wave kernels: shapes / epilogues they do not take run on the eight-wave kernel)
   if (v == 5 && sizeof(T) != 2) v = 4;
   if constexpr (sizeof(T) == 2) {
     // very skinny (the decoder): 64×64 tiles, K split over the workgroup's four waves — see gemm_nt_skinny_kernel
@@ -2412,7 +2450,9 @@ LAKO_SET_MAX_LDS((&gemm_nt_skinny_kernel<TO, 8, 16, 4>), 8 * 16384);
       else launch_nt_256<T, TO>(a, tu, s);
     }
   } else if (v == 9 && nt4_ok<T, TO>(a)) {
-    launch_nt4(a, tu, s);
+    launch_nt4<8>(a, tu, s);
+  } else if (v == 3 && nt4_ok<T, TO>(a)) {
+    launch_nt4<6>(a, tu, s);
   } else if (v == 6 && sizeof(T) == 2) launch_nt_cfg<T, TO, 2, 2, 8, 8>(a, tu, s);   // EXPERIMENT: 256x256 on 4 waves of 128x128 (hipBLASLt's MT256x256x64 MIWT8_8 shape)
   else if (v == 1) launch_nt_cfg<T, TO, 4, 2, 4, 4>(a, tu, s);
   else launch_nt_cfg<T, TO, 2, 2, 4, 4>(a, tu, s);

@@ -77,11 +77,12 @@ def test_gemm_nt_plain(ops, ref, dt, M, N, K):
         close(C, Cr, T, f"gemm_nt {dt}->{out_t} {M}x{N}x{K}", tight=True)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 7, 8])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 7, 8, 9])
 @pytest.mark.parametrize("M,N,K", [(1024, 768, 768), (700, 520, 200), (256, 256, 32), (2048, 2304, 768), (300, 264, 3072), (128, 768, 72),
                                    (128, 768, 768), (100, 200, 160), (16, 3072, 768), (130, 776, 3072)])
 def test_gemm_nt_tile_variants(ops, ref, variant, M, N, K):
-    """every tile variant of the bf16 NT kernel (0: 128², 1: 256×128, 2: 256² 2-buffer, 3: 256² 4-slot ring, 4: the 128²
+    """every tile variant of the bf16 NT kernel (0: 128², 1: 256×128, 2: 256² 2-buffer, 3 / 9 (round 6): the four-wave kernels with the
+    hand-placed K loop, 192- / 256-row tiles — shapes and epilogues they do not take run on variant 2, 4: the 128²
     4-slot ring that skinny problems are dispatched to, 5: the 64² kernel whose four waves split K, for M <= 256 rows — it
     falls back to the ring when K is not a multiple of 32, 7: 192×256 tiles — the 256² kernel's MT = 6 instantiation, whose last
     wave keeps its epilogue scratch behind the K-slice buffers, 8: 288×256 tiles — MT = 9: the last A piece of a K-slice exists for
@@ -362,6 +363,38 @@ def test_gemm_nt_tile_height_plan(ops, ref):
         ops.set_tuning("gemm_nt_tile192", 0)
         ops.set_tuning("gemm_nt_tile288", 1)
         ops.probe = None
+
+
+@pytest.mark.parametrize("M,N,K", [(47757, 768, 256), (16500, 1032, 384), (65600, 264, 128 * 5), (9000, 2304, 768), (25000, 520, 3072)])
+def test_gemm_nt_four_wave_kernels(ops, ref, M, N, K):
+    """(round 6, csrc/gemm_nt4.h) The four-wave kernels with the hand-placed K loop — two K-slices of LDS-DMA in flight, counted waits, the
+    stream running on into the workgroup's next tile — forced (variant 9: 256-row tiles, 3: 192-row tiles) and as the default plan
+    (`gemm_nt_four`, which picks the height by the rounds of the chip), against the eight-wave kernels of rounds 1-5 (`gemm_nt_four` 0):
+    BIT-identical outputs (each element's K loop is the same sequence of MFMAs, the epilogue the same fp32 operations in the same order and
+    one rounding), for every epilogue the four-wave kernels take and — through the fallback — for those they do not (ReLU + residual);
+    ragged last tiles in M and N, several tiles per workgroup (the DMA stream crosses tile boundaries), an odd number of K-slice pairs."""
+    T = torch.bfloat16
+    A, B = rnd(M, K, dtype=T, seed=71), rnd(N, K, dtype=T, seed=72)
+    R, X = rnd(M, N, dtype=T, seed=73), rnd(M, N, dtype=T, seed=74)
+    try:
+        for kw in (dict(), dict(relu=True, drop=(0.1, 5, 6)), dict(alpha=0.5, drop=(0.1, 5, 6)), dict(resid=R, drop=(0.1, 7, 8), alpha=0.5), dict(resid=R),
+                   dict(aux=X, aux_scale=1.1), dict(relu=True, resid=R)):
+            got = {}
+            for name, four, variant in (("eight-wave", 0, -1), ("default plan", 1, -1), ("256-row", 1, 9), ("192-row", 1, 3)):
+                ops.set_tuning("gemm_nt_four", four)
+                ops.set_tuning("gemm_nt_variant", variant)
+                C = torch.full((M, N), float("nan"), dtype=T, device=dev())
+                ops.gemm_nt(A, B, C, **kw)
+                torch.cuda.synchronize()
+                got[name] = C
+            for name in ("default plan", "256-row", "192-row"):
+                assert torch.equal(got[name].view(torch.int16), got["eight-wave"].view(torch.int16)), f"{name} vs eight-wave kernels, {list(kw)} {M}x{N}x{K}"
+            Cr = torch.zeros(M, N, device=dev())
+            ref.gemm_nt(A, B, Cr, **kw)
+            close(got["default plan"], Cr, T, f"gemm_nt four-wave {list(kw)} {M}x{N}x{K}", tight=True)
+    finally:
+        ops.set_tuning("gemm_nt_four", 1)
+        ops.set_tuning("gemm_nt_variant", -1)
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f32"])

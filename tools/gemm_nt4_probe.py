@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Round 6: the four-wave hand-scheduled 256² NT kernel (csrc/gemm_nt4.h, tuning variant 9) against the shipped heuristics (variant -1), the
+"""Round 6: the four-wave hand-scheduled 256² NT kernel (csrc/gemm_nt4.h, tuning variant 9: 256-row tiles, 3: 192-row tiles) against the shipped heuristics (variant -1), the
 forced eight-wave 256² kernel (variant 2) and — a yardstick only — torch.matmul (hipBLASLt), interleaved in ONE process on the same random
 operands.  Checks bit-equality of variant 9 with variant 2 first (same accumulation order per element).
     python tools/gemm_nt4_probe.py [--rows 47757] [--iters 20] [--rounds 3] [--no-vendor]"""
@@ -17,7 +17,8 @@ ap.add_argument("--rows", type=int, default=47757)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--no-vendor", action="store_true")
-ap.add_argument("--variants", default="-1,2,9")
+ap.add_argument("--variants", default="-1,2,9,3")
+ap.add_argument("--epis", default="plain,relu+drop,res+drop,aux")
 ap.add_argument("--shapes", default="all")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -48,33 +49,36 @@ def time_fn(fn):
     return e0.elapsed_time(e1) * 1e3 / args.iters
 
 
+EPIS = {"plain": {}, "relu+drop": dict(relu=True, drop=(0.1, 1, 2)), "res+drop": dict(resid=True, drop=(0.1, 1, 2)), "aux": dict(aux=True)}
 for nm, (M, N, K) in shapes:
     A = torch.randn(M, K, device=dev).bfloat16()
     B = torch.randn(N, K, device=dev).bfloat16()
-    C2, C9 = torch.empty(M, N, dtype=torch.bfloat16, device=dev), torch.empty(M, N, dtype=torch.bfloat16, device=dev)
-    run(2, A, B, C2)
-    C9.fill_(float("nan"))
-    run(9, A, B, C9)
-    torch.cuda.synchronize()
-    same = torch.equal(C2.view(torch.int16), C9.view(torch.int16))
-    nbad = 0 if same else int((C2.view(torch.int16) != C9.view(torch.int16)).sum())
-    # relu + dropout epilogue too
-    run(2, A, B, C2, relu=True, drop=(0.1, 1, 2))
-    run(9, A, B, C9, relu=True, drop=(0.1, 1, 2))
-    torch.cuda.synchronize()
-    same_rd = torch.equal(C2.view(torch.int16), C9.view(torch.int16))
+    Cr, Ct = torch.empty(M, N, dtype=torch.bfloat16, device=dev), torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    side = torch.randn(M, N, device=dev).bfloat16()
     fl = 2.0 * M * N * K
-    best = {}
-    for _ in range(args.rounds):
+    for epi in args.epis.split(","):
+        kw = dict(EPIS[epi])
+        if kw.pop("resid", False):
+            kw["resid"] = side
+        if kw.pop("aux", False):
+            kw["aux"], kw["aux_scale"] = side, 1.1
+        run(2, A, B, Cr, **kw)
+        eq = {}
         for v in variants:
-            us = time_fn(lambda: run(v, A, B, C9))
-            best.setdefault(v, []).append(us)
-        if not args.no_vendor:
-            us = time_fn(lambda: torch.matmul(A, B.t(), out=C2))
-            best.setdefault("vendor", []).append(us)
-    line = f"{nm:28s} equal={same}({nbad}) relu+drop equal={same_rd} |"
-    for k, v in best.items():
-        med = sorted(v)[len(v) // 2]
-        line += f" v{k}: {med:8.1f} us {fl / med / 1e6:7.1f} TF (min {min(v):.1f}) |"
-    print(line, flush=True)
-    del A, B, C2, C9
+            if v in (3, 9):
+                Ct.fill_(float("nan"))
+                run(v, A, B, Ct, **kw)
+                torch.cuda.synchronize()
+                eq[v] = torch.equal(Cr.view(torch.int16), Ct.view(torch.int16))
+        best = {}
+        for _ in range(args.rounds):
+            for v in variants:
+                best.setdefault(v, []).append(time_fn(lambda: run(v, A, B, Ct, **kw)))
+            if not args.no_vendor and epi == "plain":
+                best.setdefault("vendor", []).append(time_fn(lambda: torch.matmul(A, B.t(), out=Ct)))
+        line = f"{nm:26s} {epi:9s} bit-equal to v2: {eq} |"
+        for k, v in best.items():
+            med = sorted(v)[len(v) // 2]
+            line += f" v{k}: {med:7.1f} us {fl / med / 1e6:6.0f} TF |"
+        print(line, flush=True)
+    del A, B, Cr, Ct, side
