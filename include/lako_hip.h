@@ -90,7 +90,10 @@ typedef struct lako_tuning {
                             the hand-placed K loop (256- or 192-row tiles, whichever needs less time for the launch's rounds of the chip);
                             0: the eight-wave kernels of rounds 1-5.  nt_variant 9 / 3 force the 256- / 192-row four-wave kernel.  Same
                             results bit for bit */
-  int32_t reserved[11];  /* zero */
+  int32_t tn_four;       /* 1 (default, round 6): the 256x256 weight-gradient kernel on four waves with the same hand-placed K loop
+                            (K ranges of at least 128 rows, no slab reduction); 0: the eight-wave kernel.  Same results bit for bit up to
+                            the order of the float atomics of K-splits */
+  int32_t reserved[10];  /* zero */
 } lako_tuning_t;
 int lako_tuning_init(lako_tuning_t* t);
 int lako_tuning_set(lako_tuning_t* t, const char* key, int value);

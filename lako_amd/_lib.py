@@ -33,7 +33,7 @@ class Tuning(C.Structure):
     """lako_tuning_t: kernel-selection knobs, owned by the caller (one per HipOps — the library keeps no tuning state)"""
     _fields_ = [(n, i32) for n in ("nt_variant", "nt_tail_split", "nt_ring", "nt_skinny", "nt_side_lds", "nt_wide_epi", "nt_group_m",
                                    "nt_persistent", "nt_stagger", "nt_dephase", "nt_dephase_n", "tn_big", "tn_split", "nt_debug",
-                                   "nt_store_aux", "nt_tile192", "nt_queue", "nt_pp", "nt_glds", "nt_tile288", "nt_four")] + [("reserved", i32 * 11)]
+                                   "nt_store_aux", "nt_tile192", "nt_queue", "nt_pp", "nt_glds", "nt_tile288", "nt_four", "tn_four")] + [("reserved", i32 * 10)]
 
 
 class GemmNT(C.Structure):

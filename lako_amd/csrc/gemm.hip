@@ -1745,6 +1745,15 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(TnArgs a) {
   }
 }
 
+#include "gemm_tn4.h"
+
+// the four-wave weight-gradient kernel takes whole-step K ranges (every unit's range a multiple of 64 rows except the last) of at least 128
+// rows by global_load_lds, without the slab reduction
+inline bool tn4_ok(const TnArgs& a, const lako_tuning_t& tu) {
+  const int last = a.K - (a.split_k - 1) * a.k_chunk;
+  return tu.tn_four && a.glds && a.k_chunk % 64 == 0 && a.slabs == nullptr && a.k_chunk >= 128 && last >= 128;
+}
+
 // ---------------------------------------------------------------------------------------------
 // NT with MX-scaled fp8 operands (BASELINE config 5: "fp8 MFMA GEMMs"): C = epilogue(alpha · A·Bᵀ), A [M,K] and B [N,K] in
 // OCP e4m3 bytes, every 32 consecutive k of a row sharing one E8M0 scale (OCP microscaling: element = q · 2^(s − 127)).
@@ -2029,6 +2038,7 @@ const TuneKey TUNE_KEYS[] = {
     {"gemm_nt_tile288", &lako_tuning_t::nt_tile288, false},
     {"gemm_nt_queue", &lako_tuning_t::nt_queue, false},           {"gemm_nt_pp", &lako_tuning_t::nt_pp, false},
     {"gemm_nt_glds", &lako_tuning_t::nt_glds, false},             {"gemm_nt_four", &lako_tuning_t::nt_four, false},
+    {"gemm_tn_four", &lako_tuning_t::tn_four, false},
 };
 
 void tuning_defaults(lako_tuning_t* t) {
@@ -2051,6 +2061,7 @@ void tuning_defaults(lako_tuning_t* t) {
   t->nt_tile288 = 1;       // 1: 288-row tiles where the round count favours them (launch_nt; plain epilogues)
   t->nt_tile192 = 0;       // 1: 192-row tiles where the round count favours them (launch_nt) — measured no faster, off
   t->nt_four = 1;          // 1: the four-wave kernels with the hand-placed K loop (gemm_nt4.h) wherever they apply
+  t->tn_four = 1;          // 1: the same for the 256² weight-gradient kernel (gemm_tn4.h)
 }
 
 int tuning_set(lako_tuning_t* t, const char* key, int value) {
@@ -2632,7 +2643,10 @@ static int tn_single(const void* A, const void* B, float* C, int64_t M, int64_t 
     a.tickets = nullptr;
     LAKO_CHECK_ARG((int64_t)64 * lda * 2 < (1ll << 31) && (int64_t)64 * ldb * 2 < (1ll << 31),
                    "lako_gemm_tn: leading dimension too large");
-    if (a.glds && a.k_chunk % 64 == 0) {
+    if (tn4_ok(a, tu)) {
+      LAKO_SET_MAX_LDS((&gemm_tn4_kernel), tn4::LDS_BYTES);
+      hipLaunchKernelGGL(gemm_tn4_kernel, dim3(tiles * a.split_k), dim3(256), tn4::LDS_BYTES, s, a);
+    } else if (a.glds && a.k_chunk % 64 == 0) {
       LAKO_SET_MAX_LDS((&gemm_tn256_kernel<true>), 4 * TN2_IMG);
       hipLaunchKernelGGL(gemm_tn256_kernel<true>, dim3(tiles * a.split_k), dim3(512), 4 * TN2_IMG, s, a);
     } else {
@@ -2816,7 +2830,10 @@ extern "C" int lako_gemm_tn_grouped(const lako_gemm_tn_item_t* items, int n_item
     }
   }
   const int grid = a.t_full > 0 ? 8 * (a.t_full / 8 + cdiv((int64_t)(tiles - a.t_full) * a.split_k, 8)) : tiles * a.split_k;
-  if (a.glds && a.k_chunk % 64 == 0) {
+  if (tn4_ok(a, tu)) {
+    LAKO_SET_MAX_LDS((&gemm_tn4_kernel), tn4::LDS_BYTES);
+    hipLaunchKernelGGL(gemm_tn4_kernel, dim3(grid), dim3(256), tn4::LDS_BYTES, (hipStream_t)stream, a);
+  } else if (a.glds && a.k_chunk % 64 == 0) {
     LAKO_SET_MAX_LDS((&gemm_tn256_kernel<true>), 4 * TN2_IMG);
     hipLaunchKernelGGL(gemm_tn256_kernel<true>, dim3(grid), dim3(512), 4 * TN2_IMG, (hipStream_t)stream, a);
   } else {

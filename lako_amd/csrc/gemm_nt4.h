@@ -130,6 +130,8 @@ __device__ __forceinline__ void dma_piece(uint32_t lds_dst, uint32_t voff, uint6
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
 }
 
+// (`s_add_u32 m0, …` overwrites SCC: every statement that contains one says so — hipcc keeps scalar compares of its own alive across asm
+// statements, and a stale SCC selected the wrong K-slice pointer in the first version of the weight-gradient kernel.)
 // One K-step from buffer X (compile-time): acc += A(step)·B(step)ᵀ; requests K-slice t + 2 (pA / pB: its first byte of row 0 of the
 // tile, voffA / voffB: the per-lane row · ld + swizzled chunk of piece j) into buffer X; leaves the k-half-0 fragments of step t + 1
 // (buffer X ^ 1) in A0 / B0.  (Recursive templates, not lambdas: hipcc rejects asm operands captured by a generic lambda.)
@@ -153,9 +155,9 @@ __device__ __forceinline__ void step_slot(f32x4 (&acc)[8][MT], u32x4 (&A0)[MT], 
       } else if constexpr (sl.op == OP_RD_A1) {
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(A1[sl.idx]) : "v"(ad.a[X][1]), "n"(sl.idx * 2048) : "memory");
       } else if constexpr (sl.op == OP_DMA_B) {
-        asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3" : : "s"(ldsB), "n"(sl.idx * 4096), "v"(voffB[sl.idx]), "s"(pB) : "memory");
+        asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3" : : "s"(ldsB), "n"(sl.idx * 4096), "v"(voffB[sl.idx]), "s"(pB) : "memory", "scc");
       } else if constexpr (sl.op == OP_DMA_A) {
-        asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3" : : "s"(ldsA), "n"(sl.idx * 4096), "v"(voffA[sl.idx]), "s"(pA) : "memory");
+        asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3" : : "s"(ldsA), "n"(sl.idx * 4096), "v"(voffA[sl.idx]), "s"(pA) : "memory", "scc");
       } else if constexpr (sl.op == OP_WAIT_L) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       } else if constexpr (sl.op == OP_BAR) {
@@ -184,10 +186,10 @@ __device__ __forceinline__ void step_slot(f32x4 (&acc)[8][MT], u32x4 (&A0)[MT], 
                    : "+a"(c), "=&v"(A0[sl.idx]) : "v"(bf), "v"(af), "v"(ad.a[X ^ 1][0]), "n"(sl.idx * 2048) : "memory");
     } else if constexpr (sl.op == OP_DMA_B) {
       asm volatile("s_add_u32 m0, %3, %4\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\tglobal_load_lds_dwordx4 %5, %6"
-                   : "+a"(c) : "v"(bf), "v"(af), "s"(ldsB), "n"(sl.idx * 4096), "v"(voffB[sl.idx]), "s"(pB) : "memory");
+                   : "+a"(c) : "v"(bf), "v"(af), "s"(ldsB), "n"(sl.idx * 4096), "v"(voffB[sl.idx]), "s"(pB) : "memory", "scc");
     } else if constexpr (sl.op == OP_DMA_A) {
       asm volatile("s_add_u32 m0, %3, %4\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\tglobal_load_lds_dwordx4 %5, %6"
-                   : "+a"(c) : "v"(bf), "v"(af), "s"(ldsA), "n"(sl.idx * 4096), "v"(voffA[sl.idx]), "s"(pA) : "memory");
+                   : "+a"(c) : "v"(bf), "v"(af), "s"(ldsA), "n"(sl.idx * 4096), "v"(voffA[sl.idx]), "s"(pA) : "memory", "scc");
     } else if constexpr (sl.op == OP_WAIT_L) {
       asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_waitcnt lgkmcnt(0)" : "+a"(c) : "v"(bf), "v"(af) : "memory");
     } else if constexpr (sl.op == OP_BAR) {

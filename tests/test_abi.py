@@ -203,14 +203,14 @@ def test_tuning_is_caller_owned_and_the_library_keeps_no_mutable_knobs(lib, monk
     src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
     body = re.search(r"typedef struct lako_tuning \{([^{}]*)\}\s*lako_tuning_t", src, re.S).group(1)
     names = [re.sub(r"^int32_t\s+", "", d.strip()) for d in body.split(";") if d.strip()]
-    assert names == [f[0] for f in _lib.Tuning._fields_[:-1]] + ["reserved[11]"]
+    assert names == [f[0] for f in _lib.Tuning._fields_[:-1]] + ["reserved[10]"]
     assert ctypes.sizeof(_lib.Tuning) == 32 * 4
     monkeypatch.delenv("LAKO_TUNING", raising=False)
     a, b = _lib.Tuning(), _lib.Tuning()
     assert L.lako_tuning_init(ctypes.byref(a)) == 0 and L.lako_tuning_init(ctypes.byref(b)) == 0
     assert (a.nt_variant, a.nt_tail_split, a.nt_ring, a.nt_skinny, a.nt_side_lds, a.nt_wide_epi, a.nt_group_m, a.nt_persistent,
-            a.nt_stagger, a.nt_dephase, a.nt_dephase_n, a.tn_big, a.tn_split, a.nt_debug, a.nt_store_aux, a.nt_tile192, a.nt_queue, a.nt_pp, a.nt_glds, a.nt_tile288, a.nt_four) == \
-        (-1, 1, 1, 1, 1, 1, 8, 1, 1, 100, 2, 1, 0, 0, 0, 0, 0, 0, 1, 1, 1)
+            a.nt_stagger, a.nt_dephase, a.nt_dephase_n, a.tn_big, a.tn_split, a.nt_debug, a.nt_store_aux, a.nt_tile192, a.nt_queue, a.nt_pp, a.nt_glds, a.nt_tile288, a.nt_four, a.tn_four) == \
+        (-1, 1, 1, 1, 1, 1, 8, 1, 1, 100, 2, 1, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1)
     assert L.lako_tuning_set(ctypes.byref(a), b"gemm_nt_variant", 2) == 0 and L.lako_tuning_set(ctypes.byref(a), b"gemm_nt_dephase_n", 0) == 0
     assert (a.nt_variant, a.nt_dephase_n, b.nt_variant, b.nt_dephase_n) == (2, 2, -1, 2)
     monkeypatch.setenv("LAKO_TUNING", "gemm_nt_variant=0, gemm_tn_split = 3")

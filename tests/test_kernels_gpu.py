@@ -515,6 +515,34 @@ def test_gemm_tn_grouped_hybrid_schedule(ops, ref, extra):
         close(C, Cr, T, f"gemm_tn_grouped hybrid {sh} extra {extra}")
 
 
+@pytest.mark.parametrize("K,M,N", [(1024, 256, 256), (1000, 512, 768), (200, 256, 520), (4813, 768, 3072), (47757, 768, 768), (131, 264, 256)])
+def test_gemm_tn_four_wave_kernel(ops, ref, K, M, N):
+    """(round 6, csrc/gemm_tn4.h) The 256 x 256 weight-gradient kernel on four waves with the hand-placed K loop (`gemm_tn_four`, default)
+    against the eight-wave kernel of rounds 1-5: with ONE contributor per output element (split_k -1 read-modify-write onto non-zero C,
+    -2 overwrite) the two are BIT-identical (same MFMAs in the same order: the incomplete K-step first, then the whole ones); with K-splits
+    the float atomics add in a different order (compared with the fp32 reference).  K ranges with and without an incomplete step, odd and
+    even step counts, ragged tile edges, a K too short for the kernel (131 rows: falls back)."""
+    T = torch.bfloat16
+    A, B = rnd(K, M, dtype=T, seed=81) * 0.25, rnd(K, N, dtype=T, seed=82) * 0.25
+    C0 = rnd(M, N, seed=83)
+    try:
+        for split in (-1, -2, 0, 3):
+            got = []
+            for four in (0, 1):
+                ops.set_tuning("gemm_tn_four", four)
+                C = C0.clone()
+                ops.gemm_tn(A, B, C, alpha=0.5, split_k=split)
+                torch.cuda.synchronize()
+                got.append(C)
+            if split < 0:
+                assert torch.equal(got[0], got[1]), f"four-wave vs eight-wave weight-gradient kernel, split_k {split}, K {K} M {M} N {N}"
+            Cr = C0.clone()
+            ref.gemm_tn(A, B, Cr, alpha=0.5, split_k=split)
+            close(got[1], Cr, T, f"gemm_tn four-wave split_k {split} K {K} M {M} N {N}", tight=True)
+    finally:
+        ops.set_tuning("gemm_tn_four", 1)
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("M,N,K", [(128, 768, 32128), (40, 264, 5000), (128, 132, 2048)])
 def test_gemm_nt_split_k_atomic(ops, ref, dt, M, N, K):
