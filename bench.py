@@ -40,14 +40,14 @@ sys.path.insert(0, ROOT)
 def gemm_traffic_bytes(args):
     """HBM-side bytes per launch of the dominant kernel from the committed PMC profile (separate rocprofv3 --pmc passes
     over tools/gemm_probe.py, FETCH_SIZE doubled as the gfx950 guide prescribes; tools/gemm_traffic.py): the mean over the encoder's
-    NT GEMM shapes weighted by their launches per layer, measured at the row count this run executes (profiles/r05_gemm_traffic.json
-    = 48 k valid tokens when padding is skipped, …_padded.json = 64 k rows on the padded path / --all-valid — re-measured in round 5 on
-    the kernels that spread their staging over the K step; the r04 / r03 files are the fallback).  null for any other workload or when the file is absent — counters cannot be collected from inside a timed run."""
+    NT GEMM shapes weighted by their launches per layer, measured at the row count this run executes (profiles/r06_gemm_traffic.json
+    = 48 k valid tokens when padding is skipped, …_padded.json = 64 k rows on the padded path / --all-valid — re-measured in round 6 on
+    the four-wave kernels; the r05 / r04 / r03 files are the fallback).  null for any other workload or when the file is absent — counters cannot be collected from inside a timed run."""
     if (args.model, args.batch, args.n_passages, args.seq_len, args.dtype) != ("base", 16, 20, 200, "bf16"):
         return None, None, None
     padded = os.environ.get("LAKO_UNPAD", "1") == "0" or args.all_valid
-    for name in (("r05_gemm_traffic_padded.json", "r04_gemm_traffic_padded.json", "r03_gemm_traffic_padded.json") if padded else
-                 ("r05_gemm_traffic.json", "r04_gemm_traffic.json", "r03_gemm_traffic.json")):
+    for name in (("r06_gemm_traffic_padded.json", "r05_gemm_traffic_padded.json", "r04_gemm_traffic_padded.json", "r03_gemm_traffic_padded.json") if padded else
+                 ("r06_gemm_traffic.json", "r05_gemm_traffic.json", "r04_gemm_traffic.json", "r03_gemm_traffic.json")):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 j = json.load(f)
@@ -427,7 +427,8 @@ def main():
                        "dp_grad_dtype": ("bf16" if sync.grad_dtype is not None else "fp32") if use_dist else None,
                        "dp_estimated_allreduce_ms": {k: round(v, 2) for k, v in sync.cost_table_ms.items()} if use_dist else None,
                        "gemm_dephase": {"ticks_10ns": int(ops.tuning.nt_dephase), "phases": int(ops.tuning.nt_dephase_n),
-                                        "note": "every other workgroup of an XCD starts late (s_memrealtime spin) in multi-round persistent GEMM launches; tuned on one box"},
+                                        "note": "eight-wave kernels only (row tails, fp32, odd K): every other workgroup of an XCD starts late in multi-round "
+                                                "persistent launches; the four-wave kernels of round 6 run in lockstep (tools/gemm_nt4_dephase.py)"},
                        "host_enqueue_ms_per_step": None if r["host_ms"] is None else round(r["host_ms"], 2),
                        "master_weights": "fp32", "final_mean_loss": round(final_loss, 4),
                        "passage_lengths": "all text_maxlength" if args.all_valid else "U{L/2..L} (SURVEY.md §8d)",
@@ -445,17 +446,20 @@ def main():
                          "traffic_over_algorithmic_bytes": round(traffic / traffic_alg, 3) if traffic and traffic_alg else None,
                          "kernel": ("gemm_nt_mx_kernel (256x256 tile, v_mfma_scale_f32_16x16x128_f8f6f4, e4m3 x e4m3 with E8M0 block scales: "
                                     "forward QKV / FFN-in / cross-K/V projections)") if args.fp8 else
-                                   ("gemm_nt_kernel<bf16,bf16,2,4,8,4> (256x256 tile, both epilogue instantiations; calls with M > 256"
-                                    " rows: the encoder's GEMMs incl. their small-tile row tails; + the cross-K/V projection under LAKO_XATTN=0)") if args.dtype == "bf16"
+                                   ("gemm_nt4_kernel<MT,SIDE> (round 6: 256x256 / 192x256 tiles on four waves, hand-placed K loop with two K-slices of "
+                                    "LDS-DMA in flight; all four instantiations; calls with M > 256 rows: the encoder's GEMMs; + the cross-K/V "
+                                    "projection under LAKO_XATTN=0)") if args.dtype == "bf16"
                                    else "gemm_nt_kernel<f32,f32>",
                          "launches_per_step": r["n_l"], "avg_launch_us": round(r["t_ms"] * 1e3 / max(r["n_l"], 1), 2),
                          "step_mfma_frac": round(r["step_frac"], 4),
+                         "nominal_step_frac": round(r["value"] / world * fl / 1e12 / peak, 4),
                          "train_gflop_per_sample": round(fl / 1e9, 1),
                          "executed_gflop_per_sample": round(r["fl_exec"] / 1e9, 1),
                          "flop_note": "train_gflop_per_sample: SURVEY.md §8a formula on every position of [B, N, L]; executed_…: the FLOPs this "
                                       "implementation issues (valid tokens only" + (", cross-attention in the encoder-state space: no K/V "
                                       "projection of the encoder states; the reference formulation on the same valid tokens would be "
-                                      f"{r['fl_proj'] / 1e9:.1f} GFLOP/sample" if r["xattn"] else "") + "); step_mfma_frac prices the executed FLOPs"},
+                                      f"{r['fl_proj'] / 1e9:.1f} GFLOP/sample" if r["xattn"] else "") + "); step_mfma_frac prices the executed FLOPs, nominal_step_frac = samples/s x train_gflop_per_sample / peak (SURVEY.md §8d's formula, "
+                                      "which counts padded positions and the K/V projection)"},
         }
         if args.fp8:
             out["roofline"]["bf16_gemm"] = r["bf16_gemm"]          # the GEMMs that stay bf16 in the same run (backward, o / wo projections)

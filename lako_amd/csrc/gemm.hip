@@ -2247,8 +2247,10 @@ bool nt4_ok(const NtArgs& a) {
   if (sizeof(T) != 2 || sizeof(TO) != 2 || a.K % 128 != 0 || a.K < 256 || (a.flags & (LAKO_EPI_ATOMIC | LAKO_EPI_NORM_A)) || a.N % 8 != 0 || a.ldc % 8 != 0 ||
       reinterpret_cast<uintptr_t>(a.C) % 16 != 0 || (int64_t)256 * std::max(a.lda, a.ldb) * 2 >= (1ll << 31))
     return false;
-  // epilogues built into the kernels: {alpha, ReLU, dropout}; residual with or without dropout; the aux mask alone
+  // epilogues built into the kernels: alpha alone; {ReLU, dropout}; residual with or without dropout; the aux mask alone (all with alpha = 1)
   const int side = a.flags & (LAKO_EPI_RESID | LAKO_EPI_AUXMASK);
+  if (a.alpha != 1.0f && (a.flags != 0 || a.drop_thresh != 0)) return false;
+  if (a.drop_thresh != 0 && (uint64_t)(a.row0 + a.M + 256) * (uint64_t)a.N >= (1ull << 34)) return false;      // dropout quads are indexed in 32 bits
   if (side == (LAKO_EPI_RESID | LAKO_EPI_AUXMASK)) return false;
   if (side && (a.flags & LAKO_EPI_RELU)) return false;
   if (side == LAKO_EPI_AUXMASK && a.drop_thresh != 0) return false;

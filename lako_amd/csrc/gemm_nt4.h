@@ -276,12 +276,7 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(NtArgs a) {
       for (int j = 0; j < 8; ++j) dma_piece(ldsB0 + x * BUF + j * 4096, voffB[j], pB + x * TKB);
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  u32x4 A0[MT], B0[8], A1[MT], B1[8];
-  read_frags<8, 0>(B0, ad.b[0][0]);
-  read_frags<MT, 0>(A0, ad.a[0][0]);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 
   int kst = 0;      // (stamps only) K-steps so far, over all tiles of the workgroup
   while (true) {
@@ -293,6 +288,13 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(NtArgs a) {
     const char* Bbase = a.B + (int64_t)n0 * ldb_b;
 
     f32x4 acc[8][MT];      // [n-tile][m-tile]; element r of lane (l & 15, g): C[m = mt·16 + (l & 15)][n = nt·16 + 4g + r]
+    // the k-half-0 fragments of the tile's first K-step (buffer 0: landed and published by the previous tile's last counted wait + barrier
+    // 3, or by the prologue).  The previous tile's last step has read them already — re-reading them here (≈ 300 cycles per tile) instead of
+    // carrying 64 registers across the epilogue is what lets the epilogue keep four passes of side-operand loads in flight without spills.
+    u32x4 A0[MT], B0[8], A1[MT], B1[8];
+    read_frags<8, 0>(B0, ad.b[0][0]);
+    read_frags<MT, 0>(A0, ad.a[0][0]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
     uint64_t pA = reinterpret_cast<uint64_t>(Abase) + 2 * TKB, pB = reinterpret_cast<uint64_t>(Bbase) + 2 * TKB;
     // the stream moves on to the workgroup's next tile (its K-slices 0 and 1) in the tile's last pair of steps; the last tile requests its
@@ -358,42 +360,69 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(NtArgs a) {
           (SIDE && rows_v > 0 && cols_v > 0) ? (rows_v - 1) * lds_b + cols_v * 2 : 0, 0x00020000);
       const int svo = in_cols ? rq * lds_b + cj * 16 : (int)0x80000000;
       const uint32_t wr_base = (uint32_t)(r16e * 512), rd_base = (uint32_t)(rq * 512);
+      // quad of (row mw + rq, column nw + 8 cj); rows 4 apart are N quads apart
+      const uint32_t quad0 = (uint32_t)((((uint64_t)(a.row0 + mw + rq)) * (uint64_t)a.N + (uint64_t)(nw + cj * 8)) >> 2);
       auto write_pass = [&](int mt) {
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt) *reinterpret_cast<f32x4*>(ep + wr_base + (((nt * 4 + ge) ^ r16e) * 16)) = acc[nt][mt];
       };
-      auto run = [&](auto RELU_, auto DROP_, auto RES_) {
+      // ALPHA: the product is scaled (only the plain epilogue is built with it: every fused epilogue of the reader has alpha = 1, and with one
+      // wave per SIMD the two packed multiplies per four outputs are a third of the plain epilogue's vector work — nt4_ok sends a fused
+      // epilogue with alpha != 1 to the eight-wave kernels)
+      auto run = [&](auto RELU_, auto DROP_, auto RES_, auto ALPHA_) {
         constexpr bool RELU = decltype(RELU_)::value, DROP = decltype(DROP_)::value, RES = SIDE && decltype(RES_)::value, AUX = SIDE && !RES;
-        u32x4 side[2][4];
+        constexpr bool ALPHA = decltype(ALPHA_)::value;
+        // the side operand's 16 bytes per lane and row, requested SD passes ahead (a ring of SD × 4 registers quads: one pass is ≈ 800 cycles of
+        // this wave's work, a load from HBM several thousand — one pass ahead left the epilogue waiting for memory in every pass:
+        // profiles/r06h_nt4_epilogue_stamps.txt)
+#ifndef LAKO_NT4_SD
+#define LAKO_NT4_SD 2
+#endif
+        constexpr int SD = LAKO_NT4_SD;
+        u32x4 side[SD][4];
         if constexpr (SIDE) {
 #pragma unroll
-          for (int it = 0; it < 4; ++it) side[0][it] = __builtin_amdgcn_raw_buffer_load_b128(srs, svo, it * 4 * lds_b, 0);
+          for (int p0 = 0; p0 < SD && p0 < MT; ++p0)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) side[p0][it] = __builtin_amdgcn_raw_buffer_load_b128(srs, svo, (p0 * 16 + it * 4) * lds_b, 0);
         }
         write_pass(0);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
+          // the pass's rows come back in two halves (2 × 4 reads): the second half is requested — and the next pass written — once the first
+          // half's arithmetic has been issued (LDS executes a wave's accesses in order: the write cannot overtake the reads)
           f32x4 v[4][2];
+          auto read_rows = [&](int it0) {
 #pragma unroll
-          for (int it = 0; it < 4; ++it)
+            for (int it = it0; it < it0 + 2; ++it)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              const int row_l = it * 4 + rq;
-              v[it][h] = *reinterpret_cast<const f32x4*>(ep + rd_base + it * 2048 + (((2 * cj + h) ^ row_l) * 16));
+              for (int h = 0; h < 2; ++h) {
+                const int row_l = it * 4 + rq;
+                v[it][h] = *reinterpret_cast<const f32x4*>(ep + rd_base + it * 2048 + (((2 * cj + h) ^ row_l) * 16));
+              }
+          };
+          read_rows(0);
+          u32x4 sv4[4];
+          if constexpr (SIDE) {      // this pass's side data out of the ring, the pass SD ahead into its place
+#pragma unroll
+            for (int it = 0; it < 4; ++it) sv4[it] = side[mt % SD][it];
+            if (mt + SD < MT) {
+#pragma unroll
+              for (int it = 0; it < 4; ++it) side[mt % SD][it] = __builtin_amdgcn_raw_buffer_load_b128(srs, svo, ((mt + SD) * 16 + it * 4) * lds_b, 0);
             }
-          if (mt + 1 < MT) {
-            if constexpr (SIDE) {
-#pragma unroll
-              for (int it = 0; it < 4; ++it) side[(mt + 1) & 1][it] = __builtin_amdgcn_raw_buffer_load_b128(srs, svo, ((mt + 1) * 16 + it * 4) * lds_b, 0);
-            }
-            write_pass(mt + 1);
           }
 #pragma unroll
           for (int it = 0; it < 4; ++it) {
+            if (it == 2) {
+              read_rows(2);
+              if (mt + 1 < MT) write_pass(mt + 1);
+            }
             bf16x8 sv = {}, o;
-            if constexpr (SIDE) sv = __builtin_bit_cast(bf16x8, side[mt & 1][it]);
+            if constexpr (SIDE) sv = __builtin_bit_cast(bf16x8, sv4[it]);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-              f32x4 x = v[it][h] * a.alpha;
+              f32x4 x = v[it][h];
+              if constexpr (ALPHA) x = x * a.alpha;
               if constexpr (RELU) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) x[r] = fmaxf(x[r], 0.f);
@@ -403,9 +432,11 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(NtArgs a) {
                 for (int r = 0; r < 4; ++r) x[r] = (float)sv[4 * h + r] > 0.f ? x[r] * a.aux_scale : 0.f;
               }
               if constexpr (DROP) {
-                const uint64_t idx = (uint64_t)(a.row0 + mw + mt * 16 + it * 4 + rq) * (uint64_t)a.N + (uint64_t)(nw + cj * 8 + 4 * h);
+                // the dropout quad (4 consecutive elements of a row) of these four outputs: element index / 4, below 2^32 (nt4_ok) — 32-bit
+                // additions from the lane's first quad instead of a 64-bit multiply per row (the index arithmetic was half of the
+                // 32-bit multiplies of this epilogue, and with one wave per SIMD they are wall time: profiles/r06h_nt4_epilogue_stamps.txt)
                 bool kp[4];
-                lako_keep4(a.drop_key, idx >> 2, a.drop_thresh, kp);
+                lako_keep4(a.drop_key, (uint64_t)(quad0 + (uint32_t)(mt * 4 + it) * (uint32_t)a.N + (uint32_t)h), a.drop_thresh, kp);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) x[r] = kp[r] ? x[r] * a.drop_scale : 0.f;
               }
@@ -424,20 +455,23 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(NtArgs a) {
       using T_ = std::true_type;
       using F_ = std::false_type;
       if constexpr (SIDE) {
-        // (the host sends here: residual with or without dropout, or the aux mask alone — nt4_ok)
+        // (the host sends here: residual with or without dropout, or the aux mask alone, alpha = 1 — nt4_ok)
         if (has_res) {
-          if (drop) run(F_{}, T_{}, T_{});
-          else run(F_{}, F_{}, T_{});
+          if (drop) run(F_{}, T_{}, T_{}, F_{});
+          else run(F_{}, F_{}, T_{}, F_{});
         } else {
-          run(F_{}, F_{}, F_{});
+          run(F_{}, F_{}, F_{}, F_{});
         }
       } else {
         if (drop) {
-          if (relu) run(T_{}, T_{}, F_{});
-          else run(F_{}, T_{}, F_{});
+          if (relu) run(T_{}, T_{}, F_{}, F_{});
+          else run(F_{}, T_{}, F_{}, F_{});
+        } else if (relu) {
+          run(T_{}, F_{}, F_{}, F_{});
+        } else if (a.alpha != 1.0f) {
+          run(F_{}, F_{}, F_{}, T_{});
         } else {
-          if (relu) run(T_{}, F_{}, F_{});
-          else run(F_{}, F_{}, F_{});
+          run(F_{}, F_{}, F_{}, F_{});
         }
       }
     }
