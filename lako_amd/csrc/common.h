@@ -137,8 +137,8 @@ __device__ __forceinline__ void store4(bf16_t* p, f32x4 v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// stateless dropout RNG: keep(seed, site, idx).  One 32-bit hash per element (lowbias32 finalizer);
-// forward and backward regenerate the same mask from (seed, site, element index), nothing is stored.
+// stateless dropout RNG: keep(seed, site, idx); forward and backward regenerate the same mask from (seed, site, element index),
+// nothing is stored.  lako_hash32 (lowbias32 finalizer) derives the per-site key on the host; the per-element draws are lako_keep4's.
 // tests/ref_ops.py carries the identical integer recipe in numpy.
 // ---------------------------------------------------------------------------------------------
 __host__ __device__ __forceinline__ uint32_t lako_hash32(uint32_t x) {
@@ -152,20 +152,28 @@ __host__ __device__ __forceinline__ uint32_t lako_hash32(uint32_t x) {
 __host__ __device__ __forceinline__ uint32_t lako_drop_key(uint32_t seed, uint32_t site) {
   return lako_hash32(seed * 0x9E3779B9U + site * 0x85EBCA6BU + 0x1234567U);
 }
-// Element-wise dropout draws: the four consecutive elements 4q … 4q+3 share ONE hash,
-//   h = hash32(lo(q) ^ key ^ hi(q)·0x27d4eb2f),  w = h · 0x9E3779B1 (low 32 bits),
-// with 16-bit draws h>>16, h&0xffff, w>>16, w&0xffff; an element is KEPT iff its draw >= round(p·65536).
+// Element-wise dropout draws (round 6: multiply-free, the attention kernels' mix): the four consecutive elements 4q … 4q+3 share
+//   x = lo(q) ^ key ^ hi(q)·0x27d4eb2f,   h = mix(x, 0x5BD1E9, 13),   w0 = mix(h, 0x6C8E95, 6),   w1 = mix(h, 0x1B873B, 11),
+//   mix(a, c, s) = t ^ (t >> 16),  t = ((a mod 2^24)·c + (a >> s)) mod 2^32        (v_mad_u32_u24 + a shift + an xor),
+// with 16-bit draws w0>>16, w0&0xffff, w1>>16, w1&0xffff; an element is KEPT iff its draw >= round(p·65536).
 // `thresh` below is that 16-bit threshold shifted left by 16, so that no field has to be extracted:
 //   x>>16 >= t  ⟺  x >= t<<16,   x&0xffff >= t  ⟺  x<<16 >= t<<16.
-// (one hash per 4 elements instead of per element: the hashes were ≈2 µs of a GEMM tile's epilogue; measured keep rate
-//  and neighbour correlations of this recipe: DESIGN.md §3.)  tests/ref_ops.py carries the same integers.
+// (Rounds 1-5 used two rounds of a 32-bit multiplicative hash + a third multiply: three quarter-rate multiplies per quad, which the
+//  compiler made four.  In the GEMM epilogues of the four-wave kernels — one wave per SIMD, nothing to hide behind — that was a third of
+//  a dropout epilogue's 16 000 cycles per tile: profiles/r06h_nt4_epilogue_stamps.txt.  Keep rate and neighbour correlations of this
+//  recipe: tests/test_engine_cpu.py::test_elementwise_dropout_recipe_statistics.)  tests/ref_ops.py carries the same integers.
+__host__ __device__ __forceinline__ uint32_t lako_mix24(uint32_t a, uint32_t c, uint32_t s) {
+  const uint32_t t = (a & 0xFFFFFFu) * c + (a >> s);      // c < 2^24: a 24-bit multiply-add on the device
+  return t ^ (t >> 16);
+}
 __host__ __device__ __forceinline__ void lako_keep4(uint32_t key, uint64_t quad, uint32_t thresh, bool (&k)[4]) {
-  const uint32_t h = lako_hash32((uint32_t)quad ^ key ^ ((uint32_t)(quad >> 32) * 0x27d4eb2fU));
-  const uint32_t w = h * 0x9E3779B1U;
-  k[0] = h >= thresh;
-  k[1] = (h << 16) >= thresh;
-  k[2] = w >= thresh;
-  k[3] = (w << 16) >= thresh;
+  const uint32_t x = (uint32_t)quad ^ key ^ ((uint32_t)(quad >> 32) * 0x27d4eb2fU);
+  const uint32_t h = lako_mix24(x, 0x5BD1E9u, 13u);
+  const uint32_t w0 = lako_mix24(h, 0x6C8E95u, 6u), w1 = lako_mix24(h, 0x1B873Bu, 11u);
+  k[0] = w0 >= thresh;
+  k[1] = (w0 << 16) >= thresh;
+  k[2] = w1 >= thresh;
+  k[3] = (w1 << 16) >= thresh;
 }
 // single element idx (callers that hold one element per lane)
 __host__ __device__ __forceinline__ bool lako_keep(uint32_t key, uint64_t idx, uint32_t thresh) {

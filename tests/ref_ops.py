@@ -43,29 +43,30 @@ def drop_key(seed: int, site: int) -> int:
 
 
 def keep_mask(drop, idx: torch.Tensor):
-    """(keep bool tensor, scale) for element indices `idx` (int64) — the integer recipe of csrc/common.h (lako_keep4):
-    elements 4q … 4q+3 share h = hash32(lo(q) ^ key ^ hi(q)·0x27d4eb2f), w = h·0x9E3779B1; 16-bit draws h>>16, h&0xffff,
-    w>>16, w&0xffff; keep iff draw >= round(p·65536)."""
+    """(keep bool tensor, scale) for element indices `idx` (int64) — the integer recipe of csrc/common.h (lako_keep4, round 6):
+    elements 4q … 4q+3 share x = lo(q) ^ key ^ hi(q)·0x27d4eb2f, h = mix(x, 0x5BD1E9, 13), w0 = mix(h, 0x6C8E95, 6),
+    w1 = mix(h, 0x1B873B, 11) with mix(a, c, s) = t ^ (t >> 16), t = (a mod 2^24)·c + (a >> s) mod 2^32; 16-bit draws w0>>16, w0&0xffff,
+    w1>>16, w1&0xffff; keep iff draw >= round(p·65536)."""
     p, seed, site = drop
     t16 = min(max(int(float(np.float32(p)) * 65536.0 + 0.5), 1), 65535)
     key = drop_key(int(seed) & M32, int(site) & M32)
     q, fld = idx >> 2, idx & 3
     lo, hi = q & M32, q >> 32
-    h = hash32(lo ^ key ^ ((hi * 0x27D4EB2F) & M32))
-    w = _mul32(h, 0x9E3779B1)
-    word = torch.where(fld >= 2, w, h)
+    h = _drop_mix(lo ^ key ^ ((hi * 0x27D4EB2F) & M32), 0x5BD1E9, 13)
+    w0, w1 = _drop_mix(h, 0x6C8E95, 6), _drop_mix(h, 0x1B873B, 11)
+    word = torch.where(fld >= 2, w1, w0)
     draw = torch.where((fld & 1).bool(), word & 0xFFFF, word >> 16)
     scale = float(np.float32(1.0) / (np.float32(1.0) - np.float32(p)))
     return draw >= t16, scale
 
 
-DROP_C0 = 0x5BD1E9
-DROP_MUL = [0x6C8E95, 0x1B873B, 0x4F1BBD, 0x7A3C6F, 0x35D2A7, 0x59E4C1, 0x2545F5, 0x63D9AB]      # [i·2 + j]
-
-
 def _drop_mix(a, c, s):
     t = ((a & 0xFFFFFF) * c + (a >> s)) & M32
     return t ^ (t >> 16)
+
+
+DROP_C0 = 0x5BD1E9
+DROP_MUL = [0x6C8E95, 0x1B873B, 0x4F1BBD, 0x7A3C6F, 0x35D2A7, 0x59E4C1, 0x2545F5, 0x63D9AB]      # [i·2 + j]
 
 
 def attn_keep_mask(BH, Lq, Lk, key, p, dev="cpu"):

@@ -215,7 +215,9 @@ def test_train_retriever_driver_end_to_end(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     evals = [float(ln.split("eval: ")[1].split(",")[0]) for ln in r.stderr.splitlines() if "eval: " in ln]
     trains = [float(ln.split("train: ")[1].split(",")[0]) for ln in r.stderr.splitlines() if "train: " in ln]
-    assert len(evals) >= 2 and all(np.isfinite(evals)) and trains[1] < trains[0], (trains, evals)      # second full epoch below the first
+    # the training loss falls over the epochs (with dropout on, one epoch of 16 noisy steps may sit above its predecessor — which one depends
+    # on the dropout masks, i.e. on the recipe of csrc/common.h — the last one must be well below the first)
+    assert len(evals) >= 2 and all(np.isfinite(evals)) and len(trains) >= 3 and trains[-1] < 0.8 * trains[0], (trains, evals)
     assert "avg top1" in r.stderr and "questions/s" in r.stderr
     ck = tmp_path / "ret" / "checkpoint" / "best_dev"
     assert (ck / "optimizer.pth.tar").exists() and (ck / "model.safetensors").exists()

@@ -617,3 +617,23 @@ def test_batch_without_padding_runs_the_encoder_without_a_key_mask(monkeypatch):
     toks = model.generate(input_ids=ids * part, attention_mask=part, max_length=4)
     assert not model._engine._all_valid
     assert toks.tolist() == O.fid_generate(w, dims, ids * part, part, 4).tolist()
+
+
+def test_elementwise_dropout_recipe_statistics():
+    """Keep rate and neighbour correlations of the element-wise dropout recipe (csrc/common.h lako_keep4 = tests/ref_ops.keep_mask, round 6:
+    multiply-free) at p = 0.1 over [rows, N] grids of the encoder's widths: along a row (inside a quad, across quads), along a column (rows
+    are N / 4 quads apart), diagonals; per-row and per-column keep fractions spread like a binomial."""
+    import numpy as np
+    import torch
+    from tests.ref_ops import keep_mask
+    for seed, site in ((0, 3), (12345, 77)):
+        for rows, N in ((4000, 768), (1500, 3072)):
+            idx = torch.arange(rows * N, dtype=torch.int64).view(rows, N)
+            k = keep_mask((0.1, seed, site), idx)[0].double()
+            assert abs(float(k.mean()) - 0.9) < 7e-4
+            c = lambda a, b: float(np.corrcoef(a.reshape(-1).numpy(), b.reshape(-1).numpy())[0, 1])   # noqa: E731
+            for a_, b_ in ((k[:, :-1], k[:, 1:]), (k[:, :-2], k[:, 2:]), (k[:, :-4], k[:, 4:]), (k[:, :-8], k[:, 8:]), (k[:-1], k[1:]),
+                           (k[:-2], k[2:]), (k[:-4], k[4:]), (k[:-1, :-1], k[1:, 1:]), (k[:-1, :-4], k[1:, 4:])):
+                assert abs(c(a_, b_)) < 3e-3
+            assert abs(float(k.mean(1).std()) / (0.09 / N) ** 0.5 - 1) < 0.06
+            assert abs(float(k.mean(0).std()) / (0.09 / rows) ** 0.5 - 1) < 0.06
