@@ -204,7 +204,12 @@ def visible_gpus() -> int:
         for d in os.listdir(root):
             with open(os.path.join(root, d, "properties")) as f:
                 props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
-            n += int(props.get("simd_count", "0")) > 0
+            if int(props.get("simd_count", "0")) <= 0:
+                continue
+            # a container may see the host's /sys but only some /dev/dri/renderD* nodes (cgroup / --device): count a GPU only when its
+            # render node is accessible to this process
+            minor = int(props.get("drm_render_minor", "0"))
+            n += (minor <= 0) or os.access(f"/dev/dri/renderD{minor}", os.R_OK | os.W_OK)
     except OSError:
         n = None
     if not n:

@@ -1945,7 +1945,10 @@ int lako_attn_enc_bwd(AttnArgs& a, hipStream_t s) {
       f.rk = padded ? (int)(a.ksb / a.kst) : 0;
       const int nslots = std::min(a.Bn, std::max(1, 256 / a.H));
       const bool drop = a.drop_t16 != 0;
-      static const int nst_env = getenv("LAKO_ATTN_FUSED_NST") ? atoi(getenv("LAKO_ATTN_FUSED_NST")) : 4;
+      // (read on every call, as LAKO_ATTN_PERSIST above: tests switch the ring depth inside one process — cached in a static the first
+      //  fused launch would fix it for the whole run and the three-stage instantiations would never be exercised)
+      const char* nst_s = getenv("LAKO_ATTN_FUSED_NST");
+      const int nst_env = nst_s ? atoi(nst_s) : 4;
       const int nst = (nst_env >= 4 && efb_lds(rows, 4) <= 160 * 1024) ? 4 : 3;
       const int lds = efb_lds(rows, nst);
       const dim3 grid(a.H * nslots);

@@ -21,6 +21,7 @@ struct Rccl {
   ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   bool ok = false;
+  char why[256] = "";      // the loader's message, captured where it happened (dlerror() clears itself when read)
 };
 
 // resolved once per process (function pointers of a shared library: not tuning state, nothing a caller could want two of)
@@ -30,6 +31,8 @@ const Rccl& rccl() {
     for (const char* name : {"librccl.so.1", "librccl.so"}) {
       x.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
       if (x.h) break;
+      const char* e = dlerror();
+      snprintf(x.why, sizeof(x.why), "%s", e ? e : "dlopen failed");
     }
     if (!x.h) return x;
     x.GetUniqueId = reinterpret_cast<decltype(x.GetUniqueId)>(dlsym(x.h, "ncclGetUniqueId"));
@@ -39,6 +42,7 @@ const Rccl& rccl() {
     x.CommCount = reinterpret_cast<decltype(x.CommCount)>(dlsym(x.h, "ncclCommCount"));
     x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(dlsym(x.h, "ncclGetErrorString"));
     x.ok = x.GetUniqueId && x.CommInitRank && x.AllReduce && x.CommDestroy && x.GetErrorString;
+    if (!x.ok) snprintf(x.why, sizeof(x.why), "the library lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy / ncclGetErrorString");
     return x;
   }();
   return r;
@@ -46,7 +50,7 @@ const Rccl& rccl() {
 
 int need_rccl(const char* fn) {
   if (rccl().ok) return 0;
-  lako_set_error("%s: RCCL (librccl.so.1) is not available in this process: %s", fn, dlerror() ? dlerror() : "symbols missing");
+  lako_set_error("%s: RCCL (librccl.so.1) is not available in this process: %s", fn, rccl().why);
   return LAKO_E_UNSUPPORTED;
 }
 

@@ -69,7 +69,7 @@ def choose_dp(n_grad: int, world: int) -> tuple:
 
 
 def estimate_dp_transport(n_grad: int, world: int) -> str:
-    """What the cost table WOULD pick (`LAKO_DP_GRAD_DTYPE=auto` opts into it; reported on every bench line as an estimate): bf16 where
+    """What the cost table WOULD pick (`LAKO_DP_GRAD_DTYPE=auto` opts into it; the table it reads is what a multi-GPU bench line prints as `dp_estimated_allreduce_ms`): bf16 where
     it saves ≥ BF16_MIN_GAIN_MS — at T5-base (892 MB of fp32 gradients) N = 2 (13.9 → 7.5 ms) and N = 4 (7.0 → 4.0 ms), not N = 8."""
     t = dp_cost_table(n_grad, world)
     return "bf16" if t["fp32"] - t["bf16"] >= BF16_MIN_GAIN_MS else "fp32"

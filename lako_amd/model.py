@@ -193,9 +193,10 @@ class FiDT5(nn.Module):
         """src/model.py:39-51: accepts [B,N,L] or already-flattened [B,N·L] (n_passages remembered).
         `passage_lengths` (extension, optional): HOST int tensor [B, N] of valid tokens per passage, for masks of the
         collator's form (valid tokens first) — lets the unpadded encoder skip the device→host read-back of the mask.  The
-        lengths are TRUSTED: they must describe `attention_mask` exactly (lengths[b, n] valid tokens, then padding); anything else
-        is undefined behaviour (wrong tokens are packed).  LAKO_CHECK_LENGTHS=1 verifies every batch on the device and raises one
-        step late (engine.Engine._check_lengths)."""
+        lengths must describe `attention_mask` exactly (lengths[b, n] valid tokens, then padding) — anything else would pack the wrong
+        tokens.  Every batch is verified on the device without a host sync; a mismatch raises ValueError a step or two later
+        (engine.Engine._check_lengths; `model._engine.check_lengths_now()` waits for the outstanding verdicts; LAKO_CHECK_LENGTHS=0
+        switches the check off)."""
         if input_ids is None or labels is None:
             raise ValueError("FiDT5.forward needs input_ids and labels (train_reader.py:67-71)")
         if input_ids.dim() == 3:
@@ -257,7 +258,17 @@ class FiDT5(nn.Module):
         with torch.no_grad():
             for k, v in state_dict.items():
                 pk = plain_name(k)
-                if pk in ALIASES or (pk in LEGACY_IGNORED and pk not in self._params_by_plain):
+                if pk in LEGACY_IGNORED and pk not in self._params_by_plain:
+                    # a checkpoint of the reference's transformers 3.0.2 carries a TRAINED relative-attention table of the decoder's
+                    # first cross-attention; this model (HF >= 4 semantics) has none: without --legacy_cross_bias the table is dropped and
+                    # losses / tokens / cross-attention scores differ from the reference's — say so instead of loading silently
+                    if bool(torch.as_tensor(v).ne(0).any()):
+                        import warnings
+                        warnings.warn(f"{k}: the checkpoint carries a non-zero cross-attention relative-position table (transformers 3.0.2 "
+                                      "semantics) that this model ignores; load it with legacy_cross_bias=True (from_pretrained / "
+                                      "--legacy_cross_bias) to reproduce the reference's numbers", stacklevel=2)
+                    continue
+                if pk in ALIASES:
                     continue
                 if pk not in self._params_by_plain:
                     if strict:

@@ -88,6 +88,27 @@ def test_comm_c_abi_world_of_one_in_child_process():
     assert r.returncode == 0 and "comm ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
 
 
+def test_wrong_passage_lengths_raise_without_a_host_sync_on_the_training_path():
+    """(round 6) The mask-vs-lengths check is on by default and asynchronous: a batch whose lengths do not describe its mask raises
+    ValueError — at the latest when the outstanding verdicts are collected (`check_lengths_now`), typically one or two batches later —
+    and consistent batches under torch's sync debug mode stay pure enqueueing (the test below runs with the check on)."""
+    import bench
+    cfg = FiDConfig.named("small", dropout_rate=0.0)
+    model = FiDT5(cfg, dtype=torch.bfloat16).cuda().train()
+    ids, mask, labels, lens = bench.synthetic_batch(2, 4, 64, 6, cfg.vocab_size, seed=77, device="cuda", with_lengths=True)
+    model(input_ids=ids, attention_mask=mask, labels=labels, passage_lengths=lens)
+    model._engine.check_lengths_now()
+    wrong = lens.clone()
+    wrong[0, 0] = max(int(wrong[0, 0]) - 1, 0) if int(wrong[0, 0]) > 1 else int(wrong[0, 0]) + 1
+    with pytest.raises(ValueError, match="passage_lengths"):
+        model(input_ids=ids, attention_mask=mask, labels=labels, passage_lengths=wrong)
+        for _ in range(3):                       # the verdict arrives behind an event: a later batch (or the explicit wait) raises
+            torch.cuda.synchronize()
+            model(input_ids=ids, attention_mask=mask, labels=labels, passage_lengths=lens)
+        model._engine.check_lengths_now()
+    model._engine.check_lengths_now()            # consumed
+
+
 def test_training_step_issues_no_host_sync_when_the_collator_hands_over_lengths():
     """(round 5; SURVEY.md §5.8 names host-side launch jitter as the data-parallel risk) With the collator's host-side passage lengths the
     whole step — forward, backward, clip, optimizer — must be pure enqueueing: no device→host read-back, no synchronise.  torch's sync

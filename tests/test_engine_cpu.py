@@ -447,25 +447,28 @@ def test_host_passage_lengths_equal_mask_readback(name):
         eng._ragged_batch(mask, *ids.shape, lengths=lens[:1])
 
 
-def test_check_lengths_switch_catches_a_mismatched_mask(monkeypatch):
-    """`passage_lengths` is trusted on the training path; LAKO_CHECK_LENGTHS=1 compares mask and lengths per batch (on the device,
-    asynchronously) and raises when the NEXT batch arrives — lengths of another batch, or a mask that is not valid-tokens-first."""
+def test_lengths_check_is_on_by_default_and_catches_a_mismatched_mask(monkeypatch):
+    """`passage_lengths` spares the training path the read-back of the mask — and wrong lengths would pack wrong tokens silently, so every
+    batch's mask is compared with them (round 6: by default; on the GPU asynchronously, here at once): lengths of another batch, or a
+    mask that is not valid-tokens-first, raise ValueError; LAKO_CHECK_LENGTHS=0 restores the trusting path."""
     z, dims, w, model = build("mid_a")
     ids, mask, labels = (torch.from_numpy(z[k]) for k in ("input_ids", "attention_mask", "labels"))
     lens = mask.sum(-1).to(torch.int32)
     model.train()
-    monkeypatch.setenv("LAKO_CHECK_LENGTHS", "1")
-    model(input_ids=ids, attention_mask=mask, labels=labels, passage_lengths=lens)       # consistent: nothing pending
+    monkeypatch.delenv("LAKO_CHECK_LENGTHS", raising=False)
+    model(input_ids=ids, attention_mask=mask, labels=labels, passage_lengths=lens)       # consistent: no error
     model._engine.check_lengths_now()
     holes = mask.clone()
     holes[0, 0, 0] = False
     holes[0, 0, int(lens[0, 0])] = True if int(lens[0, 0]) < mask.shape[2] else holes[0, 0, 0]   # same count, not a prefix
-    model(input_ids=ids, attention_mask=holes, labels=labels, passage_lengths=lens)
     with pytest.raises(ValueError, match="passage_lengths"):
-        model(input_ids=ids, attention_mask=mask, labels=labels, passage_lengths=lens)
-    model._engine.check_lengths_now()                                                    # the verdict was consumed
+        model(input_ids=ids, attention_mask=holes, labels=labels, passage_lengths=lens)
+    wrong = lens.clone()
+    wrong[0, 0] -= 1
+    with pytest.raises(ValueError, match="passage_lengths"):
+        model(input_ids=ids, attention_mask=mask, labels=labels, passage_lengths=wrong)
     monkeypatch.setenv("LAKO_CHECK_LENGTHS", "0")
-    model(input_ids=ids, attention_mask=holes, labels=labels, passage_lengths=lens)      # off: trusted (documented UB), no raise
+    model(input_ids=ids, attention_mask=holes, labels=labels, passage_lengths=lens)      # off: trusted, no raise
     model(input_ids=ids, attention_mask=mask, labels=labels, passage_lengths=lens)
 
 
