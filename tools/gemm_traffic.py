@@ -9,7 +9,7 @@ Units and corrections (MI355X_MICROARCH.md § HBM): both counters are in KiB; on
 coalesced reads (16 B per lane: LDS-DMA and global loads alike) and is DOUBLED here; WRITE_SIZE is exact for 16-byte stores and float
 atomics.  Infinity-Cache hits are counted, so these are fabric-side (L2-miss) bytes, an upper bound of the HBM bytes.  A call of the
 library may be two dispatches (the 256x256 kernel on the rows of the full rounds + a small-tile launch on the row tail): dispatches
-are grouped into calls by order — a call starts at a gemm_nt_kernel<…,2,4,{6,8,9},4,…> / gemm_tn256_kernel dispatch."""
+are grouped into calls by order — a call starts at a gemm_nt_kernel<…,2,4,{6,8,9},4,…> / gemm_tn256_kernel / gemm_nt4_kernel / gemm_tn4_kernel dispatch."""
 import collections
 import csv
 import glob
@@ -41,7 +41,8 @@ def calls_of(disp):
     """[(kind, [kernel names], counter sum)] in dispatch order"""
     out = []
     for name, val in disp:
-        head = ("gemm_nt_kernel" in name and re.search(r"Li2ELi4ELi[689]ELi4E", name) is not None) or "gemm_tn256_kernel" in name   # 256- / 192- / 288-row tiles
+        head = ("gemm_nt_kernel" in name and re.search(r"Li2ELi4ELi[689]ELi4E", name) is not None) or "gemm_tn256_kernel" in name or \
+            "gemm_nt4_kernel" in name or "gemm_tn4_kernel" in name   # 256- / 192- / 288-row tiles; round 6: the four-wave kernels (one dispatch per call)
         if head or not out:
             out.append(["tn" if "gemm_tn" in name else "nt", [name], val])
         else:
@@ -77,7 +78,7 @@ def main():
     wr = sum(c[2] for c in wc) / CALLS * 1024
     alg_r = sum(rows * (M + N) * 2 for M, N in TN_GROUP)
     alg_w = sum(M * N * 4 for M, N in TN_GROUP)
-    tn = {"kernel": "gemm_tn256_kernel (grouped launch: the four weight gradients of an encoder layer, K = rows)", "K": rows,
+    tn = {"kernel": "gemm_tn4_kernel / gemm_tn256_kernel (grouped launch: the four weight gradients of an encoder layer, K = rows)", "K": rows,
           "items_MxN": TN_GROUP, "fetch_size_raw_bytes": round(fetch_raw), "fetch_bytes_gfx950_corrected": round(2 * fetch_raw),
           "write_bytes": round(wr), "algorithmic_read_bytes": alg_r, "algorithmic_write_bytes": alg_w,
           "traffic_bytes": round(2 * fetch_raw + wr), "algorithmic_bytes": alg_r + alg_w,
