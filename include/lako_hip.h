@@ -204,6 +204,13 @@ int lako_embed_fwd(const int64_t* ids, const void* table, void* out, int64_t n_t
                    int dtype, lako_dropout_t drop, lako_stream_t stream);
 int lako_embed_bwd(const int64_t* ids, const void* dout, float* dtable, int64_t n_tok, int d, int64_t vocab,
                    int dtype, lako_dropout_t drop, lako_stream_t stream);
+/* The same sum added in a fixed order (LAKO_DETERMINISTIC=1): `perm` [n_tok] sorts the token positions by id, equal
+ * ids in position order (a stable argsort: index plumbing of the caller); each row of dtable is written once, by one wave. */
+int lako_embed_bwd_ordered(const int64_t* ids, const int64_t* perm, const void* dout, float* dtable, int64_t n_tok, int d,
+                           int64_t vocab, int dtype, lako_dropout_t drop, lako_stream_t stream);
+/* 1 when the library runs in the bit-reproducible mode (environment LAKO_DETERMINISTIC=1, read once per process): every float
+ * accumulation shared between workgroups is then order-independent (fixed-point integer atomics, one-contributor splits). */
+int lako_deterministic(void);
 
 /* ---- relative position bias (HF5:217-279): the bias depends only on (key_pos - query_pos), so the
  * [nb, H] embedding is expanded once per stack into rel[H, R] with rel[h][r] = table[lut[r]][h];

@@ -101,6 +101,8 @@ SIGNATURES = {
     "lako_rmsnorm_bwd": [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, Dropout, vp, Dropout, vp],
     "lako_embed_fwd": [vp, vp, vp, i64, i32, i64, i32, Dropout, vp],
     "lako_embed_bwd": [vp, vp, vp, i64, i32, i64, i32, Dropout, vp],
+    "lako_embed_bwd_ordered": [vp, vp, vp, vp, i64, i32, i64, i32, Dropout, vp],
+    "lako_deterministic": [],
     "lako_relpos_expand": [vp, vp, vp, i32, i32, i32, vp],
     "lako_relpos_reduce": [vp, vp, vp, i32, i32, i32, vp],
     "lako_attn_fwd": [C.POINTER(AttnFwd), vp],

@@ -20,8 +20,11 @@
 // INIT, the causal mask is one select, and dropout draws two 16-bit keep decisions from one 32-bit hash.
 // bf16: v_mfma_f32_16x16x32_bf16; fp32 (parity mode): v_mfma_f32_16x16x4_f32.
 #include "attn_shared.h"
+#include "det.h"
 
 namespace {
+
+LAKO_DET_STORAGE      // LAKO_DETERMINISTIC=1: see det.h
 
 // Stage rows [r0, r0 + nrows) of a strided [L, ·] tensor into a padded LDS image; rows >= L are
 // zero-filled (so padded keys/queries contribute exact zeros).  8 independent loads in flight per thread.
@@ -473,6 +476,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
     for (int i = threadIdx.x; i < a.R; i += 256) bias_l[i] = a.rel_bias[(int64_t)h * a.R + i];
   if (want_drel)
     for (int i = threadIdx.x; i < a.R; i += 256) drel_l[i] = 0.f;
+  // one contribution to the bias gradient of offset idx: an LDS float atomic into the workgroup's table — or, LAKO_DETERMINISTIC (det.h), a
+  // fixed-point integer atomic straight into the launch's table (slower: global instead of LDS; in that mode this kernel serves the
+  // decoder's eight-token self-attention and whatever the encoder's one-pass backward does not take)
+  auto drel_add = [&](int idx, float v) {
+    if (a.det) lako_det::add(&lako_det_slots[h * a.R + idx], v);
+    else atomicAdd(&drel_l[idx], v);
+  };
   const int hq = (a.Lk + 3) >> 2, hqq = (a.Lq + 3) >> 2;
   const uint32_t t_hi = a.drop_t16 << 16;
 
@@ -701,7 +711,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
           if (MODE == 0 && fast_drel) dsacc[2 * tp + t] += ds[t];
           else if (want_drel) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(&drel_l[clampi(bi0 + r, 0, a.R - 1)], ds[t][r]);
+            for (int r = 0; r < 4; ++r) drel_add(clampi(bi0 + r, 0, a.R - 1), ds[t][r]);
           }
         }
         if constexpr (MODE == 0) {
@@ -762,7 +772,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
         for (int t = 0; t < 16; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            atomicAdd(&drel_l[clampi(t * 16 + 4 * g + r - yq + a.rel_off, 0, a.R - 1)], dsacc[t][r]);
+            drel_add(clampi(t * 16 + 4 * g + r - yq + a.rel_off, 0, a.R - 1), dsacc[t][r]);
       }
     } else if (yb_begin + wave < yb_end) {
       float* reg = reinterpret_cast<float*>(smem) + wave * 16 * CH;
@@ -785,9 +795,17 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
           pos = pos >= CH ? pos - CH : pos;
           if (key >= 0 && key < CH) sum += reg[q * CH + pos];
         }
-        if (sum != 0.f) atomicAdd(&drel_l[clampi(dd - 15 - yq0 + a.rel_off, 0, a.R - 1)], sum);
+        if (sum != 0.f) drel_add(clampi(dd - 15 - yq0 + a.rel_off, 0, a.R - 1), sum);
       }
     }
+  }
+  if (want_drel && a.det) {
+    // (the XCD-grouped 1-D grid of the dQ pass carries surplus workgroups that left at the top: they draw no ticket)
+    const unsigned int nblocks = a.grid_x > 0 ? (unsigned)(a.grid_x * a.H * a.grid_z) : gridDim.x * gridDim.y * gridDim.z;
+    // (the flag: first word of the dynamic allocation, dead after the barrier inside last_block — no static LDS next to `smem`)
+    if (lako_det::last_block(&lako_det_ticket, nblocks, reinterpret_cast<int*>(smem)))
+      for (int i = threadIdx.x; i < a.H * a.R; i += 256) a.drel[i] += lako_det::take(&lako_det_slots[i]);
+    return;
   }
   if (want_drel && !ATTN_DBG(a, 4)) {
     __syncthreads();
@@ -932,6 +950,7 @@ void set_drop(AttnArgs& a, const lako_dropout_t& d) {
     a.drop_scale = 1.0f / (1.0f - d.p);
   }
   a.drop_key = lako_drop_key(d.seed, d.site);
+  a.det = lako_det::on() ? 1 : 0;
 }
 
 }  // namespace
@@ -1014,8 +1033,13 @@ extern "C" int lako_attn_bwd(const lako_attn_bwd_t* p, lako_stream_t stream) {
   a.order = p->order;
   LAKO_CHECK_ARG(!(p->key_mask && p->k_off), "lako_attn_bwd: ragged keys carry no padding — pass key_mask = NULL");
   set_drop(a, p->drop);
-  if (lako_attn_enc_supported(a, p->dtype, p->d_head)) lako_attn_enc_bwd(a, (hipStream_t)stream);
-  else ATTN_DISPATCH(p->dtype, p->d_head, run_bwd, a, (hipStream_t)stream);
+  if (a.det && a.drel && (int64_t)a.H * a.R > lako_det::SLOTS) {
+    lako_set_error("lako_attn_bwd: LAKO_DETERMINISTIC holds the bias gradient of %d heads x %d offsets in a table of %d slots", a.H, a.R, lako_det::SLOTS);
+    return LAKO_E_UNSUPPORTED;
+  }
+  bool done = false;      // (the encoder's fast path declines in LAKO_DETERMINISTIC mode where its one-pass kernel does not apply)
+  if (lako_attn_enc_supported(a, p->dtype, p->d_head)) done = lako_attn_enc_bwd(a, (hipStream_t)stream) == 0;
+  if (!done) ATTN_DISPATCH(p->dtype, p->d_head, run_bwd, a, (hipStream_t)stream);
   LAKO_LAUNCH_CHECK();
   return LAKO_OK;
 }

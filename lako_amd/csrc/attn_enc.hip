@@ -28,9 +28,12 @@
 #include <algorithm>
 
 #include "attn_shared.h"
+#include "det.h"
 #include "lds_image.h"
 
 namespace {
+
+LAKO_DET_STORAGE      // LAKO_DETERMINISTIC=1: see det.h
 
 constexpr int EB_PADLO = 16;              // bias table: entries in front of index 0 (queries past Lq in the last block)
 constexpr int EB_ST = 592;                // floats per shifted copy: ≥ 511 + 16 + 36, ≡ 16 (mod 64) → the 4 copies sit 16 banks apart
@@ -1795,7 +1798,14 @@ __global__ __launch_bounds__(FB_NW * 64) void enc_bwd_fused_kernel(AttnArgs a) {
           }
         }
       }
-      if (sum != 0.f) atomicAdd(a.drel + (int64_t)h * a.R + d, sum);
+      if (a.det) lako_det::add(&lako_det_slots[h * a.R + d], sum);      // LAKO_DETERMINISTIC: fixed point, converted once below
+      else if (sum != 0.f) atomicAdd(a.drel + (int64_t)h * a.R + d, sum);
+    }
+    if (a.det) {
+      // (the flag lives in the dynamic allocation — F[0], dead after the barrier inside last_block: a static __shared__ variable would move
+      //  the base of `smem`, and the LDS-DMA destinations of this kernel are absolute LDS addresses)
+      if (lako_det::last_block(&lako_det_ticket, gridDim.x, reinterpret_cast<int*>(smem)))
+        for (int i = threadIdx.x; i < a.H * a.R; i += 14 * 64) a.drel[i] += lako_det::take(&lako_det_slots[i]);      // (waves 14 / 15 have left)
     }
   }
   FB_STAMP_AT(255, 3);
@@ -1938,7 +1948,8 @@ int lako_attn_enc_bwd(AttnArgs& a, hipStream_t s) {
     const bool padded = !a.q_off && !a.k_off && a.qst > 0 && a.ost > 0 && a.kst > 0 && a.vst > 0 && a.qsb % a.qst == 0 && a.osb % a.ost == 0 &&
                         a.qsb / a.qst == a.osb / a.ost && a.ksb % a.kst == 0 && a.vsb % a.vst == 0 && a.ksb / a.kst == a.vsb / a.vst &&
                         a.qsb / a.qst * a.Bn < (1ll << 31) && a.ksb / a.kst * a.Bn < (1ll << 31);
-    if ((m & 16) && a.H <= 256 && fits32 && (ragged || padded) && rows <= 224 && a.Lq <= 256 && efb_lds(rows, 3) <= 160 * 1024) {
+    if ((m & 16 || a.det) && a.H <= 256 && fits32 && (ragged || padded) && rows <= 224 && a.Lq <= 256 && efb_lds(rows, 3) <= 160 * 1024 &&
+        (!a.det || a.H * a.R <= lako_det::SLOTS)) {
       AttnArgs f = a;
       f.chunk_rows = rows;
       f.rq = padded ? (int)(a.qsb / a.qst) : 0;
@@ -1967,6 +1978,9 @@ int lako_attn_enc_bwd(AttnArgs& a, hipStream_t s) {
       return 0;
     }
   }
+  // LAKO_DETERMINISTIC: the two-pass kernels below add into the workgroup's bias-gradient table by LDS float atomics in arrival order —
+  // not taken in that mode: the caller runs the generic kernels (attn.hip), whose contributions go through det.h
+  if (a.det) return 1;
   {  // dQ pass: every query block of a sequence in one workgroup, several batch rows per workgroup (bias gradient in registers)
     AttnArgs q = a;
     q.chunk_rows = ((a.Lk + 31) / 32) * 32;

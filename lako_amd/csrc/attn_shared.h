@@ -50,6 +50,7 @@ struct AttnArgs {
   int grid_x, grid_z; // dQ pass, grid_x > 0: 1-D XCD-grouped grid standing for (grid_x, H, grid_z) — see attn_bwd_kernel
   uint32_t drop_t16, drop_key;   // attention dropout: keep iff 16-bit half >= drop_t16 (0 = off)
   float drop_scale;
+  int det;            // LAKO_DETERMINISTIC=1 (det.h): the bias gradient is summed in fixed point and converted once by the last workgroup
 };
 
 // i-th item in processing order → sequence id

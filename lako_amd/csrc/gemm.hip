@@ -1003,6 +1003,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(NtArgs a) {
   }
 }
 
+#include "det.h"
 #include "gemm_nt4.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -2596,6 +2597,7 @@ static int tn_single(const void* A, const void* B, float* C, int64_t M, int64_t 
   LAKO_CHECK_ARG(split_k >= -2, "lako_gemm_tn: split_k %d", split_k);
   const int out_mode = split_k < 0 ? -split_k : 0;      // -1: exclusive read-modify-write, -2: overwrite (one K-split either way)
   if (split_k < 0) split_k = 1;
+  if (lako_det::on() && split_k == 0) split_k = 1;      // LAKO_DETERMINISTIC=1: K-splits meet by float atomics in arrival order — one contributor
   LAKO_CHECK_ARG(in_dtype == LAKO_F32 || in_dtype == LAKO_BF16, "lako_gemm_tn: bad in_dtype");
   const int esz = in_dtype == LAKO_F32 ? 4 : 2;
   LAKO_CHECK_ARG((M * esz) % 16 == 0 && (N * esz) % 16 == 0 && (lda * esz) % 16 == 0 && (ldb * esz) % 16 == 0,
@@ -2690,6 +2692,7 @@ static int tn_grouped_plan(const lako_gemm_tn_item_t* items, int n_items, int64_
   int tiles = 0;
   for (int i = 0; i < n_items; ++i) tiles += cdiv((int)items[i].M, 256) * cdiv((int)items[i].N, 256);
   const int max_split = cdiv(K, 64 * 4);
+  if (lako_det::on() && split_k == -3) split_k = 0;      // (as the launch)
   int sk = tn_pick_split(tiles, K, max_split);
   if (tu.tn_split > 0) sk = tu.tn_split;
   if (split_k > 0) sk = split_k;
@@ -2742,6 +2745,10 @@ extern "C" int lako_gemm_tn_grouped(const lako_gemm_tn_item_t* items, int n_item
       }
     }
   }
+  // LAKO_DETERMINISTIC=1: no hybrid schedule (its short units meet by float atomics); the uniform splits below go through the
+  // workspace slabs, summed in split order — and without a workspace one contributor per element
+  const bool det = lako_det::on();
+  if (det && split_k == -3) split_k = 0;
   bool big = in_dtype == LAKO_BF16 && tu.tn_big;
   for (int i = 0; i < n_items; ++i) big = big && items[i].M >= 256 && items[i].N >= 256;
   if (!big) {   // shapes the 256×256 kernel does not take: one launch per problem
@@ -2830,6 +2837,10 @@ extern "C" int lako_gemm_tn_grouped(const lako_gemm_tn_item_t* items, int n_item
         a.tickets = nullptr;
       }
     }
+  }
+  if (det && a.split_k > 1 && a.slabs == nullptr) {
+    a.split_k = 1;
+    a.k_chunk = cdiv(K, 64) * 64;
   }
   const int grid = a.t_full > 0 ? 8 * (a.t_full / 8 + cdiv((int64_t)(tiles - a.t_full) * a.split_k, 8)) : tiles * a.split_k;
   if (tn4_ok(a, tu)) {

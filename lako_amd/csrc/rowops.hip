@@ -10,6 +10,7 @@
 #include <utility>
 
 #include "common.h"
+#include "det.h"
 
 // ---- error string (thread local) ------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -31,6 +32,8 @@ extern "C" int lako_last_error(char* buf, size_t n) {
 extern "C" int lako_version(void) { return LAKO_ABI_VERSION; }
 
 namespace {
+
+LAKO_DET_STORAGE      // LAKO_DETERMINISTIC=1: see det.h
 
 // keep decisions of 8 consecutive elements starting at idx0 (a multiple of 4): two quads
 __device__ __forceinline__ void keep8(uint32_t key, uint64_t idx0, uint32_t thresh, bool (&k)[8]) {
@@ -149,7 +152,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* dy, const T* x, const float* __restrict__ w,
                                                           const float* __restrict__ rstd, const T* dres, T* dx,
                                                           float* __restrict__ dw, int64_t rows, int d, DropDev dr,
-                                                          T* __restrict__ dx_drop, DropDev dr_out) {
+                                                          T* __restrict__ dx_drop, DropDev dr_out, int det) {
   const int lane = threadIdx.x & 63;
   const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t nw = (int64_t)gridDim.x * 4;
@@ -245,6 +248,13 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const T* dy, const T* 
     }
   }
   __syncthreads();
+  if (det) {      // LAKO_DETERMINISTIC: fixed-point adds, converted once by the workgroup that arrives last (det.h)
+    __shared__ int last;
+    for (int c = threadIdx.x; c < d; c += 256) lako_det::add(&lako_det_slots[c], red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+    if (lako_det::last_block(&lako_det_ticket, gridDim.x, &last))
+      for (int c = threadIdx.x; c < d; c += 256) dw[c] += lako_det::take(&lako_det_slots[c]);
+    return;
+  }
   for (int c = threadIdx.x; c < d; c += 256) atomicAdd(dw + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
 }
 
@@ -372,6 +382,46 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
       if (dr.thresh) v = lako_keep(dr.key, (uint64_t)t * d + c, dr.thresh) ? v * dr.scale : 0.f;
       if (__ballot(v != 0.f) == 0) continue;
       atomicAdd(dtable + id * d + c, v);
+    }
+  }
+}
+
+// LAKO_DETERMINISTIC: the same sums with ONE writer per table row and a fixed order.  `perm` is a stable ascending sort of the token
+// positions by id (index plumbing of the caller: torch.argsort); the wave of sorted position j works only if j opens a run of equal ids,
+// and then adds that run's rows in run order — position order — into registers and the row once.
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_ordered_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ perm,
+                                                                const T* __restrict__ dout, float* __restrict__ dtable, int64_t n_tok,
+                                                                int d, int64_t vocab, DropDev dr) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  auto id_of = [&](int64_t j) {
+    int64_t id = ids[perm[j]];
+    return (id < 0 || id >= vocab) ? (int64_t)0 : id;
+  };
+  for (int64_t j = wid; j < n_tok; j += nw) {
+    const int64_t id = id_of(j);
+    if (j > 0 && id_of(j - 1) == id) continue;          // not the first of its run
+    for (int c0 = 0; c0 < d; c0 += 64 * 4) {             // 4 columns per lane and sweep: the run is walked once per 256 columns
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int64_t jj = j; jj < n_tok && id_of(jj) == id; ++jj) {
+        const int64_t t = perm[jj];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int c = c0 + u * 64 + lane;
+          if (c < d) {
+            float v = (float)dout[t * d + c];
+            if (dr.thresh) v = lako_keep(dr.key, (uint64_t)t * d + c, dr.thresh) ? v * dr.scale : 0.f;
+            acc[u] += v;
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = c0 + u * 64 + lane;
+        if (c < d) dtable[id * d + c] += acc[u];
+      }
     }
   }
 }
@@ -667,7 +717,7 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
 }
 
 // ---- optimizer ----------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out, int det) {
   __shared__ float red[4];
   float s = 0.f;
   int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -681,6 +731,12 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
+  if (det) {      // LAKO_DETERMINISTIC (det.h): the squared norm in fixed point — block sums of squares stay far below 2^23
+    __shared__ int last;
+    if (threadIdx.x == 0) lako_det::add(&lako_det_slots[lako_det::SLOTS - 1], red[0] + red[1] + red[2] + red[3]);
+    if (lako_det::last_block(&lako_det_ticket, gridDim.x, &last) && threadIdx.x == 0) out[0] += lako_det::take(&lako_det_slots[lako_det::SLOTS - 1]);
+    return;
+  }
   if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
 }
 
@@ -742,12 +798,17 @@ __global__ void relpos_expand_kernel(const float* table, const int32_t* lut, flo
   int b = lut[r];
   rel[i] = (b >= 0 && b < nb) ? table[b * H + h] : 0.f;
 }
+// (round 6) a GATHER: thread (bucket b, head h) sums the offsets r whose bucket is b in ascending r and adds the sum to its table entry —
+// one writer per entry, a fixed order, no atomics (rounds 1-5 scattered every offset into its bucket by a float atomic: ≤ 2L − 1 adders
+// per entry in arrival order).  nb · H threads of ≤ 2L − 1 iterations: nothing next to the launch itself.
 __global__ void relpos_reduce_kernel(const float* drel, const int32_t* lut, float* dtable, int H, int R, int nb) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= H * R) return;
-  int h = i / R, r = i % R;
-  int b = lut[r];
-  if (b >= 0 && b < nb) atomicAdd(dtable + b * H + h, drel[i]);
+  if (i >= nb * H) return;
+  int b = i / H, h = i % H;
+  float s = 0.f;
+  for (int r = 0; r < R; ++r)
+    if (lut[r] == b) s += drel[(int64_t)h * R + r];
+  dtable[b * H + h] += s;
 }
 
 // ---- int helpers ------------------------------------------------------------------------------
@@ -965,7 +1026,7 @@ extern "C" int lako_rmsnorm_bwd(const void* dy, const void* x, const float* w, c
 #endif
   DISPATCH_T(dtype, hipLaunchKernelGGL((rmsnorm_bwd_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
                                        (const T*)dy, (const T*)x, w, rstd, (const T*)dres, (T*)dx, dw, rows, d, dr, (T*)dx_drop,
-                                       dr_out));
+                                       dr_out, lako_det::on() ? 1 : 0));
   LAKO_LAUNCH_CHECK();
   return LAKO_OK;
 }
@@ -993,6 +1054,19 @@ extern "C" int lako_embed_bwd(const int64_t* ids, const void* dout, float* dtabl
   LAKO_LAUNCH_CHECK();
   return LAKO_OK;
 }
+
+extern "C" int lako_embed_bwd_ordered(const int64_t* ids, const int64_t* perm, const void* dout, float* dtable, int64_t n_tok, int d,
+                                      int64_t vocab, int dtype, lako_dropout_t drop, lako_stream_t stream) {
+  CHECK_DTYPE("lako_embed_bwd_ordered", dtype);
+  LAKO_CHECK_ARG(n_tok > 0 && d > 0 && vocab > 0 && ids && perm, "lako_embed_bwd_ordered: bad arguments");
+  DropDev dr = make_drop(drop);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((embed_bwd_ordered_kernel<T>), dim3(rows_grid(n_tok)), dim3(256), 0, (hipStream_t)stream,
+                                       ids, perm, (const T*)dout, dtable, n_tok, d, vocab, dr));
+  LAKO_LAUNCH_CHECK();
+  return LAKO_OK;
+}
+
+extern "C" int lako_deterministic(void) { return lako_det::on() ? 1 : 0; }
 
 extern "C" int lako_dropout_apply(const void* x, void* y, int64_t n, int dtype, lako_dropout_t drop,
                                   lako_stream_t stream) {
@@ -1084,7 +1158,7 @@ extern "C" int lako_sumsq(const float* g, int64_t n, float* out, lako_stream_t s
   LAKO_CHECK_ALIGN(g, 16);
   int grid = elems_grid(n, 4);
   if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, n, out);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, n, out, lako_det::on() ? 1 : 0);
   LAKO_LAUNCH_CHECK();
   return LAKO_OK;
 }
@@ -1117,7 +1191,7 @@ extern "C" int lako_relpos_expand(const float* table, const int32_t* lut, float*
 extern "C" int lako_relpos_reduce(const float* drel, const int32_t* lut, float* dtable, int H, int R, int nb,
                                   lako_stream_t stream) {
   LAKO_CHECK_ARG(H > 0 && R > 0 && nb > 0, "lako_relpos_reduce: bad dims");
-  hipLaunchKernelGGL(relpos_reduce_kernel, dim3((H * R + 255) / 256), dim3(256), 0, (hipStream_t)stream, drel, lut,
+  hipLaunchKernelGGL(relpos_reduce_kernel, dim3((nb * H + 255) / 256), dim3(256), 0, (hipStream_t)stream, drel, lut,
                      dtable, H, R, nb);
   LAKO_LAUNCH_CHECK();
   return LAKO_OK;

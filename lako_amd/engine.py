@@ -180,6 +180,8 @@ class Engine:
         if cfg.d_model % 8 or cfg.d_ff % 8 or cfg.vocab_size % 8:
             raise ValueError("d_model, d_ff and vocab_size must be multiples of 8")
         self.cfg, self.ops, self.device, self.dtype = cfg, ops, torch.device(device), dtype
+        # LAKO_DETERMINISTIC=1 (read once by the library; RefOps has no such mode — its torch sums are what they are): bit-identical steps
+        self.det = bool(getattr(ops, "det", False))
         self.blocks = build_layout(cfg)
         self.n_param, self.n_trans = layout_sizes(self.blocks)
         dev = self.device
@@ -376,12 +378,21 @@ class Engine:
         OFF by default (LAKO_TN_SLABS=1 switches it on): measured +0.6 ms per step against the float atomics (round 4,
         profiles/r04s_tn_slab_reduction.txt) — the atomics are fire-and-forget, the last arriver's slab reads and read-modify-write are
         a serial tail.  What it buys is bit-reproducible encoder weight gradients."""
-        if os.environ.get("LAKO_TN_SLABS", "0") != "1":
+        if os.environ.get("LAKO_TN_SLABS", "0") != "1" and not self.det:      # (LAKO_DETERMINISTIC=1 takes it: DESIGN.md §4)
             return None
         t = getattr(self, "_tn_ws", None)
         if t is None or t.numel() < nbytes:
             t = self._tn_ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
         return t
+
+    def _embed_bwd(self, ids, dout, drop):
+        """shared-embedding gradient += scatter of dropout_bwd(dout).  LAKO_DETERMINISTIC=1: rows of one id are added in position order by
+        one wave (the sort is index plumbing, torch's stable argsort on the same stream) instead of by float atomics in arrival order."""
+        if self.det:
+            ids = ids.reshape(-1)
+            self.ops.embed_bwd_ordered(ids, torch.argsort(ids, stable=True), dout, self.shared.g, drop)
+        else:
+            self.ops.embed_bwd(ids, dout, self.shared.g, drop)
 
     def _workspace(self, key):
         return self._ws_cache.setdefault(key, {})
@@ -942,7 +953,7 @@ class Engine:
             nxt = (R(f"d.dy.ffn.{i - 1}", d), dr(_dec_site(i - 1, 5)))
         ops.rmsnorm_bwd(dxn, sl(ws[f"d.h{i}"]), lw["ln1"].p, sl(ws[f"d.rs1.{i}"]), dh, dh, lw["ln1"].g, **self._nxt(nxt))
         if i == 0:
-            ops.embed_bwd(ws["d.ids"].view(-1)[r0:r1], dh, self.shared.g, dr(S_DEC_EMBED))
+            self._embed_bwd(ws["d.ids"].view(-1)[r0:r1], dh, dr(S_DEC_EMBED))
 
     def forward_loss(self, input_ids, attention_mask, labels, training: bool, lengths=None):
         """input_ids/attention_mask [B,N,L], labels [B,T] (−100 = ignore) → (loss 0-d fp32, logits [B,T,V] fp32).
@@ -1071,10 +1082,13 @@ class Engine:
         # K = vocabulary (32128) for an [Md, d] output of a handful of tiles: accumulate in fp32 with atomics so that the
         # library may split K over the idle CUs (gemm_nt_ring_kernel), then round once to the compute dtype
         dout32 = dout if dout.dtype == torch.float32 else self._buf(tmp, "d.dout32", (Md, d), torch.float32)
-        ops.zero_(dout32)
-        ops.gemm_nt(dlog, self.shared.wt, dout32, alpha=alpha, atomic=True)
-        if dout32 is not dout:
-            ops.cast(dout32.view(-1), dout.view(-1))
+        if self.det:      # LAKO_DETERMINISTIC=1: one workgroup per output tile walks the whole vocabulary (no K-split, no atomics)
+            ops.gemm_nt(dlog, self.shared.wt, dout, alpha=alpha)
+        else:
+            ops.zero_(dout32)
+            ops.gemm_nt(dlog, self.shared.wt, dout32, alpha=alpha, atomic=True)
+            if dout32 is not dout:
+                ops.cast(dout32.view(-1), dout.view(-1))
         # (K = B·T rows, 378 tiles: one K-split; nothing else touches the embedding gradient until the embedding backward kernels later on
         # this stream: plain read-modify-write instead of 99 MB of float atomics)
         # (and the FIRST writer of a freshly zeroed gradient buffer overwrites: no read at all.  A second backward without zero_grad —
@@ -1193,7 +1207,7 @@ class Engine:
                 for li in dw_layers:
                     self._ready(f"enc.{li}.qkv", f"enc.{li}.ln2")
                 dw_layers = []
-        ops.embed_bwd(ctx.enc_ids, deh, self.shared.g, dr(S_ENC_EMBED))
+        self._embed_bwd(ctx.enc_ids, deh, dr(S_ENC_EMBED))
         ops.relpos_reduce(drel_e, self._lut(L, L, True), self.enc_rel.g)
         self._ready("enc.rel", "shared")
         self.step_count += 1   # next forward draws fresh dropout masks

@@ -73,6 +73,9 @@ class HipOps:
         self.tuning = _lib.Tuning()
         check(self.lib.lako_tuning_init(C.byref(self.tuning)), "lako_tuning_init")
         self._tuning_p = C.addressof(self.tuning)
+        # LAKO_DETERMINISTIC=1: the library's shared float sums are order-independent; here the weight-gradient
+        # products take one contributor per output element unless the caller names a split (the engine's slab path)
+        self.det = bool(self.lib.lako_deterministic())
 
     @staticmethod
     def _stream():
@@ -212,6 +215,8 @@ class HipOps:
         M2, N2, ldc = _rowmajor2d(Cm, "gemm_tn C")
         if K != K2 or M != M2 or N != N2 or A.dtype != B.dtype or Cm.dtype != torch.float32:
             raise LakoError(f"gemm_tn: shape/dtype mismatch A{tuple(A.shape)} B{tuple(B.shape)} C{tuple(Cm.shape)}")
+        if self.det and split_k == 0:
+            split_k = 1
         self._timed("gemm_tn", 2.0 * M * N * K, lambda: check(self.lib.lako_gemm_tn(_p(A), _p(B), _p(Cm), M, N, K, lda, ldb, ldc, _dt(A), float(alpha), int(split_k),
                                     self._tuning_p, self._stream()), "lako_gemm_tn"))
 
@@ -269,6 +274,11 @@ class HipOps:
     def embed_bwd(self, ids, dout, dtable, drop=None):
         self._timed("embed_bwd", 0.0, lambda: check(self.lib.lako_embed_bwd(_p(ids), _p(dout), _p(dtable), ids.numel(), dtable.shape[1], dtable.shape[0],
                                       _dt(dout), _drop(drop), self._stream()), "lako_embed_bwd"))
+
+    def embed_bwd_ordered(self, ids, perm, dout, dtable, drop=None):
+        """embed_bwd with the rows of one id added in position order by one wave (`perm`: stable argsort of ids)."""
+        self._timed("embed_bwd", 0.0, lambda: check(self.lib.lako_embed_bwd_ordered(_p(ids), _p(perm), _p(dout), _p(dtable), ids.numel(), dtable.shape[1],
+                                      dtable.shape[0], _dt(dout), _drop(drop), self._stream()), "lako_embed_bwd_ordered"))
 
     def dropout_apply(self, x, y, drop):
         self._timed("dropout_apply", 0.0, lambda: check(self.lib.lako_dropout_apply(_p(x), _p(y), x.numel(), _dt(x), _drop(drop), self._stream()), "lako_dropout_apply"))

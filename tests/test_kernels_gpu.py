@@ -648,6 +648,16 @@ def test_embed_dropout(ops, ref, dt):
         ops.embed_bwd(ids, dout, dt_, drop)
         ref.embed_bwd(ids, dout, dtr, drop)
         close(dt_, dtr, torch.float32, "embed_bwd", k=5)
+        # the ordered form (LAKO_DETERMINISTIC=1): the same scatter, rows of one id added in position order by one wave — an exact
+        # repeat, and on top of a non-zero gradient (the decoder's and the encoder's scatter land in one table)
+        perm = torch.argsort(ids, stable=True)
+        seen = []
+        for _ in range(2):
+            dto = torch.full((V, d), 0.5, device=dev())
+            ops.embed_bwd_ordered(ids, perm, dout, dto, drop)
+            seen.append(dto)
+        assert torch.equal(seen[0], seen[1])
+        close(seen[0] - 0.5, dtr, torch.float32, "embed_bwd_ordered", k=5)
     x = rnd(4096 * 8, dtype=T, seed=18)
     y, yr = torch.empty_like(x), torch.empty(x.numel(), device=dev())
     ops.dropout_apply(x, y, (0.1, 42, 7))

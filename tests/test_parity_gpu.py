@@ -311,6 +311,43 @@ def test_train_reader_driver_end_to_end(tmp_path):
 
 
 @pytest.mark.gpu
+def test_deterministic_mode_repeats_bit_for_bit():
+    """LAKO_DETERMINISTIC=1: two processes running the same three seeded bf16 training steps (dropout on, ragged
+    passages, AdamW + clipping) end with bit-identical losses and weights — every float sum shared between workgroups (norm-weight and
+    position-bias gradients, gradient norm, embedding scatter, the K-splits of the weight-gradient products, the LM-head input
+    gradient) is order-independent in that mode."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LAKO_DETERMINISTIC="1")
+    outs = []
+    for _ in range(2):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "det_run.py")], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0]["deterministic"] is True
+    assert outs[0] == outs[1], outs
+    first = float.fromhex(outs[0]["losses"][0])
+    assert 8.0 < first < 13.0                              # a real step: ln(32128) = 10.4 at random init
+
+
+@pytest.mark.gpu
+def test_deterministic_mode_kernels_match_the_reference():
+    """The kernels that change their accumulation under LAKO_DETERMINISTIC=1 (attention bias gradient, norm-weight gradient, gradient
+    norm, embedding scatter, weight-gradient K-splits) against the same fp32 doubles as in the default mode: the kernel tests of those
+    ops once more in a child pytest with the variable set (the library reads it once per process)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_kernels_gpu.py"), "-q", "-x", "-m", "gpu", "-p",
+                        "no:cacheprovider", "-k", "attention and not race or rmsnorm or embed or relpos or optimizer or gemm_tn"],
+                       env=dict(os.environ, LAKO_DETERMINISTIC="1"), capture_output=True, text=True, timeout=1200, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1500:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_unpadded_path_equals_padded_path_gpu(dtype, monkeypatch):
     """HIP path, T5-small shapes with ragged passages (one of them empty): unpadded (default) vs LAKO_UNPAD=0 — same loss,
