@@ -109,6 +109,7 @@ struct NtArgs {
   int64_t row0;   // rows [row0, row0 + M) of a larger problem (tail launch): only the dropout element index needs it
   int group_m;    // >0: tile ids walk bands of group_m tile-rows column-major (an XCD's 32 resident tiles form a ≈group_m × 32/group_m block)
   int store_aux;  // cache-policy bits for the 256² kernel's 16-byte output stores (store_b128_policy)
+  int epi_direct; // gemm_nt4_kernel: 1 = the dropout epilogues without a side operand straight from the accumulator layout, 0 = through the LDS transposition
   int dephase;    // (phases << 16) | ticks: workgroup w of an XCD starts (w mod phases)·ticks·10 ns late (breaks the lockstep of main loops / epilogues)
   int wide_epi;   // 256² bf16 tile: LDS-transposed epilogue with 16-B row-major stores (needs N, ldc, ldr, ldaux % 8 == 0)
   int glds;       // 1: K-slice pieces by global_load_lds where the slice is whole (tuning nt_glds)
@@ -2273,9 +2274,25 @@ void launch_nt4(NtArgs a, const lako_tuning_t& tu, hipStream_t s) {
   a.dephase = 0;
   a.debug = tu.nt_debug;
   a.queue = nullptr;
+  // gemm_nt_four = 1: the dropout epilogues without a side operand straight from the accumulator layout (gemm_nt4.h), 3: through the LDS
+  // transposition like the others (A/B measurements)
+  a.epi_direct = (tu.nt_four >> 1) ? 0 : 1;
 #ifdef LAKO_EXPERIMENTS
   if (tu.nt_debug & 64) a.queue = reinterpret_cast<int*>(lako_exp_nt_stamp_buffer());
 #endif
+  const bool relu = a.flags & LAKO_EPI_RELU, drop = a.drop_thresh != 0;
+  const int epi = (!side && drop && a.epi_direct) ? (relu ? 2 : 1) : 0;
+#define LAKO_NT4_DIRECT(E)                                                                                    \
+  case E:                                                                                                     \
+    LAKO_SET_MAX_LDS((&gemm_nt4_kernel<MT, false, E>), nt4::LDS_BYTES);                                       \
+    hipLaunchKernelGGL((gemm_nt4_kernel<MT, false, E>), dim3(grid), dim3(256), nt4::LDS_BYTES, s, a);        \
+    return;
+  switch (epi) {
+    LAKO_NT4_DIRECT(1)
+    LAKO_NT4_DIRECT(2)
+    default: break;
+  }
+#undef LAKO_NT4_DIRECT
   if (side) {
     LAKO_SET_MAX_LDS((&gemm_nt4_kernel<MT, true>), nt4::LDS_BYTES);
     hipLaunchKernelGGL((gemm_nt4_kernel<MT, true>), dim3(grid), dim3(256), nt4::LDS_BYTES, s, a);

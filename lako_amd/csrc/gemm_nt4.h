@@ -224,7 +224,10 @@ __device__ __forceinline__ void piece_offsets(uint32_t (&voff)[NP], int rows_val
 
 // MT: m-tiles per wave (8: 256-row tiles, 6: 192-row tiles).  SIDE = false: alpha, ReLU, dropout; true: also the aux mask and the residual
 // (the arithmetic then happens after the transposition, on row-major fp32 values — same operations in the same order on every element).
-template <int MT, bool SIDE>
+// EPI (SIDE = false only): 0 = the epilogues through the LDS transposition, chosen at run time from the flags; 1 / 2 = dropout / ReLU + dropout straight
+// from the accumulator layout — its own instantiation each: as sibling branches of one kernel the accumulator reads common to them are
+// hoisted above the branch (256 live VGPRs: spills), and pinned in place they cost register copies inside the K loop.
+template <int MT, bool SIDE, int EPI = 0>
 __global__ __launch_bounds__(256) void gemm_nt4_kernel(NtArgs a) {
   using namespace nt4;
   constexpr int BM = MT * 32;
@@ -451,10 +454,59 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(NtArgs a) {
           }
         }
       };
+      // DIRECT form of the dropout epilogues without a side operand.  The MFMAs run with the operands swapped, so a lane already holds four
+      // consecutive COLUMNS of one row — a dropout quad — per 16 × 16 tile: the same arithmetic in the accumulator layout, rounded to bf16, then
+      // `v_permlane16_swap` (gfx950: the odd 16-lane rows of one register against the even rows of another) pairs the halves of two
+      // neighbouring n-tiles into 16 bytes of a row per lane — no LDS pass; a store covers 16 rows × 64 bytes.  Measured
+      // (tools/gemm_nt4_direct.py, profiles/r06m_nt4_direct_epilogue.txt): −1 … −3 % per launch for dropout and ReLU + dropout, +3 … +7 % for
+      // plain / ReLU / alpha (the 64-byte runs cost the stores more than the LDS pass cost the wave) — so only the dropout forms exist.
+      auto run_direct = [&](auto RELU_, auto DROP_, auto ALPHA_) {
+        constexpr bool RELU = decltype(RELU_)::value, DROP = decltype(DROP_)::value, ALPHA = decltype(ALPHA_)::value;
+        const int mrow = le & 15;
+        const int colb = ((ge & 1) * 16 + (ge >> 1) * 8) * 2;                  // first byte of the lane's 16: g = 0 / 1 / 2 / 3 → 0 / 32 / 16 / 48
+        int dvo[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) dvo[p] = (p * 32 + colb / 2 < cols_v && !NT_DBG(a, 8)) ? mrow * ldc_b + colb + p * 64 : (int)0x80000000;
+        // quad of (row mw + mrow, column nw + 4 g): rows 16 apart are 4 N quads apart, n-tiles 4 quads
+        const uint32_t dq0 = (uint32_t)((((uint64_t)(a.row0 + mw + mrow)) * (uint64_t)a.N + (uint64_t)(nw + ge * 4)) >> 2);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            uint32_t pk[2][2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              f32x4 x = acc[2 * p + h][mt];
+              if constexpr (ALPHA) x = x * a.alpha;
+              if constexpr (RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[r] = fmaxf(x[r], 0.f);
+              }
+              if constexpr (DROP) {
+                bool kp[4];
+                lako_keep4(a.drop_key, (uint64_t)(dq0 + (uint32_t)(mt * 4) * (uint32_t)a.N + (uint32_t)((2 * p + h) * 4)), a.drop_thresh, kp);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[r] = kp[r] ? x[r] * a.drop_scale : 0.f;
+              }
+              const bf16x4 o4 = {(bf16_t)x[0], (bf16_t)x[1], (bf16_t)x[2], (bf16_t)x[3]};
+              const u32x2 w = __builtin_bit_cast(u32x2, o4);
+              pk[h][0] = w[0];
+              pk[h][1] = w[1];
+            }
+            // even rows of lanes keep n-tile 2p (their own half + the neighbour's), odd rows n-tile 2p + 1
+            const u32x2 s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+            const u32x2 s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, crs, dvo[p], (mt * 16) * ldc_b, 0);
+            __builtin_amdgcn_sched_barrier(0);      // (the scheduler otherwise copies the accumulators of many groups out at once: spills)
+          }
+        }
+      };
       const bool relu = a.flags & LAKO_EPI_RELU, drop = a.drop_thresh != 0;
       using T_ = std::true_type;
       using F_ = std::false_type;
-      if constexpr (SIDE) {
+      if constexpr (EPI == 1) run_direct(F_{}, T_{}, F_{});
+      else if constexpr (EPI == 2) run_direct(T_{}, T_{}, F_{});
+      else if constexpr (SIDE) {
         // (the host sends here: residual with or without dropout, or the aux mask alone, alpha = 1 — nt4_ok)
         if (has_res) {
           if (drop) run(F_{}, T_{}, T_{}, F_{});

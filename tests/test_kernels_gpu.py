@@ -377,17 +377,19 @@ def test_gemm_nt_four_wave_kernels(ops, ref, M, N, K):
     A, B = rnd(M, K, dtype=T, seed=71), rnd(N, K, dtype=T, seed=72)
     R, X = rnd(M, N, dtype=T, seed=73), rnd(M, N, dtype=T, seed=74)
     try:
-        for kw in (dict(), dict(relu=True, drop=(0.1, 5, 6)), dict(alpha=0.5, drop=(0.1, 5, 6)), dict(resid=R, drop=(0.1, 7, 8), alpha=0.5), dict(resid=R),
-                   dict(aux=X, aux_scale=1.1), dict(relu=True, resid=R)):
+        for kw in (dict(), dict(relu=True, drop=(0.1, 5, 6)), dict(drop=(0.1, 9, 10)), dict(alpha=0.5, drop=(0.1, 5, 6)), dict(resid=R, drop=(0.1, 7, 8), alpha=0.5),
+                   dict(resid=R), dict(aux=X, aux_scale=1.1), dict(relu=True, resid=R)):
             got = {}
-            for name, four, variant in (("eight-wave", 0, -1), ("default plan", 1, -1), ("256-row", 1, 9), ("192-row", 1, 3)):
+            # (gemm_nt_four 3: the dropout epilogues through the LDS transposition like the others; 1: straight from the accumulator layout)
+            for name, four, variant in (("eight-wave", 0, -1), ("default plan", 1, -1), ("256-row", 1, 9), ("192-row", 1, 3), ("256-row, LDS epilogues", 3, 9),
+                                        ("192-row, LDS epilogues", 3, 3)):
                 ops.set_tuning("gemm_nt_four", four)
                 ops.set_tuning("gemm_nt_variant", variant)
                 C = torch.full((M, N), float("nan"), dtype=T, device=dev())
                 ops.gemm_nt(A, B, C, **kw)
                 torch.cuda.synchronize()
                 got[name] = C
-            for name in ("default plan", "256-row", "192-row"):
+            for name in got:
                 assert torch.equal(got[name].view(torch.int16), got["eight-wave"].view(torch.int16)), f"{name} vs eight-wave kernels, {list(kw)} {M}x{N}x{K}"
             Cr = torch.zeros(M, N, device=dev())
             ref.gemm_nt(A, B, Cr, **kw)
