@@ -31,7 +31,7 @@ pids=()
 for f in gemm rowops attn attn_enc xattn index pq bertops bertbwd comm; do
   [ -f $f.hip ] || continue
   o=$f.$SFX
-  if [ $FORCE = 1 ] || [ ! -f $o ] || [ $f.hip -nt $o ] || [ common.h -nt $o ] || [ attn_shared.h -nt $o ] || [ lds_image.h -nt $o ] || [ gemm_nt4.h -nt $o ] || [ gemm_tn4.h -nt $o ] || [ det.h -nt $o ] || [ ../../include/lako_hip.h -nt $o ] || [ build.sh -nt $o ]; then
+  if [ $FORCE = 1 ] || [ ! -f $o ] || [ $f.hip -nt $o ] || [ common.h -nt $o ] || [ attn_shared.h -nt $o ] || [ lds_image.h -nt $o ] || [ gemm_nt4.h -nt $o ] || [ gemm_tn4.h -nt $o ] || [ gemm_nt4_mx.h -nt $o ] || [ det.h -nt $o ] || [ ../../include/lako_hip.h -nt $o ] || [ build.sh -nt $o ]; then
     extra=""
     # attention is VALU-bound on the score tiles: keep MFMA results in VGPRs (no v_accvgpr_read/write round trips)
     { [ $f = attn ] || [ $f = attn_enc ]; } && extra="-mllvm -amdgpu-mfma-vgpr-form=1"

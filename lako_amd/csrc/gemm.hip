@@ -1969,6 +1969,8 @@ __global__ __launch_bounds__(512) void gemm_nt_mx_kernel(MxArgs ma) {
   }
 }
 
+#include "gemm_nt4_mx.h"
+
 // MX quantisation of a bf16 matrix: per row and per 32 consecutive k one E8M0 scale 2^(e − 127), e − 127 = floor(log2(amax)) − 8
 // (8 = the exponent of e4m3's largest normal, 448 = 1.75·2^8: the OCP microscaling rule), elements q = sat_e4m3(x · 2^−(e−127)).
 // One lane = 8 consecutive k (a 16-byte load, an 8-byte store); the 4 lanes of a block agree on amax by two shuffles.
@@ -2934,6 +2936,39 @@ extern "C" int lako_gemm_nt_mx(const lako_gemm_nt_t* p, const uint8_t* a_scales,
   m.sa = a_scales;
   m.sb = b_scales;
   m.ksp = (int)(((p->K / 128) + 3) / 4 * 4);
+  // round 6: the four-wave tile with two K-slices in flight (gemm_nt4_mx.h) where it applies — whole groups of four K-steps, at least one
+  // round of the chip, the epilogues nt4_epilogue has (nt4_ok's rules), 32-bit offsets; the tile height by the rounds of the chip as for bf16
+  {
+    const int side = a.flags & (LAKO_EPI_RESID | LAKO_EPI_AUXMASK);
+    bool ok = tu.nt_four && a.K % 512 == 0 && (int64_t)cdiv(a.M, 256) * cdiv(a.N, 256) >= 256 && (int64_t)256 * std::max(a.lda, a.ldb) < (1ll << 31) &&
+              (int64_t)128 * a.ldc * 2 < (1ll << 31) && !(a.alpha != 1.0f && (a.flags != 0 || a.drop_thresh != 0)) &&
+              !(a.drop_thresh != 0 && (uint64_t)(a.M + 256) * (uint64_t)a.N >= (1ull << 34)) && side != (LAKO_EPI_RESID | LAKO_EPI_AUXMASK) &&
+              !(side && (a.flags & LAKO_EPI_RELU)) && !(side == LAKO_EPI_AUXMASK && a.drop_thresh != 0);
+    if (side == LAKO_EPI_RESID) ok = ok && a.ldr % 8 == 0 && reinterpret_cast<uintptr_t>(a.resid) % 16 == 0 && (int64_t)128 * a.ldr * 2 < (1ll << 31);
+    if (side == LAKO_EPI_AUXMASK) ok = ok && a.ldaux % 8 == 0 && reinterpret_cast<uintptr_t>(a.aux) % 16 == 0 && (int64_t)128 * a.ldaux * 2 < (1ll << 31);
+    if (ok) {
+      const int nkx = a.K / 128, tn = cdiv(a.N, 256);
+      const double c8 = (double)cdiv((int64_t)cdiv(a.M, 256) * tn, 256) * (4.5 + 1.6 * nkx);
+      const double c6 = (double)cdiv((int64_t)cdiv(a.M, 192) * tn, 256) * (4.5 + 1.25 * nkx);
+      const bool six = tu.nt_variant == 3 || (tu.nt_variant != 9 && c6 < c8);
+      a.tiles_m = cdiv(a.M, six ? 192 : 256);
+      a.group_m = tu.nt_group_m < 0 ? -tu.nt_group_m : (a.tiles_n >= 8 ? tu.nt_group_m : 0);
+      a.dephase = 0;
+      a.epi_direct = 0;
+      int g4 = a.tiles_m * a.tiles_n;
+      if (g4 > 256) g4 = 256;
+#define LAKO_MX4(MT_, SIDE_)                                                                                         \
+  do {                                                                                                               \
+    LAKO_SET_MAX_LDS((&gemm_nt4_mx_kernel<MT_, SIDE_>), nt4::LDS_BYTES);                                             \
+    hipLaunchKernelGGL((gemm_nt4_mx_kernel<MT_, SIDE_>), dim3(g4), dim3(256), nt4::LDS_BYTES, (hipStream_t)stream, m); \
+  } while (0)
+      if (six) { if (side) LAKO_MX4(6, true); else LAKO_MX4(6, false); }
+      else { if (side) LAKO_MX4(8, true); else LAKO_MX4(8, false); }
+#undef LAKO_MX4
+      LAKO_LAUNCH_CHECK();
+      return LAKO_OK;
+    }
+  }
   int grid = a.tiles_m * a.tiles_n;
   if (grid > 256) grid = 256;
   a.dephase = (tu.nt_dephase > 0 && a.tiles_m * a.tiles_n > grid) ? ((tu.nt_dephase_n << 16) | (tu.nt_dephase & 0xffff)) : 0;

@@ -222,6 +222,202 @@ __device__ __forceinline__ void piece_offsets(uint32_t (&voff)[NP], int rows_val
 
 }  // namespace nt4
 
+// ---- epilogue of one tile (shared by the bf16 kernels and the MX kernel below: the accumulator layout is the same).
+// The MFMA pipes idle while it runs (the accumulators are the next tile's too), so it is built for latency: the
+// wave's (16·MT) × 128 fp32 region goes through its 8 KiB of LDS scratch 16 rows at a time — written straight from the accumulator
+// registers (`ds_write_b128` takes AGPR data: no register copies, no arithmetic in the accumulator layout) — and comes back
+// row-major, a lane owning 8 consecutive columns of a row (two dropout quads): alpha, ReLU, aux mask, dropout, residual in the generic
+// epilogue's order on every element, one rounding, ONE 16-byte buffer store per lane and 4 rows (4 × 256 B per wave-instruction;
+// rows past the edge fall out of the descriptor's range, lanes past the last column start from an out-of-range offset; the row
+// offsets are scalar).  LDS executes a wave's accesses in order: pass p + 1 is written as soon as pass p's reads have been ISSUED,
+// and its write latency hides behind pass p's arithmetic and stores.  (Every lane-derived value is rebuilt from an opaque lane id:
+// as invariants of the tile loop they would be hoisted above the K loop and spilled.)
+template <int MT, bool SIDE, int EPI>
+__device__ __forceinline__ void nt4_epilogue(const NtArgs& a, f32x4 (&acc)[8][MT], char* smem, int wave, int wr, int wc, int m0, int n0) {
+  using namespace nt4;
+  const int le = fresh_lane();
+  const int r16e = le & 15, ge = le >> 4, cj = le & 15, rq = le >> 4;
+  char* ep = smem + SCRATCH + wave * 8192;
+  const int mw = m0 + wr * (MT * 16), nw = n0 + wc * 128;                       // first row / column of the wave's region
+  const int rows_v = min(MT * 16, a.M - mw), cols_v = min(128, a.N - nw);
+  const int ldc_b = (int)a.ldc * 2;
+  const bool in_cols = cj * 8 < cols_v;
+  const auto crs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<bf16_t*>(a.C) + (int64_t)mw * a.ldc + nw, 0,
+                                                     (rows_v > 0 && cols_v > 0) ? (rows_v - 1) * ldc_b + cols_v * 2 : 0, 0x00020000);
+  const int cvo = (in_cols && !NT_DBG(a, 8)) ? rq * ldc_b + cj * 16 : (int)0x80000000;
+  // side operand (SIDE instantiation): same addressing on its own descriptor
+  const bool has_res = SIDE && (a.flags & LAKO_EPI_RESID);
+  const int lds_b = SIDE ? (int)(has_res ? a.ldr : a.ldaux) * 2 : 0;
+  const auto srs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(has_res ? a.resid : a.aux)) + (SIDE ? (int64_t)mw * (has_res ? a.ldr : a.ldaux) + nw : 0), 0,
+      (SIDE && rows_v > 0 && cols_v > 0) ? (rows_v - 1) * lds_b + cols_v * 2 : 0, 0x00020000);
+  const int svo = in_cols ? rq * lds_b + cj * 16 : (int)0x80000000;
+  const uint32_t wr_base = (uint32_t)(r16e * 512), rd_base = (uint32_t)(rq * 512);
+  // quad of (row mw + rq, column nw + 8 cj); rows 4 apart are N quads apart
+  const uint32_t quad0 = (uint32_t)((((uint64_t)(a.row0 + mw + rq)) * (uint64_t)a.N + (uint64_t)(nw + cj * 8)) >> 2);
+  auto write_pass = [&](int mt) {
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) *reinterpret_cast<f32x4*>(ep + wr_base + (((nt * 4 + ge) ^ r16e) * 16)) = acc[nt][mt];
+  };
+  // ALPHA: the product is scaled (only the plain epilogue is built with it: every fused epilogue of the reader has alpha = 1, and with one
+  // wave per SIMD the two packed multiplies per four outputs are a third of the plain epilogue's vector work — nt4_ok sends a fused
+  // epilogue with alpha != 1 to the eight-wave kernels)
+  auto run = [&](auto RELU_, auto DROP_, auto RES_, auto ALPHA_) {
+    constexpr bool RELU = decltype(RELU_)::value, DROP = decltype(DROP_)::value, RES = SIDE && decltype(RES_)::value, AUX = SIDE && !RES;
+    constexpr bool ALPHA = decltype(ALPHA_)::value;
+    // the side operand's 16 bytes per lane and row, requested SD passes ahead (a ring of SD × 4 registers quads: one pass is ≈ 800 cycles of
+    // this wave's work, a load from HBM several thousand — one pass ahead left the epilogue waiting for memory in every pass:
+    // profiles/r06h_nt4_epilogue_stamps.txt)
+#ifndef LAKO_NT4_SD
+#define LAKO_NT4_SD 2
+#endif
+    constexpr int SD = LAKO_NT4_SD;
+    u32x4 side[SD][4];
+    if constexpr (SIDE) {
+#pragma unroll
+      for (int p0 = 0; p0 < SD && p0 < MT; ++p0)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) side[p0][it] = __builtin_amdgcn_raw_buffer_load_b128(srs, svo, (p0 * 16 + it * 4) * lds_b, 0);
+    }
+    write_pass(0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      // the pass's rows come back in two halves (2 × 4 reads): the second half is requested — and the next pass written — once the first
+      // half's arithmetic has been issued (LDS executes a wave's accesses in order: the write cannot overtake the reads)
+      f32x4 v[4][2];
+      auto read_rows = [&](int it0) {
+#pragma unroll
+        for (int it = it0; it < it0 + 2; ++it)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int row_l = it * 4 + rq;
+            v[it][h] = *reinterpret_cast<const f32x4*>(ep + rd_base + it * 2048 + (((2 * cj + h) ^ row_l) * 16));
+          }
+      };
+      read_rows(0);
+      u32x4 sv4[4];
+      if constexpr (SIDE) {      // this pass's side data out of the ring, the pass SD ahead into its place
+#pragma unroll
+        for (int it = 0; it < 4; ++it) sv4[it] = side[mt % SD][it];
+        if (mt + SD < MT) {
+#pragma unroll
+          for (int it = 0; it < 4; ++it) side[mt % SD][it] = __builtin_amdgcn_raw_buffer_load_b128(srs, svo, ((mt + SD) * 16 + it * 4) * lds_b, 0);
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        if (it == 2) {
+          read_rows(2);
+          if (mt + 1 < MT) write_pass(mt + 1);
+        }
+        bf16x8 sv = {}, o;
+        if constexpr (SIDE) sv = __builtin_bit_cast(bf16x8, sv4[it]);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          f32x4 x = v[it][h];
+          if constexpr (ALPHA) x = x * a.alpha;
+          if constexpr (RELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = fmaxf(x[r], 0.f);
+          }
+          if constexpr (AUX) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = (float)sv[4 * h + r] > 0.f ? x[r] * a.aux_scale : 0.f;
+          }
+          if constexpr (DROP) {
+            // the dropout quad (4 consecutive elements of a row) of these four outputs: element index / 4, below 2^32 (nt4_ok) — 32-bit
+            // additions from the lane's first quad instead of a 64-bit multiply per row (the index arithmetic was half of the
+            // 32-bit multiplies of this epilogue, and with one wave per SIMD they are wall time: profiles/r06h_nt4_epilogue_stamps.txt)
+            bool kp[4];
+            lako_keep4(a.drop_key, (uint64_t)(quad0 + (uint32_t)(mt * 4 + it) * (uint32_t)a.N + (uint32_t)h), a.drop_thresh, kp);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = kp[r] ? x[r] * a.drop_scale : 0.f;
+          }
+          if constexpr (RES) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] += (float)sv[4 * h + r];
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[4 * h + r] = (bf16_t)x[r];
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), crs, cvo, (mt * 16 + it * 4) * ldc_b, 0);
+      }
+    }
+  };
+  // DIRECT form of the dropout epilogues without a side operand.  The MFMAs run with the operands swapped, so a lane already holds four
+  // consecutive COLUMNS of one row — a dropout quad — per 16 × 16 tile: the same arithmetic in the accumulator layout, rounded to bf16, then
+  // `v_permlane16_swap` (gfx950: the odd 16-lane rows of one register against the even rows of another) pairs the halves of two
+  // neighbouring n-tiles into 16 bytes of a row per lane — no LDS pass; a store covers 16 rows × 64 bytes.  Measured
+  // (tools/gemm_nt4_direct.py, profiles/r06m_nt4_direct_epilogue.txt): −1 … −3 % per launch for dropout and ReLU + dropout, +3 … +7 % for
+  // plain / ReLU / alpha (the 64-byte runs cost the stores more than the LDS pass cost the wave) — so only the dropout forms exist.
+  auto run_direct = [&](auto RELU_, auto DROP_, auto ALPHA_) {
+    constexpr bool RELU = decltype(RELU_)::value, DROP = decltype(DROP_)::value, ALPHA = decltype(ALPHA_)::value;
+    const int mrow = le & 15;
+    const int colb = ((ge & 1) * 16 + (ge >> 1) * 8) * 2;                  // first byte of the lane's 16: g = 0 / 1 / 2 / 3 → 0 / 32 / 16 / 48
+    int dvo[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) dvo[p] = (p * 32 + colb / 2 < cols_v && !NT_DBG(a, 8)) ? mrow * ldc_b + colb + p * 64 : (int)0x80000000;
+    // quad of (row mw + mrow, column nw + 4 g): rows 16 apart are 4 N quads apart, n-tiles 4 quads
+    const uint32_t dq0 = (uint32_t)((((uint64_t)(a.row0 + mw + mrow)) * (uint64_t)a.N + (uint64_t)(nw + ge * 4)) >> 2);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        uint32_t pk[2][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          f32x4 x = acc[2 * p + h][mt];
+          if constexpr (ALPHA) x = x * a.alpha;
+          if constexpr (RELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = fmaxf(x[r], 0.f);
+          }
+          if constexpr (DROP) {
+            bool kp[4];
+            lako_keep4(a.drop_key, (uint64_t)(dq0 + (uint32_t)(mt * 4) * (uint32_t)a.N + (uint32_t)((2 * p + h) * 4)), a.drop_thresh, kp);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = kp[r] ? x[r] * a.drop_scale : 0.f;
+          }
+          const bf16x4 o4 = {(bf16_t)x[0], (bf16_t)x[1], (bf16_t)x[2], (bf16_t)x[3]};
+          const u32x2 w = __builtin_bit_cast(u32x2, o4);
+          pk[h][0] = w[0];
+          pk[h][1] = w[1];
+        }
+        // even rows of lanes keep n-tile 2p (their own half + the neighbour's), odd rows n-tile 2p + 1
+        const u32x2 s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+        const u32x2 s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, crs, dvo[p], (mt * 16) * ldc_b, 0);
+        __builtin_amdgcn_sched_barrier(0);      // (the scheduler otherwise copies the accumulators of many groups out at once: spills)
+      }
+    }
+  };
+  const bool relu = a.flags & LAKO_EPI_RELU, drop = a.drop_thresh != 0;
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  if constexpr (EPI == 1) run_direct(F_{}, T_{}, F_{});
+  else if constexpr (EPI == 2) run_direct(T_{}, T_{}, F_{});
+  else if constexpr (SIDE) {
+    // (the host sends here: residual with or without dropout, or the aux mask alone, alpha = 1 — nt4_ok)
+    if (has_res) {
+      if (drop) run(F_{}, T_{}, T_{}, F_{});
+      else run(F_{}, F_{}, T_{}, F_{});
+    } else {
+      run(F_{}, F_{}, F_{}, F_{});
+    }
+  } else {
+    if (drop) {
+      if (relu) run(T_{}, T_{}, F_{}, F_{});
+      else run(F_{}, T_{}, F_{}, F_{});
+    } else if (relu) {
+      run(T_{}, F_{}, F_{}, F_{});
+    } else if (a.alpha != 1.0f) {
+      run(F_{}, F_{}, F_{}, T_{});
+    } else {
+      run(F_{}, F_{}, F_{}, F_{});
+    }
+  }
+}
+
 // MT: m-tiles per wave (8: 256-row tiles, 6: 192-row tiles).  SIDE = false: alpha, ReLU, dropout; true: also the aux mask and the residual
 // (the arithmetic then happens after the transposition, on row-major fp32 values — same operations in the same order on every element).
 // EPI (SIDE = false only): 0 = the epilogues through the LDS transposition, chosen at run time from the flags; 1 / 2 = dropout / ReLU + dropout straight
@@ -332,200 +528,12 @@ __global__ __launch_bounds__(256) void gemm_nt4_kernel(NtArgs a) {
       pB += 2 * TKB;
     }
 
-    // ---- epilogue.  The MFMA pipes idle while it runs (the accumulators are the next tile's too), so it is built for latency: the
-    // wave's (16·MT) × 128 fp32 region goes through its 8 KiB of LDS scratch 16 rows at a time — written straight from the accumulator
-    // registers (`ds_write_b128` takes AGPR data: no register copies, no arithmetic in the accumulator layout) — and comes back
-    // row-major, a lane owning 8 consecutive columns of a row (two dropout quads): alpha, ReLU, aux mask, dropout, residual in the generic
-    // epilogue's order on every element, one rounding, ONE 16-byte buffer store per lane and 4 rows (4 × 256 B per wave-instruction;
-    // rows past the edge fall out of the descriptor's range, lanes past the last column start from an out-of-range offset; the row
-    // offsets are scalar).  LDS executes a wave's accesses in order: pass p + 1 is written as soon as pass p's reads have been ISSUED,
-    // and its write latency hides behind pass p's arithmetic and stores.  (Every lane-derived value is rebuilt from an opaque lane id:
-    // as invariants of the tile loop they would be hoisted above the K loop and spilled.)
+    // ---- epilogue (nt4_epilogue above) ----
     NT_STAMP(2);
     if (NT_DBG(a, 128)) {      // (experiments build: no epilogue at all — what a tile costs outside its K loop)
       asm volatile("" :: "a"(acc[0][0]), "a"(acc[7][MT - 1]));
     } else {
-      const int le = fresh_lane();
-      const int r16e = le & 15, ge = le >> 4, cj = le & 15, rq = le >> 4;
-      char* ep = smem + SCRATCH + wave * 8192;
-      const int mw = m0 + wr * (MT * 16), nw = n0 + wc * 128;                       // first row / column of the wave's region
-      const int rows_v = min(MT * 16, a.M - mw), cols_v = min(128, a.N - nw);
-      const int ldc_b = (int)a.ldc * 2;
-      const bool in_cols = cj * 8 < cols_v;
-      const auto crs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<bf16_t*>(a.C) + (int64_t)mw * a.ldc + nw, 0,
-                                                         (rows_v > 0 && cols_v > 0) ? (rows_v - 1) * ldc_b + cols_v * 2 : 0, 0x00020000);
-      const int cvo = (in_cols && !NT_DBG(a, 8)) ? rq * ldc_b + cj * 16 : (int)0x80000000;
-      // side operand (SIDE instantiation): same addressing on its own descriptor
-      const bool has_res = SIDE && (a.flags & LAKO_EPI_RESID);
-      const int lds_b = SIDE ? (int)(has_res ? a.ldr : a.ldaux) * 2 : 0;
-      const auto srs = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<bf16_t*>(reinterpret_cast<const bf16_t*>(has_res ? a.resid : a.aux)) + (SIDE ? (int64_t)mw * (has_res ? a.ldr : a.ldaux) + nw : 0), 0,
-          (SIDE && rows_v > 0 && cols_v > 0) ? (rows_v - 1) * lds_b + cols_v * 2 : 0, 0x00020000);
-      const int svo = in_cols ? rq * lds_b + cj * 16 : (int)0x80000000;
-      const uint32_t wr_base = (uint32_t)(r16e * 512), rd_base = (uint32_t)(rq * 512);
-      // quad of (row mw + rq, column nw + 8 cj); rows 4 apart are N quads apart
-      const uint32_t quad0 = (uint32_t)((((uint64_t)(a.row0 + mw + rq)) * (uint64_t)a.N + (uint64_t)(nw + cj * 8)) >> 2);
-      auto write_pass = [&](int mt) {
-#pragma unroll
-        for (int nt = 0; nt < 8; ++nt) *reinterpret_cast<f32x4*>(ep + wr_base + (((nt * 4 + ge) ^ r16e) * 16)) = acc[nt][mt];
-      };
-      // ALPHA: the product is scaled (only the plain epilogue is built with it: every fused epilogue of the reader has alpha = 1, and with one
-      // wave per SIMD the two packed multiplies per four outputs are a third of the plain epilogue's vector work — nt4_ok sends a fused
-      // epilogue with alpha != 1 to the eight-wave kernels)
-      auto run = [&](auto RELU_, auto DROP_, auto RES_, auto ALPHA_) {
-        constexpr bool RELU = decltype(RELU_)::value, DROP = decltype(DROP_)::value, RES = SIDE && decltype(RES_)::value, AUX = SIDE && !RES;
-        constexpr bool ALPHA = decltype(ALPHA_)::value;
-        // the side operand's 16 bytes per lane and row, requested SD passes ahead (a ring of SD × 4 registers quads: one pass is ≈ 800 cycles of
-        // this wave's work, a load from HBM several thousand — one pass ahead left the epilogue waiting for memory in every pass:
-        // profiles/r06h_nt4_epilogue_stamps.txt)
-#ifndef LAKO_NT4_SD
-#define LAKO_NT4_SD 2
-#endif
-        constexpr int SD = LAKO_NT4_SD;
-        u32x4 side[SD][4];
-        if constexpr (SIDE) {
-#pragma unroll
-          for (int p0 = 0; p0 < SD && p0 < MT; ++p0)
-#pragma unroll
-            for (int it = 0; it < 4; ++it) side[p0][it] = __builtin_amdgcn_raw_buffer_load_b128(srs, svo, (p0 * 16 + it * 4) * lds_b, 0);
-        }
-        write_pass(0);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          // the pass's rows come back in two halves (2 × 4 reads): the second half is requested — and the next pass written — once the first
-          // half's arithmetic has been issued (LDS executes a wave's accesses in order: the write cannot overtake the reads)
-          f32x4 v[4][2];
-          auto read_rows = [&](int it0) {
-#pragma unroll
-            for (int it = it0; it < it0 + 2; ++it)
-#pragma unroll
-              for (int h = 0; h < 2; ++h) {
-                const int row_l = it * 4 + rq;
-                v[it][h] = *reinterpret_cast<const f32x4*>(ep + rd_base + it * 2048 + (((2 * cj + h) ^ row_l) * 16));
-              }
-          };
-          read_rows(0);
-          u32x4 sv4[4];
-          if constexpr (SIDE) {      // this pass's side data out of the ring, the pass SD ahead into its place
-#pragma unroll
-            for (int it = 0; it < 4; ++it) sv4[it] = side[mt % SD][it];
-            if (mt + SD < MT) {
-#pragma unroll
-              for (int it = 0; it < 4; ++it) side[mt % SD][it] = __builtin_amdgcn_raw_buffer_load_b128(srs, svo, ((mt + SD) * 16 + it * 4) * lds_b, 0);
-            }
-          }
-#pragma unroll
-          for (int it = 0; it < 4; ++it) {
-            if (it == 2) {
-              read_rows(2);
-              if (mt + 1 < MT) write_pass(mt + 1);
-            }
-            bf16x8 sv = {}, o;
-            if constexpr (SIDE) sv = __builtin_bit_cast(bf16x8, sv4[it]);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              f32x4 x = v[it][h];
-              if constexpr (ALPHA) x = x * a.alpha;
-              if constexpr (RELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) x[r] = fmaxf(x[r], 0.f);
-              }
-              if constexpr (AUX) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) x[r] = (float)sv[4 * h + r] > 0.f ? x[r] * a.aux_scale : 0.f;
-              }
-              if constexpr (DROP) {
-                // the dropout quad (4 consecutive elements of a row) of these four outputs: element index / 4, below 2^32 (nt4_ok) — 32-bit
-                // additions from the lane's first quad instead of a 64-bit multiply per row (the index arithmetic was half of the
-                // 32-bit multiplies of this epilogue, and with one wave per SIMD they are wall time: profiles/r06h_nt4_epilogue_stamps.txt)
-                bool kp[4];
-                lako_keep4(a.drop_key, (uint64_t)(quad0 + (uint32_t)(mt * 4 + it) * (uint32_t)a.N + (uint32_t)h), a.drop_thresh, kp);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) x[r] = kp[r] ? x[r] * a.drop_scale : 0.f;
-              }
-              if constexpr (RES) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) x[r] += (float)sv[4 * h + r];
-              }
-#pragma unroll
-              for (int r = 0; r < 4; ++r) o[4 * h + r] = (bf16_t)x[r];
-            }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), crs, cvo, (mt * 16 + it * 4) * ldc_b, 0);
-          }
-        }
-      };
-      // DIRECT form of the dropout epilogues without a side operand.  The MFMAs run with the operands swapped, so a lane already holds four
-      // consecutive COLUMNS of one row — a dropout quad — per 16 × 16 tile: the same arithmetic in the accumulator layout, rounded to bf16, then
-      // `v_permlane16_swap` (gfx950: the odd 16-lane rows of one register against the even rows of another) pairs the halves of two
-      // neighbouring n-tiles into 16 bytes of a row per lane — no LDS pass; a store covers 16 rows × 64 bytes.  Measured
-      // (tools/gemm_nt4_direct.py, profiles/r06m_nt4_direct_epilogue.txt): −1 … −3 % per launch for dropout and ReLU + dropout, +3 … +7 % for
-      // plain / ReLU / alpha (the 64-byte runs cost the stores more than the LDS pass cost the wave) — so only the dropout forms exist.
-      auto run_direct = [&](auto RELU_, auto DROP_, auto ALPHA_) {
-        constexpr bool RELU = decltype(RELU_)::value, DROP = decltype(DROP_)::value, ALPHA = decltype(ALPHA_)::value;
-        const int mrow = le & 15;
-        const int colb = ((ge & 1) * 16 + (ge >> 1) * 8) * 2;                  // first byte of the lane's 16: g = 0 / 1 / 2 / 3 → 0 / 32 / 16 / 48
-        int dvo[4];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) dvo[p] = (p * 32 + colb / 2 < cols_v && !NT_DBG(a, 8)) ? mrow * ldc_b + colb + p * 64 : (int)0x80000000;
-        // quad of (row mw + mrow, column nw + 4 g): rows 16 apart are 4 N quads apart, n-tiles 4 quads
-        const uint32_t dq0 = (uint32_t)((((uint64_t)(a.row0 + mw + mrow)) * (uint64_t)a.N + (uint64_t)(nw + ge * 4)) >> 2);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-          for (int p = 0; p < 4; ++p) {
-            uint32_t pk[2][2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              f32x4 x = acc[2 * p + h][mt];
-              if constexpr (ALPHA) x = x * a.alpha;
-              if constexpr (RELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) x[r] = fmaxf(x[r], 0.f);
-              }
-              if constexpr (DROP) {
-                bool kp[4];
-                lako_keep4(a.drop_key, (uint64_t)(dq0 + (uint32_t)(mt * 4) * (uint32_t)a.N + (uint32_t)((2 * p + h) * 4)), a.drop_thresh, kp);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) x[r] = kp[r] ? x[r] * a.drop_scale : 0.f;
-              }
-              const bf16x4 o4 = {(bf16_t)x[0], (bf16_t)x[1], (bf16_t)x[2], (bf16_t)x[3]};
-              const u32x2 w = __builtin_bit_cast(u32x2, o4);
-              pk[h][0] = w[0];
-              pk[h][1] = w[1];
-            }
-            // even rows of lanes keep n-tile 2p (their own half + the neighbour's), odd rows n-tile 2p + 1
-            const u32x2 s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
-            const u32x2 s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, crs, dvo[p], (mt * 16) * ldc_b, 0);
-            __builtin_amdgcn_sched_barrier(0);      // (the scheduler otherwise copies the accumulators of many groups out at once: spills)
-          }
-        }
-      };
-      const bool relu = a.flags & LAKO_EPI_RELU, drop = a.drop_thresh != 0;
-      using T_ = std::true_type;
-      using F_ = std::false_type;
-      if constexpr (EPI == 1) run_direct(F_{}, T_{}, F_{});
-      else if constexpr (EPI == 2) run_direct(T_{}, T_{}, F_{});
-      else if constexpr (SIDE) {
-        // (the host sends here: residual with or without dropout, or the aux mask alone, alpha = 1 — nt4_ok)
-        if (has_res) {
-          if (drop) run(F_{}, T_{}, T_{}, F_{});
-          else run(F_{}, F_{}, T_{}, F_{});
-        } else {
-          run(F_{}, F_{}, F_{}, F_{});
-        }
-      } else {
-        if (drop) {
-          if (relu) run(T_{}, T_{}, F_{}, F_{});
-          else run(F_{}, T_{}, F_{}, F_{});
-        } else if (relu) {
-          run(T_{}, F_{}, F_{}, F_{});
-        } else if (a.alpha != 1.0f) {
-          run(F_{}, F_{}, F_{}, T_{});
-        } else {
-          run(F_{}, F_{}, F_{}, F_{});
-        }
-      }
+      nt4_epilogue<MT, SIDE, EPI>(a, acc, smem, wave, wr, wc, m0, n0);
     }
     NT_STAMP(3);
     if (!has_next) break;

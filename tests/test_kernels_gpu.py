@@ -1364,3 +1364,41 @@ def test_gemm_nt_mx_epilogues(ops, ref):
         ops.gemm_nt_mx(Aq, As, Bq, Bs, got, **kw)
         ref.gemm_nt(Ad, Bd, want, **kw)                    # same epilogue recipe on the dequantised (bf16-exact) operands
         close(got, want, torch.bfloat16, f"gemm_nt_mx epilogue {sorted(kw)}", k=0.5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(70000, 768, 1024), (40000, 1032, 512), (50001, 520, 2048), (16500, 3072, 1024)])
+def test_gemm_nt_mx_four_wave(ops, ref, M, N, K):
+    """(round 6, csrc/gemm_nt4_mx.h) The MX product on the four-wave tile — two K-slices of LDS-DMA in flight behind a counted wait, scale bytes
+    picked by op_sel from a dword per group of four K-steps, nt4_epilogue — forced to 256-row and 192-row tiles and as the default plan, against
+    the eight-wave MX kernel (`gemm_nt_four` 0): BIT-identical outputs (the same MFMAs in the same K order per element, the same epilogue
+    arithmetic) for every epilogue, ragged last tiles in M and N, several tiles per workgroup, one and several scale groups per tile; and
+    against the dequantised fp32 product."""
+    from tests.ref_ops import mx_dequant_ref, mx_quantize_ref
+    T = torch.bfloat16
+    A, B = rnd(M, K, seed=91).to(T), rnd(N, K, seed=92, scale=0.6).to(T)
+    R, X = rnd(M, N, dtype=T, seed=93), rnd(M, N, dtype=T, seed=94)
+    Aq, Bq = (torch.zeros(t.shape, dtype=torch.uint8, device=dev()) for t in (A, B))
+    As, Bs = (torch.zeros(t.shape[0], ops.mx_scale_cols(K), dtype=torch.uint8, device=dev()) for t in (A, B))
+    ops.mx_quantize(A, Aq, As)
+    ops.mx_quantize(B, Bq, Bs)
+    try:
+        for kw in (dict(), dict(relu=True, drop=(0.1, 5, 6)), dict(alpha=0.5), dict(resid=R, drop=(0.1, 7, 8)), dict(resid=R), dict(aux=X, aux_scale=1.1)):
+            got = {}
+            for name, four, variant in (("eight-wave", 0, -1), ("default plan", 1, -1), ("256-row", 1, 9), ("192-row", 1, 3)):
+                ops.set_tuning("gemm_nt_four", four)
+                ops.set_tuning("gemm_nt_variant", variant)
+                C = torch.full((M, N), float("nan"), dtype=T, device=dev())
+                ops.gemm_nt_mx(Aq, As, Bq, Bs, C, **kw)
+                torch.cuda.synchronize()
+                got[name] = C
+            for name in got:
+                assert torch.equal(got[name].view(torch.int16), got["eight-wave"].view(torch.int16)), f"{name} vs the eight-wave MX kernel, {list(kw)} {M}x{N}x{K}"
+        if M <= 20000:
+            Ad = mx_dequant_ref(*mx_quantize_ref(A.float().cpu())).to(dev())
+            Bd = mx_dequant_ref(*mx_quantize_ref(B.float().cpu())).to(dev())
+            close(got["default plan"], (Ad @ Bd.t()) * 1.1 * (X.float() > 0), T, f"gemm_nt_mx four-wave {M}x{N}x{K}", k=0.5)
+    finally:
+        ops.set_tuning("gemm_nt_four", 1)
+        ops.set_tuning("gemm_nt_variant", -1)
+
