@@ -449,10 +449,11 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(r["achieved"], 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(r["achieved"] / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_over_algorithmic_bytes": round(traffic / traffic_alg, 3) if traffic and traffic_alg else None,
-                         "kernel": ("gemm_nt_mx_kernel (256x256 tile, v_mfma_scale_f32_16x16x128_f8f6f4, e4m3 x e4m3 with E8M0 block scales: "
+                         "kernel": ("gemm_nt4_mx_kernel<MT,SIDE> (round 6: 256x256 / 192x256 tiles on four waves, two K-slices of LDS-DMA in flight, "
+                                    "v_mfma_scale_f32_16x16x128_f8f6f4, e4m3 x e4m3 with E8M0 block scales; gemm_nt_mx_kernel where K % 512 != 0: "
                                     "forward QKV / FFN-in / cross-K/V projections)") if args.fp8 else
-                                   ("gemm_nt4_kernel<MT,SIDE> (round 6: 256x256 / 192x256 tiles on four waves, hand-placed K loop with two K-slices of "
-                                    "LDS-DMA in flight; all four instantiations; calls with M > 256 rows: the encoder's GEMMs; + the cross-K/V "
+                                   ("gemm_nt4_kernel<MT,SIDE,EPI> (round 6: 256x256 / 192x256 tiles on four waves, hand-placed K loop with two K-slices of "
+                                    "LDS-DMA in flight; all instantiations; calls with M > 256 rows: the encoder's GEMMs; + the cross-K/V "
                                     "projection under LAKO_XATTN=0)") if args.dtype == "bf16"
                                    else "gemm_nt_kernel<f32,f32>",
                          "launches_per_step": r["n_l"], "avg_launch_us": round(r["t_ms"] * 1e3 / max(r["n_l"], 1), 2),

@@ -50,7 +50,8 @@ step_trace() {
 step_c45() {
   python bench.py --model large --n-passages 40 --batch 8 --no-cpu-baseline --all-valid-steps 0 --steps 15 --warmup 4 > $OUT/bench_c4.json 2> $OUT/bench_c4.err
   python bench.py --model large --n-passages 100 --batch 8 --no-cpu-baseline --all-valid-steps 0 --steps 8 --warmup 3 > $OUT/bench_c5.json 2> $OUT/bench_c5.err
-  cut -c1-200 $OUT/bench_c4.json $OUT/bench_c5.json
+  python bench.py --model large --n-passages 100 --batch 8 --no-cpu-baseline --all-valid-steps 0 --steps 8 --warmup 3 --fp8 > $OUT/bench_c5_fp8.json 2> $OUT/bench_c5_fp8.err
+  cut -c1-200 $OUT/bench_c4.json $OUT/bench_c5.json $OUT/bench_c5_fp8.json
 }
 step_generate() { python tools/generate_probe.py > $OUT/generate_probe.txt 2>&1; tail -2 $OUT/generate_probe.txt; }
 step_pmcstep() {
