@@ -89,7 +89,10 @@ typedef struct lako_tuning {
                             one of the epilogues {alpha, ReLU, dropout} / {residual, dropout} / {aux mask} run on the four-wave kernels with
                             the hand-placed K loop (256- or 192-row tiles, whichever needs less time for the launch's rounds of the chip);
                             0: the eight-wave kernels of rounds 1-5.  nt_variant 9 / 3 force the 256- / 192-row four-wave kernel.  Same
-                            results bit for bit */
+                            results bit for bit.  3 (= 1 | 2): as 1, but the dropout epilogues without a side operand go through the LDS
+                            transposition like the others instead of leaving straight from the accumulator layout (A/B measurements).
+                            lako_gemm_nt_mx follows the same key: non-zero = the four-wave MX kernel where K % 512 == 0 and the launch
+                            fills the chip */
   int32_t tn_four;       /* 1 (default, round 6): the 256x256 weight-gradient kernel on four waves with the same hand-placed K loop
                             (K ranges of at least 128 rows, no slab reduction); 0: the eight-wave kernel.  Same results bit for bit up to
                             the order of the float atomics of K-splits */
