@@ -28,7 +28,7 @@ extern "C" {
 /* 2 (round 4): the struct and argument changes of round 3 (lako_gemm_nt_t.tuning, the tuning / alpha arguments of lako_gemm_tn*,
  * lako_fact_scores, no lako_set_tuning) are incompatible with callers built against version 1 — such a caller must be rebuilt.
  * lako_amd/_lib.py::load() refuses a library whose lako_version() is not the one it was written for. */
-#define LAKO_ABI_VERSION 3
+#define LAKO_ABI_VERSION 4
 
 enum { LAKO_F32 = 0, LAKO_BF16 = 1, LAKO_FP8_E4M3 = 2 /* MX block-scaled operands of lako_gemm_nt_mx only */ };
 enum { LAKO_OK = 0, LAKO_E_BADARG = -1, LAKO_E_ALIGN = -2, LAKO_E_LAUNCH = -3, LAKO_E_UNSUPPORTED = -4 };
@@ -148,6 +148,11 @@ int lako_gemm_nt(const lako_gemm_nt_t* p, lako_stream_t stream);
  * lako_gemm_nt_mx: C [M,N] bf16 = epilogue(alpha * A.B^T), p->A / p->B the e4m3 matrices (in_dtype LAKO_FP8_E4M3, lda / ldb in
  *   bytes), a_scales / b_scales as written by lako_mx_quantize; epilogue flags RELU, RESID, AUXMASK and dropout as lako_gemm_nt. */
 int lako_mx_quantize(const void* x, int64_t rows, int64_t K, int64_t ld, void* q, uint8_t* scales, lako_stream_t stream);
+/* T5LayerNorm (lako_rmsnorm_fwd without dropout, bf16) with lako_mx_quantize of its output fused in (round 6, ABI 4): y bf16 [rows, d]
+ * and rstd as lako_rmsnorm_fwd writes them, q [rows, d] e4m3 and scales [rows, 4, KSP(d)] as lako_mx_quantize(y) would — bit for bit —
+ * in one pass over the rows (the fp8 forward products of a layer consume the normalised rows next).  d % 128 == 0. */
+int lako_rmsnorm_fwd_mx(const void* x, const float* w, void* y, float* rstd, void* q, uint8_t* scales, int64_t rows, int d, float eps,
+                        lako_stream_t stream);
 int lako_gemm_nt_mx(const lako_gemm_nt_t* p, const uint8_t* a_scales, const uint8_t* b_scales, lako_stream_t stream);
 
 /* C[M,N] (fp32) += alpha * Aᵀ·B with A [K, M], B [K, N] row-major (weight gradients dW = dYᵀ·X —

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LAKO_LIB") or os.path.join(_HERE, "liblako_hip.so")   # LAKO_LIB: A/B measurements of two builds
 
-ABI_VERSION = 3          # include/lako_hip.h LAKO_ABI_VERSION this binding was written for
+ABI_VERSION = 4          # include/lako_hip.h LAKO_ABI_VERSION this binding was written for
 LAKO_F32, LAKO_BF16, LAKO_FP8_E4M3 = 0, 1, 2
 EPI_RELU, EPI_RESID, EPI_AUXMASK, EPI_ATOMIC, EPI_NORM_A = 1, 2, 4, 8, 16
 
@@ -85,6 +85,7 @@ SIGNATURES = {
     "lako_last_error": [C.c_char_p, C.c_size_t],
     "lako_gemm_nt": [C.POINTER(GemmNT), vp],
     "lako_mx_quantize": [vp, i64, i64, i64, vp, vp, vp],
+    "lako_rmsnorm_fwd_mx": [vp, vp, vp, vp, vp, vp, i64, i32, f32, vp],
     "lako_gemm_nt_mx": [C.POINTER(GemmNT), vp, vp, vp],
     "lako_gemm_tn": [vp, vp, vp, i64, i64, i64, i64, i64, i64, i32, f32, i32, vp, vp],
     "lako_gemm_tn_grouped": [C.POINTER(GemmTNItem), i32, i64, i32, i32, vp, vp, i64, vp],

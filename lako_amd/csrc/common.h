@@ -189,6 +189,43 @@ static inline uint32_t lako_drop_thresh(float p) {   // 0 = dropout off
 }
 
 // ---------------------------------------------------------------------------------------------
+// MX (OCP microscaling) quantiser of 8 consecutive k held by one lane: the 4 lanes l, l^1, l^2, l^3 of a 32-element block agree on amax
+// by two shuffles; scale exponent e = exponent(amax) − 8 clamped to [0, 254] (8 = the exponent of e4m3's largest normal, 448 = 1.75·2^8),
+// elements sat_e4m3(x · 2^(127 − e)).  ±Inf saturates to ±448·scale; a NaN anywhere in the block makes the block's scale the E8M0 NaN
+// (0xFF) and the element 0x7F.  Returns the scale byte; w[0..1] = the 8 e4m3 bytes.  (mx_quantize_kernel and the fused RMSNorm forward.)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint8_t mx_quant8(const float (&f)[8], uint32_t (&w)[2]) {
+  float amax = 0.f;
+  int has_nan = 0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    amax = fmaxf(amax, fabsf(f[e]));            // fmaxf drops a NaN: tracked separately
+    has_nan |= f[e] != f[e];
+  }
+  amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+  amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+  has_nan |= __shfl_xor(has_nan, 1, 64);
+  has_nan |= __shfl_xor(has_nan, 2, 64);
+  int ex = (int)((__builtin_bit_cast(uint32_t, amax) >> 23) & 0xff) - 8;
+  ex = min(max(ex, 0), 254);
+  const float inv = __builtin_bit_cast(float, (uint32_t)(254 - ex) << 23);        // 2^(127 − ex): exact
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    float t[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t[e] = fminf(fmaxf(f[4 * h + e] * inv, -448.f), 448.f);
+    int p = __builtin_amdgcn_cvt_pk_fp8_f32(t[0], t[1], 0, false);
+    p = __builtin_amdgcn_cvt_pk_fp8_f32(t[2], t[3], p, true);
+    uint32_t pw = (uint32_t)p;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)                           // fminf / fmaxf turned a NaN into ∓448: put the e4m3 NaN back
+      if (f[4 * h + e] != f[4 * h + e]) pw = (pw & ~(0xffu << (8 * e))) | (0x7fu << (8 * e));
+    w[h] = pw;
+  }
+  return has_nan ? (uint8_t)0xff : (uint8_t)ex;
+}
+
+// ---------------------------------------------------------------------------------------------
 // wave helpers (wave = 64 lanes)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

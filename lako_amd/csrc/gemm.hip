@@ -1982,41 +1982,15 @@ __global__ __launch_bounds__(256) void mx_quantize_kernel(const bf16_t* __restri
     const int64_t row = i / per_row;
     const int c = (int)(i - row * per_row);                 // 8-element chunk of the row
     const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + row * ld + c * 8);
-    float f[8], amax = 0.f;
-    int has_nan = 0;
+    float f[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      f[e] = (float)v[e];
-      amax = fmaxf(amax, fabsf(f[e]));            // fmaxf drops a NaN: tracked separately
-      has_nan |= f[e] != f[e];
-    }
-    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
-    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
-    has_nan |= __shfl_xor(has_nan, 1, 64);
-    has_nan |= __shfl_xor(has_nan, 2, 64);
-    // exponent of amax from its bits (0 and subnormals: the smallest scale); ±Inf saturates to ±448·scale; a NaN anywhere in the
-    // block makes the block's scale the E8M0 NaN (0xFF: every product that touches the block is NaN) and the element 0x7F
-    int ex = (int)((__builtin_bit_cast(uint32_t, amax) >> 23) & 0xff) - 8;
-    ex = min(max(ex, 0), 254);
-    const float inv = __builtin_bit_cast(float, (uint32_t)(254 - ex) << 23);        // 2^(127 − ex): exact
+    for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
     uint32_t w[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      float t[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) t[e] = fminf(fmaxf(f[4 * h + e] * inv, -448.f), 448.f);
-      int p = __builtin_amdgcn_cvt_pk_fp8_f32(t[0], t[1], 0, false);
-      p = __builtin_amdgcn_cvt_pk_fp8_f32(t[2], t[3], p, true);
-      uint32_t pw = (uint32_t)p;
-#pragma unroll
-      for (int e = 0; e < 4; ++e)                           // fminf / fmaxf turned a NaN into ∓448: put the e4m3 NaN back
-        if (f[4 * h + e] != f[4 * h + e]) pw = (pw & ~(0xffu << (8 * e))) | (0x7fu << (8 * e));
-      w[h] = pw;
-    }
+    const uint8_t scale = mx_quant8(f, w);
     *reinterpret_cast<u32x2*>(q + row * K + c * 8) = u32x2{w[0], w[1]};
     if ((c & 3) == 0) {
       const int blk = c >> 2;                               // 32-element block of the row
-      sc[row * 4 * ksp + (blk & 3) * ksp + (blk >> 2)] = has_nan ? (uint8_t)0xff : (uint8_t)ex;
+      sc[row * 4 * ksp + (blk & 3) * ksp + (blk >> 2)] = scale;
     }
   }
 }

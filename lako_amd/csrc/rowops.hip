@@ -119,6 +119,58 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const T* __restrict__ 
   }
 }
 
+// The same with the MX quantiser of the normalised row fused in (round 6, bf16, d % 128 == 0, no dropout): y as above, plus its e4m3 bytes and
+// E8M0 block scales in lako_mx_quantize's layout — what the fp8 forward product of the row consumes next, without a second pass over y
+// (the quantiser reads the ROUNDED bf16 values: bit-identical to lako_rmsnorm_fwd + lako_mx_quantize).  Lane l holds the chunks l + 64 k
+// of 8 elements: the four lanes of a 32-element block are neighbours.
+__global__ __launch_bounds__(256) void rmsnorm_fwd_mx_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w, bf16_t* __restrict__ y,
+                                                             float* __restrict__ rstd, uint8_t* __restrict__ q, uint8_t* __restrict__ sc, int ksp,
+                                                             int64_t rows, int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  for (int64_t row = wid; row < rows; row += nw) {
+    const bf16_t* xr = x + row * d;
+    float ss = 0.f;
+    for (int c = lane * 8; c < d; c += 512) {
+      float v[8];
+      load8(xr + c, v);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ss += v[i] * v[i];
+    }
+    ss = wave_sum(ss);
+    const float rs = rsqrtf(ss / (float)d + eps);
+    if (lane == 0) rstd[row] = rs;
+    bf16_t* yr = y + row * d;
+    for (int c0 = 0; c0 < d; c0 += 512) {        // (every lane takes every iteration: the quantiser's shuffles need whole blocks of four lanes; d % 32 == 0)
+      const int c = c0 + lane * 8;
+      const bool in = c < d;
+      float v[8], wv[8];
+      if (in) {
+        load8(xr + c, v);
+        load8(w + c, wv);
+      }
+      bf16x8 o;
+      float f[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        o[i] = (bf16_t)(in ? wv[i] * (v[i] * rs) : 0.f);
+        f[i] = (float)o[i];
+      }
+      uint32_t wq[2];
+      const uint8_t scale = mx_quant8(f, wq);
+      if (in) {
+        *reinterpret_cast<bf16x8*>(yr + c) = o;
+        *reinterpret_cast<u32x2*>(q + row * d + c) = u32x2{wq[0], wq[1]};
+        if ((lane & 3) == 0) {
+          const int blk = c >> 5;
+          sc[row * 4 * ksp + (blk & 3) * ksp + (blk >> 2)] = scale;
+        }
+      }
+    }
+  }
+}
+
 // 8 consecutive elements as they sit in memory (a prefetched row costs 4 registers per 8 bf16, converted when it is used)
 template <typename T>
 struct Raw8;
@@ -991,6 +1043,29 @@ extern "C" int lako_rmsnorm_fwd(const void* x, const float* w, void* y, float* r
   }
   DISPATCH_T(dtype, hipLaunchKernelGGL((rmsnorm_fwd_kernel<T>), dim3(rows_grid(rows)), dim3(256), 0,
                                        (hipStream_t)stream, (const T*)x, w, (T*)y, rstd, rows, d, eps, dr));
+  LAKO_LAUNCH_CHECK();
+  return LAKO_OK;
+}
+
+extern "C" int lako_rmsnorm_fwd_mx(const void* x, const float* w, void* y, float* rstd, void* q, uint8_t* scales, int64_t rows, int d, float eps,
+                                   lako_stream_t stream) {
+  LAKO_CHECK_ARG(rows > 0 && d > 0 && d % 128 == 0, "lako_rmsnorm_fwd_mx: rows=%lld d=%d (d %% 128 == 0)", (long long)rows, d);
+  LAKO_CHECK_ARG(x && w && y && rstd && q && scales, "lako_rmsnorm_fwd_mx: null tensor");
+  LAKO_CHECK_ALIGN(x, 16);
+  LAKO_CHECK_ALIGN(y, 16);
+  LAKO_CHECK_ALIGN(w, 16);
+  LAKO_CHECK_ALIGN(q, 8);
+  const int ksp = (d / 128 + 3) / 4 * 4;      // scale columns per 32-k lane group, as lako_mx_scale_cols(d) / 4
+  if (d == 768) {
+    // lako_rmsnorm_fwd has its own kernel for this width (two rows per wave: another summation order of the squares): "bit for bit" means
+    // that kernel followed by the quantiser — two launches, only the call is fused (T5-base is no fp8 configuration of the benchmark)
+    lako_dropout_t none{};
+    int rc = lako_rmsnorm_fwd(x, w, y, rstd, rows, d, eps, LAKO_BF16, none, stream);
+    if (rc != LAKO_OK) return rc;
+    return lako_mx_quantize(y, rows, d, d, q, scales, stream);
+  }
+  hipLaunchKernelGGL(rmsnorm_fwd_mx_kernel, dim3(rows_grid(rows)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, w, (bf16_t*)y, rstd, (uint8_t*)q, scales,
+                     ksp, rows, d, eps);
   LAKO_LAUNCH_CHECK();
   return LAKO_OK;
 }

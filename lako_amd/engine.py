@@ -312,6 +312,26 @@ class Engine:
             q, sc = self._w8[b.name]
             self.ops.mx_quantize(self._view(self.W, b), q, sc)
 
+    def _norm_gemm_w(self, ws, h, lnp, xn, rs, eps, name, w, out, **epi):
+        """xn = RMSNorm(h); out = epilogue(xn · wᵀ).  With an fp8 shadow of this weight the norm also emits the e4m3 bytes and block scales of xn
+        (lako_rmsnorm_fwd_mx: one pass instead of norm + quantiser — the same bytes), which the MX product consumes."""
+        w8 = self._w8.get(name) if self.fp8 else None
+        M, K = h.shape
+        if w8 is None or K % 128 != 0 or not hasattr(self.ops, "rmsnorm_fwd_mx") or os.environ.get("LAKO_FP8_FUSED_NORM", "1") == "0":
+            self.ops.rmsnorm_fwd(h, lnp, xn, rs, eps)
+            return self._gemm_w(ws, xn, name, w, out, **epi)
+        xq, xs = self._q8_buffers(ws, M, K)
+        self.ops.rmsnorm_fwd_mx(h, lnp, xn, rs, eps, xq, xs)
+        self.ops.gemm_nt_mx(xq, xs, w8[0], w8[1], out, **epi)
+
+    def _q8_buffers(self, ws, M, K):
+        xq = self._buf(ws, f"q8.{K}", (M, K), torch.uint8)
+        fresh = ws.get(f"^s8.{K}")
+        xs = self._buf(ws, f"s8.{K}", (M, self.ops.mx_scale_cols(K)), torch.uint8)
+        if ws[f"^s8.{K}"] is not fresh:
+            self.ops.zero_(ws[f"^s8.{K}"])      # the quantiser writes ⌈K/128⌉ of the KSP scale columns: the padding stays 0
+        return xq, xs
+
     def _gemm_w(self, ws, x, name, w, out, **epi):
         """out = epilogue(x · wᵀ): on the block-scaled fp8 matrix cores when this weight has an fp8 shadow (x is quantised into
         workspace scratch first), else the bf16 GEMM"""
@@ -319,11 +339,7 @@ class Engine:
         if w8 is None:
             return self.ops.gemm_nt(x, w, out, **epi)
         M, K = x.shape
-        xq = self._buf(ws, f"q8.{K}", (M, K), torch.uint8)
-        fresh = ws.get(f"^s8.{K}")
-        xs = self._buf(ws, f"s8.{K}", (M, self.ops.mx_scale_cols(K)), torch.uint8)
-        if ws[f"^s8.{K}"] is not fresh:
-            self.ops.zero_(ws[f"^s8.{K}"])      # the quantiser writes ⌈K/128⌉ of the KSP scale columns: the padding stays 0
+        xq, xs = self._q8_buffers(ws, M, K)
         self.ops.mx_quantize(x, xq, xs)
         self.ops.gemm_nt_mx(xq, xs, w8[0], w8[1], out, **epi)
 
@@ -416,9 +432,8 @@ class Engine:
         d, f, inner, H, eps = cfg.d_model, cfg.d_ff, cfg.inner_dim, cfg.num_heads, cfg.layer_norm_epsilon
         Me, lw = (rag.M if rag is not None else BN * L), self.enc[i]
         xn1 = self._buf(ws, f"e.xn1.{j}", (Me, d))
-        ops.rmsnorm_fwd(h, lw["ln1"].p, xn1, self._buf(ws, f"e.rs1.{j}", (Me,), torch.float32), eps)
         qkv = self._buf(ws, f"e.qkv.{j}", (Me, 3 * inner))
-        self._gemm_w(ws, xn1, f"enc.{i}.qkv", lw["qkv"].w, qkv)
+        self._norm_gemm_w(ws, h, lw["ln1"].p, xn1, self._buf(ws, f"e.rs1.{j}", (Me,), torch.float32), eps, f"enc.{i}.qkv", lw["qkv"].w, qkv)
         ctx = self._buf(ws, f"e.ctx.{j}", (Me, inner))
         hb, ht, akw = self._enc_attn_layout(rag, BN, L, mask_u8)
         ops.attn_fwd(self._heads(qkv, hb, ht, 0), self._heads(qkv, hb, ht, inner), self._heads(qkv, hb, ht, 2 * inner),
@@ -427,9 +442,9 @@ class Engine:
         h1 = self._buf(ws, f"e.h1.{j}", (Me, d))
         ops.gemm_nt(ctx, lw["o"].w, h1, resid=h, drop=dr(_enc_site(i, 1)))
         xn2 = self._buf(ws, f"e.xn2.{j}", (Me, d))
-        ops.rmsnorm_fwd(h1, lw["ln2"].p, xn2, self._buf(ws, f"e.rs2.{j}", (Me,), torch.float32), eps)
         a1 = self._buf(ws, f"e.a1.{j}", (Me, f))
-        self._gemm_w(ws, xn2, f"enc.{i}.wi", lw["wi"].w, a1, relu=True, drop=dr(_enc_site(i, 2)))
+        self._norm_gemm_w(ws, h1, lw["ln2"].p, xn2, self._buf(ws, f"e.rs2.{j}", (Me,), torch.float32), eps, f"enc.{i}.wi", lw["wi"].w, a1, relu=True,
+                          drop=dr(_enc_site(i, 2)))
         if h_out is not None:
             ops.gemm_nt(a1, lw["wo"].w, h_out, resid=h1, drop=dr(_enc_site(i, 3)))
 

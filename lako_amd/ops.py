@@ -259,6 +259,15 @@ class HipOps:
         self._timed("rmsnorm_fwd", 0.0, lambda: check(self.lib.lako_rmsnorm_fwd(_p(x), _p(w), _p(y), _p(rstd), rows, d, float(eps), _dt(x), _drop(drop),
                                         self._stream()), "lako_rmsnorm_fwd"))
 
+    def rmsnorm_fwd_mx(self, x, w, y, rstd, eps, q, scales):
+        """rmsnorm_fwd (no dropout, bf16) + mx_quantize(y) in one pass: q / scales as mx_quantize would write them"""
+        rows, d = x.shape
+        if x.dtype != torch.bfloat16 or q.dtype != torch.uint8 or tuple(q.shape) != (rows, d) or not q.is_contiguous() or \
+                tuple(scales.shape) != (rows, self.mx_scale_cols(d)) or not scales.is_contiguous() or not x.is_contiguous() or not y.is_contiguous():
+            raise LakoError("rmsnorm_fwd_mx: bf16 contiguous x / y [rows, d], q uint8 [rows, d], scales uint8 [rows, mx_scale_cols(d)]")
+        self._timed("rmsnorm_fwd", 0.0, lambda: check(self.lib.lako_rmsnorm_fwd_mx(_p(x), _p(w), _p(y), _p(rstd), _p(q), _p(scales), rows, d, float(eps), self._stream()),
+                                                      "lako_rmsnorm_fwd_mx"))
+
     def rmsnorm_bwd(self, dy, x, w, rstd, dres, dx, dw, drop=None, dx_drop=None, drop_out=None):
         """dx_drop (optional): also receives dropout_apply(dx, drop_out) — the next residual branch's incoming gradient"""
         rows, d = x.shape

@@ -72,7 +72,7 @@ def test_bad_arguments_return_error_codes(lib):
     from lako_amd import _lib
     _lib._lib = None
     L = _lib.load()
-    assert L.lako_version() == 3 == _lib.ABI_VERSION
+    assert L.lako_version() == 4 == _lib.ABI_VERSION
     p = _lib.GemmNT()               # all zeros: M = N = K = 0
     rc = L.lako_gemm_nt(ctypes.byref(p), None)
     assert rc == -1

@@ -1290,6 +1290,30 @@ def test_mx_quantize(ops, rows, K):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rows,d", [(300, 1024), (1000, 768), (65, 128), (4099, 512)])
+def test_rmsnorm_fwd_mx_equals_norm_then_quantise(ops, rows, d):
+    """lako_rmsnorm_fwd_mx (round 6): the RMSNorm forward with the MX quantiser of its output fused in — y, rstd, the e4m3 bytes and the scale
+    bytes are BIT-identical to lako_rmsnorm_fwd followed by lako_mx_quantize (the quantiser reads the rounded bf16 row either way); a row
+    holding a NaN and a row of zeros included."""
+    T = torch.bfloat16
+    x = rnd(rows, d, dtype=T, seed=51, scale=3.0)
+    x[3, 7] = float("nan")
+    x[5] = 0
+    w = rnd(d, seed=52) + 1.0
+    y0, y1 = (torch.zeros(rows, d, dtype=T, device=dev()) for _ in range(2))
+    r0, r1 = (torch.zeros(rows, device=dev()) for _ in range(2))
+    q0, q1 = (torch.zeros(rows, d, dtype=torch.uint8, device=dev()) for _ in range(2))
+    s0, s1 = (torch.zeros(rows, ops.mx_scale_cols(d), dtype=torch.uint8, device=dev()) for _ in range(2))
+    ops.rmsnorm_fwd(x, w, y0, r0, 1e-6)
+    ops.mx_quantize(y0, q0, s0)
+    ops.rmsnorm_fwd_mx(x, w, y1, r1, 1e-6, q1, s1)
+    torch.cuda.synchronize()
+    assert torch.equal(y0.view(torch.int16), y1.view(torch.int16)) and torch.equal(r0.view(torch.int32), r1.view(torch.int32))
+    assert torch.equal(q0, q1) and torch.equal(s0, s1)
+    assert int(s1[3].max()) == 0xFF and int((q1[5] & 0x7F).max()) == 0      # (a NaN row: every block's scale is the E8M0 NaN; zeros: ±0)
+
+
+@pytest.mark.gpu
 def test_mx_quantize_propagates_nan(ops):
     """a NaN activation must stay visible in the fp8 forward: its element becomes the e4m3 NaN (0x7F), its
     block's scale the E8M0 NaN (0xFF), the other blocks are untouched, and the product rows that meet the block are NaN"""

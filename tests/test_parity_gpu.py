@@ -51,7 +51,7 @@ def test_hip_library_is_what_runs():
     from lako_amd import _lib
     from lako_amd.ops import HipOps
     ops = HipOps()
-    assert ops.lib.lako_version() == 3
+    assert ops.lib.lako_version() == 4
     import os
     with open(f"/proc/{os.getpid()}/maps") as f:
         assert "liblako_hip.so" in f.read()
