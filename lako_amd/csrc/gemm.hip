@@ -2248,6 +2248,7 @@ void launch_nt4(NtArgs a, const lako_tuning_t& tu, hipStream_t s) {
   // no start offsets between the workgroups: with this loop every offset costs at the end of the launch what it saves in the store
   // phases (tools/gemm_nt4_dephase.py, profiles/r06d_nt4_dephase.txt: lockstep is the fastest of nine settings on all five shapes)
   a.dephase = 0;
+  if (tu.nt_debug & 256) a.dephase = tu.nt_dephase > 0 ? ((tu.nt_dephase_n << 16) | (tu.nt_dephase & 0xffff)) : 0;      // (A/B hook: tools/gemm_nt4_dephase.py)
   a.debug = tu.nt_debug;
   a.queue = nullptr;
   // gemm_nt_four = 1: the dropout epilogues without a side operand straight from the accumulator layout (gemm_nt4.h), 3: through the LDS
